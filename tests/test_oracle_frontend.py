@@ -1,0 +1,99 @@
+"""Known-answer tests pinning the front-end restatement (oracle/frontend_np.py).  librosa is not
+available offline and the reference holds no golden vectors at this boundary, so parity against
+librosa itself is UNPINNED; these identities need no oracle."""
+import numpy as np
+import pytest
+
+from oracle import frontend_np as fe
+
+
+def test_sinusoid_at_bin_centre_has_analytic_hann_magnitude():
+    n_fft, hop, k0, A = 2048, 512, 37, 0.7
+    n = np.arange(40 * hop)
+    y = A * np.cos(2 * np.pi * k0 * n / n_fft + 0.3)
+    S = np.abs(fe.stft(y, n_fft, hop, center=True, lv='0.10'))
+    mid = S[:, 10:-10]                                     # frames untouched by the edge padding
+    np.testing.assert_allclose(mid[k0], A * n_fft / 4, rtol=1e-9)
+    np.testing.assert_allclose(mid[k0 - 1], A * n_fft / 8, rtol=1e-9)
+    np.testing.assert_allclose(mid[k0 + 1], A * n_fft / 8, rtol=1e-9)
+    assert mid[k0 + 3].max() < 1e-6 * A * n_fft
+
+
+def test_parseval_per_frame():
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(9000)
+    n_fft, hop = 512, 128
+    X = fe.stft(y, n_fft, hop, center=True, lv='0.9')
+    ypad = fe.pad_center_audio(y, n_fft, '0.9')
+    w = fe.fft_window(n_fft)
+    for t in (0, 3, X.shape[1] - 1):
+        fr = ypad[t * hop:t * hop + n_fft] * w
+        p = np.abs(X[:, t]) ** 2
+        total = p[0] + p[-1] + 2 * p[1:-1].sum()
+        np.testing.assert_allclose(total, n_fft * np.sum(fr ** 2), rtol=1e-10)
+
+
+def test_center_padding_modes_and_frame_count():
+    y = np.arange(1, 1001, dtype=np.float64)
+    assert np.all(fe.pad_center_audio(y, 64, '0.10')[:32] == 0)
+    np.testing.assert_array_equal(fe.pad_center_audio(y, 64, '0.9')[:32], y[32:0:-1])
+    for N in (1, 511, 512, 513, 319999):
+        T = fe.stft(np.zeros(N), 2048, 512).shape[1]
+        assert T == 1 + N // 512 == fe.expected_frames(N, 512)
+    assert fe.expected_frames(0, 512) == 0
+    r = fe.sample_range(625, 512)
+    assert r[0] == 624 * 512 and r[-1] == 319999 and fe.expected_frames(r[0], 512) == 625
+    assert fe.expected_frames(r[-1] + 1, 512) == 626
+
+
+@pytest.mark.parametrize('htk', [False, True])
+@pytest.mark.parametrize('sr', [16000, 22050])
+def test_mel_filterbank_geometry(sr, htk):
+    n_fft, n_mels = 2048, 229
+    W = fe.mel_filterbank(sr, n_fft, n_mels, htk=htk, dtype=np.float64)
+    assert W.shape == (n_mels, n_fft // 2 + 1) and np.all(W >= 0)
+    mel_f = fe.mel_frequencies(n_mels + 2, 0.0, sr / 2, htk)
+    freqs = np.linspace(0, sr / 2, n_fft // 2 + 1)
+    assert np.all((W > 0).sum(axis=0) <= 2)               # every FFT bin feeds at most two filters
+    assert np.all((W > 0).sum(axis=1) >= 1)               # no empty rows
+    for i in (0, 50, 150, 228):
+        nz = np.nonzero(W[i])[0]
+        assert np.all(np.diff(nz) == 1)                    # contiguous support
+        assert freqs[nz[0]] > mel_f[i] and freqs[nz[-1]] < mel_f[i + 2]
+        k = nz[np.argmax(W[i, nz])]                        # peak is the bin nearest the centre frequency
+        assert abs(freqs[k] - mel_f[i + 1]) <= (freqs[1] - freqs[0])
+        # Slaney area normalisation: the continuous triangle has height 2/(f[i+2]-f[i])
+        f = np.linspace(mel_f[i], mel_f[i + 2], 20001)
+        tri = np.maximum(0, np.minimum((f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]),
+                                       (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1])))
+        np.testing.assert_allclose(np.interp(freqs[nz], f, tri) * 2.0 / (mel_f[i + 2] - mel_f[i]), W[i, nz],
+                                   rtol=1e-6, atol=1e-12)
+    if not htk:   # Slaney: linear below 1 kHz (200/3 Hz per mel), log above
+        np.testing.assert_allclose(fe.hz_to_mel(500.0), 7.5)
+        np.testing.assert_allclose(fe.hz_to_mel(1000.0), 15.0)
+        np.testing.assert_allclose(fe.mel_to_hz(fe.hz_to_mel(np.array([30.0, 999.0, 4000.0]))), [30.0, 999.0, 4000.0])
+    else:
+        np.testing.assert_allclose(fe.hz_to_mel(700.0, htk=True), 2595.0 * np.log10(2.0))
+
+
+def test_db_scaling_end_points():
+    S = np.array([[1.0, 1e-3, 1e-8, 1e-12, 0.0]])
+    out = fe.post_proc(fe.power_to_db(S))
+    assert out.shape == (1, 1, 5)
+    np.testing.assert_allclose(out[0, 0], [1.0, 1 - 30 / 80, 0.0, 0.0, 0.0], atol=1e-12)
+    A = np.array([[2.0, 2e-2, 2e-6]])
+    np.testing.assert_allclose(fe.post_proc(fe.amplitude_to_db(A))[0, 0], [1.0, 0.5, 0.0], atol=1e-12)
+
+
+def test_melspec_process_audio_shapes_and_range():
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal(5000).astype(np.float32)
+    m = fe.melspec_process_audio(y, 22050, 512, 229, 2048)
+    assert m.shape == (1, 229, 1 + 5000 // 512)
+    assert m.max() == 1.0 and m.min() >= 0.0
+    assert fe.melspec_process_audio(np.zeros(0), 22050).shape == (1, 229, 0)
+    assert fe.stft_process_audio(np.zeros(0)).shape == (1, 2048, 0)       # reference quirk, stft.py:57-59
+    s = fe.stft_process_audio(y, 512, 2048)
+    assert s.shape == (1, 1025, 10) and s.max() == 1.0
+    t = fe.frame_times(10, 22050, 512)
+    np.testing.assert_array_equal(t, np.arange(10) * 512 / 22050.0)

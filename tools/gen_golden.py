@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""
+Golden-vector generator.  Runs ONLY in the build container (needs /root/reference); the GPU box and
+the test-suite never execute it -- they read the small .npz fixtures it wrote to tests/golden/.
+
+It imports the *real* reference classes (amt_tools.models.OnsetsFrames / OnsetsFrames2,
+amt_tools.transcribe.NoteTranscriber, amt_tools.tools.*) with import-time stubs for the third-party
+packages this image lacks (librosa, mir_eval, jams, ...; recipe from SURVEY.md Appendix C), loads
+seed-generated weights (amt_tools_amd.synth.synth_state_dict, so the fixture stores a seed rather
+than 19 MB of parameters) and records inputs + the reference's outputs.
+"""
+import importlib.machinery
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, n):
+        if n.startswith('__') and n.endswith('__'):
+            raise AttributeError(n)
+        return MagicMock(name=f'{self.__name__}.{n}')
+
+
+for m in ['librosa', 'librosa.util', 'librosa.core', 'librosa.core.constantq', 'librosa.filters', 'mir_eval',
+          'mir_eval.transcription', 'mir_eval.multipitch', 'mir_eval.util', 'jams', 'mido', 'tensorboardX',
+          'mirdata', 'mirdata.datasets', 'sounddevice', 'pynput', 'sacred', 'tqdm']:
+    if m in ('tqdm',):
+        continue
+    s = _Stub(m)
+    s.__spec__ = importlib.machinery.ModuleSpec(m, None)
+    s.__path__ = []
+    sys.modules[m] = s
+
+import amt_tools                                    # noqa: E402  (the reference)
+from amt_tools import tools as rtools               # noqa: E402
+from amt_tools.models import OnsetsFrames, OnsetsFrames2   # noqa: E402
+from amt_tools.transcribe import NoteTranscriber   # noqa: E402
+
+from amt_tools_amd.synth import synth_state_dict, of_state_dict_shapes   # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def load_weights(model, seed, **kw):
+    sd_np = synth_state_dict(seed, **kw)
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(sd_np.keys()), 'state_dict key order differs from the reference'
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(sd_np[k].shape), (k, v.shape, sd_np[k].shape)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    return sd_np
+
+
+def weight_checksum(sd_np):
+    return np.array([float(np.abs(np.asarray(v, dtype=np.float64)).sum()) for v in sd_np.values()])
+
+
+def features(seed, B, C, F, T):
+    rng = np.random.default_rng(seed)
+    # smooth-ish values in [0, 1] like dB-scaled spectrogram features
+    x = rng.random((B, C, F, T)).astype(np.float32)
+    x = 0.5 * x + 0.5 * np.roll(x, 1, axis=-1)
+    return x.astype(np.float32)
+
+
+def labels(seed, B, T, p):
+    rng = np.random.default_rng(seed)
+    return (rng.random((B, 88, T)) < p).astype(np.float32)
+
+
+def gen_of_eval(name, cls, seed, dim_in, in_channels, mc, B, T, offsets):
+    profile = rtools.PianoProfile()
+    model = cls(dim_in, profile, in_channels, mc)
+    sd_np = load_weights(model, seed, dim_in=dim_in, in_channels=in_channels, model_complexity=mc, offsets=offsets)
+    model.eval()
+    feats = features(seed + 100, B, in_channels, dim_in, T)
+    times = (np.arange(T) * 512 / 22050.0)
+    with torch.no_grad():
+        batch = {rtools.KEY_FEATS: torch.from_numpy(feats), rtools.KEY_TIMES: torch.from_numpy(np.tile(times, (B, 1)))}
+        pre = model.pre_proc(dict(batch))
+        raw = model(pre[rtools.KEY_FEATS])
+        out = model.run_on_batch(dict(batch))
+        pitch_head = model.pitch_head(pre[rtools.KEY_FEATS])
+    rec = dict(seed=seed, dim_in=dim_in, in_channels=in_channels, model_complexity=mc, offsets=int(offsets),
+               feats=feats, wsum=weight_checksum(sd_np),
+               logits_onsets=raw[rtools.KEY_ONSETS].numpy(), logits_multi_pitch=raw[rtools.KEY_MULTIPITCH].numpy(),
+               logits_pitch_head=pitch_head.numpy(),
+               out_onsets=out[rtools.KEY_ONSETS].numpy(), out_multi_pitch=out[rtools.KEY_MULTIPITCH].numpy(),
+               out_times=out[rtools.KEY_TIMES].numpy())
+    if offsets:
+        rec['logits_offsets'] = raw[rtools.KEY_OFFSETS].numpy()
+        rec['out_offsets'] = out[rtools.KEY_OFFSETS].numpy()
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, {k: getattr(v, 'shape', v) for k, v in rec.items()})
+
+
+def gen_of_train(name, seed, dim_in, mc, B, T):
+    """Training-mode golden: BatchNorm batch statistics, Dropout disabled (p=0) so the result is
+    deterministic; labels given -> the reference's losses and a few gradients."""
+    profile = rtools.PianoProfile()
+    model = OnsetsFrames(dim_in, profile, 1, mc)
+    sd_np = load_weights(model, seed, dim_in=dim_in, in_channels=1, model_complexity=mc, offsets=False)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    feats = features(seed + 100, B, 1, dim_in, T)
+    mp = labels(seed + 200, B, T, 0.05)
+    on = labels(seed + 300, B, T, 0.01)
+    batch = {rtools.KEY_FEATS: torch.from_numpy(feats), rtools.KEY_MULTIPITCH: torch.from_numpy(mp),
+             rtools.KEY_ONSETS: torch.from_numpy(on)}
+    out = model.run_on_batch(batch)
+    loss = out[rtools.KEY_LOSS]
+    loss[rtools.KEY_LOSS_TOTAL].backward()
+    named = dict(model.named_parameters())
+    gkeys = ['onset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'onset_head.1.mlm.weight_hh_l0',
+             'pitch_head.0.fc1.0.bias', 'adjoin.0.mlm.weight_ih_l0_reverse', 'adjoin.1.output_layer.weight',
+             'pitch_head.1.output_layer.bias']
+    rec = dict(seed=seed, dim_in=dim_in, model_complexity=mc, feats=feats, multi_pitch=mp, onsets=on,
+               wsum=weight_checksum(sd_np),
+               loss_pitch=loss[rtools.KEY_LOSS_PITCH].item(), loss_onsets=loss[rtools.KEY_LOSS_ONSETS].item(),
+               loss_total=loss[rtools.KEY_LOSS_TOTAL].item(),
+               out_onsets=out[rtools.KEY_ONSETS].numpy(), out_multi_pitch=out[rtools.KEY_MULTIPITCH].numpy())
+    for i, k in enumerate(gkeys):
+        rec[f'grad_{i}'] = named[k].grad.detach().numpy().copy()
+    rec['grad_keys'] = np.array(gkeys)
+    # NOTE: the labels-without-onsets branch (onsetsframes.py:176-178) cannot be recorded: with tensor
+    # labels tools.multi_pitch_to_onsets returns an ndarray and LogisticBank.get_loss then fails on
+    # `.clone()` (models/common.py:566) -- the reference only works when onsets labels are supplied.
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, 'losses', rec['loss_pitch'], rec['loss_onsets'], rec['loss_total'])
+
+
+def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
+    rng = np.random.default_rng(seed)
+    profile = rtools.PianoProfile()
+    est = NoteTranscriber(profile=profile)
+    # sticky activations so notes have duration
+    mp = np.zeros((88, T), dtype=np.float32)
+    state = rng.random(88) < p_mp
+    for t in range(T):
+        flip = rng.random(88)
+        state = np.where(state, flip > 0.15, flip < p_mp * 0.3)
+        mp[:, t] = state
+    on = (rng.random((88, T)) < p_on).astype(np.float32)
+    times = np.arange(T) * hop / float(sr)
+    raw = {rtools.KEY_MULTIPITCH: mp.copy(), rtools.KEY_TIMES: times.copy()}
+    if with_onsets:
+        raw[rtools.KEY_ONSETS] = on.copy()
+    notes = est.estimate(raw)
+    rec = dict(multi_pitch=mp, times=times, notes=np.asarray(notes, dtype=np.float64), with_onsets=int(with_onsets))
+    if with_onsets:
+        rec['onsets'] = on
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, 'notes', rec['notes'].shape)
+
+
+if __name__ == '__main__':
+    gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
+    gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
+    gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
+    gen_of_train('of1_train.npz', seed=21, dim_in=229, mc=2, B=2, T=24)
+    gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
+    gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
+    gen_notes('notes_noonsets.npz', 33, 200, 0.0, 0.06, False)
+    gen_notes('notes_empty.npz', 34, 64, 0.0, 0.0, True)
