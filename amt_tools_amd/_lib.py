@@ -1,0 +1,90 @@
+"""
+ctypes binding of the amtx C ABI (include/amtx.h -> amt_tools_amd/csrc/libamtx.so).
+
+The product path has NO fallback: if the shared library is missing or a call fails, an exception is
+raised.  Pointers handed to the library are raw device addresses (`tensor.data_ptr()`), the stream is
+the current torch HIP stream's handle.
+"""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libamtx.so')
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'amtx.h')
+
+_lib = None
+
+
+class AmtxError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every function name include/amtx.h declares."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(amtx_[a-z0-9_]+)\s*\(', text)))
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+
+_SIGNATURES = {
+    'amtx_last_error': (C.c_char_p, []),
+    'amtx_version': (_I, []),
+    'amtx_spec_plan_create': (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I, _I, _I]),
+    'amtx_spec_plan_destroy': (_I, [_P]),
+    'amtx_spec_num_bins': (_I, [_P]),
+    'amtx_spec_num_frames': (_L, [_P, _L]),
+    'amtx_spec_filterbank': (_I, [_P, _P]),
+    'amtx_spec_power': (_I, [_P, _P, _L, _L, _I, _P, _P, _P]),
+    'amtx_spec_scale': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
+}
+
+
+def lib():
+    """Load libamtx.so (once).  Raises AmtxError when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AmtxError(f'{LIB_PATH} is missing: build the HIP extension first '
+                            f'(python -m amt_tools_amd.build, or __graft_entry__.build()). '
+                            f'There is no CPU fallback for the product path.')
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise AmtxError(f'cannot load {LIB_PATH}: {e}') from e
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise AmtxError(f'{LIB_PATH} does not export {name}') from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=''):
+    if rc is None or rc < 0:
+        msg = lib().amtx_last_error()
+        raise AmtxError(f'{what} failed ({rc}): {msg.decode() if msg else "?"}')
+    return rc
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def current_stream(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,56 @@
+"""
+In-tree build of the HIP extension: every source under amt_tools_amd/csrc is compiled for gfx950 with
+hipcc and linked into amt_tools_amd/csrc/libamtx.so (the C ABI of include/amtx.h).  hipcc cross-compiles
+without a GPU, so this runs in the CPU-only build container; the .so travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(CSRC, 'libamtx.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
+
+
+def _deps():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs.append(os.path.join(ROOT, 'include', 'amtx.h'))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, hdr_mtime, verbose):
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
+    path = os.path.join(CSRC, src)
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_mtime):
+        return obj
+    cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', path, '-o', obj]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return obj
+
+
+def build(verbose=True, jobs=4):
+    """Compile + link; rebuilds only what changed.  Returns the path of libamtx.so."""
+    hdr_mtime = _deps()
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(lambda s: _compile(s, hdr_mtime, verbose), _sources()))
+    if not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(verbose=True)
+    print(LIB)
+    sys.exit(0)

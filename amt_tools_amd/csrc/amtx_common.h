@@ -1,0 +1,105 @@
+// Shared host/device helpers for the amtx HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/amtx.h"
+
+// ------------------------------------------------------------------ error plumbing
+void amtx_set_error(const char* fmt, ...);
+
+#define AMTX_CHECK_HIP(expr)                                                             \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            amtx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return AMTX_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+#define AMTX_REQUIRE(cond, ...)                                                          \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            amtx_set_error(__VA_ARGS__);                                                 \
+            return AMTX_ERR_ARG;                                                         \
+        }                                                                                \
+    } while (0)
+
+#define AMTX_CHECK_LAUNCH()                                                              \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            amtx_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return AMTX_ERR_HIP;                                                         \
+        }                                                                                \
+    } while (0)
+
+// ------------------------------------------------------------------ bf16 helpers
+typedef uint16_t bf16_t;   // raw bf16 bits
+
+static inline __host__ __device__ bf16_t f32_to_bf16_rn(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    memcpy(&u, &f, 4);
+#endif
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+
+static inline __host__ __device__ float bf16_to_f32(bf16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
+#if defined(__HIPCC__)
+// vector types matching MFMA operand register counts
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = 4 VGPRs (A/B operand of 16x16x32)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 4 bf16 = 2 VGPRs
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // C/D of 16x16
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // C/D of 32x32
+
+// pack two floats into one dword of 2 x bf16 (round to nearest even); lo -> bits 0..15
+static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_rn(lo) | ((uint32_t)f32_to_bf16_rn(hi) << 16);
+}
+
+// split x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the two planes of the "x3" (split-bf16,
+// fp32-class accuracy) MFMA path.
+static __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+    hi = f32_to_bf16_rn(x);
+    lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+}
+
+static __device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+static __device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// observed (speed only, never correctness): block b runs on XCD b % 8.  Remap so consecutive logical
+// work items share an XCD (and its L2).  Bijective for any grid size.
+static __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {
+    const unsigned nx = 8;
+    unsigned q = nblocks / nx, r = nblocks % nx;
+    unsigned xcd = bid % nx, idx = bid / nx;
+    unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+#endif

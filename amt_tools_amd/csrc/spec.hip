@@ -1,0 +1,528 @@
+// Spectral front-end for gfx950: framed real FFT (n_fft = 2048) with LDS butterfly staging ->
+// power spectrum -> sparse triangular mel filterbank (wave-parallel rows) -> per-clip max [K1],
+// then dB / scale / layout [K2].
+//
+// Replaces librosa.stft + librosa.feature.melspectrogram + power_to_db / amplitude_to_db as the
+// reference calls them from amt_tools/features/stft.py:66-72, mel.py:64-71,94, common.py:199,218-228.
+//
+// K1 mapping (one wave64 = one frame at a time; one 256-thread block = FPB consecutive frames of a clip):
+//   * the 2048 real samples of a frame are read straight from HBM/L2 as 1024 complex z[m] = x[2m] + i x[2m+1]
+//     (lane j reads m = 64*n1 + j: consecutive lanes -> consecutive addresses; the four waves of a block
+//     work on adjacent frames, so the 4x frame overlap is served by L1/L2, HBM sees each sample ~once),
+//   * 1024-point complex FFT = radix-16 (in registers) x radix-16 (in registers) x radix-4, with two
+//     wave-private LDS exchanges (no workgroup barrier: a wave's LDS operations retire in order),
+//   * the radix-4 tail is merged into the real-FFT untangling pass that produces |X[k]|^2 for k and
+//     n_fft/2-k together, written to a wave-private LDS power row,
+//   * mel rows are contiguous bin ranges (<= ~30 taps): lane-per-row gather from that LDS row,
+//     4 rounds of 64 rows, coalesced store of the [T][n_mels] row, running max for the dB reference.
+// Algorithmic HBM bytes per frame: hop*4 read + n_out*4 written (2048 + 916 B for mel-229).
+
+#include "amtx_common.h"
+
+#include <math.h>
+#include <vector>
+
+namespace {
+
+constexpr int NFFT = 2048;
+constexpr int M = NFFT / 2;          // complex FFT length
+constexpr int XB_PITCH = 68;         // LDS row pitch (complex) of the exchange buffer: conflict-free for both passes
+constexpr int XB_ELEMS = 16 * XB_PITCH;
+constexpr int PB_ELEMS = 1028;       // power row (1025 used)
+constexpr int WAVES = 4;
+constexpr int MAX_MEL_ROUNDS = 8;    // up to 512 output rows
+
+struct SpecDev {
+    const float* window;     // [NFFT]
+    const float2* tw_fft;    // [M]   exp(-2 pi i k / M)
+    const float2* tw_post;   // [M]   exp(-2 pi i k / NFFT), k < M
+    const int* mel_start;    // [n_mels] first bin of the row's support
+    const int* mel_count;    // [n_mels] number of taps
+    const int* mel_off;      // [n_mels] offset of the row's weights in mel_w
+    const float* mel_w;      // concatenated row weights
+    int round_max[MAX_MEL_ROUNDS];   // max tap count of rows [64r, 64r+64)
+    int hop, n_out, n_mels, center, pad_mode;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// forward DFT-4 in place: X[k] = sum_n x[n] exp(-2 pi i n k / 4)
+__device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3) {
+    float2 t0 = make_float2(x0.x + x2.x, x0.y + x2.y);
+    float2 t1 = make_float2(x0.x - x2.x, x0.y - x2.y);
+    float2 t2 = make_float2(x1.x + x3.x, x1.y + x3.y);
+    float2 t3 = make_float2(x1.x - x3.x, x1.y - x3.y);
+    x0 = make_float2(t0.x + t2.x, t0.y + t2.y);
+    x2 = make_float2(t0.x - t2.x, t0.y - t2.y);
+    x1 = make_float2(t1.x + t3.y, t1.y - t3.x);
+    x3 = make_float2(t1.x - t3.y, t1.y + t3.x);
+}
+
+// forward DFT-16 in registers.  Input v[n] natural order; output X[k] lands in v[4*(k&3) + (k>>2)].
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+    constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
+    constexpr float R2 = 0.70710678118654752f;   // sqrt(1/2)
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    // v[4*k1 + n2] *= W16^(n2*k1),  W16^m = (cos(pi m/8), -sin(pi m/8))
+    v[5] = cmul(v[5], make_float2(C1, -S1));     // m = 1
+    v[6] = cmul(v[6], make_float2(R2, -R2));     // m = 2
+    v[7] = cmul(v[7], make_float2(S1, -C1));     // m = 3
+    v[9] = cmul(v[9], make_float2(R2, -R2));     // m = 2
+    v[10] = make_float2(v[10].y, -v[10].x);      // m = 4: -i
+    v[11] = cmul(v[11], make_float2(-R2, -R2));  // m = 6
+    v[13] = cmul(v[13], make_float2(S1, -C1));   // m = 3
+    v[14] = cmul(v[14], make_float2(-R2, -R2));  // m = 6
+    v[15] = cmul(v[15], make_float2(-C1, S1));   // m = 9: (cos(9pi/8), -sin(9pi/8)) = (-C1, +S1)
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // same-wave LDS traffic retires in order; this only stops the compiler from moving LDS accesses
+    // of different lanes' data across the exchange point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float fetch_padded(const float* clip, int64_t idx, int64_t n, int pad_mode) {
+    if (idx >= 0 && idx < n) return clip[idx];
+    if (pad_mode == AMTX_PAD_REFLECT) {
+        if (idx < 0) idx = -idx;
+        if (idx >= n) idx = 2 * (n - 1) - idx;
+        if (idx >= 0 && idx < n) return clip[idx];
+    }
+    return 0.0f;
+}
+
+// |E + W O|^2 and |E - W O|^2 for the real-FFT untangling of the pair (Z[k], Z[M-k]).
+__device__ __forceinline__ void untangle_pair(float2 zk, float2 zp, float2 w, float& pk, float& pmk) {
+    // E = (Zk + conj(Zp))/2 ; O = (Zk - conj(Zp))/(2i)
+    float2 e = make_float2(0.5f * (zk.x + zp.x), 0.5f * (zk.y - zp.y));
+    float2 d = make_float2(0.5f * (zk.x - zp.x), 0.5f * (zk.y + zp.y));
+    float2 o = make_float2(d.y, -d.x);                    // d / i
+    float2 wo = cmul(w, o);
+    float ar = e.x + wo.x, ai = e.y + wo.y;
+    float br = e.x - wo.x, bi = e.y - wo.y;
+    pk = ar * ar + ai * ai;
+    pmk = br * br + bi * bi;
+}
+
+template <int FPW, bool MEL>
+__global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float* __restrict__ audio, int64_t num_samples,
+                                                         int64_t audio_stride, int64_t num_frames,
+                                                         float* __restrict__ power, unsigned* __restrict__ clip_max) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float2* xb = reinterpret_cast<float2*>(smem) + wave * XB_ELEMS;
+    float* pb = reinterpret_cast<float*>(smem + WAVES * XB_ELEMS * sizeof(float2)) + wave * PB_ELEMS;
+    float2* twp = reinterpret_cast<float2*>(smem + WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float));
+
+    constexpr int FPB = FPW * WAVES;
+    const unsigned chunks = (unsigned)((num_frames + FPB - 1) / FPB);
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned clip_idx = logical / chunks;
+    const unsigned chunk = logical % chunks;
+    const float* clip = audio + (int64_t)clip_idx * audio_stride;
+
+    // block-shared untangling twiddles exp(-2 pi i k / 2048), k < 1024
+    for (int i = threadIdx.x; i < M; i += 256) twp[i] = p.tw_post[i];
+
+    // per-lane constants, reused by every frame this wave transforms
+    float wre[16], wim[16];
+    float2 tw1[16], tw2[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int m = n1 * 64 + lane;
+        wre[n1] = p.window[2 * m];
+        wim[n1] = p.window[2 * m + 1];
+        tw1[n1] = p.tw_fft[(lane * n1) & (M - 1)];
+        tw2[n1] = p.tw_fft[(16 * (lane & 3) * n1) & (M - 1)];
+    }
+    // mel rows owned by this lane
+    int r_start[MAX_MEL_ROUNDS], r_count[MAX_MEL_ROUNDS], r_off[MAX_MEL_ROUNDS];
+    const int rounds = MEL ? (p.n_mels + 63) / 64 : 0;
+    if (MEL) {
+#pragma unroll
+        for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
+            const int row = r * 64 + lane;
+            const bool ok = (r < rounds) && row < p.n_mels;
+            r_start[r] = ok ? p.mel_start[row] : 0;
+            r_count[r] = ok ? p.mel_count[row] : 0;
+            r_off[r] = ok ? p.mel_off[row] : 0;
+        }
+    }
+    __syncthreads();
+
+    float run_max = 0.0f;
+    const int64_t half = p.center ? NFFT / 2 : 0;
+
+#pragma unroll 1
+    for (int i = 0; i < FPW; ++i) {
+        const int64_t t = (int64_t)chunk * FPB + i * WAVES + wave;
+        if (t >= num_frames) break;
+        const int64_t s0 = t * p.hop - half;
+
+        // ---- load + window: v[n1] = z[64 n1 + lane]
+        float2 v[16];
+        if (s0 >= 0 && s0 + NFFT <= num_samples) {
+            const float* src = clip + s0 + 2 * lane;
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                v[n1] = make_float2(src[128 * n1] * wre[n1], src[128 * n1 + 1] * wim[n1]);
+            }
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const int64_t idx = s0 + 2 * (n1 * 64 + lane);
+                v[n1] = make_float2(fetch_padded(clip, idx, num_samples, p.pad_mode) * wre[n1],
+                                    fetch_padded(clip, idx + 1, num_samples, p.pad_mode) * wim[n1]);
+            }
+        }
+
+        // ---- pass A: DFT-16 over n1, twiddle W_1024^(lane*k1), exchange 1
+        dft16(v);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const float2 y = cmul(v[4 * (k1 & 3) + (k1 >> 2)], tw1[k1]);
+            xb[k1 * XB_PITCH + lane] = y;
+        }
+        wave_lds_sync();
+        // lane = (k1 = lane>>2, b = lane&3) gathers B[k1][4a + b], a = 0..15
+        {
+            const float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
+#pragma unroll
+            for (int a = 0; a < 16; ++a) v[a] = row[4 * a];
+        }
+        wave_lds_sync();
+        // ---- pass B: DFT-16 over a, twiddle W_64^(b*c), exchange 2 into [k1][c][b]
+        dft16(v);
+        {
+            float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) row[4 * c] = cmul(v[4 * (c & 3) + (c >> 2)], tw2[c]);
+        }
+        wave_lds_sync();
+
+        // ---- radix-4 tail merged with the real-FFT untangling: 129 (group, partner-group) tasks
+#pragma unroll 1
+        for (int q = lane; q < 129; q += 64) {
+            int k1, c;
+            if (q < 112) { k1 = 1 + (q >> 4); c = q & 15; }
+            else if (q < 120) { k1 = 8; c = q - 112; }
+            else { k1 = 0; c = q - 120; }
+            const int pk1 = (16 - k1) & 15;
+            const int pc = (k1 == 0) ? ((16 - c) & 15) : (15 - c);
+            const float4* ga = reinterpret_cast<const float4*>(xb + k1 * XB_PITCH + 4 * c);
+            const float4* gb = reinterpret_cast<const float4*>(xb + pk1 * XB_PITCH + 4 * pc);
+            float4 a01 = ga[0], a23 = ga[1], b01 = gb[0], b23 = gb[1];
+            float2 za[4] = {make_float2(a01.x, a01.y), make_float2(a01.z, a01.w), make_float2(a23.x, a23.y), make_float2(a23.z, a23.w)};
+            float2 zb[4] = {make_float2(b01.x, b01.y), make_float2(b01.z, b01.w), make_float2(b23.x, b23.y), make_float2(b23.z, b23.w)};
+            dft4(za[0], za[1], za[2], za[3]);
+            dft4(zb[0], zb[1], zb[2], zb[3]);
+            const bool is00 = (k1 == 0) && (c == 0);
+            if (is00) {   // partner of k = 256 d inside the same group: Z[(4-d)&3]
+                zb[0] = za[1]; zb[1] = za[2]; zb[2] = za[3]; zb[3] = za[0];
+            }
+            const int kbase = k1 + 16 * c;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int k = kbase + 256 * d;
+                float pk, pmk;
+                untangle_pair(za[d], zb[3 - d], twp[k], pk, pmk);
+                pb[k] = pk;
+                pb[M - k] = pmk;
+            }
+        }
+        wave_lds_sync();
+
+        float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
+        if (MEL) {
+            // ---- sparse mel: lane-per-row gather over contiguous bin ranges
+#pragma unroll
+            for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
+                if (r < rounds) {
+                    const float* w = p.mel_w + r_off[r];
+                    const float* src = pb + r_start[r];
+                    float acc = 0.0f;
+                    const int nmax = p.round_max[r];
+                    for (int j = 0; j < nmax; ++j) {
+                        if (j < r_count[r]) acc = fmaf(w[j], src[j], acc);
+                    }
+                    const int row = r * 64 + lane;
+                    if (row < p.n_mels) {
+                        out_row[row] = acc;
+                        run_max = fmaxf(run_max, acc);
+                    }
+                }
+            }
+        } else {
+            for (int k = lane; k < p.n_out; k += 64) {
+                const float val = pb[k];
+                out_row[k] = val;
+                run_max = fmaxf(run_max, val);
+            }
+        }
+        wave_lds_sync();   // pb / xb are rewritten by the next frame
+    }
+
+    run_max = wave_max_f32(run_max);
+    if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));   // values >= 0: uint order == float order
+}
+
+// K2: dB conversion / scaling / layout.  One block = 32 frames x 32 bins tile.
+__global__ __launch_bounds__(256) void spec_scale_kernel(const float* __restrict__ power, const float* __restrict__ clip_max,
+                                                         const float* __restrict__ ref, int64_t num_frames, int n_bins,
+                                                         int transform, int layout, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int64_t t0 = (int64_t)blockIdx.x * 32;
+    const int f0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+
+    float offs = 0.0f, floor_db = 0.0f;
+    if (transform == AMTX_SCALE_DB) {
+        const float amin = 1e-10f;
+        const float own = clip_max[b];
+        const float r = ref ? ref[b] : own;
+        offs = 10.0f * log10f(fmaxf(amin, r));
+        floor_db = (10.0f * log10f(fmaxf(amin, own)) - offs) - 80.0f;   // log_spec.max() - top_db
+    }
+    const float* src = power + (int64_t)b * num_frames * n_bins;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = t0 + ty + 8 * i;
+        const int f = f0 + tx;
+        float v = 0.0f;
+        if (t < num_frames && f < n_bins) {
+            const float s = src[t * n_bins + f];
+            if (transform == AMTX_SCALE_DB) {
+                float db = 10.0f * log10f(fmaxf(1e-10f, s)) - offs;
+                db = fmaxf(db, floor_db);
+                v = db / 80.0f + 1.0f;
+            } else if (transform == AMTX_SCALE_MAGNITUDE) {
+                v = sqrtf(s);
+            } else {
+                v = s;
+            }
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+    if (layout == AMTX_LAYOUT_BTF_F32) {
+        float* dst = out + (int64_t)b * num_frames * n_bins;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t t = t0 + ty + 8 * i;
+            const int f = f0 + tx;
+            if (t < num_frames && f < n_bins) dst[t * n_bins + f] = tile[ty + 8 * i][tx];
+        }
+    } else {
+        float* dst = out + (int64_t)b * n_bins * num_frames;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = f0 + ty + 8 * i;
+            const int64_t t = t0 + tx;
+            if (t < num_frames && f < n_bins) dst[(int64_t)f * num_frames + t] = tile[tx][ty + 8 * i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host-side table construction
+double hz_to_mel(double f, bool htk) {
+    if (htk) return 2595.0 * log10(1.0 + f / 700.0);
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+}
+double mel_to_hz(double m, bool htk) {
+    if (htk) return 700.0 * (pow(10.0, m / 2595.0) - 1.0);
+    const double f_sp = 200.0 / 3, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = log(6.4) / 27.0;
+    return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+}  // namespace
+
+struct amtx_spec_plan {
+    int sample_rate, n_fft, hop, win, n_mels, htk, center, pad_mode;
+    int n_bins_fft;   // n_fft/2 + 1
+    int n_out;        // n_mels, or n_bins_fft for an STFT plan
+    std::vector<float> fb_dense;   // host copy, n_mels x n_bins_fft
+    SpecDev dev;
+    void* d_blob;
+};
+
+extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int n_fft, int hop_length, int win_length,
+                                     int n_mels, int htk, int center, int pad_mode) {
+    AMTX_REQUIRE(out != nullptr, "amtx_spec_plan_create: null plan pointer");
+    *out = nullptr;
+    if (n_fft != NFFT) {
+        amtx_set_error("amtx_spec_plan_create: only n_fft = 2048 is implemented (got %d)", n_fft);
+        return AMTX_ERR_UNSUPPORTED;
+    }
+    if (win_length <= 0) win_length = n_fft;
+    AMTX_REQUIRE(win_length <= n_fft && hop_length > 0 && sample_rate > 0, "amtx_spec_plan_create: bad win/hop/sr");
+    AMTX_REQUIRE(n_mels >= 0 && n_mels <= 64 * MAX_MEL_ROUNDS, "amtx_spec_plan_create: n_mels out of range (0..%d)", 64 * MAX_MEL_ROUNDS);
+    AMTX_REQUIRE(pad_mode == AMTX_PAD_CONSTANT || pad_mode == AMTX_PAD_REFLECT, "amtx_spec_plan_create: bad pad_mode");
+
+    amtx_spec_plan* pl = new amtx_spec_plan();
+    pl->sample_rate = sample_rate; pl->n_fft = n_fft; pl->hop = hop_length; pl->win = win_length;
+    pl->n_mels = n_mels; pl->htk = htk; pl->center = center; pl->pad_mode = pad_mode;
+    pl->n_bins_fft = n_fft / 2 + 1;
+    pl->n_out = n_mels > 0 ? n_mels : pl->n_bins_fft;
+    pl->d_blob = nullptr;
+
+    const double PI = 3.14159265358979323846;
+    // periodic Hann of win_length, centre-padded to n_fft (librosa.stft / util.pad_center)
+    std::vector<float> window(n_fft, 0.0f);
+    const int lpad = (n_fft - win_length) / 2;
+    for (int n = 0; n < win_length; ++n) window[lpad + n] = (float)(0.5 - 0.5 * cos(2.0 * PI * n / win_length));
+    std::vector<float2> tw_fft(M), tw_post(M);
+    for (int k = 0; k < M; ++k) {
+        tw_fft[k] = make_float2((float)cos(2.0 * PI * k / M), (float)(-sin(2.0 * PI * k / M)));
+        tw_post[k] = make_float2((float)cos(2.0 * PI * k / n_fft), (float)(-sin(2.0 * PI * k / n_fft)));
+    }
+    // librosa.filters.mel (norm='slaney', fmin=0, fmax=sr/2), rounded to float32 like librosa does
+    std::vector<int> m_start(n_mels > 0 ? n_mels : 1, 0), m_count(n_mels > 0 ? n_mels : 1, 0), m_off(n_mels > 0 ? n_mels : 1, 0);
+    std::vector<float> m_w;
+    memset(pl->dev.round_max, 0, sizeof(pl->dev.round_max));
+    if (n_mels > 0) {
+        const int nb = pl->n_bins_fft;
+        pl->fb_dense.assign((size_t)n_mels * nb, 0.0f);
+        const double fmax = sample_rate / 2.0;
+        std::vector<double> mel_f(n_mels + 2);
+        const double mlo = hz_to_mel(0.0, htk), mhi = hz_to_mel(fmax, htk);
+        for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(mlo + (mhi - mlo) * i / (n_mels + 1), htk);
+        for (int i = 0; i < n_mels; ++i) {
+            const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+            int first = -1, last = -1;
+            const double fstep = fmax / (nb - 1);
+            for (int k = 0; k < nb; ++k) {
+                const double f = k * fstep;
+                const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+                const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+                const double w = lower < upper ? lower : upper;
+                // librosa stores the triangle in float32, then scales in place by the float64 area norm
+                const float w32 = (float)(w > 0 ? w : 0);
+                const float wf = (float)((double)w32 * enorm);
+                pl->fb_dense[(size_t)i * nb + k] = wf;
+                if (wf != 0.0f) { if (first < 0) first = k; last = k; }
+            }
+            m_off[i] = (int)m_w.size();
+            if (first >= 0) {
+                m_start[i] = first; m_count[i] = last - first + 1;
+                for (int k = first; k <= last; ++k) m_w.push_back(pl->fb_dense[(size_t)i * nb + k]);
+            }
+            const int r = i / 64;
+            if (m_count[i] > pl->dev.round_max[r]) pl->dev.round_max[r] = m_count[i];
+        }
+    }
+    if (m_w.empty()) m_w.push_back(0.0f);
+
+    // one device blob for all tables
+    auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    size_t o_win = 0, o_twf = align16(o_win + window.size() * 4), o_twp = align16(o_twf + tw_fft.size() * 8);
+    size_t o_ms = align16(o_twp + tw_post.size() * 8), o_mc = align16(o_ms + m_start.size() * 4);
+    size_t o_mo = align16(o_mc + m_count.size() * 4), o_mw = align16(o_mo + m_off.size() * 4);
+    size_t total = align16(o_mw + m_w.size() * 4);
+    std::vector<char> host(total, 0);
+    memcpy(host.data() + o_win, window.data(), window.size() * 4);
+    memcpy(host.data() + o_twf, tw_fft.data(), tw_fft.size() * 8);
+    memcpy(host.data() + o_twp, tw_post.data(), tw_post.size() * 8);
+    memcpy(host.data() + o_ms, m_start.data(), m_start.size() * 4);
+    memcpy(host.data() + o_mc, m_count.data(), m_count.size() * 4);
+    memcpy(host.data() + o_mo, m_off.data(), m_off.size() * 4);
+    memcpy(host.data() + o_mw, m_w.data(), m_w.size() * 4);
+    hipError_t e = hipMalloc(&pl->d_blob, total);
+    if (e == hipSuccess) e = hipMemcpy(pl->d_blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        amtx_set_error("amtx_spec_plan_create: device table upload failed: %s", hipGetErrorString(e));
+        if (pl->d_blob) (void)hipFree(pl->d_blob);
+        delete pl;
+        return AMTX_ERR_HIP;
+    }
+    char* d = (char*)pl->d_blob;
+    pl->dev.window = (const float*)(d + o_win);
+    pl->dev.tw_fft = (const float2*)(d + o_twf);
+    pl->dev.tw_post = (const float2*)(d + o_twp);
+    pl->dev.mel_start = (const int*)(d + o_ms);
+    pl->dev.mel_count = (const int*)(d + o_mc);
+    pl->dev.mel_off = (const int*)(d + o_mo);
+    pl->dev.mel_w = (const float*)(d + o_mw);
+    pl->dev.hop = hop_length; pl->dev.n_out = pl->n_out; pl->dev.n_mels = n_mels;
+    pl->dev.center = center; pl->dev.pad_mode = pad_mode;
+    *out = pl;
+    return AMTX_OK;
+}
+
+extern "C" int amtx_spec_plan_destroy(amtx_spec_plan* plan) {
+    if (!plan) return AMTX_OK;
+    if (plan->d_blob) (void)hipFree(plan->d_blob);
+    delete plan;
+    return AMTX_OK;
+}
+
+extern "C" int amtx_spec_num_bins(const amtx_spec_plan* plan) { return plan ? plan->n_out : AMTX_ERR_ARG; }
+
+extern "C" int64_t amtx_spec_num_frames(const amtx_spec_plan* plan, int64_t n) {
+    if (!plan || n < 0) return AMTX_ERR_ARG;
+    if (n == 0) return 0;
+    if (plan->center) return 1 + n / plan->hop;                       // features/common.py:64
+    // not centred: the reference zero-pads to a whole number of hops first (features/common.py:137-166)
+    int64_t divisor = plan->win;
+    if (n > divisor) divisor = plan->hop;
+    const int64_t padded = ((n + divisor - 1) / divisor) * divisor;
+    if (padded < plan->n_fft) return 0;
+    return 1 + (padded - plan->n_fft) / plan->hop;
+}
+
+extern "C" int amtx_spec_filterbank(const amtx_spec_plan* plan, float* host_out) {
+    AMTX_REQUIRE(plan && host_out, "amtx_spec_filterbank: null argument");
+    AMTX_REQUIRE(plan->n_mels > 0, "amtx_spec_filterbank: plan has no mel filterbank");
+    memcpy(host_out, plan->fb_dense.data(), plan->fb_dense.size() * sizeof(float));
+    return AMTX_OK;
+}
+
+extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride,
+                               int batch, float* power, float* clip_max, void* stream_) {
+    AMTX_REQUIRE(plan && audio && power && clip_max, "amtx_spec_power: null argument");
+    AMTX_REQUIRE(batch > 0 && num_samples > 0 && audio_stride >= num_samples, "amtx_spec_power: bad batch/num_samples/stride");
+    if (plan->pad_mode == AMTX_PAD_REFLECT)
+        AMTX_REQUIRE(num_samples > plan->n_fft / 2, "amtx_spec_power: reflect padding needs more than n_fft/2 samples");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t T = amtx_spec_num_frames(plan, num_samples);
+    AMTX_REQUIRE(T > 0, "amtx_spec_power: clip too short for one frame");
+    AMTX_CHECK_HIP(hipMemsetAsync(clip_max, 0, sizeof(float) * batch, stream));
+    constexpr int FPW = 4;
+    constexpr int FPB = FPW * WAVES;
+    const int64_t chunks = (T + FPB - 1) / FPB;
+    const int64_t nblocks = chunks * batch;
+    AMTX_REQUIRE(nblocks < (1ll << 31), "amtx_spec_power: grid too large");
+    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + M * sizeof(float2);
+    if (plan->n_mels > 0)
+        hipLaunchKernelGGL((spec_power_kernel<FPW, true>), dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio,
+                           num_samples, audio_stride, T, power, (unsigned*)clip_max);
+    else
+        hipLaunchKernelGGL((spec_power_kernel<FPW, false>), dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio,
+                           num_samples, audio_stride, T, power, (unsigned*)clip_max);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+extern "C" int amtx_spec_scale(const amtx_spec_plan* plan, const float* power, const float* clip_max, const float* ref,
+                               int batch, int64_t num_frames, int transform, int layout, float* out, void* stream_) {
+    AMTX_REQUIRE(plan && power && out, "amtx_spec_scale: null argument");
+    AMTX_REQUIRE(transform != AMTX_SCALE_DB || clip_max, "amtx_spec_scale: dB scaling needs clip_max");
+    AMTX_REQUIRE(batch > 0 && batch < 65536 && num_frames > 0, "amtx_spec_scale: bad batch/num_frames");
+    AMTX_REQUIRE(layout == AMTX_LAYOUT_BFT_F32 || layout == AMTX_LAYOUT_BTF_F32, "amtx_spec_scale: bad layout");
+    hipStream_t stream = (hipStream_t)stream_;
+    dim3 grid((unsigned)((num_frames + 31) / 32), (unsigned)((plan->n_out + 31) / 32), (unsigned)batch);
+    hipLaunchKernelGGL(spec_scale_kernel, grid, dim3(256), 0, stream, power, clip_max, ref, num_frames, plan->n_out, transform,
+                       layout, out);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}

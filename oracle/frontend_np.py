@@ -112,7 +112,9 @@ def mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm='
     mel_f = mel_frequencies(n_mels + 2, fmin, fmax, htk)
     fdiff = np.diff(mel_f)
     ramps = np.subtract.outer(mel_f, fftfreqs)
-    weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=np.float64)
+    # librosa allocates `weights` in `dtype` (float32), assigns the float64 triangles into it and then
+    # scales in place by the float64 area norm: two roundings when dtype is float32.
+    weights = np.zeros((n_mels, 1 + n_fft // 2), dtype=dtype)
     for i in range(n_mels):
         lower = -ramps[i] / fdiff[i]
         upper = ramps[i + 2] / fdiff[i + 1]
@@ -120,7 +122,7 @@ def mel_filterbank(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm='
     if norm == 'slaney':
         enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
         weights *= enorm[:, None]
-    return weights.astype(dtype)
+    return weights
 
 
 def melspectrogram(y, sr, n_mels=229, n_fft=2048, hop_length=512, win_length=None, center=True,

@@ -1,0 +1,129 @@
+"""GPU parity: HIP spectral front-end (through the C ABI) vs the fp64 oracle restatement.
+
+Tolerance: the scaled features live in [0, 1]; the fp32 on-device FFT differs from the fp64 oracle by
+rounding noise that is largest (in dB) in bins near the -80 dB floor.  Bound: 1e-4 absolute in the
+scaled domain (SURVEY 8(c) suggests 1e-5..1e-4), 2e-6 relative on linear power."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import frontend_np as fe          # noqa: E402
+from amt_tools_amd.synth import synth_clip    # noqa: E402
+
+TOL_SCALED = 1e-4
+
+
+def _mods():
+    from amt_tools_amd.features import MelSpec, STFT
+    return MelSpec, STFT
+
+
+@pytest.mark.parametrize('lv', ['0.10', '0.9'])
+@pytest.mark.parametrize('htk', [False, True])
+def test_melspec_matches_oracle(lv, htk):
+    MelSpec, _ = _mods()
+    y = synth_clip(3, num_samples=60000)
+    mod = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048, htk=htk, librosa_version=lv)
+    got = mod.process_audio(y)
+    ref = fe.melspec_process_audio(y, 22050, 512, 229, 2048, htk=htk, lv=lv)
+    assert got.shape == ref.shape == (1, 229, 1 + 60000 // 512) and got.dtype == np.float32
+    assert np.abs(got - ref).max() < TOL_SCALED
+    assert got.max() == 1.0 and got.min() >= 0.0
+
+
+def test_melspec_linear_power_and_filterbank():
+    MelSpec, _ = _mods()
+    y = synth_clip(5, num_samples=40000)
+    mod = MelSpec(sample_rate=16000, hop_length=512, decibels=False)
+    got = mod.process_audio(y)
+    ref = fe.melspec_process_audio(y, 16000, 512, 229, 2048, decibels=False)
+    assert np.abs(got - ref).max() <= 2e-6 * ref.max() + 1e-12
+    # identical up to triangle-corner taps that are ~1e-16 in one construction and exactly 0 in the other
+    np.testing.assert_allclose(mod.filterbank(), fe.mel_filterbank(16000, 2048, 229), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('decibels', [True, False])
+def test_stft_matches_oracle(decibels):
+    _, STFT = _mods()
+    y = synth_clip(7, num_samples=30000)
+    mod = STFT(sample_rate=22050, hop_length=512, n_fft=2048, decibels=decibels)
+    got = mod.process_audio(y)
+    ref = fe.stft_process_audio(y, 512, 2048, decibels=decibels)
+    assert got.shape == ref.shape == (1, 1025, 1 + 30000 // 512)
+    if decibels:
+        assert np.abs(got - ref).max() < TOL_SCALED
+    else:
+        assert np.abs(got - ref).max() <= 2e-6 * ref.max()
+
+
+@pytest.mark.parametrize('n', [1, 2, 511, 512, 513, 1023, 1025, 2047, 2048, 2049, 5000])
+def test_short_and_ragged_lengths(n):
+    MelSpec, _ = _mods()
+    rng = np.random.default_rng(n)
+    y = rng.standard_normal(n).astype(np.float32)
+    mod = MelSpec(sample_rate=22050)
+    got = mod.process_audio(y)
+    ref = fe.melspec_process_audio(y, 22050)
+    assert got.shape == ref.shape == (1, 229, mod.get_expected_frames(y))
+    assert np.abs(got - ref).max() < TOL_SCALED
+
+
+def test_empty_audio_conventions():
+    MelSpec, STFT = _mods()
+    assert MelSpec().process_audio(np.zeros(0, dtype=np.float32)).shape == (1, 229, 0)
+    assert STFT().process_audio(np.zeros(0, dtype=np.float32)).shape == (1, 2048, 0)   # reference quirk
+
+
+def test_silence_maps_to_one():
+    MelSpec, _ = _mods()
+    got = MelSpec(sample_rate=22050).process_audio(np.zeros(4096, dtype=np.float32))
+    ref = fe.melspec_process_audio(np.zeros(4096, dtype=np.float32), 22050)
+    np.testing.assert_array_equal(got, ref.astype(np.float32))
+
+
+def test_not_centered_matches_oracle():
+    MelSpec, _ = _mods()
+    y = synth_clip(9, num_samples=20000)
+    mod = MelSpec(sample_rate=22050, center=False)
+    got = mod.process_audio(y)
+    ref = fe.melspec_process_audio(y, 22050, center=False)
+    assert got.shape == ref.shape and got.shape[-1] == mod.get_expected_frames(y)
+    assert np.abs(got - ref).max() < TOL_SCALED
+
+
+def test_batch_clip_maxima_are_independent_and_ref_override():
+    MelSpec, _ = _mods()
+    clips = np.stack([synth_clip(i, num_samples=33333) * (10.0 ** (-i)) for i in range(3)])
+    mod = MelSpec(sample_rate=22050)
+    x = torch.from_numpy(clips).cuda()
+    got = mod.process_batch(x).cpu().numpy()
+    assert got.shape == (3, 1, 229, 1 + 33333 // 512)
+    for i in range(3):
+        ref = fe.melspec_process_audio(clips[i], 22050)
+        assert np.abs(got[i] - ref).max() < TOL_SCALED
+    # model layout is the transpose
+    got_t = mod.process_batch(x, model_layout=True).cpu().numpy()
+    np.testing.assert_array_equal(got_t, np.swapaxes(got, -1, -2))
+    # track-level reference (finding F7): features of a slice normalised by a larger track maximum
+    power, cmax = mod.power_batch(x)
+    ref_pow = (cmax * 100.0).contiguous()
+    shifted = mod.scale_batch(power, cmax, ref=ref_pow).cpu().numpy()
+    S = fe.melspectrogram(clips[0], 22050)
+    db = 10 * np.log10(np.maximum(1e-10, S)) - 10 * np.log10(S.max() * 100.0)
+    db = np.maximum(db, db.max() - 80.0)
+    assert np.abs(shifted[0, 0] - (db / 80 + 1)).max() < TOL_SCALED
+
+
+def test_full_size_clip_properties():
+    """BASELINE-size clip (319 999 samples -> 625 frames): linearity of the power map in amplitude^2
+    and agreement of the map maximum with the reduction output."""
+    MelSpec, _ = _mods()
+    mod = MelSpec(sample_rate=22050, decibels=False)
+    y = synth_clip(0)
+    x = torch.from_numpy(np.stack([y, 3.0 * y])).cuda()
+    power, cmax = mod.power_batch(x)
+    assert power.shape == (2, 625, 229)
+    assert torch.allclose(power[1], 9.0 * power[0], rtol=2e-5, atol=0)
+    assert torch.equal(cmax, power.amax(dim=(1, 2)))
