@@ -43,6 +43,23 @@ _SIGNATURES = {
     'amtx_spec_filterbank': (_I, [_P, _P]),
     'amtx_spec_power': (_I, [_P, _P, _L, _L, _I, _P, _P, _P]),
     'amtx_spec_scale': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
+    'amtx_of_model_create': (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I]),
+    'amtx_of_model_destroy': (_I, [_P]),
+    'amtx_of_model_set_tensor': (_I, [_P, C.c_char_p, _P, _L]),
+    'amtx_of_model_finalize': (_I, [_P]),
+    'amtx_of_workspace_bytes': (C.c_size_t, [_P, _I, _I]),
+    'amtx_of_forward': (_I, [_P, _P, _L, _L, _L, _L, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
+    'amtx_linear_packed_elems': (_L, [_I, _I, _I]),
+    'amtx_linear_pack': (_I, [_P, _I, _I, _I, _P]),
+    'amtx_linear_fwd': (_I, [_P, _L, _I, _P, _I, _P, _P, _L, _I, _L, _I, _I, _P]),
+    'amtx_conv3x3_packed_elems': (_L, [_I, _I]),
+    'amtx_conv3x3_pack': (_I, [_P, _P, _I, _I, _P]),
+    'amtx_conv3x3_fwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    'amtx_conv1_fwd': (_I, [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'amtx_bilstm_packed_elems': (_L, [_I]),
+    'amtx_bilstm_pack': (_I, [_P, _P, _I, _P]),
+    'amtx_bilstm_fwd': (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
+    'amtx_pianoroll_fwd': (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
 }
 
 

@@ -1,0 +1,65 @@
+// Internal launch interface of the dense kernels (shared by the op-level C ABI and the model engine).
+#pragma once
+#include "amtx_common.h"
+
+// element types of activations held in HBM
+enum { AMTX_T_BF16 = 0, AMTX_T_F32 = 1 };
+
+static inline size_t amtx_tsize(int t) { return t == AMTX_T_BF16 ? 2 : 4; }
+
+// ---------------------------------------------------------------- GEMM  C[M,N] = A[M,K] . W[N,K]^T + bias
+// W is pre-packed: [planes][n_pad][k_pad] bf16 (planes = 1 for bf16, 2 = hi/lo for x3), zero padded.
+struct GemmArgs {
+    const void* A; int64_t lda; int a_type;            // row-major, K contiguous, rows 16-byte aligned
+    const bf16_t* W; int n_pad, k_pad, planes;
+    const float* bias;                                   // [N] or null
+    void* C; int64_t ldc; int c_type;
+    int64_t M; int N, K;
+    int groups; int64_t a_gs, w_gs, bias_gs, c_gs;       // per-group strides in elements (grid.z = groups)
+};
+int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);
+void amtx_gemm_pack_dims(int N, int K, int* n_pad, int* k_pad);
+// host packing: W (N x K fp32 row-major, leading dim ldw) -> [planes][n_pad][k_pad] bf16
+void amtx_gemm_pack_host(const float* W, int64_t ldw, int N, int K, int planes, bf16_t* out);
+
+// ---------------------------------------------------------------- conv3x3 (C_in = 32) + folded BN + ReLU + MaxPool(1,2)
+struct ConvArgs {
+    const void* in; int in_type;                         // [B][T][F][32] channels-last
+    const bf16_t* wfrag; int planes;                     // packed fragments, see conv.hip
+    const float* shift;                                  // [c_out] folded BN shift (+ conv bias)
+    void* out; int out_type;                             // [B][T][F/2][c_out]
+    int B, T, F, c_out;
+    int groups; int64_t in_gs, w_gs, shift_gs, out_gs;   // per-group strides in elements
+};
+int amtx_launch_conv3x3(const ConvArgs& c, hipStream_t stream);
+size_t amtx_conv3x3_wfrag_elems(int c_out, int planes);
+// host packing: weight (c_out, 32, 3, 3) fp32 * scale[c_out] -> fragment order
+void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int planes, bf16_t* out);
+
+// ---------------------------------------------------------------- first conv (small C_in) + folded BN + ReLU, direct
+struct Conv1Args {
+    const float* in; int64_t stride_b, stride_c, stride_t, stride_f;   // fp32 features, arbitrary strides (elements)
+    const float* w;                                      // [c_out][c_in][3][3] fp32, BN scale folded in
+    const float* shift;                                  // [c_out]
+    void* out; int out_type;                             // [B][T][F][c_out] channels-last
+    int B, T, F, c_in, c_out;
+    int groups; int64_t w_gs, shift_gs, out_gs;
+};
+int amtx_launch_conv1(const Conv1Args& c, hipStream_t stream);
+
+// ---------------------------------------------------------------- BiLSTM recurrence (hidden = 128 per direction)
+struct LstmArgs {
+    const void* xproj; int x_type;                       // [B][T][2][512]: W_ih x + b_ih + b_hh, gate order i,f,g,o
+    const bf16_t* whh; int planes;                       // packed fragments [dir][...], see lstm.hip
+    void* out; int out_type;                             // [B][T][256] = h_fwd | h_bwd
+    int B, T;
+    int groups; int64_t x_gs, w_gs, out_gs;
+};
+int amtx_launch_bilstm(const LstmArgs& l, hipStream_t stream);
+size_t amtx_bilstm_wfrag_elems(int planes);              // per LSTM (both directions)
+void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out);   // each (512,128)
+
+// ---------------------------------------------------------------- logits -> piano roll
+// out[b][k][t] = threshold < 0 ? sigmoid(x) : (sigmoid(x) < threshold ? 0 : 1), x = logits[(b*T+t)*ld + col0 + k]
+int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int T, int keys, float threshold, float* out,
+                          hipStream_t stream);

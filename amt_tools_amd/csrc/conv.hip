@@ -1,0 +1,320 @@
+// Convolution stages of the Onsets & Frames acoustic model for gfx950
+// (amt_tools/models/onsetsframes.py:375-416: Conv2d 3x3 pad 1 + BatchNorm2d + ReLU [+ MaxPool(1,2)]).
+//
+// conv1  (C_in = 1 or 6 -> 32/48): direct VALU kernel, BN folded, channels-last output.
+// conv3x3 (C_in = 32 -> 32/64..): implicit GEMM on v_mfma_f32_16x16x32_bf16 with
+//   * K = 32 input channels = exactly one MFMA per 3x3 tap,
+//   * the folded (BN-scaled) weights stationary in registers for the whole block (9 x C_out/16 fragments),
+//   * the input tile (18 x (FT+2) positions x 32 ch) staged once in LDS, every tap is a shifted 16-byte
+//     fragment read (row pitch odd + XOR chunk swizzle by row -> 16 distinct 16-byte slots per read),
+//   * computed "swapped" (D' = W . X^T): a lane holds 4*NT consecutive output channels of one position,
+//     so bias + ReLU + MaxPool(1,2) over the frequency pair and the channels-last store are lane-local.
+// Eval-mode BatchNorm is folded on the host: scale into the weights, shift (+ conv bias) into `shift`.
+// Algorithmic HBM bytes per output position: 32 ch in + C_out/2 ch out (pooled), element size of the mode.
+
+#include "amtx_kernels.h"
+
+namespace {
+
+constexpr int CIN = 32;
+constexpr int TT = 16;              // frames per block tile = one MFMA N-tile
+constexpr int FT_MAX = 48;          // frequency columns per block tile (even)
+constexpr int PITCH = FT_MAX + 3;   // LDS positions per tile row (odd)
+constexpr int ROWS = TT + 2;
+constexpr int PLANE_BYTES = ROWS * PITCH * 64;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int tile_off(int i, int j, int c) { return ((i * PITCH + j) * 4 + (c ^ ((i >> 2) & 3))) * 16; }
+
+__device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16_t h0, h1, l0 = 0, l1 = 0;
+        if (split) {
+            split_bf16(f[2 * i], h0, l0);
+            split_bf16(f[2 * i + 1], h1, l1);
+        } else {
+            h0 = f32_to_bf16_rn(f[2 * i]);
+            h1 = f32_to_bf16_rn(f[2 * i + 1]);
+        }
+        h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int NT, int NS, int IN_TYPE, int OUT_TYPE>
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int COUT = NT * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.y;
+    int bid = blockIdx.x;
+    const int tf = bid % ntf; bid /= ntf;
+    const int tt = bid % ntt; bid /= ntt;
+    const int b = bid;
+    const int f0 = tf * ft, t0 = tt * TT;
+
+    const char* in = reinterpret_cast<const char*>(a.in) + ((int64_t)grp * a.in_gs + (int64_t)b * a.T * a.F * CIN) * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
+
+    // ---- stationary weights: 9 taps x NT tiles (x NS planes), one 16-byte fragment per lane each
+    uint4 wf[9][NT][NS];
+    {
+        const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) wf[tap][nt][p] = w[((tap * NT + nt) * NS + p) * 64];
+    }
+
+    // ---- stage the (TT+2) x (ft+2) x 32 input tile in LDS, zero outside the map
+    const int cols = ft + 2;
+    const int items = ROWS * cols * 4;
+    for (int it = tid; it < items; it += 256) {
+        const int c = it & 3;
+        const int pos = it >> 2;
+        const int j = pos % cols, i = pos / cols;
+        const int t = t0 - 1 + i, f = f0 - 1 + j;
+        uint4 hi = make_uint4(0, 0, 0, 0), lo = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < a.T && f >= 0 && f < a.F) {
+            const int64_t e = ((int64_t)t * a.F + f) * CIN + c * 8;
+            if (IN_TYPE == AMTX_T_BF16) {
+                hi = *reinterpret_cast<const uint4*>(in + e * 2);
+            } else {
+                const float4* p = reinterpret_cast<const float4*>(in + e * 4);
+                const float4 x0 = p[0], x1 = p[1];
+                const float fv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                cvt8(fv, NS == 2, hi, lo);
+            }
+        }
+        const int off = tile_off(i, j, c);
+        *reinterpret_cast<uint4*>(smem + off) = hi;
+        if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+    }
+
+    // folded BN shift for this lane's 4*NT consecutive channels
+    const int g = lane >> 4, trow = lane & 15;
+    float sh[NT][4];
+    {
+        const float* s = a.shift + (int64_t)grp * a.shift_gs + g * 4 * NT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[nt][r] = s[4 * nt + r];
+    }
+    __syncthreads();
+
+    const int Fo = a.F >> 1;
+    const int t = t0 + trow;
+    char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)b * a.T + t) * Fo * COUT) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+
+    for (int jp = wave; jp < (ft >> 1); jp += 4) {
+        f32x4_t acc[2][NT];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[e][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                uint4 x[NS];
+                const int off = tile_off(trow + kh, 2 * jp + cc, g);
+                x[0] = *reinterpret_cast<const uint4*>(smem + off);
+                if (NS == 2) x[1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int kw = cc - e;
+                    if (kw < 0 || kw > 2) continue;
+                    const int tap = kh * 3 + kw;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[e][nt] = mfma16(wf[tap][nt][0], x[0], acc[e][nt]);
+                        if (NS == 2) {
+                            acc[e][nt] = mfma16(wf[tap][nt][0], x[1], acc[e][nt]);
+                            acc[e][nt] = mfma16(wf[tap][nt][1], x[0], acc[e][nt]);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- + shift, ReLU, MaxPool(1,2) over the (f, f+1) pair, channels-last store
+        const int fo = (f0 >> 1) + jp;
+        if (t < a.T && fo < Fo) {
+            float v[NT * 4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float y0 = fmaxf(acc[0][nt][r] + sh[nt][r], 0.f);
+                    const float y1 = fmaxf(acc[1][nt][r] + sh[nt][r], 0.f);
+                    v[nt * 4 + r] = fmaxf(y0, y1);
+                }
+            if (OUT_TYPE == AMTX_T_BF16) {
+                uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
+#pragma unroll
+                for (int q = 0; q < NT / 2; ++q)
+                    dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                                        pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
+            } else {
+                float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 4);
+#pragma unroll
+                for (int q = 0; q < NT; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
+        }
+    }
+}
+
+template <int NT, int NS, int IN_TYPE, int OUT_TYPE>
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+    const int fe = (a.F + 1) & ~1;
+    const int ntf = (fe + FT_MAX - 1) / FT_MAX;
+    const int ft = 2 * (((fe >> 1) + ntf - 1) / ntf);
+    const int ntt = (a.T + TT - 1) / TT;
+    const int64_t nblocks = (int64_t)ntf * ntt * a.B;
+    AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
+    const size_t lds = (size_t)NS * PLANE_BYTES;
+    auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE>;
+    if (lds > 64 * 1024) {
+        static bool done = false;   // per instantiation
+        if (!done) {
+            AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+template <int NT, int NS>
+int dispatch_types(const ConvArgs& a, hipStream_t s) {
+    if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16>(a, s);
+    if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32>(a, s);
+    amtx_set_error("conv3x3: in/out element types must match (bf16/bf16 or f32/f32)");
+    return AMTX_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------ first conv: direct, fp32 math
+template <int OUT_TYPE>
+__global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                 // [c_in*9][c_out]
+    float* sl = wl + a.c_in * 9 * a.c_out;                      // [c_out]
+    const int grp = blockIdx.y;
+    const float* w = a.w + (int64_t)grp * a.w_gs;
+    const int nw = a.c_out * a.c_in * 9;
+    for (int i = threadIdx.x; i < nw; i += 256) {
+        const int co = i / (a.c_in * 9), rest = i % (a.c_in * 9);
+        wl[rest * a.c_out + co] = w[i];
+    }
+    for (int i = threadIdx.x; i < a.c_out; i += 256) sl[i] = a.shift[(int64_t)grp * a.shift_gs + i];
+    __syncthreads();
+
+    const int cgroups = a.c_out >> 3;                           // 8 output channels per thread
+    const int64_t total = (int64_t)a.B * a.T * a.F * cgroups;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(idx % cgroups);
+        int64_t pos = idx / cgroups;
+        const int f = (int)(pos % a.F); pos /= a.F;
+        const int t = (int)(pos % a.T);
+        const int b = (int)(pos / a.T);
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        const float* inb = a.in + (int64_t)b * a.stride_b;
+        for (int ci = 0; ci < a.c_in; ++ci) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int tt = t + kh - 1;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ff = f + kw - 1;
+                    float x = 0.f;
+                    if (tt >= 0 && tt < a.T && ff >= 0 && ff < a.F) x = inb[ci * a.stride_c + tt * a.stride_t + ff * a.stride_f];
+                    const float4* wp = reinterpret_cast<const float4*>(wl + ((ci * 3 + kh) * 3 + kw) * a.c_out + cg * 8);
+                    const float4 w0 = wp[0], w1 = wp[1];
+                    acc[0] = fmaf(x, w0.x, acc[0]); acc[1] = fmaf(x, w0.y, acc[1]);
+                    acc[2] = fmaf(x, w0.z, acc[2]); acc[3] = fmaf(x, w0.w, acc[3]);
+                    acc[4] = fmaf(x, w1.x, acc[4]); acc[5] = fmaf(x, w1.y, acc[5]);
+                    acc[6] = fmaf(x, w1.z, acc[6]); acc[7] = fmaf(x, w1.w, acc[7]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k] + sl[cg * 8 + k], 0.f);
+        const int64_t o = (((int64_t)b * a.T + t) * a.F + f) * a.c_out + cg * 8;
+        if (OUT_TYPE == AMTX_T_BF16) {
+            bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (int64_t)grp * a.out_gs + o;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                                        pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+        } else {
+            float* dst = reinterpret_cast<float*>(a.out) + (int64_t)grp * a.out_gs + o;
+            reinterpret_cast<float4*>(dst)[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            reinterpret_cast<float4*>(dst)[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
+}  // namespace
+
+size_t amtx_conv3x3_wfrag_elems(int c_out, int planes) { return (size_t)9 * (c_out / 16) * planes * 64 * 8; }
+
+void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int planes, bf16_t* out) {
+    const int NT = c_out / 16;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int nt = 0; nt < NT; ++nt)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 15;
+                const int co = (row >> 2) * (4 * NT) + 4 * nt + (row & 3);
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = (l >> 4) * 8 + j;
+                    const float v = w[((size_t)co * CIN + ci) * 9 + tap] * (scale ? scale[co] : 1.0f);
+                    const bf16_t hi = f32_to_bf16_rn(v);
+                    const size_t base = ((size_t)(tap * NT + nt) * planes) * 64 * 8 + (size_t)l * 8 + j;
+                    out[base] = hi;
+                    if (planes == 2) out[base + 64 * 8] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                }
+            }
+}
+
+int amtx_launch_conv3x3(const ConvArgs& a, hipStream_t stream) {
+    AMTX_REQUIRE(a.in && a.wfrag && a.shift && a.out, "conv3x3: null pointer");
+    AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F >= 2 && a.groups > 0, "conv3x3: bad sizes");
+    AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3: planes must be 1 or 2");
+    const int key = (a.c_out / 16) * 10 + a.planes;
+    switch (key) {
+        case 21: return dispatch_types<2, 1>(a, stream);
+        case 22: return dispatch_types<2, 2>(a, stream);
+        case 41: return dispatch_types<4, 1>(a, stream);
+        case 42: return dispatch_types<4, 2>(a, stream);
+    }
+    amtx_set_error("conv3x3: unsupported c_out=%d (supported: 32 and 64, with C_in = 32)", a.c_out);
+    return AMTX_ERR_UNSUPPORTED;
+}
+
+int amtx_launch_conv1(const Conv1Args& a, hipStream_t stream) {
+    AMTX_REQUIRE(a.in && a.w && a.shift && a.out, "conv1: null pointer");
+    AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F > 0 && a.c_in > 0 && a.c_out % 8 == 0 && a.groups > 0, "conv1: bad sizes");
+    const size_t lds = ((size_t)a.c_in * 9 * a.c_out + a.c_out) * sizeof(float);
+    AMTX_REQUIRE(lds <= 64 * 1024, "conv1: weights do not fit LDS");
+    const int64_t total = (int64_t)a.B * a.T * a.F * (a.c_out / 8);
+    int64_t nblocks = (total + 255) / 256;
+    if (nblocks > 256 * 32) nblocks = 256 * 32;
+    if (a.out_type == AMTX_T_BF16)
+        hipLaunchKernelGGL(conv1_kernel<AMTX_T_BF16>, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL(conv1_kernel<AMTX_T_F32>, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(256), lds, stream, a);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}

@@ -1,0 +1,240 @@
+// MFMA GEMM for gfx950:  C[M,N] = A[M,K] . W[N,K]^T + bias   (fc1, LSTM input projections, LogisticBank heads)
+//
+// Replaces the nn.Linear / nn.LSTM input-projection matmuls of the reference
+// (amt_tools/models/onsetsframes.py:422-427 fc1, :498-501 nn.LSTM W_ih, amt_tools/models/common.py:539 output_layer).
+//
+// * v_mfma_f32_16x16x32_bf16, fp32 accumulate.  Computed "swapped" (D' = W . A^T) so that a lane ends up
+//   holding 4 consecutive output columns of one row -> 8/16-byte stores.
+// * AMTX_PREC_X3: operands are split hi+lo bf16 planes and every product is hi*hi + hi*lo + lo*hi
+//   (3 MFMAs): fp32-class accuracy (~1e-5 relative) at 3/16 of the cost of f32 MFMA.
+// * 128x128x32 block tile, 4 waves (2x2) of 64x64, register-staged double-buffered LDS with an XOR chunk
+//   swizzle so the 16 rows of a fragment read hit 16 distinct 16-byte slots.
+
+#include "amtx_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int TILE_BYTES = BM * BK * 2;   // one operand plane: 8 KiB
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+template <int A_TYPE, int NS>
+struct AStage {
+    // one 8-element K chunk of one A row, converted to bf16 planes
+    uint4 hi, lo;
+    __device__ __forceinline__ void load(const char* base, int64_t row_off_elems, bool valid) {
+        if (A_TYPE == AMTX_T_BF16) {
+            hi = valid ? *reinterpret_cast<const uint4*>(base + row_off_elems * 2) : make_uint4(0, 0, 0, 0);
+            lo = make_uint4(0, 0, 0, 0);
+        } else {
+            float4 x0 = make_float4(0, 0, 0, 0), x1 = make_float4(0, 0, 0, 0);
+            if (valid) {
+                const float4* p = reinterpret_cast<const float4*>(base + row_off_elems * 4);
+                x0 = p[0];
+                x1 = p[1];
+            }
+            const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16_t h0, h1, l0 = 0, l1 = 0;
+                if (NS == 2) {
+                    split_bf16(f[2 * i], h0, l0);
+                    split_bf16(f[2 * i + 1], h1, l1);
+                } else {
+                    h0 = f32_to_bf16_rn(f[2 * i]);
+                    h1 = f32_to_bf16_rn(f[2 * i + 1]);
+                }
+                h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+            }
+            hi = make_uint4(h[0], h[1], h[2], h[3]);
+            lo = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    }
+};
+
+template <int A_TYPE, int C_TYPE, int NS>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // layout: [buf][A planes NS][W planes NS] x TILE_BYTES
+    constexpr int BUF_BYTES = 2 * NS * TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = blockIdx.z;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    const char* Abase = reinterpret_cast<const char*>(g.A) + (int64_t)grp * g.a_gs * (A_TYPE == AMTX_T_BF16 ? 2 : 4);
+    const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
+    const int64_t plane_elems = (int64_t)g.n_pad * g.k_pad;
+
+    // per-thread staging slots: 2 chunks of A and 2 of W per k-step (idx = tid, tid + 256)
+    const int srow0 = tid >> 2, srow1 = srow0 + 64, schunk = tid & 3;
+    const bool arow_ok0 = (m0 + srow0) < g.M, arow_ok1 = (m0 + srow1) < g.M;
+    const int64_t a_off0 = (m0 + srow0) * g.lda + schunk * 8, a_off1 = (m0 + srow1) * g.lda + schunk * 8;
+    const int64_t w_off0 = (int64_t)(n0 + srow0) * g.k_pad + schunk * 8, w_off1 = (int64_t)(n0 + srow1) * g.k_pad + schunk * 8;
+    const int soff0 = lds_off(srow0, schunk), soff1 = lds_off(srow1, schunk);
+
+    AStage<A_TYPE, NS> sa0, sa1;
+    uint4 sw0h, sw1h, sw0l = make_uint4(0, 0, 0, 0), sw1l = make_uint4(0, 0, 0, 0);
+#define LOAD_TILE(k0)                                                                              \
+    do {                                                                                           \
+        const bool kok = ((k0) + schunk * 8) < g.K;                                                \
+        sa0.load(Abase, a_off0 + (k0), arow_ok0 && kok);                                           \
+        sa1.load(Abase, a_off1 + (k0), arow_ok1 && kok);                                           \
+        sw0h = *reinterpret_cast<const uint4*>(Wbase + w_off0 + (k0));                             \
+        sw1h = *reinterpret_cast<const uint4*>(Wbase + w_off1 + (k0));                             \
+        if (NS == 2) {                                                                             \
+            sw0l = *reinterpret_cast<const uint4*>(Wbase + plane_elems + w_off0 + (k0));           \
+            sw1l = *reinterpret_cast<const uint4*>(Wbase + plane_elems + w_off1 + (k0));           \
+        }                                                                                          \
+    } while (0)
+#define STORE_TILE(buf)                                                                            \
+    do {                                                                                           \
+        char* sb = smem + (buf) * BUF_BYTES;                                                       \
+        *reinterpret_cast<uint4*>(sb + soff0) = sa0.hi;                                            \
+        *reinterpret_cast<uint4*>(sb + soff1) = sa1.hi;                                            \
+        if (NS == 2) {                                                                             \
+            *reinterpret_cast<uint4*>(sb + TILE_BYTES + soff0) = sa0.lo;                           \
+            *reinterpret_cast<uint4*>(sb + TILE_BYTES + soff1) = sa1.lo;                           \
+        }                                                                                          \
+        *reinterpret_cast<uint4*>(sb + NS * TILE_BYTES + soff0) = sw0h;                            \
+        *reinterpret_cast<uint4*>(sb + NS * TILE_BYTES + soff1) = sw1h;                            \
+        if (NS == 2) {                                                                             \
+            *reinterpret_cast<uint4*>(sb + 3 * TILE_BYTES + soff0) = sw0l;                         \
+            *reinterpret_cast<uint4*>(sb + 3 * TILE_BYTES + soff1) = sw1l;                         \
+        }                                                                                          \
+    } while (0)
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.k_pad / BK;
+    LOAD_TILE(0);
+    STORE_TILE(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) LOAD_TILE((kt + 1) * BK);
+        const char* b = smem + cur * BUF_BYTES;
+        uint4 af[4][NS], wf[4][NS];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ar = wm * 64 + t * 16 + frow;
+            const int wr = wn * 64 + t * 16 + frow;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                af[t][p] = *reinterpret_cast<const uint4*>(b + p * TILE_BYTES + lds_off(ar, fchunk));
+                wf[t][p] = *reinterpret_cast<const uint4*>(b + (NS + p) * TILE_BYTES + lds_off(wr, fchunk));
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                acc[nt][mt] = mfma16(wf[nt][0], af[mt][0], acc[nt][mt]);
+                if (NS == 2) {
+                    acc[nt][mt] = mfma16(wf[nt][0], af[mt][1], acc[nt][mt]);
+                    acc[nt][mt] = mfma16(wf[nt][1], af[mt][0], acc[nt][mt]);
+                }
+            }
+        if (kt + 1 < nk) STORE_TILE(cur ^ 1);
+        __syncthreads();
+    }
+
+#undef LOAD_TILE
+#undef STORE_TILE
+    // epilogue: lane holds D'[n = 4*(lane>>4) + r][m = lane&15] of every 16x16 tile
+    const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
+    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+        if (n >= g.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            const f32x4_t v = acc[nt][mt];
+            const float o0 = v[0] + bv[0], o1 = v[1] + bv[1], o2 = v[2] + bv[2], o3 = v[3] + bv[3];
+            if (C_TYPE == AMTX_T_F32) {
+                *reinterpret_cast<float4*>(Cbase + (m * g.ldc + n) * 4) = make_float4(o0, o1, o2, o3);
+            } else {
+                *reinterpret_cast<uint2*>(Cbase + (m * g.ldc + n) * 2) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            }
+        }
+    }
+}
+
+template <int A_TYPE, int C_TYPE, int NS>
+int launch(const GemmArgs& g, hipStream_t stream) {
+    dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)(g.n_pad / BN), (unsigned)g.groups);
+    const size_t lds = 2 * 2 * NS * TILE_BYTES;
+    hipLaunchKernelGGL((gemm_kernel<A_TYPE, C_TYPE, NS>), grid, dim3(256), lds, stream, g);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+}  // namespace
+
+void amtx_gemm_pack_dims(int N, int K, int* n_pad, int* k_pad) {
+    *n_pad = ((N + BN - 1) / BN) * BN;
+    *k_pad = ((K + BK - 1) / BK) * BK;
+}
+
+void amtx_gemm_pack_host(const float* W, int64_t ldw, int N, int K, int planes, bf16_t* out) {
+    int n_pad, k_pad;
+    amtx_gemm_pack_dims(N, K, &n_pad, &k_pad);
+    const size_t plane = (size_t)n_pad * k_pad;
+    memset(out, 0, plane * planes * sizeof(bf16_t));
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) {
+            const float w = W[(int64_t)n * ldw + k];
+            const bf16_t hi = f32_to_bf16_rn(w);
+            out[(size_t)n * k_pad + k] = hi;
+            if (planes == 2) out[plane + (size_t)n * k_pad + k] = f32_to_bf16_rn(w - bf16_to_f32(hi));
+        }
+}
+
+int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
+    AMTX_REQUIRE(g.A && g.W && g.C, "gemm: null pointer");
+    AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
+    AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
+    AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
+    AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
+    AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
+    AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
+    const int key = (g.a_type << 2) | (g.c_type << 1) | (g.planes - 1);
+    switch (key) {
+        case 0: return launch<AMTX_T_BF16, AMTX_T_BF16, 1>(g, stream);
+        case 1: return launch<AMTX_T_BF16, AMTX_T_BF16, 2>(g, stream);
+        case 2: return launch<AMTX_T_BF16, AMTX_T_F32, 1>(g, stream);
+        case 3: return launch<AMTX_T_BF16, AMTX_T_F32, 2>(g, stream);
+        case 4: return launch<AMTX_T_F32, AMTX_T_BF16, 1>(g, stream);
+        case 5: return launch<AMTX_T_F32, AMTX_T_BF16, 2>(g, stream);
+        case 6: return launch<AMTX_T_F32, AMTX_T_F32, 1>(g, stream);
+        case 7: return launch<AMTX_T_F32, AMTX_T_F32, 2>(g, stream);
+    }
+    amtx_set_error("gemm: unsupported type combination");
+    return AMTX_ERR_UNSUPPORTED;
+}

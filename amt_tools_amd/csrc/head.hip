@@ -1,0 +1,46 @@
+// logits -> piano roll for gfx950.
+// Replaces LogisticBank.finalize_output (amt_tools/models/common.py:586-620): sigmoid -> transpose to
+// (B, keys, T) -> threshold_activations (amt_tools/tools/utils.py:2896-2919: x < thr -> 0, else 1).
+// HBM-bound byte work: reads keys*4 B and writes keys*4 B per frame; 32x32 LDS tile transpose so both
+// the [B][T][ld] reads and the [B][keys][T] writes are coalesced.
+
+#include "amtx_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void pianoroll_kernel(const float* __restrict__ logits, int64_t ld, int col0, int T, int keys,
+                                                        float threshold, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (t < T && k < keys) {
+            const float x = logits[((int64_t)b * T + t) * ld + col0 + k];
+            const float s = 1.0f / (1.0f + expf(-x));            // torch.sigmoid in fp32
+            v = threshold < 0.f ? s : (s < threshold ? 0.f : 1.f);
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, t = t0 + tx;
+        if (t < T && k < keys) out[((int64_t)b * keys + k) * T + t] = tile[tx][ty + 8 * i];
+    }
+}
+
+}  // namespace
+
+int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int T, int keys, float threshold, float* out,
+                          hipStream_t stream) {
+    AMTX_REQUIRE(logits && out, "pianoroll: null pointer");
+    AMTX_REQUIRE(B > 0 && B < 65536 && T > 0 && keys > 0, "pianoroll: bad sizes");
+    dim3 grid((unsigned)((T + 31) / 32), (unsigned)((keys + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(pianoroll_kernel, grid, dim3(256), 0, stream, logits, ld, col0, T, keys, threshold, out);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}

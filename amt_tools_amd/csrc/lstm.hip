@@ -1,0 +1,218 @@
+// Persistent BiLSTM recurrence for gfx950 (hidden = 128 per direction).
+//
+// Replaces the time loop of nn.LSTM(batch_first, bidirectional) inside LanguageModel.forward
+// (amt_tools/models/onsetsframes.py:466-575; the reference's 512-frame eval chunking is a numerical
+// no-op, SURVEY finding F9).  The input projection W_ih x + b_ih + b_hh is a separate GEMM (gemm.hip);
+// this kernel runs the T dependent steps
+//     gates = xproj_t + W_hh h_{t-1};  c = sig(f) c + sig(i) tanh(g);  h = sig(o) tanh(c)   (gate order i,f,g,o)
+//
+// One 256-thread block = one direction x 16 clips, resident for the whole sequence:
+//   * W_hh (512x128) lives in registers for all T steps: wave w owns hidden units [32w, 32w+32) and their
+//     four gates = 8 MFMA row tiles x 4 k-steps (128 VGPRs in bf16, 256 in x3),
+//   * h_{t-1} (16 clips x 128) is the MFMA B operand, exchanged through a double-buffered 4 KiB LDS tile
+//     (row pitch 272 B -> conflict-free 16-byte fragment reads), one barrier per step,
+//   * computed swapped (D' = W_hh . h^T) so i,f,g,o of one (clip, unit) land in the same lane and the
+//     cell update is lane-local; c stays in registers,
+//   * xproj of step t+1 is prefetched into registers while step t's MFMAs run and is used as the MFMA
+//     accumulator init (no separate add).
+// The recurrence is a dependency chain (latency-bound, not roofline-bound): throughput comes from running
+// ceil(B/16) x 2 directions x groups blocks concurrently.
+
+#include "amtx_kernels.h"
+
+namespace {
+
+constexpr int H = 128;
+constexpr int HP = H + 8;                    // bf16 elements per LDS row
+constexpr int HBUF_BYTES = 16 * HP * 2;      // one plane of one buffer
+
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+__device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool FAST>
+__device__ __forceinline__ float sigmoid_f(float x) {
+    if (FAST) return __fdividef(1.0f, 1.0f + __expf(-x));
+    return 1.0f / (1.0f + expf(-x));
+}
+template <bool FAST>
+__device__ __forceinline__ float tanh_f(float x) {
+    if (FAST) return 2.0f * __fdividef(1.0f, 1.0f + __expf(-2.0f * x)) - 1.0f;
+    return tanhf(x);
+}
+
+template <int NS, int X_TYPE, int OUT_TYPE>
+__global__ __launch_bounds__(256) void bilstm_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16
+    constexpr bool FAST = (NS == 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int clip = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * 16, dir = blockIdx.y, grp = blockIdx.z;
+    const int b = b0 + clip;
+    const bool clip_ok = b < a.B;
+    const int T = a.T;
+
+    // ---- stationary recurrent weights
+    uint4 wf[2][4][4][NS];
+    {
+        const uint4* w = reinterpret_cast<const uint4*>(a.whh + (int64_t)grp * a.w_gs) + lane;
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int p = 0; p < NS; ++p)
+                        wf[ub][q][ks][p] = w[((((((dir * 4 + wave) * 2 + ub) * 4 + q) * 4 + ks) * NS) + p) * 64];
+    }
+
+    for (int i = tid; i < 2 * NS * HBUF_BYTES / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    float c[2][4];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[ub][r] = 0.f;
+
+    const int64_t xrow = 1024;   // elements per (b, t)
+    const char* xbase = reinterpret_cast<const char*>(a.xproj) +
+                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * xrow + dir * 512 + 32 * wave + 4 * g) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
+    char* obase = reinterpret_cast<char*>(a.out) +
+                  ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + 32 * wave + 4 * g) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+
+    f32x4_t xv[2][4], xn[2][4];
+    auto load_x = [&](int t, f32x4_t (&dst)[2][4]) {
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t e = (int64_t)t * xrow + q * 128 + 16 * ub;
+                if (X_TYPE == AMTX_T_F32) {
+                    const float4 v = *reinterpret_cast<const float4*>(xbase + e * 4);
+                    dst[ub][q] = (f32x4_t){v.x, v.y, v.z, v.w};
+                } else {
+                    const uint2 v = *reinterpret_cast<const uint2*>(xbase + e * 2);
+                    dst[ub][q] = (f32x4_t){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                           __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+                }
+            }
+    };
+    load_x(dir == 0 ? 0 : T - 1, xv);
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        const int t = dir == 0 ? s : T - 1 - s;
+        const char* hb = smem + cur * NS * HBUF_BYTES;
+        uint4 hf[4][NS];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBUF_BYTES + (clip * HP + 32 * ks + 8 * g) * 2);
+
+        if (s + 1 < T) load_x(dir == 0 ? s + 1 : T - 2 - s, xn);
+
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[ub][q] = xv[ub][q];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][0], acc[ub][q]);
+                    if (NS == 2) {
+                        acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][1], acc[ub][q]);
+                        acc[ub][q] = mfma16(wf[ub][q][ks][1], hf[ks][0], acc[ub][q]);
+                    }
+                }
+
+        char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub) {
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigmoid_f<FAST>(acc[ub][0][r]);
+                const float fg = sigmoid_f<FAST>(acc[ub][1][r]);
+                const float gg = tanh_f<FAST>(acc[ub][2][r]);
+                const float og = sigmoid_f<FAST>(acc[ub][3][r]);
+                c[ub][r] = fg * c[ub][r] + ig * gg;
+                h[r] = og * tanh_f<FAST>(c[ub][r]);
+            }
+            bf16_t hi[4], lo[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (NS == 2) split_bf16(h[r], hi[r], lo[r]);
+                else hi[r] = f32_to_bf16_rn(h[r]);
+            }
+            const int hoff = (clip * HP + 32 * wave + 16 * ub + 4 * g) * 2;
+            const uint2 hiw = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+            *reinterpret_cast<uint2*>(hn + hoff) = hiw;
+            if (NS == 2)
+                *reinterpret_cast<uint2*>(hn + HBUF_BYTES + hoff) =
+                    make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+            if (clip_ok) {
+                const int64_t e = (int64_t)t * 256 + 16 * ub;
+                if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<uint2*>(obase + e * 2) = hiw;
+                else *reinterpret_cast<float4*>(obase + e * 4) = make_float4(h[0], h[1], h[2], h[3]);
+            }
+        }
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[ub][q] = xn[ub][q];
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+template <int NS, int X_TYPE, int OUT_TYPE>
+int launch(const LstmArgs& a, hipStream_t stream) {
+    dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
+    const size_t lds = 2 * NS * HBUF_BYTES;
+    hipLaunchKernelGGL((bilstm_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(256), lds, stream, a);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+}  // namespace
+
+size_t amtx_bilstm_wfrag_elems(int planes) { return (size_t)2 * 512 * 128 * planes; }
+
+void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out) {
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* W = dir == 0 ? whh_fwd : whh_bwd;   // (512, 128) row-major, gate-major rows i,f,g,o
+        for (int w = 0; w < 4; ++w)
+            for (int ub = 0; ub < 2; ++ub)
+                for (int q = 0; q < 4; ++q)
+                    for (int ks = 0; ks < 4; ++ks)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int row = q * 128 + 32 * w + 16 * ub + (l & 15);
+                                const int k = 32 * ks + 8 * (l >> 4) + j;
+                                const float v = W[(size_t)row * H + k];
+                                const bf16_t hi = f32_to_bf16_rn(v);
+                                const size_t base = ((((((size_t)dir * 4 + w) * 2 + ub) * 4 + q) * 4 + ks) * planes) * 512 + (size_t)l * 8 + j;
+                                out[base] = hi;
+                                if (planes == 2) out[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                            }
+    }
+}
+
+int amtx_launch_bilstm(const LstmArgs& a, hipStream_t stream) {
+    AMTX_REQUIRE(a.xproj && a.whh && a.out, "bilstm: null pointer");
+    AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.groups > 0, "bilstm: bad sizes");
+    AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "bilstm: planes must be 1 or 2");
+    if (a.planes == 1 && a.x_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch<1, AMTX_T_BF16, AMTX_T_BF16>(a, stream);
+    if (a.planes == 1 && a.x_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch<1, AMTX_T_F32, AMTX_T_F32>(a, stream);
+    if (a.planes == 2 && a.x_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch<2, AMTX_T_F32, AMTX_T_F32>(a, stream);
+    amtx_set_error("bilstm: unsupported precision/type combination");
+    return AMTX_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,412 @@
+// Onsets & Frames inference engine for gfx950: weight packing + the launch sequence of one
+// `run_on_batch` forward (amt_tools/models/onsetsframes.py:94-136 forward, :138-196 post_proc without the
+// loss; TranscriptionModel.run_on_batch amt_tools/models/common.py:151-184).
+//
+// Tensors are handed over under the reference's own state_dict names (e.g. "onset_head.0.layer2.0.weight"),
+// eval-mode BatchNorm is folded, fc1's columns are permuted from the reference's (channel, freq) flatten
+// order to the channels-last (freq, channel) order the conv kernels write, LSTM biases b_ih + b_hh are merged
+// into the input-projection GEMM, everything is packed into MFMA fragment order once.
+//
+// Launch sequence (acoustic heads batched as kernel groups):
+//   conv1 -> conv2+pool -> conv3+pool -> fc1            [groups = heads: onset, (offset), pitch]
+//   onset(/offset) x-proj GEMM -> BiLSTM -> head GEMM -> joint[:, 0:88(:176)]
+//   pitch head GEMM -> joint[:, 88:176]
+//   adjoin x-proj GEMM (A = joint logits, fp32) -> BiLSTM -> head GEMM -> frame logits
+//   piano-roll finalize (sigmoid, threshold 0.5, transpose) x2
+
+#include "amtx_kernels.h"
+
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Tensor { std::vector<float> v; };
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int upload(const void* host, size_t n) {
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = n;
+        AMTX_CHECK_HIP(hipMalloc(&p, n));
+        AMTX_CHECK_HIP(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return AMTX_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+struct LinearPack { DevBuf w, b; int N = 0, K = 0, n_pad = 0, k_pad = 0; };
+
+}  // namespace
+
+struct amtx_of_model {
+    int dim_in, in_channels, mc, n_out, has_offsets, precision;
+    int planes, act_type;
+    int nf1, nf2, nf3, dim_am, dim_lm, fq, kfc;
+    int n_heads;                               // acoustic heads: onset, (offset), pitch
+    int n_rec;                                 // recurrent heads feeding the joint: onset, (offset)
+    std::vector<std::string> head_names;       // state_dict prefixes of the acoustic models, group order
+    std::map<std::string, Tensor> tensors;
+    bool finalized = false;
+    // packed device weights (group-major)
+    DevBuf conv1_w, conv1_s, conv2_w, conv2_s, conv3_w, conv3_s;
+    LinearPack fc1;                            // groups = n_heads
+    LinearPack rec_ih;                         // groups = n_rec, N = 1024
+    DevBuf rec_hh;                             // groups = n_rec
+    LinearPack rec_out;                        // groups = n_rec, N = n_out, K = dim_lm
+    LinearPack pitch_out;                      // K = dim_am
+    LinearPack adj_ih;                         // K = dim_aj, N = 1024
+    DevBuf adj_hh;
+    LinearPack adj_out;
+    int dim_aj;
+};
+
+namespace {
+
+int need(const amtx_of_model* m, const std::string& name, size_t numel, const float** out) {
+    auto it = m->tensors.find(name);
+    if (it == m->tensors.end()) {
+        amtx_set_error("of_model: tensor '%s' was not provided", name.c_str());
+        return AMTX_ERR_ARG;
+    }
+    if (it->second.v.size() != numel) {
+        amtx_set_error("of_model: tensor '%s' has %zu elements, expected %zu", name.c_str(), it->second.v.size(), numel);
+        return AMTX_ERR_ARG;
+    }
+    *out = it->second.v.data();
+    return AMTX_OK;
+}
+
+#define NEED(name, numel, ptr)                                         \
+    do {                                                               \
+        int _rc = need(m, name, numel, &(ptr));                        \
+        if (_rc != AMTX_OK) return _rc;                                \
+    } while (0)
+
+// fold eval-mode BatchNorm2d behind a conv: scale[c] and shift[c]
+int fold_bn(const amtx_of_model* m, const std::string& conv, const std::string& bn, int c_out, std::vector<float>& scale,
+            std::vector<float>& shift) {
+    const float *cb, *g, *be, *mu, *var;
+    NEED(conv + ".bias", (size_t)c_out, cb);
+    NEED(bn + ".weight", (size_t)c_out, g);
+    NEED(bn + ".bias", (size_t)c_out, be);
+    NEED(bn + ".running_mean", (size_t)c_out, mu);
+    NEED(bn + ".running_var", (size_t)c_out, var);
+    scale.resize(c_out); shift.resize(c_out);
+    for (int c = 0; c < c_out; ++c) {
+        const double s = (double)g[c] / std::sqrt((double)var[c] + 1e-5);
+        scale[c] = (float)s;
+        shift[c] = (float)((double)be[c] + ((double)cb[c] - (double)mu[c]) * s);
+    }
+    return AMTX_OK;
+}
+
+int pack_linear_groups(amtx_of_model* m, LinearPack& lp, const std::vector<std::vector<float>>& Ws, const std::vector<std::vector<float>>& bs,
+                       int N, int K) {
+    lp.N = N; lp.K = K;
+    amtx_gemm_pack_dims(N, K, &lp.n_pad, &lp.k_pad);
+    const size_t per = (size_t)lp.n_pad * lp.k_pad * m->planes;
+    std::vector<bf16_t> packed(per * Ws.size());
+    std::vector<float> bias((size_t)N * Ws.size());
+    for (size_t g = 0; g < Ws.size(); ++g) {
+        amtx_gemm_pack_host(Ws[g].data(), K, N, K, m->planes, packed.data() + g * per);
+        memcpy(bias.data() + g * N, bs[g].data(), sizeof(float) * N);
+    }
+    int rc = lp.w.upload(packed.data(), packed.size() * sizeof(bf16_t));
+    if (rc != AMTX_OK) return rc;
+    return lp.b.upload(bias.data(), bias.size() * sizeof(float));
+}
+
+int pack_lstm(amtx_of_model* m, const std::string& prefix, int dim_in, std::vector<float>& w_ih, std::vector<float>& b, std::vector<bf16_t>& hh) {
+    const int H = m->dim_lm / 2, G = 4 * H;
+    const float *wif, *wib, *whf, *whb, *bif, *bib, *bhf, *bhb;
+    NEED(prefix + ".mlm.weight_ih_l0", (size_t)G * dim_in, wif);
+    NEED(prefix + ".mlm.weight_ih_l0_reverse", (size_t)G * dim_in, wib);
+    NEED(prefix + ".mlm.weight_hh_l0", (size_t)G * H, whf);
+    NEED(prefix + ".mlm.weight_hh_l0_reverse", (size_t)G * H, whb);
+    NEED(prefix + ".mlm.bias_ih_l0", (size_t)G, bif);
+    NEED(prefix + ".mlm.bias_ih_l0_reverse", (size_t)G, bib);
+    NEED(prefix + ".mlm.bias_hh_l0", (size_t)G, bhf);
+    NEED(prefix + ".mlm.bias_hh_l0_reverse", (size_t)G, bhb);
+    w_ih.resize((size_t)2 * G * dim_in);
+    memcpy(w_ih.data(), wif, sizeof(float) * G * dim_in);
+    memcpy(w_ih.data() + (size_t)G * dim_in, wib, sizeof(float) * G * dim_in);
+    b.resize(2 * G);
+    for (int i = 0; i < G; ++i) { b[i] = bif[i] + bhf[i]; b[G + i] = bib[i] + bhb[i]; }
+    hh.resize(amtx_bilstm_wfrag_elems(m->planes));
+    amtx_bilstm_pack_host(whf, whb, m->planes, hh.data());
+    return AMTX_OK;
+}
+
+struct Workspace {
+    char *a1, *a2, *a3, *e, *xp, *l1, *joint, *xp2, *l2, *mp;
+    size_t total;
+};
+
+Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
+    Workspace w;
+    const size_t es = amtx_tsize(m->act_type);
+    const size_t BT = (size_t)B * T;
+    const int F = m->dim_in, F2 = F / 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    w.a1 = take(BT * F * m->nf1 * es * m->n_heads);
+    w.a2 = take(BT * F2 * m->nf2 * es * m->n_heads);
+    w.a3 = take(BT * m->fq * m->nf3 * es * m->n_heads);
+    w.e = take(BT * m->dim_am * es * m->n_heads);
+    w.xp = take(BT * 1024 * es * m->n_rec);
+    w.l1 = take(BT * m->dim_lm * es * m->n_rec);
+    w.joint = take(BT * m->dim_aj * sizeof(float));
+    w.xp2 = take(BT * 1024 * es);
+    w.l2 = take(BT * m->dim_lm * es);
+    w.mp = take(BT * m->n_out * sizeof(float));
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_channels, int model_complexity, int n_out,
+                                    int has_offsets, int precision) {
+    AMTX_REQUIRE(out, "amtx_of_model_create: null model pointer");
+    *out = nullptr;
+    AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3, "amtx_of_model_create: bad precision");
+    AMTX_REQUIRE(dim_in >= 4 && in_channels >= 1 && n_out > 0 && n_out % 4 == 0, "amtx_of_model_create: bad dims");
+    if (model_complexity != 2 || has_offsets) {
+        amtx_set_error("amtx_of_model_create: only OnsetsFrames with model_complexity=2 (C_in 32 convs, LSTM hidden 128) is implemented "
+                       "(got model_complexity=%d, offsets=%d)", model_complexity, has_offsets);
+        return AMTX_ERR_UNSUPPORTED;
+    }
+    amtx_of_model* m = new amtx_of_model();
+    m->dim_in = dim_in; m->in_channels = in_channels; m->mc = model_complexity; m->n_out = n_out;
+    m->has_offsets = has_offsets; m->precision = precision;
+    m->planes = precision == AMTX_PREC_X3 ? 2 : 1;
+    m->act_type = precision == AMTX_PREC_X3 ? AMTX_T_F32 : AMTX_T_BF16;
+    m->nf1 = 16 * model_complexity; m->nf2 = m->nf1; m->nf3 = 32 * model_complexity;
+    m->dim_am = 256 * model_complexity; m->dim_lm = 256 * (model_complexity - 1);
+    m->fq = dim_in / 4;                      // two MaxPool(1,2): floor(floor(F/2)/2) == F//4
+    m->kfc = m->nf3 * m->fq;
+    m->head_names = {"onset_head"};
+    if (has_offsets) m->head_names.push_back("offset_head");
+    m->n_rec = (int)m->head_names.size();
+    m->head_names.push_back("pitch_head");
+    m->n_heads = (int)m->head_names.size();
+    m->dim_aj = (m->n_rec + 1) * n_out;
+    *out = m;
+    return AMTX_OK;
+}
+
+extern "C" int amtx_of_model_destroy(amtx_of_model* m) {
+    if (!m) return AMTX_OK;
+    DevBuf* bufs[] = {&m->conv1_w, &m->conv1_s, &m->conv2_w, &m->conv2_s, &m->conv3_w, &m->conv3_s, &m->fc1.w, &m->fc1.b,
+                      &m->rec_ih.w, &m->rec_ih.b, &m->rec_hh, &m->rec_out.w, &m->rec_out.b, &m->pitch_out.w, &m->pitch_out.b,
+                      &m->adj_ih.w, &m->adj_ih.b, &m->adj_hh, &m->adj_out.w, &m->adj_out.b};
+    for (DevBuf* b : bufs) b->release();
+    delete m;
+    return AMTX_OK;
+}
+
+extern "C" int amtx_of_model_set_tensor(amtx_of_model* m, const char* name, const float* host_data, int64_t numel) {
+    AMTX_REQUIRE(m && name && host_data && numel > 0, "amtx_of_model_set_tensor: bad argument");
+    Tensor& t = m->tensors[name];
+    t.v.assign(host_data, host_data + numel);
+    m->finalized = false;
+    return AMTX_OK;
+}
+
+extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
+    AMTX_REQUIRE(m, "amtx_of_model_finalize: null model");
+    const int nh = m->n_heads;
+    // ---- acoustic heads
+    std::vector<float> c1w((size_t)nh * m->nf1 * m->in_channels * 9), c1s((size_t)nh * m->nf1);
+    std::vector<bf16_t> c2w(amtx_conv3x3_wfrag_elems(m->nf2, m->planes) * nh), c3w(amtx_conv3x3_wfrag_elems(m->nf3, m->planes) * nh);
+    std::vector<float> c2s((size_t)nh * m->nf2), c3s((size_t)nh * m->nf3);
+    std::vector<std::vector<float>> fcw(nh), fcb(nh);
+    for (int h = 0; h < nh; ++h) {
+        const std::string am = m->head_names[h] + ".0";
+        std::vector<float> scale, shift;
+        const float* w;
+        int rc = fold_bn(m, am + ".layer1.0", am + ".layer1.1", m->nf1, scale, shift);
+        if (rc != AMTX_OK) return rc;
+        NEED(am + ".layer1.0.weight", (size_t)m->nf1 * m->in_channels * 9, w);
+        for (int co = 0; co < m->nf1; ++co)
+            for (int i = 0; i < m->in_channels * 9; ++i)
+                c1w[((size_t)h * m->nf1 + co) * m->in_channels * 9 + i] = w[(size_t)co * m->in_channels * 9 + i] * scale[co];
+        memcpy(c1s.data() + (size_t)h * m->nf1, shift.data(), sizeof(float) * m->nf1);
+
+        rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
+        if (rc != AMTX_OK) return rc;
+        NEED(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
+        amtx_conv3x3_pack_host(w, scale.data(), m->nf2, m->planes, c2w.data() + amtx_conv3x3_wfrag_elems(m->nf2, m->planes) * h);
+        memcpy(c2s.data() + (size_t)h * m->nf2, shift.data(), sizeof(float) * m->nf2);
+
+        rc = fold_bn(m, am + ".layer3.0", am + ".layer3.1", m->nf3, scale, shift);
+        if (rc != AMTX_OK) return rc;
+        NEED(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
+        amtx_conv3x3_pack_host(w, scale.data(), m->nf3, m->planes, c3w.data() + amtx_conv3x3_wfrag_elems(m->nf3, m->planes) * h);
+        memcpy(c3s.data() + (size_t)h * m->nf3, shift.data(), sizeof(float) * m->nf3);
+
+        // fc1: reference column index c*fq + f  ->  ours f*nf3 + c
+        const float* fb;
+        NEED(am + ".fc1.0.weight", (size_t)m->dim_am * m->kfc, w);
+        NEED(am + ".fc1.0.bias", (size_t)m->dim_am, fb);
+        fcw[h].resize((size_t)m->dim_am * m->kfc);
+        for (int n = 0; n < m->dim_am; ++n)
+            for (int c = 0; c < m->nf3; ++c)
+                for (int f = 0; f < m->fq; ++f)
+                    fcw[h][(size_t)n * m->kfc + (size_t)f * m->nf3 + c] = w[(size_t)n * m->kfc + (size_t)c * m->fq + f];
+        fcb[h].assign(fb, fb + m->dim_am);
+    }
+    int rc;
+    if ((rc = m->conv1_w.upload(c1w.data(), c1w.size() * 4)) != AMTX_OK) return rc;
+    if ((rc = m->conv1_s.upload(c1s.data(), c1s.size() * 4)) != AMTX_OK) return rc;
+    if ((rc = m->conv2_w.upload(c2w.data(), c2w.size() * 2)) != AMTX_OK) return rc;
+    if ((rc = m->conv2_s.upload(c2s.data(), c2s.size() * 4)) != AMTX_OK) return rc;
+    if ((rc = m->conv3_w.upload(c3w.data(), c3w.size() * 2)) != AMTX_OK) return rc;
+    if ((rc = m->conv3_s.upload(c3s.data(), c3s.size() * 4)) != AMTX_OK) return rc;
+    if ((rc = pack_linear_groups(m, m->fc1, fcw, fcb, m->dim_am, m->kfc)) != AMTX_OK) return rc;
+
+    // ---- recurrent heads (onset, offset): LSTM + LogisticBank
+    {
+        std::vector<std::vector<float>> wih(m->n_rec), bih(m->n_rec), wo(m->n_rec), bo(m->n_rec);
+        std::vector<bf16_t> hh_all;
+        for (int r = 0; r < m->n_rec; ++r) {
+            std::vector<bf16_t> hh;
+            if ((rc = pack_lstm(m, m->head_names[r] + ".1", m->dim_am, wih[r], bih[r], hh)) != AMTX_OK) return rc;
+            hh_all.insert(hh_all.end(), hh.begin(), hh.end());
+            const float *w, *b;
+            NEED(m->head_names[r] + ".2.output_layer.weight", (size_t)m->n_out * m->dim_lm, w);
+            NEED(m->head_names[r] + ".2.output_layer.bias", (size_t)m->n_out, b);
+            wo[r].assign(w, w + (size_t)m->n_out * m->dim_lm);
+            bo[r].assign(b, b + m->n_out);
+        }
+        if ((rc = pack_linear_groups(m, m->rec_ih, wih, bih, 1024, m->dim_am)) != AMTX_OK) return rc;
+        if ((rc = m->rec_hh.upload(hh_all.data(), hh_all.size() * 2)) != AMTX_OK) return rc;
+        if ((rc = pack_linear_groups(m, m->rec_out, wo, bo, m->n_out, m->dim_lm)) != AMTX_OK) return rc;
+    }
+    // ---- pitch head LogisticBank
+    {
+        const float *w, *b;
+        NEED("pitch_head.1.output_layer.weight", (size_t)m->n_out * m->dim_am, w);
+        NEED("pitch_head.1.output_layer.bias", (size_t)m->n_out, b);
+        std::vector<std::vector<float>> W{std::vector<float>(w, w + (size_t)m->n_out * m->dim_am)}, Bv{std::vector<float>(b, b + m->n_out)};
+        if ((rc = pack_linear_groups(m, m->pitch_out, W, Bv, m->n_out, m->dim_am)) != AMTX_OK) return rc;
+    }
+    // ---- adjoin: LSTM over the joint logits + LogisticBank
+    {
+        std::vector<std::vector<float>> wih(1), bih(1);
+        std::vector<bf16_t> hh;
+        if ((rc = pack_lstm(m, "adjoin.0", m->dim_aj, wih[0], bih[0], hh)) != AMTX_OK) return rc;
+        if ((rc = pack_linear_groups(m, m->adj_ih, wih, bih, 1024, m->dim_aj)) != AMTX_OK) return rc;
+        if ((rc = m->adj_hh.upload(hh.data(), hh.size() * 2)) != AMTX_OK) return rc;
+        const float *w, *b;
+        NEED("adjoin.1.output_layer.weight", (size_t)m->n_out * m->dim_lm, w);
+        NEED("adjoin.1.output_layer.bias", (size_t)m->n_out, b);
+        std::vector<std::vector<float>> W{std::vector<float>(w, w + (size_t)m->n_out * m->dim_lm)}, Bv{std::vector<float>(b, b + m->n_out)};
+        if ((rc = pack_linear_groups(m, m->adj_out, W, Bv, m->n_out, m->dim_lm)) != AMTX_OK) return rc;
+    }
+    m->tensors.clear();
+    m->finalized = true;
+    return AMTX_OK;
+}
+
+extern "C" size_t amtx_of_workspace_bytes(const amtx_of_model* m, int batch, int num_frames) {
+    if (!m || batch <= 0 || num_frames <= 0) return 0;
+    return carve(m, batch, num_frames, nullptr).total;
+}
+
+static GemmArgs gemm_args(const void* A, int64_t lda, int a_type, const LinearPack& lp, int planes, void* C, int64_t ldc, int c_type,
+                          int64_t M, int groups, int64_t a_gs, int64_t c_gs) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.a_type = a_type;
+    g.W = (const bf16_t*)lp.w.p; g.n_pad = lp.n_pad; g.k_pad = lp.k_pad; g.planes = planes;
+    g.bias = (const float*)lp.b.p;
+    g.C = C; g.ldc = ldc; g.c_type = c_type;
+    g.M = M; g.N = lp.N; g.K = lp.K;
+    g.groups = groups; g.a_gs = a_gs; g.w_gs = (int64_t)lp.n_pad * lp.k_pad * planes; g.bias_gs = lp.N; g.c_gs = c_gs;
+    return g;
+}
+
+extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+                               int64_t stride_f, int batch, int num_frames, void* workspace, size_t workspace_bytes,
+                               float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
+                               float* logits_pitch_head, void* stream_) {
+    AMTX_REQUIRE(m && m->finalized, "amtx_of_forward: model not finalized");
+    AMTX_REQUIRE(feats && workspace, "amtx_of_forward: null pointer");
+    AMTX_REQUIRE(batch > 0 && num_frames > 0, "amtx_of_forward: bad batch/num_frames");
+    const int B = batch, T = num_frames;
+    Workspace w = carve(m, B, T, (char*)workspace);
+    AMTX_REQUIRE(workspace_bytes >= w.total, "amtx_of_forward: workspace too small (%zu < %zu)", workspace_bytes, w.total);
+    AMTX_REQUIRE(((uintptr_t)workspace % 256) == 0, "amtx_of_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t BT = (int64_t)B * T;
+    const int F = m->dim_in, F2 = F / 2, at = m->act_type, pl = m->planes;
+    int rc;
+
+    Conv1Args c1;
+    c1.in = feats; c1.stride_b = stride_b; c1.stride_c = stride_c; c1.stride_t = stride_t; c1.stride_f = stride_f;
+    c1.w = (const float*)m->conv1_w.p; c1.shift = (const float*)m->conv1_s.p; c1.out = w.a1; c1.out_type = at;
+    c1.B = B; c1.T = T; c1.F = F; c1.c_in = m->in_channels; c1.c_out = m->nf1;
+    c1.groups = m->n_heads; c1.w_gs = (int64_t)m->nf1 * m->in_channels * 9; c1.shift_gs = m->nf1; c1.out_gs = BT * F * m->nf1;
+    if ((rc = amtx_launch_conv1(c1, s)) != AMTX_OK) return rc;
+
+    ConvArgs c2;
+    c2.in = w.a1; c2.in_type = at; c2.wfrag = (const bf16_t*)m->conv2_w.p; c2.planes = pl; c2.shift = (const float*)m->conv2_s.p;
+    c2.out = w.a2; c2.out_type = at; c2.B = B; c2.T = T; c2.F = F; c2.c_out = m->nf2;
+    c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf2, pl); c2.shift_gs = m->nf2;
+    c2.out_gs = BT * F2 * m->nf2;
+    if ((rc = amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
+
+    ConvArgs c3 = c2;
+    c3.in = w.a2; c3.wfrag = (const bf16_t*)m->conv3_w.p; c3.shift = (const float*)m->conv3_s.p; c3.out = w.a3;
+    c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2; c3.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl);
+    c3.shift_gs = m->nf3; c3.out_gs = BT * m->fq * m->nf3;
+    if ((rc = amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
+
+    // fc1 for every acoustic head
+    GemmArgs g = gemm_args(w.a3, m->kfc, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_heads, BT * m->kfc, BT * m->dim_am);
+    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+
+    // recurrent heads: heads 0..n_rec-1 of `e`
+    g = gemm_args(w.e, m->dim_am, at, m->rec_ih, pl, w.xp, 1024, at, BT, m->n_rec, BT * m->dim_am, BT * 1024);
+    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    LstmArgs l;
+    l.xproj = w.xp; l.x_type = at; l.whh = (const bf16_t*)m->rec_hh.p; l.planes = pl; l.out = w.l1; l.out_type = at;
+    l.B = B; l.T = T; l.groups = m->n_rec; l.x_gs = BT * 1024; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems(pl); l.out_gs = BT * m->dim_lm;
+    if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
+    // LogisticBank of each recurrent head -> joint[:, r*n_out : (r+1)*n_out]; group stride of C = n_out columns
+    g = gemm_args(w.l1, m->dim_lm, at, m->rec_out, pl, w.joint, m->dim_aj, AMTX_T_F32, BT, m->n_rec, BT * m->dim_lm, m->n_out);
+    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    // pitch head LogisticBank -> last n_out columns of joint
+    g = gemm_args(w.e + (size_t)(m->n_heads - 1) * BT * m->dim_am * amtx_tsize(at), m->dim_am, at, m->pitch_out, pl,
+                  w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
+    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+
+    // adjoin
+    g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
+    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    l.xproj = w.xp2; l.whh = (const bf16_t*)m->adj_hh.p; l.out = w.l2; l.groups = 1;
+    if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
+    g = gemm_args(w.l2, m->dim_lm, at, m->adj_out, pl, w.mp, m->n_out, AMTX_T_F32, BT, 1, 0, 0);
+    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+
+    // piano rolls (LogisticBank.finalize_output with threshold 0.5)
+    if (out_onsets && (rc = amtx_launch_pianoroll((const float*)w.joint, m->dim_aj, 0, B, T, m->n_out, 0.5f, out_onsets, s)) != AMTX_OK) return rc;
+    if (out_multi_pitch && (rc = amtx_launch_pianoroll((const float*)w.mp, m->n_out, 0, B, T, m->n_out, 0.5f, out_multi_pitch, s)) != AMTX_OK) return rc;
+
+    // optional raw logits, contiguous (B, T, n_out)
+    const size_t row = (size_t)m->n_out * sizeof(float);
+    if (logits_onsets)
+        AMTX_CHECK_HIP(hipMemcpy2DAsync(logits_onsets, row, w.joint, (size_t)m->dim_aj * 4, row, BT, hipMemcpyDeviceToDevice, s));
+    if (logits_pitch_head)
+        AMTX_CHECK_HIP(hipMemcpy2DAsync(logits_pitch_head, row, w.joint + (size_t)m->n_rec * row, (size_t)m->dim_aj * 4, row, BT,
+                                        hipMemcpyDeviceToDevice, s));
+    if (logits_multi_pitch)
+        AMTX_CHECK_HIP(hipMemcpyAsync(logits_multi_pitch, w.mp, row * BT, hipMemcpyDeviceToDevice, s));
+    return AMTX_OK;
+}

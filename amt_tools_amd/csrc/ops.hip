@@ -1,0 +1,73 @@
+// Op-level C ABI wrappers around the kernel launchers (include/amtx.h, "Op-level entry points").
+#include "amtx_kernels.h"
+
+extern "C" int64_t amtx_linear_packed_elems(int n, int k, int planes) {
+    int n_pad, k_pad;
+    amtx_gemm_pack_dims(n, k, &n_pad, &k_pad);
+    return (int64_t)n_pad * k_pad * planes;
+}
+
+extern "C" int amtx_linear_pack(const float* host_w, int n, int k, int planes, uint16_t* host_out) {
+    AMTX_REQUIRE(host_w && host_out && n > 0 && k > 0 && (planes == 1 || planes == 2), "amtx_linear_pack: bad argument");
+    amtx_gemm_pack_host(host_w, k, n, k, planes, host_out);
+    return AMTX_OK;
+}
+
+extern "C" int amtx_linear_fwd(const void* a, int64_t lda, int a_type, const uint16_t* w_packed, int planes, const float* bias, void* c,
+                               int64_t ldc, int c_type, int64_t m, int n, int k, void* stream) {
+    GemmArgs g;
+    g.A = a; g.lda = lda; g.a_type = a_type; g.W = w_packed; g.planes = planes;
+    amtx_gemm_pack_dims(n, k, &g.n_pad, &g.k_pad);
+    g.bias = bias; g.C = c; g.ldc = ldc; g.c_type = c_type; g.M = m; g.N = n; g.K = k;
+    g.groups = 1; g.a_gs = g.w_gs = g.bias_gs = g.c_gs = 0;
+    return amtx_launch_gemm(g, (hipStream_t)stream);
+}
+
+extern "C" int64_t amtx_conv3x3_packed_elems(int c_out, int planes) { return (int64_t)amtx_conv3x3_wfrag_elems(c_out, planes); }
+
+extern "C" int amtx_conv3x3_pack(const float* host_w, const float* host_scale, int c_out, int planes, uint16_t* host_out) {
+    AMTX_REQUIRE(host_w && host_out && c_out % 16 == 0 && (planes == 1 || planes == 2), "amtx_conv3x3_pack: bad argument");
+    amtx_conv3x3_pack_host(host_w, host_scale, c_out, planes, host_out);
+    return AMTX_OK;
+}
+
+extern "C" int amtx_conv3x3_fwd(const void* in, int elem_type, const uint16_t* w_packed, int planes, const float* shift, void* out,
+                                int batch, int num_frames, int num_bins, int c_out, void* stream) {
+    ConvArgs a;
+    a.in = in; a.in_type = elem_type; a.wfrag = w_packed; a.planes = planes; a.shift = shift; a.out = out; a.out_type = elem_type;
+    a.B = batch; a.T = num_frames; a.F = num_bins; a.c_out = c_out;
+    a.groups = 1; a.in_gs = a.w_gs = a.shift_gs = a.out_gs = 0;
+    return amtx_launch_conv3x3(a, (hipStream_t)stream);
+}
+
+extern "C" int amtx_conv1_fwd(const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t, int64_t stride_f, const float* w,
+                              const float* shift, void* out, int out_type, int batch, int num_frames, int num_bins, int c_in, int c_out,
+                              void* stream) {
+    Conv1Args a;
+    a.in = feats; a.stride_b = stride_b; a.stride_c = stride_c; a.stride_t = stride_t; a.stride_f = stride_f;
+    a.w = w; a.shift = shift; a.out = out; a.out_type = out_type;
+    a.B = batch; a.T = num_frames; a.F = num_bins; a.c_in = c_in; a.c_out = c_out;
+    a.groups = 1; a.w_gs = a.shift_gs = a.out_gs = 0;
+    return amtx_launch_conv1(a, (hipStream_t)stream);
+}
+
+extern "C" int64_t amtx_bilstm_packed_elems(int planes) { return (int64_t)amtx_bilstm_wfrag_elems(planes); }
+
+extern "C" int amtx_bilstm_pack(const float* host_whh_fwd, const float* host_whh_bwd, int planes, uint16_t* host_out) {
+    AMTX_REQUIRE(host_whh_fwd && host_whh_bwd && host_out && (planes == 1 || planes == 2), "amtx_bilstm_pack: bad argument");
+    amtx_bilstm_pack_host(host_whh_fwd, host_whh_bwd, planes, host_out);
+    return AMTX_OK;
+}
+
+extern "C" int amtx_bilstm_fwd(const void* xproj, const uint16_t* whh_packed, int planes, int elem_type, void* out, int batch,
+                               int num_frames, void* stream) {
+    LstmArgs l;
+    l.xproj = xproj; l.x_type = elem_type; l.whh = whh_packed; l.planes = planes; l.out = out; l.out_type = elem_type;
+    l.B = batch; l.T = num_frames; l.groups = 1; l.x_gs = l.w_gs = l.out_gs = 0;
+    return amtx_launch_bilstm(l, (hipStream_t)stream);
+}
+
+extern "C" int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold,
+                                  float* out, void* stream) {
+    return amtx_launch_pianoroll(logits, ld, col0, batch, num_frames, keys, threshold, out, (hipStream_t)stream);
+}

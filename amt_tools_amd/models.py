@@ -1,0 +1,342 @@
+"""
+Host-side mirror of amt-tools' TranscriptionModel plugin API (amt_tools/models/common.py,
+amt_tools/models/onsetsframes.py) for the Onsets & Frames hot path.
+
+Same class names, constructor arguments, attributes (`dim_in, profile, in_channels, model_complexity,
+frame_width, device, iter, frontend`), methods (`change_device, pre_proc, forward, post_proc,
+run_on_batch, model_name`) and -- because the sub-modules keep the reference's attribute names --
+the same `state_dict()` keys, so reference checkpoints load and `amt_tools.train.train()` /
+`amt_tools.inference.run_offline()` accept these objects unchanged (seam S2).
+
+Execution paths
+---------------
+* eval mode on a CUDA (ROCm) device  -> the HIP inference engine behind include/amtx.h
+  (`amtx_of_forward`): conv1 -> conv3x3+BN+ReLU+pool (MFMA) -> fc1 (MFMA GEMM) -> persistent BiLSTM ->
+  LogisticBank heads -> piano roll.  No fallback: a missing extension raises.
+* training mode (autograd) and CPU devices -> stock torch ops on the same parameters (ATen; the
+  reference's own arithmetic).  Hand-written backward kernels are future work.
+
+`precision='bf16'` (default; bf16 MFMA operands, fp32 accumulate) or `'x3'` (split-bf16, fp32-class
+accuracy) selects the engine's dense arithmetic.
+"""
+
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import _lib, tools
+
+__all__ = ['TranscriptionModel', 'OutputLayer', 'LogisticBank', 'AcousticModel', 'LanguageModel', 'OnsetsFrames',
+           'SpectralFrontend']
+
+
+class TranscriptionModel(nn.Module):
+    """Generic transcription model (amt_tools/models/common.py:19-199)."""
+
+    def __init__(self, dim_in, profile, in_channels=1, model_complexity=1, frame_width=1, device='cpu'):
+        nn.Module.__init__(self)
+        self.dim_in = dim_in
+        self.profile = profile
+        self.in_channels = in_channels
+        self.model_complexity = model_complexity
+        self.frame_width = frame_width
+        self.device = device
+        self.iter = 0
+        # hook for on-device front-ends (models/common.py:56-57); empty by default
+        self.frontend = nn.Sequential()
+
+    def change_device(self, device=None):
+        if device is None:
+            device = self.device
+        if isinstance(device, int):
+            device = torch.device(f'cuda:{device}' if torch.cuda.is_available() else 'cpu')
+        self.device = device
+        self.to(self.device)
+
+    def pre_proc(self, batch):
+        """To-device copy (the caller's dict is not modified) + optional front-end on the raw audio
+        (models/common.py:83-122)."""
+        batch = tools.dict_to_device(batch, self.device)
+        audio = tools.unpack_dict(batch, tools.KEY_AUDIO)
+        feats = tools.unpack_dict(batch, tools.KEY_FEATS)
+        if audio is not None and len(self.frontend):
+            frontend_feats = self.frontend(audio.unsqueeze(-2))
+            feats = frontend_feats if feats is None else torch.cat((feats, frontend_feats), dim=1)
+        batch[tools.KEY_FEATS] = feats
+        return batch
+
+    def forward(self, feats):
+        raise NotImplementedError
+
+    def post_proc(self, batch):
+        raise NotImplementedError
+
+    def run_on_batch(self, batch):
+        batch = self.pre_proc(batch)
+        batch[tools.KEY_OUTPUT] = self(batch[tools.KEY_FEATS])
+        output = self.post_proc(batch)
+        if tools.query_dict(batch, tools.KEY_TIMES):
+            output[tools.KEY_TIMES] = batch[tools.KEY_TIMES]
+        return output
+
+    @classmethod
+    def model_name(cls):
+        return cls.__name__
+
+
+class OutputLayer(nn.Module):
+    def __init__(self, dim_in, dim_out, weights=None):
+        super().__init__()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.weights = None
+        if weights is not None:
+            self.set_weights(np.asarray(weights).flatten())
+
+    def set_weights(self, weights, device='cpu'):
+        if isinstance(device, int):
+            device = torch.device(f'cuda:{device}' if torch.cuda.is_available() else 'cpu')
+        self.weights = torch.Tensor(weights).to(device)
+
+
+class LogisticBank(OutputLayer):
+    """Multi-label logistic output layer (amt_tools/models/common.py:486-620)."""
+
+    def __init__(self, dim_in, dim_out, weights=None):
+        super().__init__(dim_in, dim_out, weights)
+        self.output_layer = nn.Linear(self.dim_in, self.dim_out)
+
+    def forward(self, feats):
+        return self.output_layer(feats)
+
+    def get_loss(self, estimated, reference):
+        """BCE with logits; mean over frames, sum over keys, mean over the batch (common.py:541-584).
+        estimated (B,T,O) logits, reference (B,O,T)."""
+        est = estimated.transpose(-2, -1)
+        weight = self.weights.unsqueeze(-1) if self.weights is not None else None
+        loss = F.binary_cross_entropy_with_logits(est.float(), reference.float(), weight=weight, reduction='none')
+        return loss.mean(dim=-1).sum(dim=-1).mean()
+
+    def finalize_output(self, raw_output, threshold=None):
+        """sigmoid -> (B,O,T) -> optional threshold (common.py:586-620)."""
+        final = torch.sigmoid(raw_output.clone().detach()).transpose(-2, -1)
+        if threshold is not None:
+            final = tools.threshold_activations(final.contiguous(), threshold)
+        return final
+
+
+class AcousticModel(nn.Module):
+    """Kelz-style acoustic model (amt_tools/models/onsetsframes.py:330-463); module layout kept for
+    state_dict compatibility: layer{1,2,3}.0 = Conv2d, .1 = BatchNorm2d, fc1.0 = Linear."""
+
+    def __init__(self, dim_in, dim_out, in_channels=1, model_complexity=2):
+        super().__init__()
+        nf1 = nf2 = 16 * model_complexity
+        nf3 = 32 * model_complexity
+        self.layer1 = nn.Sequential(nn.Conv2d(in_channels, nf1, (3, 3), padding=1), nn.BatchNorm2d(nf1), nn.ReLU())
+        self.layer2 = nn.Sequential(nn.Conv2d(nf1, nf2, (3, 3), padding=1), nn.BatchNorm2d(nf2), nn.ReLU(),
+                                    nn.MaxPool2d((1, 2)), nn.Dropout(0.25))
+        self.layer3 = nn.Sequential(nn.Conv2d(nf2, nf3, (3, 3), padding=1), nn.BatchNorm2d(nf3), nn.ReLU(),
+                                    nn.MaxPool2d((1, 2)), nn.Dropout(0.25))
+        self.fc1 = nn.Sequential(nn.Linear(nf3 * (dim_in // 4), dim_out), nn.Dropout(0.50))
+
+    def forward(self, in_feats):
+        x = self.layer3(self.layer2(self.layer1(in_feats)))
+        x = x.transpose(-3, -2).flatten(-2)
+        return self.fc1(x)
+
+
+class LanguageModel(nn.Module):
+    """BiLSTM language model (amt_tools/models/onsetsframes.py:466-575).  The reference processes eval
+    inputs in `chunk_len`-frame chunks carrying the state; that is numerically the full-sequence
+    result (SURVEY finding F9), which is what this module computes."""
+
+    def __init__(self, dim_in, dim_out, chunk_len=512, bidirectional=True):
+        super().__init__()
+        self.dim_in = dim_in
+        self.dim_out = dim_out
+        self.chunk_len = chunk_len
+        self.num_directions = int(bidirectional) + 1
+        self.hidden_size = self.dim_out // self.num_directions
+        self.mlm = nn.LSTM(input_size=self.dim_in, hidden_size=self.hidden_size, batch_first=True, bidirectional=bidirectional)
+
+    def forward(self, in_feats):
+        return self.mlm(in_feats)[0]
+
+
+class SpectralFrontend(nn.Module):
+    """`TranscriptionModel.frontend` entry wrapping a GPU FeatureModule: (B,1,N) audio -> (B,C,F,T).
+    The tensor is produced in the model's (T,F)-major memory order and returned as a transposed view, so
+    the model's own transpose (onsetsframes.py:90) yields contiguous data without a copy."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, audio):
+        assert audio.dim() == 3 and audio.shape[1] == 1
+        feats = self.module.process_batch(audio[:, 0].float(), model_layout=True)    # (B,1,T,F)
+        return feats.transpose(-1, -2)
+
+
+class _OFEngine(object):
+    """ctypes handle of an amtx_of_model + its workspace, bound to one device."""
+
+    def __init__(self, model, device):
+        self.device = device
+        self.handle = C.c_void_p()
+        prec = {'bf16': 0, 'x3': 1}[model.precision]
+        L = _lib.lib()
+        with torch.cuda.device(device):
+            _lib.check(L.amtx_of_model_create(C.byref(self.handle), int(model.dim_in), int(model.in_channels),
+                                              int(model.model_complexity), int(model.profile.get_range_len()),
+                                              int(model.has_offsets), prec), 'amtx_of_model_create')
+        self.version = None
+        self.workspace = None
+
+    def sync_weights(self, model):
+        sd = model.state_dict()
+        version = tuple((k, v._version, v.data_ptr()) for k, v in sd.items() if v.dtype.is_floating_point)
+        if version == self.version:
+            return
+        L = _lib.lib()
+        keep = []
+        for k, v in sd.items():
+            if not v.dtype.is_floating_point or k.startswith('frontend.'):
+                continue
+            arr = v.detach().to('cpu', torch.float32).contiguous().numpy()
+            keep.append(arr)
+            _lib.check(L.amtx_of_model_set_tensor(self.handle, k.encode(), _lib.ptr(arr), arr.size), 'amtx_of_model_set_tensor')
+        with torch.cuda.device(self.device):
+            _lib.check(L.amtx_of_model_finalize(self.handle), 'amtx_of_model_finalize')
+        self.version = version
+
+    def forward(self, feats, want_logits=True):
+        """feats: (B,C,T,F) fp32 CUDA tensor (any strides).  Returns binary maps + raw logits."""
+        L = _lib.lib()
+        B, Cc, T, Fd = feats.shape
+        need = L.amtx_of_workspace_bytes(self.handle, B, T)
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(int(need), dtype=torch.uint8, device=feats.device)
+        n_out = self.n_out
+        opts = dict(dtype=torch.float32, device=feats.device)
+        onsets = torch.empty((B, n_out, T), **opts)
+        multi_pitch = torch.empty((B, n_out, T), **opts)
+        lo = torch.empty((B, T, n_out), **opts) if want_logits else None
+        lm = torch.empty((B, T, n_out), **opts) if want_logits else None
+        lp = torch.empty((B, T, n_out), **opts) if want_logits else None
+        sb, sc, st, sf = feats.stride()
+        with torch.cuda.device(feats.device):
+            _lib.check(L.amtx_of_forward(self.handle, _lib.ptr(feats), sb, sc, st, sf, B, T, _lib.ptr(self.workspace),
+                                         self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch), _lib.ptr(lo),
+                                         _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)), 'amtx_of_forward')
+        return onsets, multi_pitch, lo, lm, lp
+
+    def __del__(self):
+        try:
+            _lib.lib().amtx_of_model_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class OnsetsFrames(TranscriptionModel):
+    """Onsets & Frames V1 (amt_tools/models/onsetsframes.py:17-196)."""
+
+    has_offsets = False
+
+    def __init__(self, dim_in, profile, in_channels=1, model_complexity=2, detach_heads=False, device='cpu',
+                 precision='bf16'):
+        super().__init__(dim_in, profile, in_channels, model_complexity, 1, device)
+        assert precision in ('bf16', 'x3')
+        self.detach_heads = detach_heads
+        self.precision = precision
+        self.dim_am = 256 * self.model_complexity
+        self.dim_lm = 256 * (self.model_complexity - 1)
+        dim_out = self.profile.get_range_len()
+        self.onset_head = nn.Sequential(AcousticModel(self.dim_in, self.dim_am, self.in_channels, self.model_complexity),
+                                        LanguageModel(self.dim_am, self.dim_lm), LogisticBank(self.dim_lm, dim_out))
+        self.pitch_head = nn.Sequential(AcousticModel(self.dim_in, self.dim_am, self.in_channels, self.model_complexity),
+                                        LogisticBank(self.dim_am, dim_out))
+        self.dim_aj = 2 * dim_out
+        self.adjoin = nn.Sequential(LanguageModel(self.dim_aj, self.dim_lm), LogisticBank(self.dim_lm, dim_out))
+
+    # ---- engine management (device handles never enter state_dict / pickles, SURVEY finding F11) ----
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_engine', None)
+        state.pop('_engine_out', None)
+        return state
+
+    def _get_engine(self, device):
+        eng = self.__dict__.get('_engine')
+        if eng is None or eng.device != device:
+            eng = _OFEngine(self, device)
+            eng.n_out = self.profile.get_range_len()
+            self.__dict__['_engine'] = eng
+        eng.sync_weights(self)
+        return eng
+
+    def pre_proc(self, batch):
+        batch = super().pre_proc(batch)
+        # frequency <-> time (onsetsframes.py:90); a view, the engine takes strides
+        batch[tools.KEY_FEATS] = batch[tools.KEY_FEATS].transpose(-1, -2)
+        return batch
+
+    def forward(self, feats):
+        """feats (B,C,T,F) -> dict of raw logits (B,T,O) under 'onsets' and 'multi_pitch'."""
+        if feats.is_cuda and not self.training:
+            eng = self._get_engine(feats.device)
+            if feats.dtype != torch.float32:
+                feats = feats.float()
+            onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats.detach())
+            output = {tools.KEY_ONSETS: lo, tools.KEY_MULTIPITCH: lm}
+            # piano rolls already thresholded on the device; post_proc picks them up for these logits
+            self.__dict__['_engine_out'] = (lo, lm, onsets_bin, mp_bin, lp)
+            return output
+        self.__dict__.pop('_engine_out', None)
+        output = dict()
+        multi_pitch = self.pitch_head(feats)
+        onsets = self.onset_head(feats)
+        output[tools.KEY_ONSETS] = onsets
+        if self.detach_heads:
+            onsets = onsets.clone().detach()
+        joint = torch.cat((onsets, multi_pitch), -1)
+        output[tools.KEY_MULTIPITCH] = self.adjoin(joint)
+        return output
+
+    def post_proc(self, batch):
+        """Losses (when ground truth is present) + final piano rolls (onsetsframes.py:138-196)."""
+        output = batch[tools.KEY_OUTPUT]
+        onset_layer, pitch_layer = self.onset_head[-1], self.adjoin[-1]
+        onsets_est, multi_pitch_est = output[tools.KEY_ONSETS], output[tools.KEY_MULTIPITCH]
+        if tools.KEY_MULTIPITCH in batch.keys():
+            loss = dict()
+            multi_pitch_ref = batch[tools.KEY_MULTIPITCH]
+            loss[tools.KEY_LOSS_PITCH] = pitch_layer.get_loss(multi_pitch_est, multi_pitch_ref)
+            if tools.KEY_ONSETS in batch.keys():
+                onsets_ref = batch[tools.KEY_ONSETS]
+            else:
+                # intended behaviour of onsetsframes.py:176-178 (the reference's NumPy helper fails on tensors)
+                onsets_ref = tools.multi_pitch_to_onsets(multi_pitch_ref)
+            loss[tools.KEY_LOSS_ONSETS] = onset_layer.get_loss(onsets_est, onsets_ref)
+            loss[tools.KEY_LOSS_TOTAL] = loss[tools.KEY_LOSS_PITCH] + loss[tools.KEY_LOSS_ONSETS]
+            output[tools.KEY_LOSS] = loss
+        cached = self.__dict__.pop('_engine_out', None)
+        if cached is not None and cached[0] is onsets_est and cached[1] is multi_pitch_est:
+            output[tools.KEY_ONSETS], output[tools.KEY_MULTIPITCH] = cached[2], cached[3]
+        else:
+            output[tools.KEY_ONSETS] = onset_layer.finalize_output(onsets_est, 0.5)
+            output[tools.KEY_MULTIPITCH] = pitch_layer.finalize_output(multi_pitch_est, 0.5)
+        return output
+
+    def engine_logits(self, feats_bcft):
+        """Raw logits of all three LogisticBanks from the HIP engine for features (B,C,F,T) on the GPU:
+        dict with 'onsets', 'multi_pitch', 'pitch_head' (B,T,O) -- used by the parity tests."""
+        feats = feats_bcft.transpose(-1, -2)
+        eng = self._get_engine(feats.device)
+        onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats.float())
+        return {'onsets': lo, 'multi_pitch': lm, 'pitch_head': lp, 'onsets_bin': onsets_bin, 'multi_pitch_bin': mp_bin}

@@ -1,0 +1,162 @@
+"""
+Host-side contract pieces of amt_tools.tools that the hot path touches: dictionary keys
+(amt_tools/tools/constants.py:46-69,118-137), the PianoProfile (amt_tools/tools/instrument.py:13-100),
+dict plumbing with the reference's semantics (amt_tools/tools/utils.py:3505-3745) but without its
+repeated whole-batch deep copies, activation helpers and RMS normalisation.
+"""
+
+import numpy as np
+
+try:
+    import torch
+except Exception:   # pragma: no cover
+    torch = None
+
+# ---- dictionary keys / constants (values are the contract, amt_tools/tools/constants.py) ----------
+KEY_TRACK = 'track'
+KEY_AUDIO = 'audio'
+KEY_FS = 'fs'
+KEY_HOP = 'hop_length'
+KEY_FEATS = 'features'
+KEY_MULTIPITCH = 'multi_pitch'
+KEY_PITCHLIST = 'pitch_list'
+KEY_ONSETS = 'onsets'
+KEY_OFFSETS = 'offsets'
+KEY_TIMES = 'times'
+KEY_NOTES = 'notes'
+KEY_OUTPUT = 'model_output'
+KEY_LOSS = 'loss'
+KEY_LOSS_TOTAL = 'loss_total'
+KEY_LOSS_ONSETS = 'loss_onsets'
+KEY_LOSS_OFFSETS = 'loss_offsets'
+KEY_LOSS_PITCH = 'loss_pitch'
+DEFAULT_PIANO_LOWEST_PITCH = 21
+DEFAULT_PIANO_HIGHEST_PITCH = 108
+FLOAT32 = 'float32'
+FLOAT64 = 'float64'
+PYT_MODEL = 'model'
+PYT_STATE = 'opt-state'
+PYT_EXT = 'pt'
+
+
+class InstrumentProfile(object):
+    def __init__(self, low, high):
+        self.low = low
+        self.high = high
+
+    def get_midi_range(self):
+        return np.arange(self.low, self.high + 1)
+
+    def get_range_len(self):
+        return self.high - self.low + 1
+
+
+class PianoProfile(InstrumentProfile):
+    """88 keys, MIDI 21..108 (amt_tools/tools/instrument.py:65-100)."""
+
+    def __init__(self, low=None, high=None):
+        super().__init__(DEFAULT_PIANO_LOWEST_PITCH if low is None else low,
+                         DEFAULT_PIANO_HIGHEST_PITCH if high is None else high)
+
+    def get_num_dofs(self):
+        return 1
+
+
+# ---- dict plumbing ---------------------------------------------------------------------------------
+def unpack_dict(data, key):
+    """Entry for `key`, or None (amt_tools/tools/utils.py:3823-3853)."""
+    return data[key] if (isinstance(data, dict) and key in data) else None
+
+
+def query_dict(dictionary, key):
+    return isinstance(dictionary, dict) and key in dictionary.keys()
+
+
+def _map_dict(track, fn):
+    """New dict (recursively), every leaf passed through fn; the caller's dict is never mutated."""
+    out = dict()
+    for k, v in track.items():
+        out[k] = _map_dict(v, fn) if isinstance(v, dict) else fn(v)
+    return out
+
+
+def dict_to_device(track, device):
+    return _map_dict(track, lambda v: v.to(device) if torch is not None and isinstance(v, torch.Tensor) else v)
+
+
+def dict_to_dtype(track, dtype):
+    return _map_dict(track, lambda v: v.astype(dtype) if isinstance(v, np.ndarray) else v)
+
+
+def dict_to_tensor(track):
+    return _map_dict(track, lambda v: torch.from_numpy(v) if isinstance(v, np.ndarray) else v)
+
+
+def tensor_to_array(data):
+    if torch is not None and isinstance(data, torch.Tensor):
+        data = data.cpu().detach().numpy()
+    return data
+
+
+def dict_to_array(track):
+    return _map_dict(track, tensor_to_array)
+
+
+def dict_unsqueeze(track, dim=0):
+    def f(v):
+        if torch is not None and isinstance(v, torch.Tensor):
+            return v.unsqueeze(dim)
+        if isinstance(v, np.ndarray):
+            return np.expand_dims(v, axis=dim)
+        return v
+    return _map_dict(track, f)
+
+
+def dict_squeeze(track, dim=None):
+    def f(v):
+        if (torch is not None and isinstance(v, torch.Tensor)) or isinstance(v, np.ndarray):
+            if dim is None:
+                return v.squeeze()
+            if v.ndim > 0 and v.shape[dim] == 1:
+                return v.squeeze(dim)
+        return v
+    out = dict()
+    for k, v in track.items():
+        # the reference recurses into nested dicts WITHOUT forwarding `dim` (utils.py:3681-3683)
+        out[k] = dict_squeeze(v) if isinstance(v, dict) else f(v)
+    return out
+
+
+# ---- activation helpers ----------------------------------------------------------------------------
+def threshold_activations(activations, threshold=0.5):
+    """In place, like the reference (amt_tools/tools/utils.py:2896-2919): < thr -> 0, everything else -> 1."""
+    activations[activations < threshold] = 0
+    activations[activations != 0] = 1
+    return activations
+
+
+def multi_pitch_to_onsets(multi_pitch):
+    """Positive first difference along time, first frame counts (amt_tools/tools/utils.py:2381-2412).
+    Accepts ndarray or tensor; returns the same kind."""
+    if torch is not None and isinstance(multi_pitch, torch.Tensor):
+        onsets = torch.cat([multi_pitch[..., :1], multi_pitch[..., 1:] - multi_pitch[..., :-1]], dim=-1)
+        return torch.clamp(onsets, min=0)
+    onsets = np.concatenate([multi_pitch[..., :1], multi_pitch[..., 1:] - multi_pitch[..., :-1]], axis=-1)
+    onsets[onsets <= 0] = 0
+    return onsets
+
+
+def rms_norm(audio):
+    """Root-mean-square normalisation (amt_tools/tools/utils.py:2789-2814)."""
+    rms = np.sqrt(np.mean(audio ** 2))
+    if rms > 0:
+        audio = audio / rms
+    return audio
+
+
+def seed_everything(seed):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    if torch is not None:
+        torch.manual_seed(seed)

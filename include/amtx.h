@@ -73,6 +73,58 @@ int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, int64_t num_
 int amtx_spec_scale(const amtx_spec_plan* plan, const float* power, const float* clip_max, const float* ref,
                     int batch, int64_t num_frames, int transform, int layout, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Onsets & Frames inference engine (one call = TranscriptionModel.run_on_batch without the loss):
+ * amt_tools/models/common.py:151-184 run_on_batch, amt_tools/models/onsetsframes.py:94-136 forward,
+ * :138-196 post_proc (finalize_output, threshold 0.5), AcousticModel :330-463, LanguageModel :466-575,
+ * LogisticBank amt_tools/models/common.py:486-620.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct amtx_of_model amtx_of_model;
+
+int amtx_of_model_create(amtx_of_model** model, int dim_in, int in_channels, int model_complexity, int n_out,
+                         int has_offsets, int precision /* AMTX_PREC_* */);
+int amtx_of_model_destroy(amtx_of_model* model);
+/* hand over one tensor of the reference's state_dict under its own key (HOST pointer, fp32, row-major) */
+int amtx_of_model_set_tensor(amtx_of_model* model, const char* name, const float* host_data, int64_t numel);
+/* fold BatchNorm, permute fc1, merge LSTM biases, pack everything into MFMA fragment order, upload */
+int amtx_of_model_finalize(amtx_of_model* model);
+size_t amtx_of_workspace_bytes(const amtx_of_model* model, int batch, int num_frames);
+/* feats: fp32 features addressed as feats[b*stride_b + c*stride_c + t*stride_t + f*stride_f] (elements), so both
+ * the reference's (B,C,F,T) layout and the transposed (B,C,T,F) layout are accepted without a copy.
+ * out_onsets / out_multi_pitch: (B, n_out, T) fp32 in {0,1}.  logits_*: optional (B, T, n_out) fp32 raw logits. */
+int amtx_of_forward(const amtx_of_model* model, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+                    int64_t stride_f, int batch, int num_frames, void* workspace, size_t workspace_bytes,
+                    float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
+                    float* logits_pitch_head, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Op-level entry points (the kernels the engine is built from; used by the parity tests).
+ * Element types: 0 = bf16, 1 = fp32.  `planes` = 1 (bf16) or 2 (x3 split).  *_pack_* run on the host.
+ * ------------------------------------------------------------------------------------------------ */
+/* nn.Linear: C[M,N] = A[M,K] W[N,K]^T + bias  (models/onsetsframes.py:422-427, models/common.py:539) */
+int64_t amtx_linear_packed_elems(int n, int k, int planes);
+int amtx_linear_pack(const float* host_w, int n, int k, int planes, uint16_t* host_out);
+int amtx_linear_fwd(const void* a, int64_t lda, int a_type, const uint16_t* w_packed, int planes, const float* bias, void* c,
+                    int64_t ldc, int c_type, int64_t m, int n, int k, void* stream);
+/* Conv2d(32 -> c_out, 3x3, pad 1) + folded BatchNorm + ReLU + MaxPool(1,2), channels-last (models/onsetsframes.py:387-416) */
+int64_t amtx_conv3x3_packed_elems(int c_out, int planes);
+int amtx_conv3x3_pack(const float* host_w /*(c_out,32,3,3)*/, const float* host_scale /*[c_out] or null*/, int c_out, int planes,
+                      uint16_t* host_out);
+int amtx_conv3x3_fwd(const void* in, int elem_type, const uint16_t* w_packed, int planes, const float* shift, void* out, int batch,
+                     int num_frames, int num_bins, int c_out, void* stream);
+/* Conv2d(c_in -> c_out, 3x3, pad 1) + folded BatchNorm + ReLU for the first layer (models/onsetsframes.py:375-384) */
+int amtx_conv1_fwd(const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t, int64_t stride_f, const float* w,
+                   const float* shift, void* out, int out_type, int batch, int num_frames, int num_bins, int c_in, int c_out,
+                   void* stream);
+/* nn.LSTM(bidirectional, hidden 128) recurrence given xproj = W_ih x + b_ih + b_hh  (models/onsetsframes.py:498-529) */
+int64_t amtx_bilstm_packed_elems(int planes);
+int amtx_bilstm_pack(const float* host_whh_fwd, const float* host_whh_bwd /* (512,128) each */, int planes, uint16_t* host_out);
+int amtx_bilstm_fwd(const void* xproj /*(B,T,2,512)*/, const uint16_t* whh_packed, int planes, int elem_type, void* out /*(B,T,256)*/,
+                    int batch, int num_frames, void* stream);
+/* LogisticBank.finalize_output: sigmoid -> (B,keys,T) -> threshold (< 0: keep probabilities)  (models/common.py:586-620) */
+int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold, float* out,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

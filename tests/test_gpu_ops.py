@@ -1,0 +1,168 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI) against plain fp32 torch-CPU
+references of the same op.  Tolerances: 'x3' (split-bf16) is held to fp32-class error; 'bf16' to the
+rounding of bf16 operands (2^-9 relative per operand) accumulated in fp32."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+from amt_tools_amd import _lib   # noqa: E402
+
+BF16, F32 = 0, 1
+
+
+def _stream():
+    return _lib.current_stream()
+
+
+def _to_act(x, planes):
+    """fp32 tensor -> device activation tensor of the mode's storage type."""
+    return x.cuda().to(torch.bfloat16 if planes == 1 else torch.float32).contiguous()
+
+
+def _tol(planes, scale):
+    return (2e-5 if planes == 2 else 1.5e-2) * scale
+
+
+@pytest.mark.parametrize('planes', [1, 2])
+@pytest.mark.parametrize('m,n,k', [(300, 512, 3648), (1000, 1024, 512), (257, 88, 256), (64, 1024, 176), (5, 88, 512)])
+def test_linear(planes, m, n, k):
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    bias = torch.randn(n, generator=g)
+    packed = np.zeros(L.amtx_linear_packed_elems(n, k, planes), dtype=np.uint16)
+    wn = w.numpy()
+    _lib.check(L.amtx_linear_pack(_lib.ptr(wn), n, k, planes, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    a_d = _to_act(a, planes)
+    ref = F.linear(a_d.float().cpu().double(), w.double(), bias.double()).float()
+    for c_type in ([F32, BF16] if planes == 1 else [F32]):
+        ldc = n + 8
+        c = torch.zeros(m, ldc, dtype=torch.float32 if c_type == F32 else torch.bfloat16, device='cuda')
+        bias_d = bias.cuda()
+        _lib.check(L.amtx_linear_fwd(_lib.ptr(a_d), k, BF16 if planes == 1 else F32, _lib.ptr(wp), planes, _lib.ptr(bias_d),
+                                     _lib.ptr(c), ldc, c_type, m, n, k, _stream()), 'amtx_linear_fwd')
+        got = c[:, :n].float().cpu()
+        tol = _tol(planes, ref.abs().max().item()) + (2e-2 if c_type == BF16 else 0)
+        assert (got - ref).abs().max().item() < tol
+        assert torch.all(c[:, n:] == 0)                       # padding columns untouched
+    if planes == 1:   # fp32 A with bf16 arithmetic (the adjoin projection reads fp32 logits)
+        a32 = a.cuda()
+        c = torch.zeros(m, n, device='cuda')
+        _lib.check(L.amtx_linear_fwd(_lib.ptr(a32), k, F32, _lib.ptr(wp), 1, None, _lib.ptr(c), n, F32, m, n, k, _stream()))
+        ref2 = F.linear(a.bfloat16().double(), w.bfloat16().double()).float()
+        assert (c.cpu() - ref2).abs().max().item() < 1e-3 * ref2.abs().max().item()
+
+
+def _conv_ref(x_btfc, w, scale, shift):
+    """x (B,T,F,C) channels-last -> conv3x3 pad1 (no bias) * scale + shift -> ReLU -> MaxPool(1,2) -> (B,T,F/2,Co)."""
+    x = x_btfc.permute(0, 3, 1, 2).double()
+    y = F.conv2d(x, (w * scale[:, None, None, None]).double(), padding=1) + shift.double()[None, :, None, None]
+    y = F.max_pool2d(F.relu(y), (1, 2))
+    return y.permute(0, 2, 3, 1).float()
+
+
+@pytest.mark.parametrize('planes', [1, 2])
+@pytest.mark.parametrize('b,t,f,cout', [(2, 40, 229, 32), (1, 17, 114, 64), (3, 5, 36, 32), (1, 33, 18, 64), (1, 1, 2, 32)])
+def test_conv3x3_bn_relu_pool(planes, b, t, f, cout):
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(b * 1000 + t * 10 + f + cout)
+    x = torch.rand(b, t, f, 32, generator=g)
+    w = torch.randn(cout, 32, 3, 3, generator=g) / 17.0
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    packed = np.zeros(L.amtx_conv3x3_packed_elems(cout, planes), dtype=np.uint16)
+    _lib.check(L.amtx_conv3x3_pack(_lib.ptr(w.numpy()), _lib.ptr(scale.numpy()), cout, planes, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    x_d = _to_act(x, planes)
+    out = torch.full((b, t, f // 2, cout), -7.0, dtype=x_d.dtype, device='cuda')
+    shift_d = shift.cuda()
+    _lib.check(L.amtx_conv3x3_fwd(_lib.ptr(x_d), BF16 if planes == 1 else F32, _lib.ptr(wp), planes, _lib.ptr(shift_d),
+                                  _lib.ptr(out), b, t, f, cout, _stream()), 'amtx_conv3x3_fwd')
+    ref = _conv_ref(x_d.float().cpu(), w, scale, shift)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < _tol(planes, ref.abs().max().item()) + (1e-2 * ref.abs().max().item() if planes == 1 else 0), err
+
+
+@pytest.mark.parametrize('cin,f', [(1, 229), (6, 72)])
+@pytest.mark.parametrize('layout', ['bcft', 'bctf'])
+def test_conv1(cin, f, layout):
+    L = _lib.lib()
+    b, t, cout = 2, 19, 32
+    g = torch.Generator().manual_seed(cin + f)
+    x = torch.rand(b, cin, f, t, generator=g)                     # reference layout (B,C,F,T)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / 3.0
+    shift = torch.randn(cout, generator=g) * 0.1
+    xd = x.cuda() if layout == 'bcft' else x.transpose(-1, -2).contiguous().cuda().transpose(-1, -2)
+    sb, sc, sf, st = xd.stride()
+    out = torch.empty(b, t, f, cout, device='cuda')
+    w_d, shift_d = w.cuda(), shift.cuda()          # keep device copies alive across the launch
+    _lib.check(L.amtx_conv1_fwd(_lib.ptr(xd), sb, sc, st, sf, _lib.ptr(w_d), _lib.ptr(shift_d), _lib.ptr(out), F32,
+                                b, t, f, cin, cout, _stream()), 'amtx_conv1_fwd')
+    ref = F.relu(F.conv2d(x.transpose(-1, -2).double(), w.double(), shift.double(), padding=1)).permute(0, 2, 3, 1).float()
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+def _lstm_ref(xproj, whh_f, whh_b):
+    """xproj (B,T,2,512) -> (B,T,256), explicit loop in fp64."""
+    B, T = xproj.shape[:2]
+    out = torch.zeros(B, T, 256, dtype=torch.float64)
+    for d, whh in enumerate((whh_f.double(), whh_b.double())):
+        h = torch.zeros(B, 128, dtype=torch.float64)
+        c = torch.zeros(B, 128, dtype=torch.float64)
+        for s in range(T):
+            t = s if d == 0 else T - 1 - s
+            gates = xproj[:, t, d].double() + h @ whh.T
+            i, f, g, o = gates.chunk(4, dim=-1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            out[:, t, 128 * d:128 * (d + 1)] = h
+    return out.float()
+
+
+@pytest.mark.parametrize('planes', [1, 2])
+@pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (32, 200)])
+def test_bilstm(planes, b, t):
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(b * 100 + t)
+    xproj = torch.randn(b, t, 2, 512, generator=g)
+    whh_f = (torch.rand(512, 128, generator=g) - 0.5) * 0.3
+    whh_b = (torch.rand(512, 128, generator=g) - 0.5) * 0.3
+    packed = np.zeros(L.amtx_bilstm_packed_elems(planes), dtype=np.uint16)
+    _lib.check(L.amtx_bilstm_pack(_lib.ptr(whh_f.numpy()), _lib.ptr(whh_b.numpy()), planes, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    x_d = _to_act(xproj, planes)
+    out = torch.full((b, t, 256), 9.0, dtype=x_d.dtype, device='cuda')
+    _lib.check(L.amtx_bilstm_fwd(_lib.ptr(x_d), _lib.ptr(wp), planes, BF16 if planes == 1 else F32, _lib.ptr(out), b, t, _stream()),
+               'amtx_bilstm_fwd')
+    ref = _lstm_ref(x_d.float().cpu(), whh_f, whh_b)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < (3e-5 if planes == 2 else 3e-2), err
+
+
+def test_pianoroll_threshold_and_probabilities():
+    L = _lib.lib()
+    b, t, keys, ld, col0 = 3, 70, 88, 176, 88
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(b, t, ld, generator=g) * 3
+    logits[0, 0, col0] = 0.0            # sigmoid(0) = 0.5 is NOT < 0.5 -> 1
+    logits[0, 1, col0] = -1e-9          # rounds to 0.5 in fp32 -> 1, like the reference
+    logits[0, 2, col0] = -1e-3
+    ld_d = logits.cuda()
+    out = torch.empty(b, keys, t, device='cuda')
+    _lib.check(L.amtx_pianoroll_fwd(_lib.ptr(ld_d), ld, col0, b, t, keys, 0.5, _lib.ptr(out), _stream()))
+    act = torch.sigmoid(logits[:, :, col0:col0 + keys]).transpose(-1, -2).contiguous()
+    ref = act.clone()
+    ref[ref < 0.5] = 0
+    ref[ref != 0] = 1
+    assert torch.equal(out.cpu(), ref)
+    assert out[0, 0, 0] == 1 and out[0, 0, 1] == 1 and out[0, 0, 2] == 0
+    _lib.check(L.amtx_pianoroll_fwd(_lib.ptr(ld_d), ld, col0, b, t, keys, -1.0, _lib.ptr(out), _stream()))
+    assert (out.cpu() - act).abs().max().item() < 1e-6
