@@ -49,6 +49,10 @@ _SIGNATURES = {
     'amtx_of_model_finalize': (_I, [_P]),
     'amtx_of_workspace_bytes': (C.c_size_t, [_P, _I, _I]),
     'amtx_of_forward': (_I, [_P, _P, _L, _L, _L, _L, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
+    'amtx_of_num_stages': (_I, []),
+    'amtx_of_stage_name': (C.c_char_p, [_I]),
+    'amtx_of_profile_enable': (_I, [_P, _I]),
+    'amtx_of_profile_read': (_I, [_P, C.POINTER(C.c_double), C.POINTER(_I)]),
     'amtx_linear_packed_elems': (_L, [_I, _I, _I]),
     'amtx_linear_pack': (_I, [_P, _I, _I, _I, _P]),
     'amtx_linear_fwd': (_I, [_P, _L, _I, _P, _I, _P, _P, _L, _I, _L, _I, _I, _P]),

@@ -70,16 +70,20 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 4 bf16 = 2 VGPR
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // C/D of 16x16
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // C/D of 32x32
 
-// pack two floats into one dword of 2 x bf16 (round to nearest even); lo -> bits 0..15
+// pack two floats into one dword of 2 x bf16 (round to nearest even); lo -> bits 0..15.
+// gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32), reached through the native __bf16 type.
+typedef __attribute__((ext_vector_type(2))) float amtx_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 amtx_bf16x2;
 static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_rn(lo) | ((uint32_t)f32_to_bf16_rn(hi) << 16);
+    const amtx_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, amtx_bf16x2));
 }
 
 // split x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the two planes of the "x3" (split-bf16,
-// fp32-class accuracy) MFMA path.
-static __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
-    hi = f32_to_bf16_rn(x);
-    lo = f32_to_bf16_rn(x - bf16_to_f32(hi));
+// fp32-class accuracy) MFMA path.  Pairs at a time: one packed dword per plane.
+static __device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a, b);
+    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
 static __device__ __forceinline__ float wave_max_f32(float v) {

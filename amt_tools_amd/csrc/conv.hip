@@ -34,16 +34,9 @@ __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi,
     uint32_t h[4], l[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        bf16_t h0, h1, l0 = 0, l1 = 0;
-        if (split) {
-            split_bf16(f[2 * i], h0, l0);
-            split_bf16(f[2 * i + 1], h1, l1);
-        } else {
-            h0 = f32_to_bf16_rn(f[2 * i]);
-            h1 = f32_to_bf16_rn(f[2 * i + 1]);
-        }
-        h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        l[i] = 0;
+        if (split) split_bf16x2(f[2 * i], f[2 * i + 1], h[i], l[i]);
+        else h[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
     }
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);

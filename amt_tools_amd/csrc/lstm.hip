@@ -31,15 +31,112 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
 
+// FAST (bf16 mode): v_exp_f32 + v_rcp_f32 (1 ulp each) -- far below the bf16 rounding of h.
 template <bool FAST>
 __device__ __forceinline__ float sigmoid_f(float x) {
-    if (FAST) return __fdividef(1.0f, 1.0f + __expf(-x));
+    if (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
     return 1.0f / (1.0f + expf(-x));
 }
 template <bool FAST>
 __device__ __forceinline__ float tanh_f(float x) {
-    if (FAST) return 2.0f * __fdividef(1.0f, 1.0f + __expf(-2.0f * x)) - 1.0f;
+    if (FAST) return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * x)), -1.0f);
     return tanhf(x);
+}
+
+// raw (still packed) x-projection registers of one step: converting bf16 -> fp32 right after the load would
+// put the wait for the prefetch at the load instead of at the first use one step later.
+template <int X_TYPE> struct XRaw { typedef float4 type; };
+template <> struct XRaw<AMTX_T_BF16> { typedef uint2 type; };
+
+template <int X_TYPE>
+__device__ __forceinline__ void load_x(const char* xbase, int64_t row_off, typename XRaw<X_TYPE>::type (&dst)[2][4]) {
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t e = row_off + q * 128 + 16 * ub;
+            dst[ub][q] = *reinterpret_cast<const typename XRaw<X_TYPE>::type*>(xbase + e * (X_TYPE == AMTX_T_F32 ? 4 : 2));
+        }
+}
+__device__ __forceinline__ f32x4_t unpack_x(float4 v) { return (f32x4_t){v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ f32x4_t unpack_x(uint2 v) {
+    return (f32x4_t){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xffff0000u)};
+}
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its global loads/stores (the
+// x-projection prefetch and the h stores stay in flight across the barrier).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // keep the next step's register-only work (e.g. unpacking the prefetched x-projection) below this point:
+    // hoisted above, it would drag the wait for the prefetch to right behind its issue
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS, int X_TYPE, int OUT_TYPE, bool FAST>
+__device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)[2][4][4][NS], const typename XRaw<X_TYPE>::type (&xcur)[2][4],
+                                          typename XRaw<X_TYPE>::type (&xnext)[2][4], float (&c)[2][4], const char* xbase, char* obase, int t, int tnext,
+                                          bool has_next, int clip, int g, int wave, bool clip_ok) {
+    const char* hb = smem + cur * NS * HBUF_BYTES;
+    uint4 hf[4][NS];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+            hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBUF_BYTES + (clip * HP + 32 * ks + 8 * g) * 2);
+
+    // unconditional (the last step re-reads its own row): a branch here would make the compiler's waitcnt
+    // pass assume the prefetch may not have been issued and wait for it right away
+    load_x<X_TYPE>(xbase, (int64_t)(has_next ? tnext : t) * 1024, xnext);
+
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[ub][q] = unpack_x(xcur[ub][q]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][0], acc[ub][q]);
+                if (NS == 2) {
+                    acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][1], acc[ub][q]);
+                    acc[ub][q] = mfma16(wf[ub][q][ks][1], hf[ks][0], acc[ub][q]);
+                }
+            }
+
+    char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub) {
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ig = sigmoid_f<FAST>(acc[ub][0][r]);
+            const float fg = sigmoid_f<FAST>(acc[ub][1][r]);
+            const float gg = tanh_f<FAST>(acc[ub][2][r]);
+            const float og = sigmoid_f<FAST>(acc[ub][3][r]);
+            c[ub][r] = fg * c[ub][r] + ig * gg;
+            h[r] = og * tanh_f<FAST>(c[ub][r]);
+        }
+        uint2 hiw, low = make_uint2(0, 0);
+        if (NS == 2) {
+            split_bf16x2(h[0], h[1], hiw.x, low.x);
+            split_bf16x2(h[2], h[3], hiw.y, low.y);
+        } else {
+            hiw = make_uint2(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]));
+        }
+        const int hoff = (clip * HP + 32 * wave + 16 * ub + 4 * g) * 2;
+        *reinterpret_cast<uint2*>(hn + hoff) = hiw;
+        if (NS == 2) *reinterpret_cast<uint2*>(hn + HBUF_BYTES + hoff) = low;
+        if (clip_ok) {
+            const int64_t e = (int64_t)t * 256 + 16 * ub;
+            if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<uint2*>(obase + e * 2) = hiw;
+            else *reinterpret_cast<float4*>(obase + e * 4) = make_float4(h[0], h[1], h[2], h[3]);
+        }
+    }
+    lds_barrier();
 }
 
 template <int NS, int X_TYPE, int OUT_TYPE>
@@ -76,100 +173,28 @@ __global__ __launch_bounds__(256) void bilstm_kernel(LstmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[ub][r] = 0.f;
 
-    const int64_t xrow = 1024;   // elements per (b, t)
     const char* xbase = reinterpret_cast<const char*>(a.xproj) +
-                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * xrow + dir * 512 + 32 * wave + 4 * g) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
+                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + 32 * wave + 4 * g) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
     char* obase = reinterpret_cast<char*>(a.out) +
                   ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + 32 * wave + 4 * g) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
 
-    f32x4_t xv[2][4], xn[2][4];
-    auto load_x = [&](int t, f32x4_t (&dst)[2][4]) {
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t e = (int64_t)t * xrow + q * 128 + 16 * ub;
-                if (X_TYPE == AMTX_T_F32) {
-                    const float4 v = *reinterpret_cast<const float4*>(xbase + e * 4);
-                    dst[ub][q] = (f32x4_t){v.x, v.y, v.z, v.w};
-                } else {
-                    const uint2 v = *reinterpret_cast<const uint2*>(xbase + e * 2);
-                    dst[ub][q] = (f32x4_t){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                                           __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
-                }
-            }
-    };
-    load_x(dir == 0 ? 0 : T - 1, xv);
+    typename XRaw<X_TYPE>::type xa[2][4], xb[2][4];
+    load_x<X_TYPE>(xbase, (int64_t)(dir == 0 ? 0 : T - 1) * 1024, xa);
     __syncthreads();
 
-    int cur = 0;
-    for (int s = 0; s < T; ++s) {
-        const int t = dir == 0 ? s : T - 1 - s;
-        const char* hb = smem + cur * NS * HBUF_BYTES;
-        uint4 hf[4][NS];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int p = 0; p < NS; ++p)
-                hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBUF_BYTES + (clip * HP + 32 * ks + 8 * g) * 2);
-
-        if (s + 1 < T) load_x(dir == 0 ? s + 1 : T - 2 - s, xn);
-
-        f32x4_t acc[2][4];
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[ub][q] = xv[ub][q];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][0], acc[ub][q]);
-                    if (NS == 2) {
-                        acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][1], acc[ub][q]);
-                        acc[ub][q] = mfma16(wf[ub][q][ks][1], hf[ks][0], acc[ub][q]);
-                    }
-                }
-
-        char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub) {
-            float h[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ig = sigmoid_f<FAST>(acc[ub][0][r]);
-                const float fg = sigmoid_f<FAST>(acc[ub][1][r]);
-                const float gg = tanh_f<FAST>(acc[ub][2][r]);
-                const float og = sigmoid_f<FAST>(acc[ub][3][r]);
-                c[ub][r] = fg * c[ub][r] + ig * gg;
-                h[r] = og * tanh_f<FAST>(c[ub][r]);
-            }
-            bf16_t hi[4], lo[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (NS == 2) split_bf16(h[r], hi[r], lo[r]);
-                else hi[r] = f32_to_bf16_rn(h[r]);
-            }
-            const int hoff = (clip * HP + 32 * wave + 16 * ub + 4 * g) * 2;
-            const uint2 hiw = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
-            *reinterpret_cast<uint2*>(hn + hoff) = hiw;
-            if (NS == 2)
-                *reinterpret_cast<uint2*>(hn + HBUF_BYTES + hoff) =
-                    make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
-            if (clip_ok) {
-                const int64_t e = (int64_t)t * 256 + 16 * ub;
-                if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<uint2*>(obase + e * 2) = hiw;
-                else *reinterpret_cast<float4*>(obase + e * 4) = make_float4(h[0], h[1], h[2], h[3]);
-            }
+    // two steps per iteration so the prefetched x-projection registers alternate (xa <-> xb) without a copy:
+    // the wait for a prefetch then sits at its first use, one full step after it was issued.
+    for (int s = 0; s < T; s += 2) {
+        {
+            const int t = dir == 0 ? s : T - 1 - s;
+            const int tn = dir == 0 ? s + 1 : T - 2 - s;
+            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, xa, xb, c, xbase, obase, t, tn, s + 1 < T, clip, g, wave, clip_ok);
         }
-#pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xv[ub][q] = xn[ub][q];
-        __syncthreads();
-        cur ^= 1;
+        if (s + 1 < T) {
+            const int t = dir == 0 ? s + 1 : T - 2 - s;
+            const int tn = dir == 0 ? s + 2 : T - 3 - s;
+            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, xb, xa, c, xbase, obase, t, tn, s + 2 < T, clip, g, wave, clip_ok);
+        }
     }
 }
 

@@ -64,7 +64,15 @@ struct amtx_of_model {
     DevBuf adj_hh;
     LinearPack adj_out;
     int dim_aj;
+    // optional per-stage timing with HIP events recorded on the launch stream (bench.py roofline)
+    mutable bool prof = false;
+    mutable std::vector<std::vector<hipEvent_t>> prof_events;
 };
+
+enum { ST_CONV1 = 0, ST_CONV2, ST_CONV3, ST_FC1, ST_REC_XPROJ, ST_REC_LSTM, ST_REC_HEAD, ST_PITCH_HEAD, ST_ADJ_XPROJ, ST_ADJ_LSTM,
+       ST_ADJ_HEAD, ST_PIANOROLL, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"conv1", "conv2_pool", "conv3_pool", "fc1_gemm", "rec_xproj_gemm", "rec_bilstm", "rec_head_gemm",
+                                            "pitch_head_gemm", "adj_xproj_gemm", "adj_bilstm", "adj_head_gemm", "pianoroll"};
 
 namespace {
 
@@ -347,6 +355,17 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     const int64_t BT = (int64_t)B * T;
     const int F = m->dim_in, F2 = F / 2, at = m->act_type, pl = m->planes;
     int rc;
+    std::vector<hipEvent_t>* evs = nullptr;
+    if (m->prof) {
+        m->prof_events.emplace_back();
+        evs = &m->prof_events.back();
+    }
+    auto mark = [&]() {
+        if (!evs) return;
+        hipEvent_t e;
+        if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, s); evs->push_back(e); }
+    };
+    mark();
 
     Conv1Args c1;
     c1.in = feats; c1.stride_b = stride_b; c1.stride_c = stride_c; c1.stride_t = stride_t; c1.stride_f = stride_f;
@@ -354,6 +373,7 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     c1.B = B; c1.T = T; c1.F = F; c1.c_in = m->in_channels; c1.c_out = m->nf1;
     c1.groups = m->n_heads; c1.w_gs = (int64_t)m->nf1 * m->in_channels * 9; c1.shift_gs = m->nf1; c1.out_gs = BT * F * m->nf1;
     if ((rc = amtx_launch_conv1(c1, s)) != AMTX_OK) return rc;
+    mark();
 
     ConvArgs c2;
     c2.in = w.a1; c2.in_type = at; c2.wfrag = (const bf16_t*)m->conv2_w.p; c2.planes = pl; c2.shift = (const float*)m->conv2_s.p;
@@ -361,44 +381,55 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf2, pl); c2.shift_gs = m->nf2;
     c2.out_gs = BT * F2 * m->nf2;
     if ((rc = amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
+    mark();
 
     ConvArgs c3 = c2;
     c3.in = w.a2; c3.wfrag = (const bf16_t*)m->conv3_w.p; c3.shift = (const float*)m->conv3_s.p; c3.out = w.a3;
     c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2; c3.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl);
     c3.shift_gs = m->nf3; c3.out_gs = BT * m->fq * m->nf3;
     if ((rc = amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
+    mark();
 
     // fc1 for every acoustic head
     GemmArgs g = gemm_args(w.a3, m->kfc, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_heads, BT * m->kfc, BT * m->dim_am);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    mark();
 
     // recurrent heads: heads 0..n_rec-1 of `e`
     g = gemm_args(w.e, m->dim_am, at, m->rec_ih, pl, w.xp, 1024, at, BT, m->n_rec, BT * m->dim_am, BT * 1024);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    mark();
     LstmArgs l;
     l.xproj = w.xp; l.x_type = at; l.whh = (const bf16_t*)m->rec_hh.p; l.planes = pl; l.out = w.l1; l.out_type = at;
     l.B = B; l.T = T; l.groups = m->n_rec; l.x_gs = BT * 1024; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems(pl); l.out_gs = BT * m->dim_lm;
     if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
+    mark();
     // LogisticBank of each recurrent head -> joint[:, r*n_out : (r+1)*n_out]; group stride of C = n_out columns
     g = gemm_args(w.l1, m->dim_lm, at, m->rec_out, pl, w.joint, m->dim_aj, AMTX_T_F32, BT, m->n_rec, BT * m->dim_lm, m->n_out);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    mark();
     // pitch head LogisticBank -> last n_out columns of joint
     g = gemm_args(w.e + (size_t)(m->n_heads - 1) * BT * m->dim_am * amtx_tsize(at), m->dim_am, at, m->pitch_out, pl,
                   w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    mark();
 
     // adjoin
     g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    mark();
     l.xproj = w.xp2; l.whh = (const bf16_t*)m->adj_hh.p; l.out = w.l2; l.groups = 1;
     if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
+    mark();
     g = gemm_args(w.l2, m->dim_lm, at, m->adj_out, pl, w.mp, m->n_out, AMTX_T_F32, BT, 1, 0, 0);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    mark();
 
     // piano rolls (LogisticBank.finalize_output with threshold 0.5)
     if (out_onsets && (rc = amtx_launch_pianoroll((const float*)w.joint, m->dim_aj, 0, B, T, m->n_out, 0.5f, out_onsets, s)) != AMTX_OK) return rc;
     if (out_multi_pitch && (rc = amtx_launch_pianoroll((const float*)w.mp, m->n_out, 0, B, T, m->n_out, 0.5f, out_multi_pitch, s)) != AMTX_OK) return rc;
 
+    mark();
     // optional raw logits, contiguous (B, T, n_out)
     const size_t row = (size_t)m->n_out * sizeof(float);
     if (logits_onsets)
@@ -408,5 +439,35 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
                                         hipMemcpyDeviceToDevice, s));
     if (logits_multi_pitch)
         AMTX_CHECK_HIP(hipMemcpyAsync(logits_multi_pitch, w.mp, row * BT, hipMemcpyDeviceToDevice, s));
+    return AMTX_OK;
+}
+
+extern "C" int amtx_of_num_stages(void) { return ST_COUNT; }
+extern "C" const char* amtx_of_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+
+extern "C" int amtx_of_profile_enable(amtx_of_model* m, int enable) {
+    AMTX_REQUIRE(m, "amtx_of_profile_enable: null model");
+    for (auto& v : m->prof_events)
+        for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    m->prof_events.clear();
+    m->prof = enable != 0;
+    return AMTX_OK;
+}
+
+// Sum of per-stage durations (ms) over all forwards since profiling was enabled; waits for them to finish.
+extern "C" int amtx_of_profile_read(amtx_of_model* m, double* stage_ms, int* num_forwards) {
+    AMTX_REQUIRE(m && stage_ms && num_forwards, "amtx_of_profile_read: null argument");
+    for (int i = 0; i < ST_COUNT; ++i) stage_ms[i] = 0.0;
+    *num_forwards = 0;
+    for (auto& v : m->prof_events) {
+        if ((int)v.size() != ST_COUNT + 1) continue;
+        AMTX_CHECK_HIP(hipEventSynchronize(v.back()));
+        for (int i = 0; i < ST_COUNT; ++i) {
+            float ms = 0.f;
+            AMTX_CHECK_HIP(hipEventElapsedTime(&ms, v[i], v[i + 1]));
+            stage_ms[i] += ms;
+        }
+        ++*num_forwards;
+    }
     return AMTX_OK;
 }

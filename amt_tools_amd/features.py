@@ -187,6 +187,7 @@ class _SpecPlanOwner(object):
     def __getstate__(self):   # plans hold device pointers: never pickle them (DataLoader workers, torch.save)
         state = dict(self.__dict__)
         state.pop('_plan', None)
+        state.pop('_prof_events', None)
         return state
 
     def __del__(self):
@@ -211,9 +212,29 @@ class _SpecPlanOwner(object):
         power = torch.empty((B, T, F), dtype=torch.float32, device=audio.device)
         clip_max = torch.empty((B,), dtype=torch.float32, device=audio.device)
         with torch.cuda.device(audio.device):
+            ev = self._prof_begin()
             _lib.check(L.amtx_spec_power(plan, _lib.ptr(audio), N, audio.stride(0), B, _lib.ptr(power), _lib.ptr(clip_max),
                                          _lib.current_stream(audio.device)), 'amtx_spec_power')
+            self._prof_end('spec_power', ev)
         return power, clip_max
+
+    # optional per-kernel timing (bench.py): events are recorded on the current stream, which is the stream
+    # the kernels are launched on
+    def _prof_begin(self):
+        if self.__dict__.get('_prof_events') is None:
+            return None
+        import torch
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
+    def _prof_end(self, name, ev):
+        if ev is None:
+            return
+        import torch
+        end = torch.cuda.Event(enable_timing=True)
+        end.record()
+        self._prof_events.append((name, ev, end))
 
     def scale_batch(self, power, clip_max, ref=None, model_layout=False):
         """K2: dB / scale + layout.  Returns (B,1,F,T) (reference layout) or (B,1,T,F) (model layout)."""
@@ -226,9 +247,11 @@ class _SpecPlanOwner(object):
             transform = 1 if self._linear_is_power else 2
         out = torch.empty((B, 1, T, F) if model_layout else (B, 1, F, T), dtype=torch.float32, device=power.device)
         with torch.cuda.device(power.device):
+            ev = self._prof_begin()
             _lib.check(L.amtx_spec_scale(self._get_plan(), _lib.ptr(power), _lib.ptr(clip_max), _lib.ptr(ref), B, T, transform,
                                          1 if model_layout else 0, _lib.ptr(out), _lib.current_stream(power.device)),
                        'amtx_spec_scale')
+            self._prof_end('spec_scale', ev)
         return out
 
     def process_batch(self, audio, ref=None, model_layout=False):

@@ -97,6 +97,13 @@ int amtx_of_forward(const amtx_of_model* model, const float* feats, int64_t stri
                     float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                     float* logits_pitch_head, void* stream);
 
+/* Per-stage timing of amtx_of_forward with HIP events recorded on the launch stream (used by bench.py for the
+ * live roofline figure; no reference counterpart -- the reference has no profiling). */
+int amtx_of_num_stages(void);
+const char* amtx_of_stage_name(int stage);
+int amtx_of_profile_enable(amtx_of_model* model, int enable);
+int amtx_of_profile_read(amtx_of_model* model, double* stage_ms /*[amtx_of_num_stages()]*/, int* num_forwards);
+
 /* ------------------------------------------------------------------------------------------------
  * Op-level entry points (the kernels the engine is built from; used by the parity tests).
  * Element types: 0 = bf16, 1 = fp32.  `planes` = 1 (bf16) or 2 (x3 split).  *_pack_* run on the host.
