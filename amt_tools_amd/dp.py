@@ -1,0 +1,138 @@
+"""
+Clip-level data parallelism for the training step (BASELINE config 4).
+
+The reference has no distributed code at all (amt_tools/train.py:62-64 is a TODO) and `train()` must
+stay unchanged, so the exchange step lives in an object `train()` already calls: the optimizer.
+
+    one process per GPU (torch.distributed, backend 'nccl' = RCCL over xGMI; 'gloo' on CPU for tests)
+    identical initial weights on every rank, each rank draws its own clips
+    train.py:130  loss.backward()            -- local gradients
+    train.py:137  optimizer.step()           -- DataParallelOptimizer.step():
+                                                 flatten grads -> ONE all-reduce (sum) over the flat fp32
+                                                 buffer (4.85 M values = 19.4 MB for OF1) -> / world ->
+                                                 unflatten -> inner optimizer step
+
+The loss is already a batch mean (amt_tools/models/common.py:582), so averaging gradients over ranks is
+the gradient of the mean over the global batch.  BatchNorm uses per-rank batch statistics (the reference
+has neither DP nor SyncBN); `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` keeps the state_dict
+keys if global statistics are wanted.
+
+`train()` re-initialises the optimizer in place on resume with
+`super(type(optimizer), optimizer).__init__(model.parameters(), optimizer.defaults)` (train.py:111); the
+wrapper therefore derives directly from `torch.optim.Optimizer` (so that call lands on the base class) and
+re-binds the inner optimizer to its own `param_groups` / `state` at every step.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+__all__ = ['init_distributed', 'DataParallelOptimizer', 'broadcast_parameters', 'shard_indices', 'rank_log_dir']
+
+
+def init_distributed(backend=None):
+    """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*).  Returns (rank, world_size, device).  Single-process runs return (0, 1, device) untouched."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    use_gpu = torch.cuda.is_available()
+    device = torch.device(f'cuda:{local_rank}') if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world)
+    return rank, world, device
+
+
+def shard_indices(num_items, rank, world):
+    """Round-robin shard of independent units (clips / tracks): item i belongs to rank i % world."""
+    return list(range(rank, num_items, world))
+
+
+def rank_log_dir(log_dir, rank):
+    """Only rank 0 writes checkpoints/events into `log_dir`; other ranks get a throw-away sibling."""
+    return log_dir if rank == 0 else os.path.join(log_dir, f'.rank{rank}')
+
+
+def broadcast_parameters(model, src=0):
+    """Make every rank start from rank `src`'s parameters and buffers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src)
+
+
+class DataParallelOptimizer(torch.optim.Optimizer):
+    """Wraps an optimizer class; `step()` averages gradients over all ranks with one flat all-reduce first."""
+
+    def __init__(self, params, optimizer_cls=torch.optim.Adam, process_group=None, **optimizer_kwargs):
+        params = list(params)
+        inner = optimizer_cls(params, **optimizer_kwargs)
+        self.__dict__['_inner'] = inner
+        self.__dict__['_group'] = process_group
+        self.__dict__['_flat'] = None
+        super().__init__(params, dict(inner.defaults))
+
+    def _bind(self):
+        inner = self._inner
+        inner.param_groups = self.param_groups
+        inner.state = self.state
+        return inner
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self._group)
+        return 1
+
+    @torch.no_grad()
+    def allreduce_gradients(self):
+        world = self._world()
+        if world == 1:
+            return
+        params = [p for g in self.param_groups for p in g['params'] if p.requires_grad]
+        if not params:
+            return
+        numel = sum(p.numel() for p in params)
+        flat = self._flat
+        if flat is None or flat.numel() != numel or flat.device != params[0].device:
+            flat = torch.zeros(numel, dtype=torch.float32, device=params[0].device)
+            self.__dict__['_flat'] = flat
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._group)
+        flat.div_(world)
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[off:off + n].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[off:off + n].view_as(p))
+            off += n
+
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self.allreduce_gradients()
+        self._bind().step()
+        return loss
+
+    def __getstate__(self):
+        state = super().__getstate__()
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)

@@ -1,0 +1,116 @@
+"""Data-parallel training wrapper on CPU with the gloo backend, world_size 2 (the N>1 path of SURVEY 8(e)):
+one averaged step over two ranks == one single-process step on the concatenated batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from amt_tools_amd import tools
+from amt_tools_amd.dp import DataParallelOptimizer, broadcast_parameters, shard_indices, rank_log_dir
+from amt_tools_amd.models import OnsetsFrames
+
+DIM_IN, T = 16, 10
+
+
+def _make_model(seed):
+    torch.manual_seed(seed)
+    model = OnsetsFrames(DIM_IN, tools.PianoProfile(), 1, 2)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(m, torch.nn.BatchNorm2d):      # per-rank batch statistics are a documented difference; freeze them here
+            m.eval()
+    return model
+
+
+def _batch(idx):
+    rng = np.random.default_rng(100 + idx)
+    return {tools.KEY_FEATS: torch.from_numpy(rng.random((1, 1, DIM_IN, T)).astype(np.float32)),
+            tools.KEY_MULTIPITCH: torch.from_numpy((rng.random((1, 88, T)) < 0.1).astype(np.float32)),
+            tools.KEY_ONSETS: torch.from_numpy((rng.random((1, 88, T)) < 0.03).astype(np.float32))}
+
+
+def _cat(batches):
+    return {k: torch.cat([b[k] for b in batches]) for k in batches[0]}
+
+
+def _train_mode(model):
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    model = _make_model(seed=rank)                 # deliberately different init per rank ...
+    broadcast_parameters(model, src=0)             # ... made identical here
+    _train_mode(model)
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=1e-2)
+    for it in range(2):
+        mine = [_batch(4 * it + i) for i in shard_indices(4, rank, world)]
+        opt.zero_grad()
+        loss = model.run_on_batch(_cat(mine))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]
+        loss.backward()
+        opt.step()
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_equals_single_process_step(tmp_path):
+    out = str(tmp_path / 'rank0.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.set_num_threads(2)
+    model = _make_model(seed=0)
+    _train_mode(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    for it in range(2):
+        opt.zero_grad()
+        model.run_on_batch(_cat([_batch(4 * it + i) for i in range(4)]))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+        opt.step()
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            assert torch.allclose(got[k], v, atol=2e-5, rtol=1e-4), k
+
+
+def test_wrapper_survives_the_in_place_reinit_of_train_py():
+    """amt_tools/train.py:111 re-runs the optimizer base-class __init__ in place on resume, then loads the state."""
+    model = _make_model(0)
+    _train_mode(model)
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4)
+    model.run_on_batch(_batch(0))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+    opt.step()
+    state = opt.state_dict()
+    model2 = _make_model(0)
+    model2.load_state_dict(model.state_dict())
+    _train_mode(model2)
+    super(type(opt), opt).__init__(model2.parameters(), opt.defaults)
+    opt.load_state_dict(state)
+    before = model2.onset_head[2].output_layer.bias.detach().clone()
+    opt.zero_grad()
+    model2.run_on_batch(_batch(1))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+    opt.step()
+    assert not torch.equal(before, model2.onset_head[2].output_layer.bias)
+    assert opt.state_dict()['state'][0]['step'] == 2 or float(opt.state_dict()['state'][0]['step']) == 2.0
+
+
+def test_shard_helpers():
+    assert shard_indices(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))
+    assert rank_log_dir('/x', 0) == '/x' and rank_log_dir('/x', 3) == '/x/.rank3'

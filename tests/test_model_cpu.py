@@ -1,0 +1,94 @@
+"""Host logic of the TranscriptionModel mirror on CPU (torch path = training / autograd path): the
+reference's golden vectors (eval outputs, training losses and gradients), dict contract, pickling."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from amt_tools_amd import tools
+from amt_tools_amd.models import OnsetsFrames
+from amt_tools_amd.synth import synth_state_dict, of_state_dict_shapes
+
+
+def _model(g, **kw):
+    model = OnsetsFrames(int(g['dim_in']), tools.PianoProfile(), int(g.get('in_channels', 1)), int(g['model_complexity']), **kw)
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=int(g.get('in_channels', 1)),
+                          model_complexity=int(g['model_complexity']))
+    assert list(model.state_dict().keys()) == list(sd.keys())          # same keys, same order as the reference
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(s) for k, s in of_state_dict_shapes(
+        dim_in=int(g['dim_in']), in_channels=int(g.get('in_channels', 1)), model_complexity=int(g['model_complexity'])).items()}
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return model
+
+
+def test_eval_run_on_batch_matches_reference_on_cpu():
+    g = load_golden('of1_eval.npz')
+    model = _model(g)
+    model.eval()
+    batch = {tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_TIMES: torch.from_numpy(g['out_times'])}
+    with torch.no_grad():
+        out = model.run_on_batch(batch)
+    assert set(out.keys()) == {tools.KEY_ONSETS, tools.KEY_MULTIPITCH, tools.KEY_TIMES}
+    for key in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
+        near = np.abs(np.swapaxes(g['logits_' + key], -1, -2)) < 2e-5
+        assert np.all((out[key].numpy() == g['out_' + key]) | near)
+    assert batch[tools.KEY_FEATS].shape == (2, 1, 229, 40)            # caller's batch untouched
+
+
+def test_training_step_matches_reference_losses_and_grads():
+    g = load_golden('of1_train.npz')
+    model = _model(g)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    batch = {tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_MULTIPITCH: torch.from_numpy(g['multi_pitch']),
+             tools.KEY_ONSETS: torch.from_numpy(g['onsets'])}
+    out = model.run_on_batch(batch)
+    loss = out[tools.KEY_LOSS]
+    assert set(loss.keys()) == {tools.KEY_LOSS_PITCH, tools.KEY_LOSS_ONSETS, tools.KEY_LOSS_TOTAL}
+    assert abs(loss[tools.KEY_LOSS_PITCH].item() - float(g['loss_pitch'])) < 1e-3
+    assert abs(loss[tools.KEY_LOSS_ONSETS].item() - float(g['loss_onsets'])) < 1e-3
+    loss[tools.KEY_LOSS_TOTAL].backward()
+    named = dict(model.named_parameters())
+    for i, k in enumerate(g['grad_keys']):
+        ref = g[f'grad_{i}']
+        assert np.abs(named[str(k)].grad.numpy() - ref).max() / max(1e-6, np.abs(ref).max()) < 2e-3, k
+    # onsets derived from the multi-pitch labels when none are given (intended behaviour of onsetsframes.py:176-178)
+    out2 = model.run_on_batch({tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_MULTIPITCH: torch.from_numpy(g['multi_pitch'])})
+    assert torch.isfinite(out2[tools.KEY_LOSS][tools.KEY_LOSS_ONSETS])
+
+
+def test_pickle_roundtrip_and_attributes():
+    g = load_golden('of1_eval.npz')
+    model = _model(g)
+    for attr in ('dim_in', 'profile', 'in_channels', 'model_complexity', 'frame_width', 'device', 'iter', 'frontend'):
+        assert hasattr(model, attr)
+    assert model.model_name() == 'OnsetsFrames' and model.frame_width == 1 and len(model.frontend) == 0
+    model.iter += 3
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    clone = torch.load(buf, weights_only=False)
+    assert clone.iter == 3
+    for (k, a), (_, b) in zip(model.state_dict().items(), clone.state_dict().items()):
+        assert torch.equal(a, b), k
+    clone.change_device('cpu')
+    assert clone.device == 'cpu'
+
+
+def test_dict_plumbing_semantics():
+    t = {'a': np.ones((2, 3), dtype=np.float64), 'n': {'b': np.zeros(4)}, 's': 'x'}
+    f = tools.dict_to_dtype(t, 'float32')
+    assert f['a'].dtype == np.float32 and t['a'].dtype == np.float64 and f['s'] == 'x'
+    tt = tools.dict_unsqueeze(tools.dict_to_tensor(f))
+    assert tt['a'].shape == (1, 2, 3) and tt['n']['b'].shape == (1, 4)
+    back = tools.dict_squeeze(tools.dict_to_array(tt), dim=0)
+    assert back['a'].shape == (2, 3) and isinstance(back['a'], np.ndarray)
+    x = torch.tensor([[0.2, 0.5, 0.7]])
+    assert torch.equal(tools.threshold_activations(x.clone(), 0.5), torch.tensor([[0., 1., 1.]]))
+    mp = np.array([[0, 1, 1, 0, 1]], dtype=np.float32)
+    np.testing.assert_array_equal(tools.multi_pitch_to_onsets(mp), [[0, 1, 0, 0, 1]])
+    np.testing.assert_array_equal(tools.multi_pitch_to_onsets(torch.from_numpy(mp)).numpy(), [[0, 1, 0, 0, 1]])
