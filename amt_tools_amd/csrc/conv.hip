@@ -18,8 +18,8 @@ namespace {
 
 constexpr int CIN = 32;
 constexpr int TT = 16;              // frames per block tile = one MFMA N-tile
-constexpr int FT_MAX = 48;          // frequency columns per block tile (even)
-constexpr int PITCH = FT_MAX + 3;   // LDS positions per tile row (odd)
+constexpr int FT_MAX = 46;          // frequency columns per block tile (even)
+constexpr int PITCH = FT_MAX + 3;   // LDS positions per tile row: 49 = 1 (mod 4), see tile_off
 constexpr int ROWS = TT + 2;
 constexpr int PLANE_BYTES = ROWS * PITCH * 64;
 
@@ -28,7 +28,12 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
 }
 
-__device__ __forceinline__ int tile_off(int i, int j, int c) { return ((i * PITCH + j) * 4 + (c ^ ((i >> 2) & 3))) * 16; }
+// Byte offset of 16-byte chunk c of tile position (row i, column j).  A fragment read takes, per lane,
+// row = (lane & 15) + kh and chunk = lane >> 4.  With PITCH = 1 (mod 4) consecutive rows rotate through the four
+// 64-byte quarters of a 256-byte bank row; XOR-ing the chunk with 2*((i >> 2) & 1) then makes every
+// ds_read_b128 lane group ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte slots for every kh and column
+// (found by exhaustive search, tools/lds_swizzle_search.py).
+__device__ __forceinline__ int tile_off(int i, int j, int c) { return ((i * PITCH + j) * 4 + (c ^ (((i >> 2) & 1) << 1))) * 16; }
 
 __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi, uint4& lo) {
     uint32_t h[4], l[4];
@@ -43,7 +48,7 @@ __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi,
 }
 
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt) {
+__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int COUT = NT * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,29 +73,50 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
                 for (int p = 0; p < NS; ++p) wf[tap][nt][p] = w[((tap * NT + nt) * NS + p) * 64];
     }
 
-    // ---- stage the (TT+2) x (ft+2) x 32 input tile in LDS, zero outside the map
+    // ---- stage the (TT+2) x (ft+2) x 32 input tile in LDS, zero outside the map.  All global loads of a
+    // batch are issued before the first LDS store, so a block pays ~2 memory round trips for its tile instead
+    // of one per 16-byte item.
     const int cols = ft + 2;
-    const int items = ROWS * cols * 4;
-    for (int it = tid; it < items; it += 256) {
-        const int c = it & 3;
-        const int pos = it >> 2;
-        const int j = pos % cols, i = pos / cols;
-        const int t = t0 - 1 + i, f = f0 - 1 + j;
-        uint4 hi = make_uint4(0, 0, 0, 0), lo = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < a.T && f >= 0 && f < a.F) {
-            const int64_t e = ((int64_t)t * a.F + f) * CIN + c * 8;
-            if (IN_TYPE == AMTX_T_BF16) {
-                hi = *reinterpret_cast<const uint4*>(in + e * 2);
-            } else {
-                const float4* p = reinterpret_cast<const float4*>(in + e * 4);
-                const float4 x0 = p[0], x1 = p[1];
-                const float fv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                cvt8(fv, NS == 2, hi, lo);
+    const int npos = ROWS * cols;
+    const int c = tid & 3;                              // chunk handled by this thread (256 % 4 == 0)
+    constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 14
+    constexpr int BATCH = ITEMS / 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint4 v0[BATCH], v1[BATCH];
+        int off[BATCH];
+#pragma unroll
+        for (int n = 0; n < BATCH; ++n) {
+            const int pos = (tid >> 2) + 64 * (half * BATCH + n);
+            const int i = (pos * inv_cols) >> 16;       // pos / cols, exact for pos < 1024 (checked on the host)
+            const int j = pos - i * cols;
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            const bool ok = pos < npos && t >= 0 && t < a.T && f >= 0 && f < a.F;
+            off[n] = pos < npos ? tile_off(i, j, c) : -1;
+            v0[n] = make_uint4(0, 0, 0, 0);
+            v1[n] = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t e = ((int64_t)t * a.F + f) * CIN + c * 8;
+                if (IN_TYPE == AMTX_T_BF16) {
+                    v0[n] = *reinterpret_cast<const uint4*>(in + e * 2);
+                } else {
+                    v0[n] = *reinterpret_cast<const uint4*>(in + e * 4);
+                    v1[n] = *reinterpret_cast<const uint4*>(in + e * 4 + 16);
+                }
             }
         }
-        const int off = tile_off(i, j, c);
-        *reinterpret_cast<uint4*>(smem + off) = hi;
-        if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+#pragma unroll
+        for (int n = 0; n < BATCH; ++n) {
+            if (off[n] < 0) continue;
+            uint4 hi = v0[n], lo = make_uint4(0, 0, 0, 0);
+            if (IN_TYPE == AMTX_T_F32) {
+                const float fv[8] = {__uint_as_float(v0[n].x), __uint_as_float(v0[n].y), __uint_as_float(v0[n].z), __uint_as_float(v0[n].w),
+                                     __uint_as_float(v1[n].x), __uint_as_float(v1[n].y), __uint_as_float(v1[n].z), __uint_as_float(v1[n].w)};
+                cvt8(fv, NS == 2, hi, lo);
+            }
+            *reinterpret_cast<uint4*>(smem + off[n]) = hi;
+            if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off[n]) = lo;
+        }
     }
 
     // folded BN shift for this lane's 4*NT consecutive channels
@@ -185,7 +211,14 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt);
+    const int cols = ft + 2;
+    const int inv_cols = 65536 / cols + 1;
+    for (int pos = 0; pos < 1024; ++pos)
+        if (((pos * inv_cols) >> 16) != pos / cols) {
+            amtx_set_error("conv3x3: internal: reciprocal division inexact for cols=%d", cols);
+            return AMTX_ERR_ARG;
+        }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt, inv_cols);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

@@ -17,8 +17,11 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int TILE_BYTES = BM * BK * 2;   // one operand plane: 8 KiB
 
+// 64-byte rows; a fragment read takes row = base16 + (lane & 15), chunk = lane >> 4.  XOR-ing the chunk with
+// [0,2,3,1][(row >> 2) & 3] makes every ds_read_b128 lane group hit 16 distinct 16-byte slots
+// (tools/lds_swizzle_search.py; the plain (row >> 2) & 3 swizzle is 2-way).
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-    return (row * 4 + (chunk ^ ((row >> 2) & 3))) * 16;
+    return (row * 4 + (chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3))) * 16;
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
