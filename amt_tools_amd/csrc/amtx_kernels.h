@@ -30,8 +30,17 @@ struct ConvArgs {
     void* out; int out_type;                             // [B][T][F/2][c_out]
     int B, T, F, c_out;
     int groups; int64_t in_gs, w_gs, shift_gs, out_gs;   // per-group strides in elements
+    // optional fused first conv (C_in*9 <= 64 -> 32 channels): when `feats` is set, `in` is ignored and the
+    // kernel computes Conv(c_in->32)+BN+ReLU from the fp32 features straight into its LDS input tile
+    const float* feats = nullptr; int64_t f_stride_b = 0, f_stride_c = 0, f_stride_t = 0, f_stride_f = 0;
+    int c_in = 0;
+    const bf16_t* w1frag = nullptr; const float* shift1 = nullptr;   // per-group strides: w1_gs, 32
+    int64_t w1_gs = 0;
 };
 int amtx_launch_conv3x3(const ConvArgs& c, hipStream_t stream);
+size_t amtx_conv1_wfrag_elems(int c_in, int planes);
+// host packing of the fused first conv: weight (32, c_in, 3, 3) fp32 * scale[32] -> fragment order
+void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int planes, bf16_t* out);
 size_t amtx_conv3x3_wfrag_elems(int c_out, int planes);
 // host packing: weight (c_out, 32, 3, 3) fp32 * scale[c_out] -> fragment order
 void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int planes, bf16_t* out);

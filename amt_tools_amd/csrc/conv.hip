@@ -47,7 +47,10 @@ __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi,
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int NT, int NS, int IN_TYPE, int OUT_TYPE>
+constexpr int FROWS = ROWS + 2;      // feature tile rows of the fused first conv
+constexpr int FW = FT_MAX + 6;       // feature tile row pitch (floats)
+
+template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1>
 __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int COUT = NT * 16;
@@ -73,11 +76,93 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
                 for (int p = 0; p < NS; ++p) wf[tap][nt][p] = w[((tap * NT + nt) * NS + p) * 64];
     }
 
+    const int cols = ft + 2;
+    const int npos = ROWS * cols;
+    if constexpr (FUSE1) {
+        // ---- fused first conv: features (c_in, 20 x (ft+4)) -> LDS, then Conv(c_in->32)+BN+ReLU on the matrix
+        // cores (K = 9*c_in padded to 32/64, im2col patches gathered from LDS as the MFMA B operand), written
+        // straight into this kernel's input tile in fragment order.  a1 never touches HBM.
+        float* ftile = reinterpret_cast<float*>(smem + NS * PLANE_BYTES);
+        const int fcols = ft + 4;
+        const float* fb = a.feats + (int64_t)b * a.f_stride_b;
+        for (int it = tid; it < a.c_in * FROWS * fcols; it += 256) {
+            const int ci = it / (FROWS * fcols), r = it - ci * (FROWS * fcols);
+            const int fi = r / fcols, fj = r - fi * fcols;
+            const int t = t0 - 2 + fi, f = f0 - 2 + fj;
+            float v = 0.f;
+            if (t >= 0 && t < a.T && f >= 0 && f < a.F) v = fb[ci * a.f_stride_c + t * a.f_stride_t + f * a.f_stride_f];
+            ftile[(ci * FROWS + fi) * FW + fj] = v;
+        }
+        const int kvalid = 9 * a.c_in;
+        const int ksteps = (kvalid + 31) >> 5;          // 1 or 2
+        const int g1 = lane >> 4;
+        int koff[2][8];
+        uint4 w1[2][2][NS];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * ks + 8 * g1 + j;
+                const int ci = k / 9, tap = k - ci * 9, kh = tap / 3, kw = tap - kh * 3;
+                koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : -1;
+            }
+            const uint4* wp = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    w1[ks][nt][p] = ks < ksteps ? wp[((ks * 2 + nt) * NS + p) * 64] : make_uint4(0, 0, 0, 0);
+        }
+        float sh1[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh1[nt][r] = a.shift1[(int64_t)grp * 32 + g1 * 8 + 4 * nt + r];
+        __syncthreads();
+        const int ngroups = (npos + 15) >> 4;
+        for (int gi = wave; gi < ngroups; gi += 4) {
+            const int pos = gi * 16 + (lane & 15);
+            const int i = (pos * inv_cols) >> 16;
+            const int j = pos - i * cols;
+            const int base = i * FW + j;
+            f32x4_t acc1[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < ksteps) {
+                    float pv[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) pv[jj] = (koff[ks][jj] >= 0 && pos < npos) ? ftile[base + koff[ks][jj]] : 0.f;
+                    uint4 ph, pl;
+                    cvt8(pv, NS == 2, ph, pl);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc1[nt] = mfma16(w1[ks][nt][0], ph, acc1[nt]);
+                        if (NS == 2) {
+                            acc1[nt] = mfma16(w1[ks][nt][0], pl, acc1[nt]);
+                            acc1[nt] = mfma16(w1[ks][nt][1], ph, acc1[nt]);
+                        }
+                    }
+                }
+            }
+            if (pos < npos) {
+                const int t = t0 - 1 + i, f = f0 - 1 + j;
+                const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
+                float y[8];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[nt][r] + sh1[nt][r], 0.f) : 0.f;
+                uint4 hi, lo;
+                cvt8(y, NS == 2, hi, lo);
+                const int off = tile_off(i, j, g1);
+                *reinterpret_cast<uint4*>(smem + off) = hi;
+                if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+            }
+        }
+    } else {
     // ---- stage the (TT+2) x (ft+2) x 32 input tile in LDS, zero outside the map.  All global loads of a
     // batch are issued before the first LDS store, so a block pays ~2 memory round trips for its tile instead
     // of one per 16-byte item.
-    const int cols = ft + 2;
-    const int npos = ROWS * cols;
     const int c = tid & 3;                              // chunk handled by this thread (256 % 4 == 0)
     constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 14
     constexpr int BATCH = ITEMS / 2;
@@ -117,6 +202,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
             *reinterpret_cast<uint4*>(smem + off[n]) = hi;
             if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off[n]) = lo;
         }
+    }
+
     }
 
     // folded BN shift for this lane's 4*NT consecutive channels
@@ -194,7 +281,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
     }
 }
 
-template <int NT, int NS, int IN_TYPE, int OUT_TYPE>
+template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int fe = (a.F + 1) & ~1;
     const int ntf = (fe + FT_MAX - 1) / FT_MAX;
@@ -202,8 +289,8 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int ntt = (a.T + TT - 1) / TT;
     const int64_t nblocks = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
-    const size_t lds = (size_t)NS * PLANE_BYTES;
-    auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE>;
+    const size_t lds = (size_t)NS * PLANE_BYTES + (FUSE1 ? (size_t)a.c_in * FROWS * FW * sizeof(float) : 0);
+    auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1>;
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
@@ -225,8 +312,16 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
 
 template <int NT, int NS>
 int dispatch_types(const ConvArgs& a, hipStream_t s) {
-    if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16>(a, s);
-    if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32>(a, s);
+    if (a.feats) {
+        if (NT != 2) {
+            amtx_set_error("conv3x3: the fused first conv feeds a 32 -> 32 layer only");
+            return AMTX_ERR_UNSUPPORTED;
+        }
+        if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true>(a, s);
+        return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true>(a, s);
+    }
+    if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16, false>(a, s);
+    if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32, false>(a, s);
     amtx_set_error("conv3x3: in/out element types must match (bf16/bf16 or f32/f32)");
     return AMTX_ERR_UNSUPPORTED;
 }
@@ -314,8 +409,31 @@ void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int p
             }
 }
 
+size_t amtx_conv1_wfrag_elems(int c_in, int planes) { return (size_t)((9 * c_in + 31) / 32) * 2 * planes * 64 * 8; }
+
+void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int planes, bf16_t* out) {
+    const int kvalid = 9 * c_in, ksteps = (kvalid + 31) / 32;
+    for (int ks = 0; ks < ksteps; ++ks)
+        for (int nt = 0; nt < 2; ++nt)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 15;
+                const int co = (row >> 2) * 8 + 4 * nt + (row & 3);
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 32 * ks + 8 * (l >> 4) + j;
+                    const float v = k < kvalid ? w[(size_t)co * kvalid + k] * (scale ? scale[co] : 1.0f) : 0.0f;
+                    const bf16_t hi = f32_to_bf16_rn(v);
+                    const size_t base = ((size_t)(ks * 2 + nt) * planes) * 64 * 8 + (size_t)l * 8 + j;
+                    out[base] = hi;
+                    if (planes == 2) out[base + 64 * 8] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                }
+            }
+}
+
 int amtx_launch_conv3x3(const ConvArgs& a, hipStream_t stream) {
-    AMTX_REQUIRE(a.in && a.wfrag && a.shift && a.out, "conv3x3: null pointer");
+    AMTX_REQUIRE((a.in || a.feats) && a.wfrag && a.shift && a.out, "conv3x3: null pointer");
+    if (a.feats) {
+        AMTX_REQUIRE(a.w1frag && a.shift1 && a.c_in > 0 && 9 * a.c_in <= 64, "conv3x3: fused first conv needs w1frag/shift1 and 9*c_in <= 64");
+    }
     AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F >= 2 && a.groups > 0, "conv3x3: bad sizes");
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3: planes must be 1 or 2");
     const int key = (a.c_out / 16) * 10 + a.planes;

@@ -54,7 +54,8 @@ struct amtx_of_model {
     std::map<std::string, Tensor> tensors;
     bool finalized = false;
     // packed device weights (group-major)
-    DevBuf conv1_w, conv1_s, conv2_w, conv2_s, conv3_w, conv3_s;
+    DevBuf conv1_w, conv1_s, conv1_frag, conv2_w, conv2_s, conv3_w, conv3_s;
+    bool fuse_conv1 = false;                   // first conv computed inside the conv2 kernel (9*C_in <= 64)
     LinearPack fc1;                            // groups = n_heads
     LinearPack rec_ih;                         // groups = n_rec, N = 1024
     DevBuf rec_hh;                             // groups = n_rec
@@ -163,7 +164,7 @@ Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
     const int F = m->dim_in, F2 = F / 2;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
-    w.a1 = take(BT * F * m->nf1 * es * m->n_heads);
+    w.a1 = take(m->fuse_conv1 ? 256 : BT * F * m->nf1 * es * m->n_heads);
     w.a2 = take(BT * F2 * m->nf2 * es * m->n_heads);
     w.a3 = take(BT * m->fq * m->nf3 * es * m->n_heads);
     w.e = take(BT * m->dim_am * es * m->n_heads);
@@ -205,13 +206,14 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->head_names.push_back("pitch_head");
     m->n_heads = (int)m->head_names.size();
     m->dim_aj = (m->n_rec + 1) * n_out;
+    m->fuse_conv1 = (9 * in_channels <= 64) && m->nf1 == 32;
     *out = m;
     return AMTX_OK;
 }
 
 extern "C" int amtx_of_model_destroy(amtx_of_model* m) {
     if (!m) return AMTX_OK;
-    DevBuf* bufs[] = {&m->conv1_w, &m->conv1_s, &m->conv2_w, &m->conv2_s, &m->conv3_w, &m->conv3_s, &m->fc1.w, &m->fc1.b,
+    DevBuf* bufs[] = {&m->conv1_w, &m->conv1_s, &m->conv1_frag, &m->conv2_w, &m->conv2_s, &m->conv3_w, &m->conv3_s, &m->fc1.w, &m->fc1.b,
                       &m->rec_ih.w, &m->rec_ih.b, &m->rec_hh, &m->rec_out.w, &m->rec_out.b, &m->pitch_out.w, &m->pitch_out.b,
                       &m->adj_ih.w, &m->adj_ih.b, &m->adj_hh, &m->adj_out.w, &m->adj_out.b};
     for (DevBuf* b : bufs) b->release();
@@ -232,6 +234,9 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     const int nh = m->n_heads;
     // ---- acoustic heads
     std::vector<float> c1w((size_t)nh * m->nf1 * m->in_channels * 9), c1s((size_t)nh * m->nf1);
+    m->fuse_conv1 = (9 * m->in_channels <= 64) && m->nf1 == 32;
+    const size_t c1f_per = amtx_conv1_wfrag_elems(m->in_channels, m->planes);
+    std::vector<bf16_t> c1f(m->fuse_conv1 ? c1f_per * nh : 0);
     std::vector<bf16_t> c2w(amtx_conv3x3_wfrag_elems(m->nf2, m->planes) * nh), c3w(amtx_conv3x3_wfrag_elems(m->nf3, m->planes) * nh);
     std::vector<float> c2s((size_t)nh * m->nf2), c3s((size_t)nh * m->nf3);
     std::vector<std::vector<float>> fcw(nh), fcb(nh);
@@ -246,6 +251,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
             for (int i = 0; i < m->in_channels * 9; ++i)
                 c1w[((size_t)h * m->nf1 + co) * m->in_channels * 9 + i] = w[(size_t)co * m->in_channels * 9 + i] * scale[co];
         memcpy(c1s.data() + (size_t)h * m->nf1, shift.data(), sizeof(float) * m->nf1);
+        if (m->fuse_conv1) amtx_conv1_pack_host(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
 
         rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
         if (rc != AMTX_OK) return rc;
@@ -273,6 +279,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     int rc;
     if ((rc = m->conv1_w.upload(c1w.data(), c1w.size() * 4)) != AMTX_OK) return rc;
     if ((rc = m->conv1_s.upload(c1s.data(), c1s.size() * 4)) != AMTX_OK) return rc;
+    if (m->fuse_conv1 && (rc = m->conv1_frag.upload(c1f.data(), c1f.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv2_w.upload(c2w.data(), c2w.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv2_s.upload(c2s.data(), c2s.size() * 4)) != AMTX_OK) return rc;
     if ((rc = m->conv3_w.upload(c3w.data(), c3w.size() * 2)) != AMTX_OK) return rc;
@@ -372,7 +379,7 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     c1.w = (const float*)m->conv1_w.p; c1.shift = (const float*)m->conv1_s.p; c1.out = w.a1; c1.out_type = at;
     c1.B = B; c1.T = T; c1.F = F; c1.c_in = m->in_channels; c1.c_out = m->nf1;
     c1.groups = m->n_heads; c1.w_gs = (int64_t)m->nf1 * m->in_channels * 9; c1.shift_gs = m->nf1; c1.out_gs = BT * F * m->nf1;
-    if ((rc = amtx_launch_conv1(c1, s)) != AMTX_OK) return rc;
+    if (!m->fuse_conv1 && (rc = amtx_launch_conv1(c1, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c2;
@@ -380,10 +387,17 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     c2.out = w.a2; c2.out_type = at; c2.B = B; c2.T = T; c2.F = F; c2.c_out = m->nf2;
     c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf2, pl); c2.shift_gs = m->nf2;
     c2.out_gs = BT * F2 * m->nf2;
+    if (m->fuse_conv1) {   // Conv(c_in->32)+BN+ReLU computed inside the conv2 kernel; a1 is never materialised
+        c2.in = nullptr;
+        c2.feats = feats; c2.f_stride_b = stride_b; c2.f_stride_c = stride_c; c2.f_stride_t = stride_t; c2.f_stride_f = stride_f;
+        c2.c_in = m->in_channels; c2.w1frag = (const bf16_t*)m->conv1_frag.p; c2.shift1 = (const float*)m->conv1_s.p;
+        c2.w1_gs = (int64_t)amtx_conv1_wfrag_elems(m->in_channels, pl);
+    }
     if ((rc = amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c3 = c2;
+    c3.feats = nullptr; c3.w1frag = nullptr; c3.shift1 = nullptr; c3.c_in = 0;
     c3.in = w.a2; c3.wfrag = (const bf16_t*)m->conv3_w.p; c3.shift = (const float*)m->conv3_s.p; c3.out = w.a3;
     c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2; c3.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl);
     c3.shift_gs = m->nf3; c3.out_gs = BT * m->fq * m->nf3;
