@@ -182,6 +182,131 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 x bf16 fast path: 128x128x64 tiles, operands DMA'd HBM/L2 -> LDS with global_load_lds_dwordx4
+// (no VGPR round trip), double-buffered, one barrier per 64-deep k-tile.  global_load_lds writes a wave's
+// 64 x 16 B linearly (M0 base + lane*16), so the bank swizzle lives on the SOURCE address: LDS chunk q of a
+// 128-byte row holds logical chunk q ^ ((row >> 1) & 7); fragment reads apply the same involution and are
+// conflict-free for every ds_read_b128 lane group (tools/lds_swizzle_search.py).
+// Block ids are remapped so the n-tiles that share an A panel run back to back on one XCD (A is then read
+// from HBM once and re-read from that XCD's L2).
+constexpr int GBK = 64;
+constexpr int GTILE = BM * GBK * 2;   // 16 KiB per operand per buffer
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int C_TYPE>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][A 16K | W 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int grp = blockIdx.z;
+    const unsigned nbn = g.n_pad / BN;
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int n0 = (logical % nbn) * BN;
+    const int64_t m0 = (int64_t)(logical / nbn) * BM;
+
+    const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)grp * g.a_gs;
+    const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
+
+    // this wave DMAs rows [32*wave, 32*wave+32) of both tiles: 4 instructions x 8 rows each
+    const bf16_t* a_src[4];
+    const bf16_t* w_src[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int row = (wave * 4 + n) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t mr = m0 + row;
+        if (mr >= g.M) mr = g.M - 1;                      // rows past M are never stored; keep the read in bounds
+        a_src[n] = Abase + mr * g.lda + c * 8;
+        w_src[n] = Wbase + (int64_t)(n0 + row) * g.k_pad + c * 8;
+    }
+#define GLDS_ISSUE(k0, buf)                                                                                   \
+    do {                                                                                                      \
+        char* sb = smem + (buf) * 2 * GTILE + wave * 4096;                                                    \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                       \
+            __builtin_amdgcn_global_load_lds((const void*)(a_src[n] + (k0)), (lds_void_t*)(sb + n * 1024), 16, 0, 0);          \
+            __builtin_amdgcn_global_load_lds((const void*)(w_src[n] + (k0)), (lds_void_t*)(sb + GTILE + n * 1024), 16, 0, 0);  \
+        }                                                                                                     \
+    } while (0)
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.k_pad / GBK;
+    GLDS_ISSUE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) GLDS_ISSUE((kt + 1) * GBK, cur ^ 1);
+        const char* b = smem + cur * 2 * GTILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ar = wm * 64 + t * 16 + frow;
+                const int wr = wn * 64 + t * 16 + frow;
+                af[t] = *reinterpret_cast<const uint4*>(b + ar * 128 + (((kk * 4 + fchunk) ^ ((ar >> 1) & 7)) << 4));
+                wf[t] = *reinterpret_cast<const uint4*>(b + GTILE + wr * 128 + (((kk * 4 + fchunk) ^ ((wr >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef GLDS_ISSUE
+
+    const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
+    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+        if (n >= g.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
+            if (m >= g.M) continue;
+            const f32x4_t v = acc[nt][mt];
+            const float o0 = v[0] + bv[0], o1 = v[1] + bv[1], o2 = v[2] + bv[2], o3 = v[3] + bv[3];
+            if (C_TYPE == AMTX_T_F32) {
+                *reinterpret_cast<float4*>(Cbase + (m * g.ldc + n) * 4) = make_float4(o0, o1, o2, o3);
+            } else {
+                *reinterpret_cast<uint2*>(Cbase + (m * g.ldc + n) * 2) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+            }
+        }
+    }
+}
+
+template <int C_TYPE>
+int launch_glds(const GemmArgs& g, hipStream_t stream) {
+    const int64_t nblocks = ((g.M + BM - 1) / BM) * (g.n_pad / BN);
+    AMTX_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
+    const size_t lds = 4 * GTILE;
+    auto kern = gemm_glds_kernel<C_TYPE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, (unsigned)g.groups), dim3(256), lds, stream, g);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
 template <int A_TYPE, int C_TYPE, int NS>
 int launch(const GemmArgs& g, hipStream_t stream) {
     dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)(g.n_pad / BN), (unsigned)g.groups);
@@ -220,6 +345,9 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
+    if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {
+        return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16>(g, stream) : launch_glds<AMTX_T_F32>(g, stream);
+    }
     const int key = (g.a_type << 2) | (g.c_type << 1) | (g.planes - 1);
     switch (key) {
         case 0: return launch<AMTX_T_BF16, AMTX_T_BF16, 1>(g, stream);
