@@ -63,6 +63,7 @@ _SIGNATURES = {
     'amtx_bilstm_packed_elems': (_L, [_I]),
     'amtx_bilstm_pack': (_I, [_P, _P, _I, _P]),
     'amtx_bilstm_fwd': (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
+    'amtx_notes_decode': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'amtx_pianoroll_fwd': (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
 }
 

@@ -1,0 +1,161 @@
+"""
+Note / pitch-list estimation for the hot path's output, mirroring the estimators of amt_tools/transcribe.py
+that the paper scripts attach to Onsets & Frames (examples/papers/of_1.py:150-155):
+
+* `NoteTranscriber.estimate(raw_output)`  -- amt_tools/transcribe.py:717-763 (+ StackedNoteTranscriber :420-481,
+  tools.multi_pitch_to_notes tools/utils.py:369-471): binary (88,T) maps + times -> (K,3) rows
+  [onset_s, offset_s, midi_pitch].  Bit-exact with the reference, including the row order among equal onsets
+  (the reference argsorts by onset three times with NumPy's default, unstable sort; the same three passes run here).
+  The per-event Python `while` walk is replaced by a vectorised next-stop scan (host arrays) or by the HIP kernel
+  behind `amtx_notes_decode` (device tensors, whole batches: `decode_notes_batch`).
+* `PitchListWrapper.estimate` -- amt_tools/transcribe.py:1038-1071, tools.multi_pitch_to_pitch_list utils.py:1023-1062.
+
+The reference's own estimators keep working on this package's model output unchanged; these classes exist so a
+batched offline driver (BASELINE config 5) does not spend its time in per-note Python loops.
+"""
+
+import numpy as np
+
+from . import _lib, tools
+
+__all__ = ['NoteTranscriber', 'PitchListWrapper', 'multi_pitch_to_notes', 'decode_notes_batch', 'estimate_hop_length']
+
+
+def estimate_hop_length(times):
+    """Median regular spacing of a time grid (amt_tools/tools/utils.py:3197-3229)."""
+    if not len(times):
+        raise ValueError('Cannot estimate hop length from an empty time array.')
+    times = np.sort(times)
+    non_gaps = np.append([False], np.isclose(np.diff(times, n=2), 0))
+    if not np.sum(non_gaps):
+        raise ValueError('Time observations are too irregular.')
+    return np.median(np.diff(times)[non_gaps])
+
+
+def _impulses(x):
+    """Positive first difference along time, first frame counts (tools/utils.py:2381-2412), as booleans."""
+    x = np.asarray(x)
+    first = x[..., :1] > 0
+    return np.concatenate([first, (x[..., 1:] - x[..., :-1]) > 0], axis=-1)
+
+
+def _sort_by_onset(batched):
+    return batched[np.argsort(batched[..., 0])]
+
+
+def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low):
+    """(key, onset frame, offset frame) events in np.nonzero order -> (K,3) rows ordered like the reference."""
+    times_ext = np.append(times, times[-1] + estimate_hop_length(times))
+    if len(pitch_idcs) == 0:
+        return np.empty([0, 3])
+    batched = np.stack([times_ext[on_frames], times_ext[off_frames], (pitch_idcs + low).astype(np.float64)], axis=-1)
+    # sort_notes in multi_pitch_to_notes (utils.py:469), notes_to_stacked_notes (:745), stacked_notes_to_notes (:531)
+    for _ in range(3):
+        batched = _sort_by_onset(batched)
+    return batched
+
+
+def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH, onsets=None):
+    """Vectorised tools.multi_pitch_to_notes for host arrays: returns (K,3) batched notes."""
+    multi_pitch = np.asarray(multi_pitch)
+    if onsets is None:
+        imp = _impulses(multi_pitch)
+        active = multi_pitch != 0
+    else:
+        onsets = np.asarray(onsets)
+        imp = _impulses(onsets)
+        active = np.logical_or(onsets, multi_pitch)
+    T = multi_pitch.shape[-1]
+    stop = np.logical_or(~active, imp)
+    idx = np.where(stop, np.arange(T), T)
+    nearest = np.minimum.accumulate(idx[..., ::-1], axis=-1)[..., ::-1]          # nearest stop at >= t
+    after = np.concatenate([nearest[..., 1:], np.full(nearest.shape[:-1] + (1,), T)], axis=-1)   # strictly after t
+    pitch_idcs, frame_idcs = imp.nonzero()
+    return _events_to_notes(pitch_idcs, frame_idcs, after[pitch_idcs, frame_idcs], np.asarray(times), low)
+
+
+def decode_notes_batch(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH):
+    """Device path: (B,88,T) fp32 CUDA tensors (onsets may be None) -> list of B (K,3) float64 arrays.
+    `times` is one (T,) grid shared by the batch or a (B,T) array."""
+    import torch
+    assert multi_pitch.is_cuda and multi_pitch.dim() == 3
+    B, K, T = multi_pitch.shape
+    multi_pitch = multi_pitch.contiguous().float()
+    if onsets is not None:
+        onsets = onsets.contiguous().float()
+    cap = T // 2 + 2
+    pairs = torch.empty((B * K, cap, 2), dtype=torch.int32, device=multi_pitch.device)
+    counts = torch.empty((B * K,), dtype=torch.int32, device=multi_pitch.device)
+    with torch.cuda.device(multi_pitch.device):
+        _lib.check(_lib.lib().amtx_notes_decode(_lib.ptr(onsets), _lib.ptr(multi_pitch), B, K, T, cap, _lib.ptr(pairs), _lib.ptr(counts),
+                                                _lib.current_stream(multi_pitch.device)), 'amtx_notes_decode')
+    counts_h = counts.cpu().numpy().reshape(B, K)
+    pairs_h = pairs.cpu().numpy().reshape(B, K, cap, 2)
+    times = np.asarray(times)
+    out = []
+    for b in range(B):
+        ks, ons, offs = [], [], []
+        for k in np.nonzero(counts_h[b])[0]:
+            ev = pairs_h[b, k, :counts_h[b, k]][::-1]                 # kernel emits descending frames
+            ks.append(np.full(len(ev), k))
+            ons.append(ev[:, 0])
+            offs.append(ev[:, 1])
+        t = times[b] if times.ndim == 2 else times
+        if ks:
+            out.append(_events_to_notes(np.concatenate(ks), np.concatenate(ons), np.concatenate(offs), t, low))
+        else:
+            out.append(np.empty([0, 3]))
+    return out
+
+
+class NoteTranscriber(object):
+    """amt_tools.transcribe.NoteTranscriber with inhibition_window=None, minimum_duration=None (the paper scripts'
+    settings); other settings are not part of the hot path and raise."""
+
+    def __init__(self, profile, inhibition_window=None, minimum_duration=None, multi_pitch_key=None, onsets_key=None,
+                 offsets_key=None, estimates_key=None, save_dir=None):
+        if inhibition_window is not None or minimum_duration is not None:
+            raise NotImplementedError('inhibition_window / minimum_duration are outside the accelerated path')
+        self.profile = profile
+        self.multi_pitch_key = tools.KEY_MULTIPITCH if multi_pitch_key is None else multi_pitch_key
+        self.onsets_key = tools.KEY_ONSETS if onsets_key is None else onsets_key
+        self.estimates_key = tools.KEY_NOTES if estimates_key is None else estimates_key
+        self.save_dir = save_dir
+
+    @staticmethod
+    def get_default_key():
+        return tools.KEY_NOTES
+
+    def get_key(self):
+        return self.estimates_key
+
+    def estimate(self, raw_output):
+        multi_pitch = tools.tensor_to_array(tools.unpack_dict(raw_output, self.multi_pitch_key))
+        onsets = tools.tensor_to_array(tools.unpack_dict(raw_output, self.onsets_key))
+        times = tools.tensor_to_array(tools.unpack_dict(raw_output, tools.KEY_TIMES))
+        return multi_pitch_to_notes(multi_pitch, times, self.profile.low, onsets)
+
+    def process_track(self, raw_output, track=None):
+        return {self.get_key(): self.estimate(raw_output)}
+
+
+class PitchListWrapper(object):
+    def __init__(self, profile, multi_pitch_key=None, estimates_key=None, save_dir=None):
+        self.profile = profile
+        self.multi_pitch_key = tools.KEY_MULTIPITCH if multi_pitch_key is None else multi_pitch_key
+        self.estimates_key = tools.KEY_PITCHLIST if estimates_key is None else estimates_key
+
+    def get_key(self):
+        return self.estimates_key
+
+    def estimate(self, raw_output):
+        multi_pitch = tools.tensor_to_array(tools.unpack_dict(raw_output, self.multi_pitch_key))
+        times = tools.tensor_to_array(tools.unpack_dict(raw_output, tools.KEY_TIMES))
+        num_frames = multi_pitch.shape[-1]
+        pitch_list = [np.empty(0)] * num_frames
+        for i in np.where(np.sum(multi_pitch, axis=-2) > 0)[-1]:
+            pitch_list[i] = (self.profile.low + np.where(multi_pitch[..., i])[-1]).astype('float')
+        return times, pitch_list
+
+    def process_track(self, raw_output, track=None):
+        return {self.get_key(): self.estimate(raw_output)}

@@ -132,6 +132,13 @@ int amtx_bilstm_fwd(const void* xproj /*(B,T,2,512)*/, const uint16_t* whh_packe
 int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold, float* out,
                        void* stream);
 
+/* Note decoding: binary piano rolls (B, keys, T) fp32 -> per (clip, key) row the list of (onset frame, offset frame)
+ * events, `capacity` int32 pairs per row in DESCENDING frame order, and counts[B*keys].  onsets may be null (onsets are
+ * then the positive first difference of multi_pitch).  Replaces the event walk of tools.multi_pitch_to_notes
+ * (tools/utils.py:369-471) used by transcribe.NoteTranscriber (transcribe.py:420-481,722-763). */
+int amtx_notes_decode(const float* onsets, const float* multi_pitch, int batch, int keys, int num_frames, int capacity,
+                      int32_t* pairs, int32_t* counts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,3 +92,22 @@ def test_dict_plumbing_semantics():
     mp = np.array([[0, 1, 1, 0, 1]], dtype=np.float32)
     np.testing.assert_array_equal(tools.multi_pitch_to_onsets(mp), [[0, 1, 0, 0, 1]])
     np.testing.assert_array_equal(tools.multi_pitch_to_onsets(torch.from_numpy(mp)).numpy(), [[0, 1, 0, 0, 1]])
+
+
+def test_run_offline_contract_on_cpu():
+    from amt_tools_amd.inference import run_offline, run_offline_batched
+    from amt_tools_amd.transcribe import NoteTranscriber
+    g = load_golden('of1_eval.npz')
+    model = _model(g)
+    model.eval()
+    track = {tools.KEY_TRACK: 'x', tools.KEY_FEATS: g['feats'][0].astype(np.float64), tools.KEY_TIMES: g['out_times'][0]}
+    pred = run_offline(track, model, NoteTranscriber(tools.PianoProfile()))
+    assert pred[tools.KEY_ONSETS].shape == (88, 40) and isinstance(pred[tools.KEY_ONSETS], np.ndarray)
+    assert pred[tools.KEY_NOTES].ndim == 2 and pred[tools.KEY_NOTES].shape[1] == 3
+    near = np.abs(g['logits_multi_pitch'][0].T) < 2e-5
+    assert np.all((pred[tools.KEY_MULTIPITCH] == g['out_multi_pitch'][0]) | near)
+    # batched driver: every clip's result equals the single-clip result; shards partition the clips
+    res0 = run_offline_batched(g['feats'], model, batch_size=1, rank=0, world=2)
+    res1 = run_offline_batched(g['feats'], model, batch_size=1, rank=1, world=2)
+    assert sorted(res0) == [0] and sorted(res1) == [1]
+    np.testing.assert_array_equal(res0[0][tools.KEY_ONSETS], pred[tools.KEY_ONSETS])

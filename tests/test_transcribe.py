@@ -1,0 +1,77 @@
+"""Note decoding of the product (vectorised host path and HIP kernel) bit-exact against the reference
+NoteTranscriber's recorded output (tests/golden/notes_*.npz) and against the oracle on random maps."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from amt_tools_amd import tools
+from amt_tools_amd.transcribe import NoteTranscriber, PitchListWrapper, multi_pitch_to_notes
+from oracle import notes_np
+
+CASES = ['notes_dense.npz', 'notes_sparse.npz', 'notes_noonsets.npz', 'notes_empty.npz']
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_host_decoder_bit_exact_with_reference(name):
+    g = load_golden(name)
+    raw = {tools.KEY_MULTIPITCH: g['multi_pitch'].copy(), tools.KEY_TIMES: g['times'].copy()}
+    if int(g['with_onsets']):
+        raw[tools.KEY_ONSETS] = g['onsets'].copy()
+    notes = NoteTranscriber(tools.PianoProfile()).estimate(raw)
+    assert notes.shape == g['notes'].shape and np.array_equal(notes, g['notes'])
+    np.testing.assert_array_equal(raw[tools.KEY_MULTIPITCH], g['multi_pitch'])      # inputs not modified
+
+
+def test_host_decoder_random_maps_vs_oracle():
+    rng = np.random.default_rng(0)
+    for T in (1, 2, 63, 64, 65, 200):
+        mp = (rng.random((88, T)) < 0.3).astype(np.float32)
+        on = (rng.random((88, T)) < 0.1).astype(np.float32)
+        times = np.arange(T) * 512 / 22050.0 if T > 2 else np.arange(3)[:T] * 0.5
+        if T < 3:
+            continue                                             # the reference cannot estimate a hop from < 3 frames
+        for o in (on, None):
+            ref = notes_np.note_transcriber(mp, o, times)
+            got = multi_pitch_to_notes(mp, times, 21, o)
+            assert np.array_equal(got, ref)
+
+
+def test_pitch_list_wrapper():
+    mp = np.zeros((88, 4), dtype=np.float32)
+    mp[[3, 10], 1] = 1
+    mp[87, 3] = 1
+    times, pl = PitchListWrapper(tools.PianoProfile()).estimate({tools.KEY_MULTIPITCH: mp, tools.KEY_TIMES: np.arange(4.0)})
+    assert [list(p) for p in pl] == [[], [24.0, 31.0], [], [108.0]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_device_decoder_bit_exact_with_reference(name):
+    torch = pytest.importorskip('torch')
+    from amt_tools_amd.transcribe import decode_notes_batch
+    g = load_golden(name)
+    mp = torch.from_numpy(g['multi_pitch'])[None].cuda()
+    on = torch.from_numpy(g['onsets'])[None].cuda() if int(g['with_onsets']) else None
+    notes = decode_notes_batch(on, mp, g['times'])[0]
+    assert notes.shape == g['notes'].shape and np.array_equal(notes, g['notes'])
+
+
+@pytest.mark.gpu
+def test_device_decoder_full_size_batch_vs_host():
+    torch = pytest.importorskip('torch')
+    from amt_tools_amd.transcribe import decode_notes_batch
+    rng = np.random.default_rng(1)
+    B, T = 6, 625
+    mp = (rng.random((B, 88, T)) < 0.2).astype(np.float32)
+    on = (rng.random((B, 88, T)) < 0.05).astype(np.float32)
+    mp[0] = 1.0                                                   # every cell active: one long note per key
+    on[1] = 0.0
+    on[2, :, ::2] = 1.0                                           # the densest possible impulse train
+    on[2, :, 1::2] = 0.0
+    times = np.arange(T) * 512 / 22050.0
+    got = decode_notes_batch(torch.from_numpy(on).cuda(), torch.from_numpy(mp).cuda(), times)
+    for b in range(B):
+        assert np.array_equal(got[b], multi_pitch_to_notes(mp[b], times, 21, on[b]))
+    got2 = decode_notes_batch(None, torch.from_numpy(mp).cuda(), times)
+    for b in range(B):
+        assert np.array_equal(got2[b], multi_pitch_to_notes(mp[b], times, 21, None))
