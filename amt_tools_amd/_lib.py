@@ -63,6 +63,12 @@ _SIGNATURES = {
     'amtx_bilstm_packed_elems': (_L, [_I]),
     'amtx_bilstm_pack': (_I, [_P, _P, _I, _P]),
     'amtx_bilstm_fwd': (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
+    'amtx_cqt_plan_create': (_I, [C.POINTER(_P), _I, _I, C.c_double, _I, _I, C.c_double, C.POINTER(C.c_double), _I, _I, _I]),
+    'amtx_cqt_plan_destroy': (_I, [_P]),
+    'amtx_cqt_num_harmonics': (_I, [_P]),
+    'amtx_cqt_num_frames': (_L, [_P, _L]),
+    'amtx_cqt_workspace_bytes': (C.c_size_t, [_P, _I, _L]),
+    'amtx_cqt_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _P]),
     'amtx_notes_decode': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'amtx_pianoroll_fwd': (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
 }

@@ -1,0 +1,523 @@
+// Constant-Q / Variable-Q / Harmonic CQT front-end for gfx950.
+//
+// Replaces librosa.vqt as called from amt_tools/features/vqt.py:183-193 (CQT: cqt.py:22; HVQT/HCQT: one VQT per
+// harmonic, hvqt.py:45-58,107-133) plus abs -> amplitude_to_db(ref=max) -> /80+1 (features/common.py:199,218-228).
+//
+// librosa evaluates, per octave, a sparse FFT-domain wavelet basis against a "ones"-window STFT of the
+// progressively 2x-decimated signal.  Here the same linear map is applied in the time domain: for every bank
+// (harmonic, octave) the sparsified one-sided FFT basis is folded back on the host (fp64) into its equivalent
+// n_fft-tap complex kernel, all banks that live on the same decimation level are stacked into one matrix, and the
+// response of a level is ONE strided-row GEMM on the matrix cores
+//        R_d[t, :] = W_d . y_d[t*hop_d - n_fft/2 : t*hop_d + n_fft/2]          (A rows overlap: lda = hop_d)
+// in split-bf16 "x3" arithmetic (fp32-class accuracy: a bf16-only product would leak a strong partial into bins
+// 50 dB below it).  Harmonics that are octaves apart share the pyramid level and the launch.
+// The pyramid itself is a 301-tap Kaiser half-band decimator (the project's documented stand-in for soxr, which
+// is not bit-reproducible anyway), then |.|, per-(clip, harmonic) max, dB, /80+1.
+
+#include "amtx_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <vector>
+
+namespace {
+
+constexpr int DEC_HALF = 150;
+constexpr int DEC_TAPS = 2 * DEC_HALF + 1;
+constexpr double DEC_CUTOFF = 0.239;
+constexpr double DEC_BETA = 10.0;
+constexpr int MAX_BANKS = 16;          // banks per pyramid level
+constexpr double PI = 3.14159265358979323846;
+constexpr double HANN_BW = 1.50018310546875;
+
+struct BankDev { int col0, nf, harm, bin0, frames; };
+struct LevelDev { int nbanks; int ncols; BankDev b[MAX_BANKS]; };
+struct HarmFrames { int f[MAX_BANKS]; };
+
+double bessel_i0(double x) {
+    double s = 1.0, t = 1.0;
+    for (int k = 1; k < 200; ++k) {
+        t *= (x / (2.0 * k)) * (x / (2.0 * k));
+        s += t;
+        if (t < 1e-18 * s) break;
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------- kernels
+__global__ __launch_bounds__(256) void cqt_level0_kernel(const float* __restrict__ audio, int64_t n, int64_t astride, float* __restrict__ pyr,
+                                                         int64_t pstride, int pad) {
+    const int b = blockIdx.y;
+    const float* src = audio + (int64_t)b * astride;
+    float* dst = pyr + (int64_t)b * pstride + pad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in)
+__global__ __launch_bounds__(256) void cqt_decimate_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
+                                                           int64_t n_out, int64_t out_stride, int pad, const float* __restrict__ taps) {
+    constexpr int CH = 1024;                        // outputs per block
+    __shared__ float xs[2 * CH + DEC_TAPS + 3];
+    __shared__ float hs[DEC_TAPS + 3];
+    const int b = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * CH;
+    const float* src = in + (int64_t)b * in_stride + pad;
+    for (int i = threadIdx.x; i < DEC_TAPS; i += 256) hs[i] = taps[i];
+    const int64_t base = 2 * m0 - DEC_HALF;
+    for (int i = threadIdx.x; i < 2 * CH + DEC_TAPS; i += 256) {
+        const int64_t g = base + i;
+        xs[i] = (g >= 0 && g < n_in) ? src[g] : 0.f;
+    }
+    __syncthreads();
+    float* dst = out + (int64_t)b * out_stride + pad;
+#pragma unroll
+    for (int r = 0; r < CH / 256; ++r) {
+        const int j = threadIdx.x + 256 * r;
+        if (m0 + j >= n_out) continue;
+        float acc = 0.f;
+        const float* x = xs + 2 * j;
+#pragma unroll 4
+        for (int k = 0; k < DEC_TAPS; ++k) acc = fmaf(hs[k], x[k], acc);
+        dst[m0 + j] = 1.41421356237309505f * acc;
+    }
+}
+
+// centre padding of one pyramid level: zeros (librosa >= 0.10) or reflection (librosa 0.9)
+__global__ __launch_bounds__(256) void cqt_pad_kernel(float* __restrict__ pyr, int64_t n, int64_t stride, int pad, int reflect) {
+    const int b = blockIdx.y;
+    float* row = pyr + (int64_t)b * stride;
+    const int64_t tail = stride - pad - n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pad + tail; i += (int64_t)gridDim.x * 256) {
+        if (i < pad) {                                      // left pad, position pad-1-i  <->  sample index i+1
+            float v = 0.f;
+            if (reflect && i + 1 < n) v = row[pad + i + 1];
+            row[pad - 1 - i] = v;
+        } else {                                            // right region, position pad+n+j  <->  sample n-2-j
+            const int64_t j = i - pad;
+            float v = 0.f;
+            if (reflect && j < pad && n - 2 - j >= 0) v = row[pad + n - 2 - j];
+            row[pad + n + j] = v;
+        }
+    }
+}
+
+// |R| of every bank of one level -> mag[b][h][bin][t] for t < frames(bank)
+__global__ __launch_bounds__(256) void cqt_mag_kernel(const float* __restrict__ R, LevelDev lv, int64_t t_level, int n_harm, int n_bins,
+                                                      int64_t t_buf, float* __restrict__ mag) {
+    const int b = blockIdx.z;
+    const int bank = blockIdx.y;
+    if (bank >= lv.nbanks) return;
+    const BankDev bk = lv.b[bank];
+    const int64_t total = (int64_t)bk.nf * bk.frames;
+    const float* Rb = R + (int64_t)b * t_level * lv.ncols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / bk.frames);
+        const int64_t t = i - (int64_t)k * bk.frames;
+        const float re = Rb[t * lv.ncols + bk.col0 + k];
+        const float im = Rb[t * lv.ncols + bk.col0 + bk.nf + k];
+        mag[(((int64_t)b * n_harm + bk.harm) * n_bins + bk.bin0 + k) * t_buf + t] = sqrtf(re * re + im * im);
+    }
+}
+
+// max over one (clip, harmonic) map [n_bins][frames_h] (row pitch t_buf)
+__global__ __launch_bounds__(256) void cqt_max_kernel(const float* __restrict__ mag, HarmFrames frames_h, int n_harm, int n_bins,
+                                                      int64_t t_buf, float* __restrict__ maxbuf) {
+    __shared__ float red[4];
+    const int bh = blockIdx.x;
+    const int frames = frames_h.f[bh % n_harm];
+    const float* m = mag + (int64_t)bh * n_bins * t_buf;
+    float v = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)n_bins * frames; i += 256) {
+        const int k = (int)(i / frames);
+        v = fmaxf(v, m[(int64_t)k * t_buf + (i - (int64_t)k * frames)]);
+    }
+    v = wave_max_f32(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) maxbuf[bh] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// amplitude_to_db(ref = max) -> clamp -80 -> /80 + 1 (or plain magnitude), truncated to t_out frames
+__global__ __launch_bounds__(256) void cqt_scale_kernel(const float* __restrict__ mag, const float* __restrict__ maxbuf, int n_bins, int64_t t_buf,
+                                                        int64_t t_out, int decibels, float* __restrict__ out) {
+    const int bh = blockIdx.y;
+    const float ref = maxbuf[bh];
+    const float amin2 = 1e-10f;                              // amin = 1e-5 on magnitude
+    const float offs = 10.0f * log10f(fmaxf(amin2, ref * ref));
+    const float floor_db = (10.0f * log10f(fmaxf(amin2, ref * ref)) - offs) - 80.0f;
+    const int64_t total = (int64_t)n_bins * t_out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i / t_out);
+        const int64_t t = i - (int64_t)k * t_out;
+        const float a = mag[((int64_t)bh * n_bins + k) * t_buf + t];
+        float v = a;
+        if (decibels) {
+            float db = 10.0f * log10f(fmaxf(amin2, a * a)) - offs;
+            db = fmaxf(db, floor_db);
+            v = db / 80.0f + 1.0f;
+        }
+        out[((int64_t)bh * n_bins + k) * t_out + t] = v;
+    }
+}
+
+struct Level {
+    int nfft = 0, ncols = 0, hop = 0;
+    std::vector<BankDev> banks;
+    std::vector<float> W;          // [ncols][nfft] fp32 row-major (built incrementally per bank at bank nfft, re-centred later)
+    std::vector<std::pair<int, std::vector<std::complex<double>>>> raw;   // (bank nfft, kernels nf x nfft)
+    bf16_t* d_w = nullptr;
+    int n_pad = 0, k_pad = 0;
+};
+
+}  // namespace
+
+struct amtx_cqt_plan {
+    int sr, hop, n_bins, bpo, n_harm, lib09, truncate;
+    double fmin, gamma, alpha;
+    std::vector<double> harmonics;
+    std::vector<int> early;           // early-downsample count per harmonic
+    std::vector<Level> levels;
+    int pad = 0;                      // centre padding of every pyramid level (max n_fft / 2)
+    float* d_taps = nullptr;
+};
+
+namespace {
+
+double alpha_of(int bpo, int lib09) {
+    const double r = std::pow(2.0, 1.0 / bpo);
+    return lib09 ? (r - 1.0) : (r * r - 1.0) / (r * r + 1.0);
+}
+
+int num_two_factors(int x) {
+    int n = 0;
+    while (x > 0 && x % 2 == 0) { ++n; x /= 2; }
+    return n;
+}
+
+int early_count(double nyquist, double cutoff, int hop, int n_oct) {
+    const int c1 = std::max(0, (int)std::ceil(std::log2(nyquist / cutoff)) - 1 - 1);
+    const int c2 = std::max(0, num_two_factors(hop) - n_oct + 1);
+    return std::min(c1, c2);
+}
+
+// time-domain equivalent of librosa's sparsified one-sided FFT basis of one octave (see header comment)
+void build_bank(const std::vector<double>& freqs, double sr_i, double sr_base, double gamma, double alpha,
+                const std::vector<double>& len_base, int& nfft, std::vector<std::complex<double>>& kern) {
+    const int nf = (int)freqs.size();
+    const double Q = 1.0 / alpha;
+    std::vector<double> ilen(nf);
+    double maxlen = 0;
+    for (int k = 0; k < nf; ++k) { ilen[k] = Q * sr_i / (freqs[k] + gamma / alpha); maxlen = std::max(maxlen, ilen[k]); }
+    nfft = (int)std::llround(std::pow(2.0, std::ceil(std::log2(maxlen))));
+    kern.assign((size_t)nf * nfft, 0.0);
+    const int nb = nfft / 2 + 1;
+    std::vector<std::complex<double>> tw(nfft);
+    for (int i = 0; i < nfft; ++i) tw[i] = std::polar(1.0, -2.0 * PI * i / nfft);
+    std::vector<std::complex<double>> basis(nfft), spec(nb);
+    std::vector<double> mags(nb), sorted(nb);
+    for (int k = 0; k < nf; ++k) {
+        const long n0 = (long)std::floor(-ilen[k] / 2.0), n1 = (long)std::floor(ilen[k] / 2.0);
+        const int cnt = (int)(n1 - n0);
+        std::fill(basis.begin(), basis.end(), 0.0);
+        const int lpad = (nfft - cnt) / 2;
+        double l1 = 0;
+        for (int n = 0; n < cnt; ++n) l1 += 0.5 - 0.5 * std::cos(2.0 * PI * n / cnt);
+        for (int n = 0; n < cnt; ++n) {
+            const double w = (0.5 - 0.5 * std::cos(2.0 * PI * n / cnt)) / l1;
+            basis[lpad + n] = std::polar(w, 2.0 * PI * freqs[k] * (double)(n0 + n) / sr_i) * (ilen[k] / nfft);
+        }
+        double norm = 0;
+        for (int f = 0; f < nb; ++f) {
+            std::complex<double> s = 0;
+            for (int n = lpad; n < lpad + cnt; ++n) s += basis[n] * tw[(int)(((long long)f * n) % nfft)];
+            spec[f] = s;
+            mags[f] = std::abs(s);
+            norm += mags[f];
+        }
+        sorted = mags;
+        std::sort(sorted.begin(), sorted.end());
+        double cum = 0, thr = sorted[0];
+        for (int f = 0; f < nb; ++f) {           // first index whose cumulative normalised magnitude reaches the 1 % quantile
+            cum += sorted[f] / norm;
+            if (!(cum < 0.01)) { thr = sorted[f]; break; }
+        }
+        const double scale = std::sqrt(sr_base / sr_i) / std::sqrt(len_base[k]);
+        for (int n = 0; n < nfft; ++n) {
+            std::complex<double> s = 0;
+            for (int f = 0; f < nb; ++f)
+                if (mags[f] >= thr) s += spec[f] * tw[(int)(((long long)f * n) % nfft)];
+            kern[(size_t)k * nfft + n] = s * scale;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int amtx_cqt_plan_destroy(amtx_cqt_plan* p) {
+    if (!p) return AMTX_OK;
+    for (auto& l : p->levels)
+        if (l.d_w) (void)hipFree(l.d_w);
+    if (p->d_taps) (void)hipFree(p->d_taps);
+    delete p;
+    return AMTX_OK;
+}
+
+extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int hop_length, double fmin, int n_bins, int bins_per_octave,
+                                    double gamma, const double* harmonics, int n_harmonics, int truncate_to_expected, int librosa09) {
+    AMTX_REQUIRE(out, "amtx_cqt_plan_create: null plan pointer");
+    *out = nullptr;
+    AMTX_REQUIRE(sample_rate > 0 && hop_length > 0 && fmin > 0 && n_bins > 0 && bins_per_octave > 0 && gamma >= 0 && n_harmonics > 0 &&
+                     n_harmonics <= MAX_BANKS && harmonics, "amtx_cqt_plan_create: bad argument");
+    amtx_cqt_plan* p = new amtx_cqt_plan();
+    p->sr = sample_rate; p->hop = hop_length; p->n_bins = n_bins; p->bpo = bins_per_octave; p->n_harm = n_harmonics;
+    p->lib09 = librosa09; p->truncate = truncate_to_expected; p->fmin = fmin; p->gamma = gamma;
+    p->alpha = alpha_of(bins_per_octave, librosa09);
+    p->harmonics.assign(harmonics, harmonics + n_harmonics);
+    const int n_oct = (n_bins + bins_per_octave - 1) / bins_per_octave;
+    const int nf_full = std::min(bins_per_octave, n_bins);
+    const double Q = 1.0 / p->alpha;
+    for (int h = 0; h < n_harmonics; ++h) {
+        const double f0 = harmonics[h] * fmin;
+        std::vector<double> freqs(n_bins);
+        double cutoff = 0;
+        for (int k = 0; k < n_bins; ++k) {
+            freqs[k] = f0 * std::pow(2.0, (double)k / bins_per_octave);
+            cutoff = std::max(cutoff, freqs[k] * (1 + 0.5 * HANN_BW / Q) + 0.5 * gamma);
+        }
+        if (cutoff > sample_rate / 2.0) {
+            amtx_set_error("amtx_cqt_plan_create: wavelet basis with max frequency=%g Hz (harmonic %g) would exceed the Nyquist frequency=%g",
+                           freqs[n_bins - 1], harmonics[h], sample_rate / 2.0);
+            amtx_cqt_plan_destroy(p);
+            return AMTX_ERR_ARG;
+        }
+        const int c = early_count(sample_rate / 2.0, cutoff, hop_length, n_oct);
+        p->early.push_back(c);
+        const double sr_base = sample_rate / std::pow(2.0, c);
+        std::vector<double> len_all(n_bins);
+        for (int k = 0; k < n_bins; ++k) len_all[k] = Q * sr_base / (freqs[k] + gamma / p->alpha);
+        for (int j = 0; j < n_oct; ++j) {
+            const int hi = n_bins - nf_full * j, lo = std::max(0, n_bins - nf_full * (j + 1));
+            if (hi <= 0) break;
+            const int level = c + j;
+            if ((hop_length >> level) << level != hop_length || (hop_length >> level) < 4) {
+                amtx_set_error("amtx_cqt_plan_create: hop_length=%d is not divisible far enough for %d pyramid levels (level hop must be a "
+                               "multiple of 4)", hop_length, level + 1);
+                amtx_cqt_plan_destroy(p);
+                return AMTX_ERR_UNSUPPORTED;
+            }
+            if ((int)p->levels.size() <= level) p->levels.resize(level + 1);
+            Level& L = p->levels[level];
+            L.hop = hop_length >> level;
+            std::vector<double> fr(freqs.begin() + lo, freqs.begin() + hi), lb(len_all.begin() + lo, len_all.begin() + hi);
+            int nfft = 0;
+            std::vector<std::complex<double>> kern;
+            build_bank(fr, sample_rate / std::pow(2.0, level), sr_base, gamma, p->alpha, lb, nfft, kern);
+            if ((int)L.banks.size() >= MAX_BANKS) {
+                amtx_set_error("amtx_cqt_plan_create: more than %d banks on one pyramid level", MAX_BANKS);
+                amtx_cqt_plan_destroy(p);
+                return AMTX_ERR_UNSUPPORTED;
+            }
+            BankDev bd; bd.col0 = L.ncols; bd.nf = hi - lo; bd.harm = h; bd.bin0 = lo; bd.frames = 0;
+            L.banks.push_back(bd);
+            L.ncols += 2 * (hi - lo);
+            L.nfft = std::max(L.nfft, nfft);
+            L.raw.emplace_back(nfft, std::move(kern));
+        }
+    }
+    // stack the banks of every level (kernels centred in the level's n_fft window), pack hi/lo planes, upload
+    for (auto& L : p->levels) {
+        if (L.banks.empty()) continue;
+        p->pad = std::max(p->pad, L.nfft / 2);
+        std::vector<float> W((size_t)L.ncols * L.nfft, 0.f);
+        for (size_t bi = 0; bi < L.banks.size(); ++bi) {
+            const BankDev& bd = L.banks[bi];
+            const int nfft = L.raw[bi].first, off = (L.nfft - nfft) / 2;
+            for (int k = 0; k < bd.nf; ++k)
+                for (int n = 0; n < nfft; ++n) {
+                    const std::complex<double> v = L.raw[bi].second[(size_t)k * nfft + n];
+                    W[(size_t)(bd.col0 + k) * L.nfft + off + n] = (float)v.real();
+                    W[(size_t)(bd.col0 + bd.nf + k) * L.nfft + off + n] = (float)v.imag();
+                }
+        }
+        L.raw.clear();
+        amtx_gemm_pack_dims(L.ncols, L.nfft, &L.n_pad, &L.k_pad);
+        std::vector<bf16_t> packed((size_t)L.n_pad * L.k_pad * 2);
+        amtx_gemm_pack_host(W.data(), L.nfft, L.ncols, L.nfft, 2, packed.data());
+        hipError_t e = hipMalloc(&L.d_w, packed.size() * 2);
+        if (e == hipSuccess) e = hipMemcpy(L.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            amtx_set_error("amtx_cqt_plan_create: weight upload failed: %s", hipGetErrorString(e));
+            amtx_cqt_plan_destroy(p);
+            return AMTX_ERR_HIP;
+        }
+    }
+    p->pad = (p->pad + 3) & ~3;
+    // decimator taps
+    std::vector<float> taps(DEC_TAPS);
+    {
+        std::vector<double> h(DEC_TAPS);
+        double sum = 0;
+        for (int i = 0; i < DEC_TAPS; ++i) {
+            const double n = i - DEC_HALF, x = 2.0 * DEC_CUTOFF * n;
+            const double sinc = (n == 0) ? 1.0 : std::sin(PI * x) / (PI * x);
+            const double r = 2.0 * i / (DEC_TAPS - 1) - 1.0;
+            h[i] = 2.0 * DEC_CUTOFF * sinc * bessel_i0(DEC_BETA * std::sqrt(std::max(0.0, 1.0 - r * r))) / bessel_i0(DEC_BETA);
+            sum += h[i];
+        }
+        for (int i = 0; i < DEC_TAPS; ++i) taps[i] = (float)(h[i] / sum);
+    }
+    hipError_t e = hipMalloc(&p->d_taps, DEC_TAPS * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), DEC_TAPS * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        amtx_set_error("amtx_cqt_plan_create: device allocation failed: %s", hipGetErrorString(e));
+        amtx_cqt_plan_destroy(p);
+        return AMTX_ERR_HIP;
+    }
+    *out = p;
+    return AMTX_OK;
+}
+
+namespace {
+
+struct CqtDims {
+    std::vector<int64_t> len, stride, frames;     // per level
+    std::vector<int> frames_h;                    // per harmonic: librosa's own output length
+    int64_t t_buf = 0, t_out = 0;
+    size_t off_pyr = 0, off_r = 0, off_mag = 0, off_max = 0, total = 0;
+    std::vector<size_t> pyr_off, r_off;
+};
+
+// VQT.get_expected_frames (features/vqt.py:102-134) with the reference's own early-downsample estimate (librosa-0.9 Q)
+int64_t reference_expected_frames(const amtx_cqt_plan* p, double f0, int64_t n) {
+    const double fmax = f0 * std::pow(2.0, (double)(p->n_bins - 1) / p->bpo);
+    const double cQ = 1.0 / (std::pow(2.0, 1.0 / p->bpo) - 1.0);
+    const double cutoff = fmax * (1 + 0.5 * HANN_BW / cQ) + 0.5 * p->gamma;
+    const int n_oct = (p->n_bins + p->bpo - 1) / p->bpo;
+    const int c = early_count(p->sr / 2.0, cutoff, p->hop, n_oct);
+    int64_t best = -1;
+    for (int k = c; k < c + n_oct; ++k) {
+        const int64_t sig = (int64_t)std::ceil((double)n / std::pow(2.0, k));
+        const int64_t hop = p->hop >> k;
+        if (hop <= 0) continue;
+        const int64_t f = sig / hop + 1;
+        if (best < 0 || f < best) best = f;
+    }
+    return best;
+}
+
+CqtDims dims(const amtx_cqt_plan* p, int B, int64_t n) {
+    CqtDims d;
+    const int nl = (int)p->levels.size();
+    d.len.resize(nl); d.stride.resize(nl); d.frames.resize(nl); d.pyr_off.resize(nl); d.r_off.resize(nl);
+    int64_t len = n;
+    size_t off = 0;
+    for (int l = 0; l < nl; ++l) {
+        if (l > 0) len = (len + 1) / 2;
+        d.len[l] = len;
+        d.stride[l] = ((2 * (int64_t)p->pad + len + 3) / 4) * 4 + 4;
+        d.frames[l] = p->levels[l].hop > 0 ? 1 + len / p->levels[l].hop : 0;
+        d.pyr_off[l] = off;
+        off += ((size_t)B * d.stride[l] * 4 + 255) & ~(size_t)255;
+    }
+    d.off_r = off;
+    for (int l = 0; l < nl; ++l) {
+        d.r_off[l] = off;
+        off += ((size_t)B * d.frames[l] * p->levels[l].ncols * 4 + 255) & ~(size_t)255;
+    }
+    const int n_oct = (p->n_bins + p->bpo - 1) / p->bpo;
+    d.frames_h.resize(p->n_harm);
+    int64_t tmin = -1, tref = -1;
+    for (int h = 0; h < p->n_harm; ++h) {
+        int64_t t = -1;
+        for (int j = 0; j < n_oct; ++j) {
+            const int l = p->early[h] + j;
+            if (l < nl && !p->levels[l].banks.empty()) t = (t < 0) ? d.frames[l] : std::min(t, d.frames[l]);
+        }
+        d.frames_h[h] = (int)t;
+        d.t_buf = std::max<int64_t>(d.t_buf, t);
+        tmin = (tmin < 0) ? t : std::min(tmin, t);
+        const int64_t r = reference_expected_frames(p, p->harmonics[h] * p->fmin, n);
+        tref = (tref < 0) ? r : std::min(tref, r);
+    }
+    d.t_out = p->truncate ? std::min(tmin, tref) : tmin;
+    d.off_mag = off;
+    off += ((size_t)B * p->n_harm * p->n_bins * d.t_buf * 4 + 255) & ~(size_t)255;
+    d.off_max = off;
+    off += ((size_t)B * p->n_harm * 4 + 255) & ~(size_t)255;
+    d.total = off;
+    return d;
+}
+
+}  // namespace
+
+extern "C" int amtx_cqt_num_harmonics(const amtx_cqt_plan* p) { return p ? p->n_harm : AMTX_ERR_ARG; }
+
+extern "C" int64_t amtx_cqt_num_frames(const amtx_cqt_plan* p, int64_t num_samples) {
+    if (!p || num_samples <= 0) return p ? 0 : AMTX_ERR_ARG;
+    return dims(p, 1, num_samples).t_out;
+}
+
+extern "C" size_t amtx_cqt_workspace_bytes(const amtx_cqt_plan* p, int batch, int64_t num_samples) {
+    if (!p || batch <= 0 || num_samples <= 0) return 0;
+    return dims(p, batch, num_samples).total;
+}
+
+extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
+                                void* workspace, size_t workspace_bytes, float* out, void* stream_) {
+    AMTX_REQUIRE(p && audio && workspace && out, "amtx_cqt_forward: null pointer");
+    AMTX_REQUIRE(batch > 0 && batch < 65536 && num_samples > 0 && audio_stride >= num_samples, "amtx_cqt_forward: bad batch/num_samples");
+    AMTX_REQUIRE(((uintptr_t)workspace % 256) == 0, "amtx_cqt_forward: workspace must be 256-byte aligned");
+    const CqtDims d = dims(p, batch, num_samples);
+    AMTX_REQUIRE(workspace_bytes >= d.total, "amtx_cqt_forward: workspace too small (%zu < %zu)", workspace_bytes, d.total);
+    AMTX_REQUIRE(d.t_out > 0, "amtx_cqt_forward: clip too short");
+    if (p->lib09) AMTX_REQUIRE(d.len.back() > p->pad, "amtx_cqt_forward: reflect padding needs a longer clip");
+    hipStream_t s = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const int B = batch, nl = (int)p->levels.size();
+    HarmFrames hf;
+    for (int h = 0; h < MAX_BANKS; ++h) hf.f[h] = h < p->n_harm ? d.frames_h[h] : 0;
+
+    for (int l = 0; l < nl; ++l) {
+        float* pyr = (float*)(ws + d.pyr_off[l]);
+        if (l == 0) {
+            const unsigned nb = (unsigned)std::min<int64_t>((num_samples + 255) / 256, 4096);
+            hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad);
+        } else {
+            const unsigned nb = (unsigned)((d.len[l] + 1023) / 1024);
+            hipLaunchKernelGGL(cqt_decimate_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
+                               d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps);
+        }
+        AMTX_CHECK_LAUNCH();
+        hipLaunchKernelGGL(cqt_pad_kernel, dim3(8, B), dim3(256), 0, s, pyr, d.len[l], d.stride[l], p->pad, p->lib09);
+        AMTX_CHECK_LAUNCH();
+    }
+    float* mag = (float*)(ws + d.off_mag);
+    float* maxbuf = (float*)(ws + d.off_max);
+    for (int l = 0; l < nl; ++l) {
+        const Level& L = p->levels[l];
+        if (L.banks.empty()) continue;
+        float* R = (float*)(ws + d.r_off[l]);
+        GemmArgs g;
+        g.A = (const float*)(ws + d.pyr_off[l]) + (p->pad - L.nfft / 2); g.lda = L.hop; g.a_type = AMTX_T_F32;
+        g.W = L.d_w; g.n_pad = L.n_pad; g.k_pad = L.k_pad; g.planes = 2; g.bias = nullptr;
+        g.C = R; g.ldc = L.ncols; g.c_type = AMTX_T_F32;
+        g.M = d.frames[l]; g.N = L.ncols; g.K = L.nfft;
+        g.groups = B; g.a_gs = d.stride[l]; g.w_gs = 0; g.bias_gs = 0; g.c_gs = d.frames[l] * L.ncols;
+        int rc = amtx_launch_gemm(g, s);
+        if (rc != AMTX_OK) return rc;
+        LevelDev lv;
+        lv.nbanks = (int)L.banks.size(); lv.ncols = L.ncols;
+        for (int i = 0; i < lv.nbanks; ++i) { lv.b[i] = L.banks[i]; lv.b[i].frames = d.frames_h[L.banks[i].harm]; }
+        hipLaunchKernelGGL(cqt_mag_kernel, dim3(16, lv.nbanks, B), dim3(256), 0, s, (const float*)R, lv, d.frames[l], p->n_harm, p->n_bins,
+                           d.t_buf, mag);
+        AMTX_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(cqt_max_kernel, dim3(B * p->n_harm), dim3(256), 0, s, (const float*)mag, hf, p->n_harm, p->n_bins,
+                       d.t_buf, maxbuf);
+    AMTX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(cqt_scale_kernel, dim3(8, B * p->n_harm), dim3(256), 0, s, (const float*)mag, (const float*)maxbuf, p->n_bins, d.t_buf,
+                       d.t_out, decibels, out);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}

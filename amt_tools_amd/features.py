@@ -29,7 +29,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ['FeatureModule', 'WaveformWrapper', 'STFT', 'MelSpec']
+__all__ = ['FeatureModule', 'WaveformWrapper', 'STFT', 'MelSpec', 'VQT', 'CQT', 'HVQT', 'HCQT']
 
 FLOAT32 = 'float32'
 
@@ -336,3 +336,207 @@ class MelSpec(STFT):
         out = np.zeros((self.n_mels, self.n_fft // 2 + 1), dtype=np.float32)
         _lib.check(_lib.lib().amtx_spec_filterbank(self._get_plan(), _lib.ptr(out)), 'amtx_spec_filterbank')
         return out
+
+
+# ======================================================================================================
+# CQT / VQT / HCQT / HVQT  (amt_tools/features/vqt.py, cqt.py, hvqt.py, hcqt.py)
+# ======================================================================================================
+C1_HZ = 32.70319566257483            # librosa.note_to_hz('C1')
+_HANN_BANDWIDTH = 1.50018310546875   # librosa.filters.window_bandwidth('hann')
+
+
+def _early_downsample_count(nyquist, filter_cutoff, hop_length, n_octaves):
+    """librosa.core.constantq.__early_downsample_count, which the reference imports (features/vqt.py:7,95)."""
+    c1 = max(0, int(np.ceil(np.log2(nyquist / filter_cutoff)) - 1) - 1)
+    twos, h = 0, int(hop_length)
+    while h > 0 and h % 2 == 0:
+        twos, h = twos + 1, h // 2
+    return min(c1, max(0, twos - n_octaves + 1))
+
+
+class _CqtPlanOwner(object):
+    """Lazily created amtx_cqt_plan shared by the VQT-family modules."""
+
+    def _cqt_args(self):
+        raise NotImplementedError
+
+    def _device_index(self):
+        import torch
+        dev = torch.device(self.device if not isinstance(self.device, int) else f'cuda:{self.device}')
+        return dev.index if dev.index is not None else 0
+
+    def _get_plan(self):
+        plan = self.__dict__.get('_plan')
+        if plan is None:
+            import torch
+            if not torch.cuda.is_available():
+                raise _lib.AmtxError('no GPU visible: the CQT front-end has no CPU fallback')
+            fmin, harmonics, truncate = self._cqt_args()
+            arr = (C.c_double * len(harmonics))(*[float(h) for h in harmonics])
+            handle = C.c_void_p()
+            with torch.cuda.device(self._device_index()):
+                _lib.check(_lib.lib().amtx_cqt_plan_create(C.byref(handle), int(self.sample_rate), int(self.hop_length), float(fmin),
+                                                           int(self.n_bins), int(self.bins_per_octave), float(self.gamma), arr,
+                                                           len(harmonics), int(truncate),
+                                                           int(str(self.librosa_version).startswith('0.9'))), 'amtx_cqt_plan_create')
+            plan = self.__dict__['_plan'] = handle
+        return plan
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop('_plan', None)
+        state.pop('_workspace', None)
+        return state
+
+    def __del__(self):
+        plan = self.__dict__.get('_plan')
+        if plan is not None:
+            try:
+                _lib.lib().amtx_cqt_plan_destroy(plan)
+            except Exception:
+                pass
+
+    def process_batch(self, audio, model_layout=False):
+        """(B, N) float32 CUDA tensor -> (B, C, F, T) float32 features on the device."""
+        import torch
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
+        audio = audio.contiguous()
+        B, N = audio.shape
+        L = _lib.lib()
+        plan = self._get_plan()
+        T = _lib.check(L.amtx_cqt_num_frames(plan, N), 'amtx_cqt_num_frames')
+        H = L.amtx_cqt_num_harmonics(plan)
+        need = L.amtx_cqt_workspace_bytes(plan, B, N)
+        ws = self.__dict__.get('_workspace')
+        if ws is None or ws.numel() < need or ws.device != audio.device:
+            self.__dict__['_workspace'] = None
+            ws = self.__dict__['_workspace'] = torch.empty(int(need), dtype=torch.uint8, device=audio.device)
+        out = torch.empty((B, H, self.n_bins, T), dtype=torch.float32, device=audio.device)
+        with torch.cuda.device(audio.device):
+            _lib.check(L.amtx_cqt_forward(plan, _lib.ptr(audio), N, audio.stride(0), B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
+                                          _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward')
+        return out
+
+    def _process_host(self, audio):
+        import torch
+        dev = torch.device('cuda', self._device_index())
+        x = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float32)).to(dev).unsqueeze(0)
+        return self.process_batch(x)[0].cpu().numpy()
+
+    def frontend(self):
+        from .models import SpectralFrontend
+        return SpectralFrontend(self)
+
+
+class VQT(FeatureModule, _CqtPlanOwner):
+    """Variable-Q transform (features/vqt.py)."""
+
+    def __init__(self, sample_rate=22050, hop_length=512, decibels=True, fmin=None, n_bins=84, bins_per_octave=12, gamma=None,
+                 librosa_version='0.10', device='cuda:0'):
+        FeatureModule.__init__(self, sample_rate, hop_length, 1, decibels)
+        self.fmin = C1_HZ if fmin is None else fmin
+        self.n_bins = n_bins
+        self.bins_per_octave = bins_per_octave
+        self.window = 'hann'
+        # the reference keeps alpha in the librosa-0.9 convention and derives the default gamma from it (vqt.py:51-58)
+        self.alpha = 2.0 ** (1.0 / self.bins_per_octave) - 1
+        self.gamma = 24.7 * self.alpha / 0.108 if gamma is None else gamma
+        self.n_octs = int(np.ceil(float(self.n_bins) / self.bins_per_octave))
+        self.librosa_version = str(librosa_version)
+        self.device = device
+
+    def _cqt_args(self):
+        return self.fmin, [1.0], False
+
+    def get_early_ds_count(self):
+        fmax = self.fmin * 2.0 ** ((self.n_bins - 1) / self.bins_per_octave)
+        cQ = 1.0 / (2.0 ** (1. / self.bins_per_octave) - 1)
+        freq_cutoff = fmax * (1 + 0.5 * (_HANN_BANDWIDTH / cQ)) + 0.5 * self.gamma
+        return _early_downsample_count(self.sample_rate / 2.0, freq_cutoff, self.hop_length, self.n_octs)
+
+    def get_expected_frames(self, audio):
+        early = self.get_early_ds_count()
+        k = np.arange(early, early + self.n_octs)
+        sig_lens = np.ceil(len(audio) / (2 ** k))
+        hop_lens = self.hop_length // (2 ** k)
+        return int(min(sig_lens // hop_lens + 1))
+
+    def get_sample_range(self, num_frames):
+        factor = 2 ** self.get_early_ds_count()
+        max_samples = ((num_frames * self.hop_length // factor) - 1) * factor
+        min_samples = max(1, max_samples - self.hop_length + 1)
+        return np.arange(min_samples, max_samples + 1)
+
+    def process_audio(self, audio):
+        return self._process_host(audio)
+
+    def get_times(self, audio, at_start=False):
+        times = super().get_times(audio)
+        if at_start:
+            # intended behaviour of vqt.py:217-225 (the reference floor-divides the tuple wavelet_lengths returns)
+            alpha = self.alpha
+            longest = (1.0 / alpha) * self.sample_rate / (self.fmin + self.gamma / alpha)
+            times -= ((longest // 2) / self.sample_rate)
+        return times
+
+    def get_feature_size(self):
+        return self.n_bins
+
+
+class CQT(VQT):
+    """Constant-Q transform = VQT with gamma = 0 (features/cqt.py)."""
+
+    def __init__(self, sample_rate=22050, hop_length=512, decibels=True, fmin=None, n_bins=84, bins_per_octave=12,
+                 librosa_version='0.10', device='cuda:0'):
+        super().__init__(sample_rate, hop_length, decibels, fmin, n_bins, bins_per_octave, gamma=0,
+                         librosa_version=librosa_version, device=device)
+
+
+class HVQT(FeatureModule, _CqtPlanOwner):
+    """Harmonic VQT (features/hvqt.py): one VQT per harmonic h * fmin, each dB-normalised on its own, truncated to the
+    smallest expected frame count, stacked on the channel axis.  All harmonics run in one device pass: harmonics that
+    are octaves apart share pyramid levels (and GEMM launches)."""
+
+    def __init__(self, sample_rate=22050, hop_length=512, decibels=True, fmin=None, harmonics=None, n_bins=84, bins_per_octave=12,
+                 gamma=None, librosa_version='0.10', device='cuda:0'):
+        self.fmin = C1_HZ if fmin is None else fmin
+        if harmonics is None:
+            harmonics = [0.5, 1, 2, 3, 4, 5]
+        harmonics.sort()
+        self.harmonics = harmonics
+        FeatureModule.__init__(self, sample_rate, hop_length, len(self.harmonics), decibels)
+        self.modules = [VQT(sample_rate=sample_rate, hop_length=hop_length, decibels=decibels, fmin=h * self.fmin, n_bins=n_bins,
+                            bins_per_octave=bins_per_octave, gamma=gamma, librosa_version=librosa_version, device=device)
+                        for h in self.harmonics]
+        self.n_bins = n_bins
+        self.bins_per_octave = bins_per_octave
+        self.gamma = self.modules[0].gamma
+        self.librosa_version = str(librosa_version)
+        self.device = device
+
+    def _cqt_args(self):
+        return self.fmin, self.harmonics, True
+
+    def get_expected_frames(self, audio):
+        return min(module.get_expected_frames(audio) for module in self.modules)
+
+    def get_sample_range(self, num_frames):
+        return self.modules[-1].get_sample_range(num_frames)
+
+    def process_audio(self, audio):
+        return self._process_host(audio)
+
+    def get_times(self, audio, at_start=False):
+        return self.modules[0].get_times(audio, at_start)[:self.get_expected_frames(audio)]
+
+    def get_feature_size(self):
+        return self.modules[0].get_feature_size()
+
+
+class HCQT(HVQT):
+    """Harmonic CQT (features/hcqt.py)."""
+
+    def __init__(self, sample_rate=22050, hop_length=512, decibels=True, fmin=None, harmonics=None, n_bins=84, bins_per_octave=12,
+                 librosa_version='0.10', device='cuda:0'):
+        super().__init__(sample_rate, hop_length, decibels, fmin, harmonics, n_bins, bins_per_octave, gamma=0,
+                         librosa_version=librosa_version, device=device)

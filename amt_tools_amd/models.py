@@ -178,8 +178,11 @@ class SpectralFrontend(nn.Module):
 
     def forward(self, audio):
         assert audio.dim() == 3 and audio.shape[1] == 1
-        feats = self.module.process_batch(audio[:, 0].float(), model_layout=True)    # (B,1,T,F)
-        return feats.transpose(-1, -2)
+        from .features import _SpecPlanOwner
+        if isinstance(self.module, _SpecPlanOwner):
+            feats = self.module.process_batch(audio[:, 0].float(), model_layout=True)    # (B,1,T,F)
+            return feats.transpose(-1, -2)
+        return self.module.process_batch(audio[:, 0].float())                            # CQT family: (B,C,F,T)
 
 
 class _OFEngine(object):

@@ -132,6 +132,26 @@ int amtx_bilstm_fwd(const void* xproj /*(B,T,2,512)*/, const uint16_t* whh_packe
 int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold, float* out,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * CQT / VQT / HCQT front-end.  Replaces librosa.vqt as called from amt_tools/features/vqt.py:183-193 (CQT:
+ * features/cqt.py:22; HVQT / HCQT: one transform per harmonic h*fmin, features/hvqt.py:45-58,107-133) plus
+ * abs -> amplitude_to_db(ref=max) per harmonic -> /80 + 1 (features/common.py:199,218-228).
+ * harmonics: n_harmonics multipliers of fmin (pass {1.0} for a plain VQT/CQT).  truncate_to_expected: cut the
+ * output to the reference's own frame estimate (HVQT.get_expected_frames, features/hvqt.py:60-83).
+ * librosa09: 1 = librosa 0.9 conventions (alpha = 2^(1/bpo) - 1, reflect centre padding), 0 = librosa >= 0.10.
+ * The 2:1 decimation between octaves is this project's documented 301-tap Kaiser low-pass (librosa's soxr
+ * resampler is not bit-reproducible).  Output: [B][n_harmonics][n_bins][T] fp32.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct amtx_cqt_plan amtx_cqt_plan;
+int amtx_cqt_plan_create(amtx_cqt_plan** plan, int sample_rate, int hop_length, double fmin, int n_bins, int bins_per_octave,
+                         double gamma, const double* harmonics, int n_harmonics, int truncate_to_expected, int librosa09);
+int amtx_cqt_plan_destroy(amtx_cqt_plan* plan);
+int amtx_cqt_num_harmonics(const amtx_cqt_plan* plan);
+int64_t amtx_cqt_num_frames(const amtx_cqt_plan* plan, int64_t num_samples);
+size_t amtx_cqt_workspace_bytes(const amtx_cqt_plan* plan, int batch, int64_t num_samples);
+int amtx_cqt_forward(const amtx_cqt_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
+                     void* workspace, size_t workspace_bytes, float* out, void* stream);
+
 /* Note decoding: binary piano rolls (B, keys, T) fp32 -> per (clip, key) row the list of (onset frame, offset frame)
  * events, `capacity` int32 pairs per row in DESCENDING frame order, and counts[B*keys].  onsets may be null (onsets are
  * then the positive first difference of multi_pitch).  Replaces the event walk of tools.multi_pitch_to_notes

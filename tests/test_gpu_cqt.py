@@ -1,0 +1,77 @@
+"""GPU parity: HIP CQT / VQT / HCQT front-end (time-domain MFMA formulation, through the C ABI) vs the
+frequency-domain fp64 oracle restatement of librosa.vqt.  Tolerance 1e-3 absolute in the scaled [0,1] domain
+(the decimation chain dominates; both sides use this project's documented decimator), 2e-4 relative to
+the map maximum on linear magnitudes."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import cqt_np as cq                 # noqa: E402
+from amt_tools_amd.synth import synth_clip      # noqa: E402
+
+TOL = 1e-3
+
+
+@pytest.mark.parametrize('lv', ['0.10', '0.9'])
+def test_cqt_config1_matches_oracle(lv):
+    """TabCNN's front-end (examples/papers/tabcnn.py:80-87): CQT(192 bins, 24 per octave), 8 octaves."""
+    from amt_tools_amd.features import CQT
+    y = synth_clip(2, num_samples=50000)
+    mod = CQT(sample_rate=22050, hop_length=512, n_bins=192, bins_per_octave=24, librosa_version=lv)
+    got = mod.process_audio(y)
+    ref = cq.cqt_process_audio(y, sample_rate=22050, hop_length=512, n_bins=192, bins_per_octave=24, lv=lv)
+    assert got.shape == ref.shape == (1, 192, 1 + 50000 // 512) and got.dtype == np.float32
+    assert np.abs(got - ref).max() < TOL
+    assert got.max() == 1.0 and got.min() >= 0.0
+
+
+def test_cqt_linear_magnitudes():
+    from amt_tools_amd.features import CQT
+    y = synth_clip(4, num_samples=30000)
+    got = CQT(n_bins=84, decibels=False).process_audio(y)
+    ref = cq.cqt_process_audio(y, n_bins=84, decibels=False)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-4 * ref.max()
+
+
+def test_vqt_default_gamma_matches_oracle():
+    from amt_tools_amd.features import VQT
+    y = synth_clip(6, num_samples=40000)
+    mod = VQT(n_bins=72)
+    got = mod.process_audio(y)
+    ref = cq.vqt_process_audio(y, n_bins=72)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < TOL
+    assert mod.get_expected_frames(y) == cq.vqt_expected_frames(len(y), 22050, 512, cq.C1_HZ, 72, 12, mod.gamma)
+
+
+def test_hcqt_config3_matches_oracle_and_bookkeeping():
+    """BASELINE config 3: HCQT(6 harmonics, 72 bins) at 22.05 kHz (84 bins exceed Nyquist)."""
+    from amt_tools_amd.features import HCQT
+    from amt_tools_amd import _lib
+    y = synth_clip(8, num_samples=512 * 60 - 1)
+    mod = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)
+    got = mod.process_audio(y)
+    ref = cq.hcqt_process_audio(y, sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)
+    assert got.shape == ref.shape == (6, 72, mod.get_expected_frames(y))
+    assert np.abs(got - ref).max() < TOL
+    assert mod.get_num_channels() == 6 and mod.get_feature_size() == 72
+    with pytest.raises(_lib.AmtxError):
+        HCQT(n_bins=84).process_audio(y)                      # harmonic 3 would exceed Nyquist
+
+
+def test_batch_and_full_size_clip_properties():
+    from amt_tools_amd.features import HCQT
+    mod = HCQT(n_bins=72)
+    clips = np.stack([synth_clip(i) for i in range(3)])
+    x = torch.from_numpy(clips).cuda()
+    full = mod.process_batch(x)
+    assert full.shape == (3, 6, 72, 625) and torch.isfinite(full).all()
+    solo = mod.process_batch(x[1:2])
+    assert torch.equal(full[1], solo[0])                          # clips are independent
+    assert torch.all(full.amax(dim=(2, 3)) == 1.0)                # every (clip, harmonic) map is normalised to its own max
+    lin = HCQT(n_bins=72, decibels=False)
+    a = lin.process_batch(x[:1])
+    b = lin.process_batch(4.0 * x[:1])
+    assert torch.allclose(b, 4.0 * a, rtol=1e-5, atol=0)          # power-of-two gain: linear in amplitude

@@ -130,3 +130,25 @@ def test_full_size_batch_properties():
     for key in ('onsets', 'multi_pitch'):
         assert torch.equal(full[key][3], solo[key][0])
         assert torch.isfinite(full[key]).all()
+
+
+def test_config3_hcqt_frontend_fused_into_the_model():
+    """BASELINE config 3: audio -> HIP HCQT (6 x 72) as model.frontend -> OnsetsFrames(dim_in=72, in_channels=6)."""
+    from oracle import cqt_np as cq, model_ref
+    from amt_tools_amd.features import HCQT
+    g = load_golden('of1_hcqt_eval.npz')
+    model = _model(g, 'x3')
+    mod = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)
+    model.frontend = torch.nn.Sequential(mod.frontend())
+    audio = np.stack([synth_clip(i, num_samples=512 * 30 - 1) for i in range(2)])
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_AUDIO: torch.from_numpy(audio)})
+    feats = np.stack([cq.hcqt_process_audio(a, n_bins=72) for a in audio]).astype(np.float32)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith('frontend')}
+    with torch.no_grad():
+        ref = model_ref.run_on_batch(torch.from_numpy(feats), sd)
+    for key in ('onsets', 'multi_pitch'):
+        assert out[key].shape == ref[key].shape == (2, 88, feats.shape[-1])
+        near = np.abs(ref['logits'][key].transpose(-1, -2).numpy()) < 5e-3      # CQT feature tolerance (1e-3) through the model
+        assert np.all((out[key].cpu().numpy() == ref[key].numpy()) | near)
+        assert (out[key].cpu().numpy() != ref[key].numpy()).mean() < 5e-3
