@@ -33,6 +33,11 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
 // 64-byte quarters of a 256-byte bank row; XOR-ing the chunk with 2*((i >> 2) & 1) then makes every
 // ds_read_b128 lane group ({0-3,12-15,20-27}, ...) hit 16 distinct 16-byte slots for every kh and column
 // (found by exhaustive search, tools/lds_swizzle_search.py).
+typedef __attribute__((ext_vector_type(4))) short mfma_s16x4;
+__device__ __forceinline__ f32x4_t mfma16k16(uint2 a, uint2 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_s16x4, a), __builtin_bit_cast(mfma_s16x4, b), c, 0, 0, 0);
+}
+
 __device__ __forceinline__ int tile_off(int i, int j, int c) { return ((i * PITCH + j) * 4 + (c ^ (((i >> 2) & 1) << 1))) * 16; }
 
 __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi, uint4& lo) {
@@ -94,24 +99,24 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
             ftile[(ci * FROWS + fi) * FW + fj] = v;
         }
         const int kvalid = 9 * a.c_in;
-        const int ksteps = (kvalid + 31) >> 5;          // 1 or 2
+        const int ksteps = (kvalid + 15) >> 4;          // K = 16 per MFMA step, <= 4 steps
         const int g1 = lane >> 4;
-        int koff[2][8];
-        uint4 w1[2][2][NS];
+        int koff[4][4];
+        uint2 w1[4][2][NS];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 32 * ks + 8 * g1 + j;
+            for (int j = 0; j < 4; ++j) {
+                const int k = 16 * ks + 4 * g1 + j;
                 const int ci = k / 9, tap = k - ci * 9, kh = tap / 3, kw = tap - kh * 3;
                 koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : -1;
             }
-            const uint4* wp = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
+            const uint2* wp = reinterpret_cast<const uint2*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
-                    w1[ks][nt][p] = ks < ksteps ? wp[((ks * 2 + nt) * NS + p) * 64] : make_uint4(0, 0, 0, 0);
+                    w1[ks][nt][p] = ks < ksteps ? wp[((ks * 2 + nt) * NS + p) * 64] : make_uint2(0, 0);
         }
         float sh1[2][4];
 #pragma unroll
@@ -120,43 +125,61 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
             for (int r = 0; r < 4; ++r) sh1[nt][r] = a.shift1[(int64_t)grp * 32 + g1 * 8 + 4 * nt + r];
         __syncthreads();
         const int ngroups = (npos + 15) >> 4;
-        for (int gi = wave; gi < ngroups; gi += 4) {
-            const int pos = gi * 16 + (lane & 15);
-            const int i = (pos * inv_cols) >> 16;
-            const int j = pos - i * cols;
-            const int base = i * FW + j;
-            f32x4_t acc1[2] = {(f32x4_t){0.f, 0.f, 0.f, 0.f}, (f32x4_t){0.f, 0.f, 0.f, 0.f}};
+        // two position groups per iteration: independent gather -> MFMA -> epilogue chains the scheduler can overlap
+        for (int gi0 = wave; gi0 < ngroups; gi0 += 8) {
+            int pos[2], ti[2], tj[2];
+            f32x4_t acc1[2][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int u = 0; u < 2; ++u) {
+                pos[u] = (gi0 + 4 * u) * 16 + (lane & 15);
+                ti[u] = (pos[u] * inv_cols) >> 16;
+                tj[u] = pos[u] - ti[u] * cols;
+                acc1[u][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                acc1[u][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
                 if (ks < ksteps) {
-                    float pv[8];
 #pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) pv[jj] = (koff[ks][jj] >= 0 && pos < npos) ? ftile[base + koff[ks][jj]] : 0.f;
-                    uint4 ph, pl;
-                    cvt8(pv, NS == 2, ph, pl);
+                    for (int u = 0; u < 2; ++u) {
+                        const int base = ti[u] * FW + tj[u];
+                        float pv[4];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc1[nt] = mfma16(w1[ks][nt][0], ph, acc1[nt]);
+                        for (int jj = 0; jj < 4; ++jj) pv[jj] = (koff[ks][jj] >= 0 && pos[u] < npos) ? ftile[base + koff[ks][jj]] : 0.f;
+                        uint2 ph, pl = make_uint2(0, 0);
                         if (NS == 2) {
-                            acc1[nt] = mfma16(w1[ks][nt][0], pl, acc1[nt]);
-                            acc1[nt] = mfma16(w1[ks][nt][1], ph, acc1[nt]);
+                            split_bf16x2(pv[0], pv[1], ph.x, pl.x);
+                            split_bf16x2(pv[2], pv[3], ph.y, pl.y);
+                        } else {
+                            ph = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+                        }
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            acc1[u][nt] = mfma16k16(w1[ks][nt][0], ph, acc1[u][nt]);
+                            if (NS == 2) {
+                                acc1[u][nt] = mfma16k16(w1[ks][nt][0], pl, acc1[u][nt]);
+                                acc1[u][nt] = mfma16k16(w1[ks][nt][1], ph, acc1[u][nt]);
+                            }
                         }
                     }
                 }
             }
-            if (pos < npos) {
-                const int t = t0 - 1 + i, f = f0 - 1 + j;
-                const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
-                float y[8];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+            for (int u = 0; u < 2; ++u) {
+                if (pos[u] < npos) {
+                    const int t = t0 - 1 + ti[u], f = f0 - 1 + tj[u];
+                    const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
+                    float y[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[nt][r] + sh1[nt][r], 0.f) : 0.f;
-                uint4 hi, lo;
-                cvt8(y, NS == 2, hi, lo);
-                const int off = tile_off(i, j, g1);
-                *reinterpret_cast<uint4*>(smem + off) = hi;
-                if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[u][nt][r] + sh1[nt][r], 0.f) : 0.f;
+                    uint4 hi, lo;
+                    cvt8(y, NS == 2, hi, lo);
+                    const int off = tile_off(ti[u], tj[u], g1);
+                    *reinterpret_cast<uint4*>(smem + off) = hi;
+                    if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+                }
             }
         }
     } else {
@@ -409,22 +432,22 @@ void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int p
             }
 }
 
-size_t amtx_conv1_wfrag_elems(int c_in, int planes) { return (size_t)((9 * c_in + 31) / 32) * 2 * planes * 64 * 8; }
+size_t amtx_conv1_wfrag_elems(int c_in, int planes) { return (size_t)((9 * c_in + 15) / 16) * 2 * planes * 64 * 4; }
 
 void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int planes, bf16_t* out) {
-    const int kvalid = 9 * c_in, ksteps = (kvalid + 31) / 32;
+    const int kvalid = 9 * c_in, ksteps = (kvalid + 15) / 16;
     for (int ks = 0; ks < ksteps; ++ks)
         for (int nt = 0; nt < 2; ++nt)
             for (int l = 0; l < 64; ++l) {
                 const int row = l & 15;
                 const int co = (row >> 2) * 8 + 4 * nt + (row & 3);
-                for (int j = 0; j < 8; ++j) {
-                    const int k = 32 * ks + 8 * (l >> 4) + j;
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 16 * ks + 4 * (l >> 4) + j;
                     const float v = k < kvalid ? w[(size_t)co * kvalid + k] * (scale ? scale[co] : 1.0f) : 0.0f;
                     const bf16_t hi = f32_to_bf16_rn(v);
-                    const size_t base = ((size_t)(ks * 2 + nt) * planes) * 64 * 8 + (size_t)l * 8 + j;
+                    const size_t base = ((size_t)(ks * 2 + nt) * planes) * 64 * 4 + (size_t)l * 4 + j;
                     out[base] = hi;
-                    if (planes == 2) out[base + 64 * 8] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                    if (planes == 2) out[base + 64 * 4] = f32_to_bf16_rn(v - bf16_to_f32(hi));
                 }
             }
 }
