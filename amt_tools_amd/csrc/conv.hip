@@ -14,6 +14,8 @@
 
 #include "amtx_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int CIN = 32;
@@ -55,19 +57,30 @@ __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi,
 constexpr int FROWS = ROWS + 2;      // feature tile rows of the fused first conv
 constexpr int FW = FT_MAX + 6;       // feature tile row pitch (floats)
 
+constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 16-byte staging items per thread (14)
+constexpr int FPRE = 4;                                        // prefetched feature values per thread (c_in = 1)
+
+struct TileCoord { int b, t0, f0; };
+__device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int ft) {
+    TileCoord c;
+    const int tf = tile % ntf; tile /= ntf;
+    const int tt = tile % ntt; tile /= ntt;
+    c.b = tile; c.t0 = tt * TT; c.f0 = tf * ft;
+    return c;
+}
+
+// Persistent blocks: each block keeps its (folded) weights in registers and walks tiles blockIdx.x, +gridDim.x, ...
+// For bf16 inputs the NEXT tile's 14 x 16 B per thread are already in flight (registers) while the current tile is
+// on the matrix cores, so the HBM/L2 latency of staging is hidden behind ~3300 MFMA cycles per wave.
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1>
-__global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols) {
+__global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int COUT = NT * 16;
+    // next-tile register prefetch only where the register budget keeps 2 waves per SIMD (C_out = 32)
+    constexpr bool PREFETCH = (IN_TYPE == AMTX_T_BF16) && !FUSE1 && NT <= 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.y;
-    int bid = blockIdx.x;
-    const int tf = bid % ntf; bid /= ntf;
-    const int tt = bid % ntt; bid /= ntt;
-    const int b = bid;
-    const int f0 = tf * ft, t0 = tt * TT;
-
-    const char* in = reinterpret_cast<const char*>(a.in) + ((int64_t)grp * a.in_gs + (int64_t)b * a.T * a.F * CIN) * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
+    const int g = lane >> 4, trow = lane & 15;
 
     // ---- stationary weights: 9 taps x NT tiles (x NS planes), one 16-byte fragment per lane each
     uint4 wf[9][NT][NS];
@@ -80,34 +93,39 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
 #pragma unroll
                 for (int p = 0; p < NS; ++p) wf[tap][nt][p] = w[((tap * NT + nt) * NS + p) * 64];
     }
+    // folded BN shift for this lane's 4*NT consecutive channels
+    float sh[NT][4];
+    {
+        const float* sp = a.shift + (int64_t)grp * a.shift_gs + g * 4 * NT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[nt][r] = sp[4 * nt + r];
+    }
 
     const int cols = ft + 2;
     const int npos = ROWS * cols;
+    const int Fo = a.F >> 1;
+    const int c = tid & 3;                              // staging chunk handled by this thread (256 % 4 == 0)
+    const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
+
+    // ---- constants of the fused first conv
+    float* ftile = reinterpret_cast<float*>(smem + NS * PLANE_BYTES);
+    const int fcols = ft + 4;
+    const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
+    const bool fprefetch = FUSE1 && fitems <= FPRE * 256;
+    int koff[4][4];
+    uint2 w1[4][2][NS];
+    float sh1[2][4];
+    int ksteps = 0;
     if constexpr (FUSE1) {
-        // ---- fused first conv: features (c_in, 20 x (ft+4)) -> LDS, then Conv(c_in->32)+BN+ReLU on the matrix
-        // cores (K = 9*c_in padded to 32/64, im2col patches gathered from LDS as the MFMA B operand), written
-        // straight into this kernel's input tile in fragment order.  a1 never touches HBM.
-        float* ftile = reinterpret_cast<float*>(smem + NS * PLANE_BYTES);
-        const int fcols = ft + 4;
-        const float* fb = a.feats + (int64_t)b * a.f_stride_b;
-        for (int it = tid; it < a.c_in * FROWS * fcols; it += 256) {
-            const int ci = it / (FROWS * fcols), r = it - ci * (FROWS * fcols);
-            const int fi = r / fcols, fj = r - fi * fcols;
-            const int t = t0 - 2 + fi, f = f0 - 2 + fj;
-            float v = 0.f;
-            if (t >= 0 && t < a.T && f >= 0 && f < a.F) v = fb[ci * a.f_stride_c + t * a.f_stride_t + f * a.f_stride_f];
-            ftile[(ci * FROWS + fi) * FW + fj] = v;
-        }
         const int kvalid = 9 * a.c_in;
-        const int ksteps = (kvalid + 15) >> 4;          // K = 16 per MFMA step, <= 4 steps
-        const int g1 = lane >> 4;
-        int koff[4][4];
-        uint2 w1[4][2][NS];
+        ksteps = (kvalid + 15) >> 4;                    // K = 16 per MFMA step, <= 4 steps
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int k = 16 * ks + 4 * g1 + j;
+                const int k = 16 * ks + 4 * g + j;
                 const int ci = k / 9, tap = k - ci * 9, kh = tap / 3, kw = tap - kh * 3;
                 koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : -1;
             }
@@ -115,193 +133,257 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(ConvArgs a, int ft, int nt
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int p = 0; p < NS; ++p)
-                    w1[ks][nt][p] = ks < ksteps ? wp[((ks * 2 + nt) * NS + p) * 64] : make_uint2(0, 0);
+                for (int p = 0; p < NS; ++p) w1[ks][nt][p] = ks < ksteps ? wp[((ks * 2 + nt) * NS + p) * 64] : make_uint2(0, 0);
         }
-        float sh1[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sh1[nt][r] = a.shift1[(int64_t)grp * 32 + g1 * 8 + 4 * nt + r];
-        __syncthreads();
-        const int ngroups = (npos + 15) >> 4;
-        // two position groups per iteration: independent gather -> MFMA -> epilogue chains the scheduler can overlap
-        for (int gi0 = wave; gi0 < ngroups; gi0 += 8) {
-            int pos[2], ti[2], tj[2];
-            f32x4_t acc1[2][2];
+            for (int r = 0; r < 4; ++r) sh1[nt][r] = a.shift1[(int64_t)grp * 32 + g * 8 + 4 * nt + r];
+    }
+
+    uint4 pre[PREFETCH ? ITEMS : 1];
+    float fpre[FPRE];
+    int tile = blockIdx.x;
+
+#define CONV_ISSUE_TILE_LOADS(TC)                                                                          \
+    do {                                                                                                   \
+        const char* inb = in_grp + (int64_t)(TC).b * a.T * a.F * CIN * 2;                                  \
+        _Pragma("unroll") for (int n = 0; n < ITEMS; ++n) {                                                \
+            const int pos = (tid >> 2) + 64 * n;                                                           \
+            const int i = (pos * inv_cols) >> 16;                                                          \
+            const int j = pos - i * cols;                                                                  \
+            const int t = (TC).t0 - 1 + i, f = (TC).f0 - 1 + j;                                            \
+            pre[n] = make_uint4(0, 0, 0, 0);                                                               \
+            if (pos < npos && t >= 0 && t < a.T && f >= 0 && f < a.F)                                      \
+                pre[n] = *reinterpret_cast<const uint4*>(inb + (((int64_t)t * a.F + f) * CIN + c * 8) * 2); \
+        }                                                                                                  \
+    } while (0)
+#define CONV_ISSUE_FEAT_LOADS(TC)                                                                          \
+    do {                                                                                                   \
+        const float* fb = a.feats + (int64_t)(TC).b * a.f_stride_b;                                        \
+        _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                                 \
+            const int it = tid + 256 * n;                                                                  \
+            const int fi = it / fcols, fj = it - fi * fcols;                                               \
+            const int t = (TC).t0 - 2 + fi, f = (TC).f0 - 2 + fj;                                          \
+            fpre[n] = 0.f;                                                                                 \
+            if (it < fitems && t >= 0 && t < a.T && f >= 0 && f < a.F) fpre[n] = fb[t * a.f_stride_t + f * a.f_stride_f]; \
+        }                                                                                                  \
+    } while (0)
+
+    if (tile < ntiles) {
+        const TileCoord tc0 = tile_coord(tile, ntf, ntt, ft);
+        if constexpr (PREFETCH) CONV_ISSUE_TILE_LOADS(tc0);
+        if (fprefetch) CONV_ISSUE_FEAT_LOADS(tc0);
+    }
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        const TileCoord tc = tile_coord(tile, ntf, ntt, ft);
+        const int t0 = tc.t0, f0 = tc.f0;
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        const TileCoord tn = tile_coord(has_next ? tile + (int)gridDim.x : tile, ntf, ntt, ft);
+
+        if constexpr (FUSE1) {
+            // ---- fused first conv: features (c_in, 20 x (ft+4)) -> LDS, then Conv(c_in->32)+BN+ReLU on the matrix cores
+            // (K = 9*c_in in steps of 16, im2col patches gathered from LDS as the MFMA B operand), written straight
+            // into this kernel's input tile in fragment order.  a1 never touches HBM.
+            if (fprefetch) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                pos[u] = (gi0 + 4 * u) * 16 + (lane & 15);
-                ti[u] = (pos[u] * inv_cols) >> 16;
-                tj[u] = pos[u] - ti[u] * cols;
-                acc1[u][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                acc1[u][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                for (int n = 0; n < FPRE; ++n) {
+                    const int it = tid + 256 * n;
+                    const int fi = it / fcols, fj = it - fi * fcols;
+                    if (it < fitems) ftile[fi * FW + fj] = fpre[n];
+                }
+            } else {
+                const float* fb = a.feats + (int64_t)tc.b * a.f_stride_b;
+                for (int it = tid; it < fitems; it += 256) {
+                    const int ci = it / (FROWS * fcols), r = it - ci * (FROWS * fcols);
+                    const int fi = r / fcols, fj = r - fi * fcols;
+                    const int t = t0 - 2 + fi, f = f0 - 2 + fj;
+                    float v = 0.f;
+                    if (t >= 0 && t < a.T && f >= 0 && f < a.F) v = fb[ci * a.f_stride_c + t * a.f_stride_t + f * a.f_stride_f];
+                    ftile[(ci * FROWS + fi) * FW + fj] = v;
+                }
             }
+            __syncthreads();
+            if (fprefetch && has_next) CONV_ISSUE_FEAT_LOADS(tn);
+            const int ngroups = (npos + 15) >> 4;
+            // two position groups per iteration: independent gather -> MFMA -> epilogue chains the scheduler can overlap
+            for (int gi0 = wave; gi0 < ngroups; gi0 += 8) {
+                int pos[2], ti[2], tj[2];
+                f32x4_t acc1[2][2];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks < ksteps) {
+                for (int u = 0; u < 2; ++u) {
+                    pos[u] = (gi0 + 4 * u) * 16 + (lane & 15);
+                    ti[u] = (pos[u] * inv_cols) >> 16;
+                    tj[u] = pos[u] - ti[u] * cols;
+                    acc1[u][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    acc1[u][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int base = ti[u] * FW + tj[u];
-                        float pv[4];
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < ksteps) {
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) pv[jj] = (koff[ks][jj] >= 0 && pos[u] < npos) ? ftile[base + koff[ks][jj]] : 0.f;
-                        uint2 ph, pl = make_uint2(0, 0);
-                        if (NS == 2) {
-                            split_bf16x2(pv[0], pv[1], ph.x, pl.x);
-                            split_bf16x2(pv[2], pv[3], ph.y, pl.y);
-                        } else {
-                            ph = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
-                        }
+                        for (int u = 0; u < 2; ++u) {
+                            const int base = ti[u] * FW + tj[u];
+                            float pv[4];
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            acc1[u][nt] = mfma16k16(w1[ks][nt][0], ph, acc1[u][nt]);
+                            for (int jj = 0; jj < 4; ++jj) pv[jj] = (koff[ks][jj] >= 0 && pos[u] < npos) ? ftile[base + koff[ks][jj]] : 0.f;
+                            uint2 ph, pl = make_uint2(0, 0);
                             if (NS == 2) {
-                                acc1[u][nt] = mfma16k16(w1[ks][nt][0], pl, acc1[u][nt]);
-                                acc1[u][nt] = mfma16k16(w1[ks][nt][1], ph, acc1[u][nt]);
+                                split_bf16x2(pv[0], pv[1], ph.x, pl.x);
+                                split_bf16x2(pv[2], pv[3], ph.y, pl.y);
+                            } else {
+                                ph = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
+                            }
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt) {
+                                acc1[u][nt] = mfma16k16(w1[ks][nt][0], ph, acc1[u][nt]);
+                                if (NS == 2) {
+                                    acc1[u][nt] = mfma16k16(w1[ks][nt][0], pl, acc1[u][nt]);
+                                    acc1[u][nt] = mfma16k16(w1[ks][nt][1], ph, acc1[u][nt]);
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (pos[u] < npos) {
+                        const int t = t0 - 1 + ti[u], f = f0 - 1 + tj[u];
+                        const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
+                        float y[8];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[u][nt][r] + sh1[nt][r], 0.f) : 0.f;
+                        uint4 hi, lo;
+                        cvt8(y, NS == 2, hi, lo);
+                        const int off = tile_off(ti[u], tj[u], g);
+                        *reinterpret_cast<uint4*>(smem + off) = hi;
+                        if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+                    }
+                }
+            }
+        } else if constexpr (PREFETCH) {
+            // ---- the tile was fetched while the previous one was computed: registers -> LDS
+#pragma unroll
+            for (int n = 0; n < ITEMS; ++n) {
+                const int pos = (tid >> 2) + 64 * n;
+                const int i = (pos * inv_cols) >> 16;
+                const int j = pos - i * cols;
+                if (pos < npos) *reinterpret_cast<uint4*>(smem + tile_off(i, j, c)) = pre[n];
+            }
+        } else {
+            // ---- stage the (TT+2) x (ft+2) x 32 tile in two batches (all loads of a batch issued before the first
+            // LDS store)
+            const char* in = in_grp + (int64_t)tc.b * a.T * a.F * CIN * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
+            constexpr int BATCH = ITEMS / 2;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint4 v0[BATCH], v1[BATCH];
+                int off[BATCH];
+#pragma unroll
+                for (int n = 0; n < BATCH; ++n) {
+                    const int pos = (tid >> 2) + 64 * (half * BATCH + n);
+                    const int i = (pos * inv_cols) >> 16;
+                    const int j = pos - i * cols;
+                    const int t = t0 - 1 + i, f = f0 - 1 + j;
+                    const bool ok = pos < npos && t >= 0 && t < a.T && f >= 0 && f < a.F;
+                    off[n] = pos < npos ? tile_off(i, j, c) : -1;
+                    v0[n] = make_uint4(0, 0, 0, 0);
+                    v1[n] = make_uint4(0, 0, 0, 0);
+                    if (ok) {
+                        const int64_t e = ((int64_t)t * a.F + f) * CIN + c * 8;
+                        if (IN_TYPE == AMTX_T_BF16) {
+                            v0[n] = *reinterpret_cast<const uint4*>(in + e * 2);
+                        } else {
+                            v0[n] = *reinterpret_cast<const uint4*>(in + e * 4);
+                            v1[n] = *reinterpret_cast<const uint4*>(in + e * 4 + 16);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < BATCH; ++n) {
+                    if (off[n] < 0) continue;
+                    uint4 hi = v0[n], lo = make_uint4(0, 0, 0, 0);
+                    if (IN_TYPE == AMTX_T_F32) {
+                        const float fv[8] = {__uint_as_float(v0[n].x), __uint_as_float(v0[n].y), __uint_as_float(v0[n].z), __uint_as_float(v0[n].w),
+                                             __uint_as_float(v1[n].x), __uint_as_float(v1[n].y), __uint_as_float(v1[n].z), __uint_as_float(v1[n].w)};
+                        cvt8(fv, NS == 2, hi, lo);
+                    }
+                    *reinterpret_cast<uint4*>(smem + off[n]) = hi;
+                    if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off[n]) = lo;
+                }
+            }
+        }
+        __syncthreads();
+        if constexpr (PREFETCH) {
+            if (has_next) CONV_ISSUE_TILE_LOADS(tn);
+        }
+
+        const int t = t0 + trow;
+        char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)tc.b * a.T + t) * Fo * COUT) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+        for (int jp = wave; jp < (ft >> 1); jp += 4) {
+            f32x4_t acc[2][NT];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    uint4 x[NS];
+                    const int off = tile_off(trow + kh, 2 * jp + cc, g);
+                    x[0] = *reinterpret_cast<const uint4*>(smem + off);
+                    if (NS == 2) x[1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int kw = cc - e;
+                        if (kw < 0 || kw > 2) continue;
+                        const int tap = kh * 3 + kw;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[e][nt] = mfma16(wf[tap][nt][0], x[0], acc[e][nt]);
+                            if (NS == 2) {
+                                acc[e][nt] = mfma16(wf[tap][nt][0], x[1], acc[e][nt]);
+                                acc[e][nt] = mfma16(wf[tap][nt][1], x[0], acc[e][nt]);
                             }
                         }
                     }
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (pos[u] < npos) {
-                    const int t = t0 - 1 + ti[u], f = f0 - 1 + tj[u];
-                    const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
-                    float y[8];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[u][nt][r] + sh1[nt][r], 0.f) : 0.f;
-                    uint4 hi, lo;
-                    cvt8(y, NS == 2, hi, lo);
-                    const int off = tile_off(ti[u], tj[u], g1);
-                    *reinterpret_cast<uint4*>(smem + off) = hi;
-                    if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
-                }
-            }
-        }
-    } else {
-    // ---- stage the (TT+2) x (ft+2) x 32 input tile in LDS, zero outside the map.  All global loads of a
-    // batch are issued before the first LDS store, so a block pays ~2 memory round trips for its tile instead
-    // of one per 16-byte item.
-    const int c = tid & 3;                              // chunk handled by this thread (256 % 4 == 0)
-    constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 14
-    constexpr int BATCH = ITEMS / 2;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        uint4 v0[BATCH], v1[BATCH];
-        int off[BATCH];
-#pragma unroll
-        for (int n = 0; n < BATCH; ++n) {
-            const int pos = (tid >> 2) + 64 * (half * BATCH + n);
-            const int i = (pos * inv_cols) >> 16;       // pos / cols, exact for pos < 1024 (checked on the host)
-            const int j = pos - i * cols;
-            const int t = t0 - 1 + i, f = f0 - 1 + j;
-            const bool ok = pos < npos && t >= 0 && t < a.T && f >= 0 && f < a.F;
-            off[n] = pos < npos ? tile_off(i, j, c) : -1;
-            v0[n] = make_uint4(0, 0, 0, 0);
-            v1[n] = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int64_t e = ((int64_t)t * a.F + f) * CIN + c * 8;
-                if (IN_TYPE == AMTX_T_BF16) {
-                    v0[n] = *reinterpret_cast<const uint4*>(in + e * 2);
-                } else {
-                    v0[n] = *reinterpret_cast<const uint4*>(in + e * 4);
-                    v1[n] = *reinterpret_cast<const uint4*>(in + e * 4 + 16);
-                }
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < BATCH; ++n) {
-            if (off[n] < 0) continue;
-            uint4 hi = v0[n], lo = make_uint4(0, 0, 0, 0);
-            if (IN_TYPE == AMTX_T_F32) {
-                const float fv[8] = {__uint_as_float(v0[n].x), __uint_as_float(v0[n].y), __uint_as_float(v0[n].z), __uint_as_float(v0[n].w),
-                                     __uint_as_float(v1[n].x), __uint_as_float(v1[n].y), __uint_as_float(v1[n].z), __uint_as_float(v1[n].w)};
-                cvt8(fv, NS == 2, hi, lo);
-            }
-            *reinterpret_cast<uint4*>(smem + off[n]) = hi;
-            if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off[n]) = lo;
-        }
-    }
 
-    }
-
-    // folded BN shift for this lane's 4*NT consecutive channels
-    const int g = lane >> 4, trow = lane & 15;
-    float sh[NT][4];
-    {
-        const float* s = a.shift + (int64_t)grp * a.shift_gs + g * 4 * NT;
+            // ---- + shift, ReLU, MaxPool(1,2) over the (f, f+1) pair, channels-last store
+            const int fo = (f0 >> 1) + jp;
+            if (t < a.T && fo < Fo) {
+                float v[NT * 4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sh[nt][r] = s[4 * nt + r];
-    }
-    __syncthreads();
-
-    const int Fo = a.F >> 1;
-    const int t = t0 + trow;
-    char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)b * a.T + t) * Fo * COUT) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
-
-    for (int jp = wave; jp < (ft >> 1); jp += 4) {
-        f32x4_t acc[2][NT];
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[e][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                uint4 x[NS];
-                const int off = tile_off(trow + kh, 2 * jp + cc, g);
-                x[0] = *reinterpret_cast<const uint4*>(smem + off);
-                if (NS == 2) x[1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int kw = cc - e;
-                    if (kw < 0 || kw > 2) continue;
-                    const int tap = kh * 3 + kw;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[e][nt] = mfma16(wf[tap][nt][0], x[0], acc[e][nt]);
-                        if (NS == 2) {
-                            acc[e][nt] = mfma16(wf[tap][nt][0], x[1], acc[e][nt]);
-                            acc[e][nt] = mfma16(wf[tap][nt][1], x[0], acc[e][nt]);
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const float y0 = fmaxf(acc[0][nt][r] + sh[nt][r], 0.f);
+                        const float y1 = fmaxf(acc[1][nt][r] + sh[nt][r], 0.f);
+                        v[nt * 4 + r] = fmaxf(y0, y1);
                     }
+                if (OUT_TYPE == AMTX_T_BF16) {
+                    uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
+#pragma unroll
+                    for (int q = 0; q < NT / 2; ++q)
+                        dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                                            pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
+                } else {
+                    float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 4);
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 }
             }
         }
-
-        // ---- + shift, ReLU, MaxPool(1,2) over the (f, f+1) pair, channels-last store
-        const int fo = (f0 >> 1) + jp;
-        if (t < a.T && fo < Fo) {
-            float v[NT * 4];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float y0 = fmaxf(acc[0][nt][r] + sh[nt][r], 0.f);
-                    const float y1 = fmaxf(acc[1][nt][r] + sh[nt][r], 0.f);
-                    v[nt * 4 + r] = fmaxf(y0, y1);
-                }
-            if (OUT_TYPE == AMTX_T_BF16) {
-                uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
-#pragma unroll
-                for (int q = 0; q < NT / 2; ++q)
-                    dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
-                                        pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
-            } else {
-                float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 4);
-#pragma unroll
-                for (int q = 0; q < NT; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-            }
-        }
+        __syncthreads();   // every wave is done with this LDS tile before the next one is staged
     }
+#undef CONV_ISSUE_TILE_LOADS
+#undef CONV_ISSUE_FEAT_LOADS
 }
 
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1>
@@ -328,7 +410,11 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
             amtx_set_error("conv3x3: internal: reciprocal division inexact for cols=%d", cols);
             return AMTX_ERR_ARG;
         }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt, inv_cols);
+    // persistent grid: two resident blocks per CU in total
+    int64_t gx = nblocks;
+    const int64_t per_group = std::max<int64_t>(1, 512 / std::max(1, a.groups));
+    if (gx > per_group) gx = per_group;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt, inv_cols, (int)nblocks);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
