@@ -191,19 +191,35 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // Block ids are remapped so the n-tiles that share an A panel run back to back on one XCD (A is then read
 // from HBM once and re-read from that XCD's L2).
 constexpr int GBK = 64;
-constexpr int GTILE = BM * GBK * 2;   // 16 KiB per operand per buffer
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int C_TYPE>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][A 16K | W 16K]
+// 16 bytes per lane HBM/L2 -> LDS without a VGPR round trip: LDS address = M0 (wave-uniform) + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // provably wave-uniform for the "s" constraint
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+// TB = tile edge (128: 4 waves as 2x2, 256: 8 waves as 2x4); every wave owns (TB/2) x 64 outputs.
+// A 256x256 tile moves 64 KiB per 4.2 M MACs (64 MAC/B); the 128x128 tile's 32 MAC/B sits right at the
+// ~64 B/clk/CU the L2 can deliver, so the big tile is used whenever N is a multiple of 256.
+template <int C_TYPE, int TB>
+__global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][A tile | W tile]
+    constexpr int TILE = TB * GBK * 2;                            // bytes per operand per buffer
+    constexpr int WAVES = TB / 32;                                // 4 or 8
+    constexpr int WN = WAVES / 2;                                 // waves along N
+    constexpr int MT = (TB / 2) / 16;                             // 16-row tiles per wave along M (4 or 8)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int grp = blockIdx.z;
-    const unsigned nbn = g.n_pad / BN;
+    const unsigned nbn = g.n_pad / TB;
     const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (logical % nbn) * BN;
-    const int64_t m0 = (int64_t)(logical / nbn) * BM;
+    const int n0 = (logical % nbn) * TB;
+    const int64_t m0 = (int64_t)(logical / nbn) * TB;
 
     const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)grp * g.a_gs;
     const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
@@ -220,20 +236,25 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         a_src[n] = Abase + mr * g.lda + c * 8;
         w_src[n] = Wbase + (int64_t)(n0 + row) * g.k_pad + c * 8;
     }
+    // The DMA is issued from inline asm on purpose: with the builtin, hipcc treats every later ds_read as a possible
+    // reader of the in-flight LDS write and puts `s_waitcnt vmcnt(0)` in front of the fragment reads, which
+    // serialises load and compute.  Hidden from the compiler, the next tile streams in while this one is on the
+    // matrix cores; ordering is restored by hand (vmcnt(0) + barrier at the end of each k-tile).
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem) + wave * 4096;
 #define GLDS_ISSUE(k0, buf)                                                                                   \
     do {                                                                                                      \
-        char* sb = smem + (buf) * 2 * GTILE + wave * 4096;                                                    \
+        const unsigned sb = lds_base + (buf) * 2 * TILE;                                                      \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                       \
-            __builtin_amdgcn_global_load_lds((const void*)(a_src[n] + (k0)), (lds_void_t*)(sb + n * 1024), 16, 0, 0);          \
-            __builtin_amdgcn_global_load_lds((const void*)(w_src[n] + (k0)), (lds_void_t*)(sb + GTILE + n * 1024), 16, 0, 0);  \
+            glds16(a_src[n] + (k0), sb + n * 1024);                                                           \
+            glds16(w_src[n] + (k0), sb + TILE + n * 1024);                                                    \
         }                                                                                                     \
     } while (0)
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][MT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.k_pad / GBK;
     GLDS_ISSUE(0, 0);
@@ -244,21 +265,24 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) GLDS_ISSUE((kt + 1) * GBK, cur ^ 1);
-        const char* b = smem + cur * 2 * GTILE;
+        const char* b = smem + cur * 2 * TILE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            uint4 af[4], wf[4];
+            uint4 af[MT], wf[4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int ar = wm * (TB / 2) + t * 16 + frow;
+                af[t] = *reinterpret_cast<const uint4*>(b + ar * 128 + (((kk * 4 + fchunk) ^ ((ar >> 1) & 7)) << 4));
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int ar = wm * 64 + t * 16 + frow;
                 const int wr = wn * 64 + t * 16 + frow;
-                af[t] = *reinterpret_cast<const uint4*>(b + ar * 128 + (((kk * 4 + fchunk) ^ ((ar >> 1) & 7)) << 4));
-                wf[t] = *reinterpret_cast<const uint4*>(b + GTILE + wr * 128 + (((kk * 4 + fchunk) ^ ((wr >> 1) & 7)) << 4));
+                wf[t] = *reinterpret_cast<const uint4*>(b + TILE + wr * 128 + (((kk * 4 + fchunk) ^ ((wr >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -277,8 +301,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
             for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
+        for (int mt = 0; mt < MT; ++mt) {
+            const int64_t m = m0 + wm * (TB / 2) + mt * 16 + (lane & 15);
             if (m >= g.M) continue;
             const f32x4_t v = acc[nt][mt];
             const float o0 = v[0] + bv[0], o1 = v[1] + bv[1], o2 = v[2] + bv[2], o3 = v[3] + bv[3];
@@ -291,18 +315,18 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     }
 }
 
-template <int C_TYPE>
+template <int C_TYPE, int TB>
 int launch_glds(const GemmArgs& g, hipStream_t stream) {
-    const int64_t nblocks = ((g.M + BM - 1) / BM) * (g.n_pad / BN);
+    const int64_t nblocks = ((g.M + TB - 1) / TB) * (g.n_pad / TB);
     AMTX_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
-    const size_t lds = 4 * GTILE;
-    auto kern = gemm_glds_kernel<C_TYPE>;
+    const size_t lds = 4 * (size_t)TB * GBK * 2;
+    auto kern = gemm_glds_kernel<C_TYPE, TB>;
     static bool attr_done = false;
     if (!attr_done) {
         AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, (unsigned)g.groups), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, (unsigned)g.groups), dim3(TB * 2), lds, stream, g);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -346,7 +370,9 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {
-        return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16>(g, stream) : launch_glds<AMTX_T_F32>(g, stream);
+        if (g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256)
+            return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 256>(g, stream) : launch_glds<AMTX_T_F32, 256>(g, stream);
+        return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 128>(g, stream) : launch_glds<AMTX_T_F32, 128>(g, stream);
     }
     const int key = (g.a_type << 2) | (g.c_type << 1) | (g.planes - 1);
     switch (key) {
