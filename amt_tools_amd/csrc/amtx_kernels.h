@@ -72,3 +72,5 @@ void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int plane
 // out[b][k][t] = threshold < 0 ? sigmoid(x) : (sigmoid(x) < threshold ? 0 : 1), x = logits[(b*T+t)*ld + col0 + k]
 int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int T, int keys, float threshold, float* out,
                           hipStream_t stream);
+
+int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream);

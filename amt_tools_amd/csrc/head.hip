@@ -33,7 +33,31 @@ __global__ __launch_bounds__(256) void pianoroll_kernel(const float* __restrict_
     }
 }
 
+// fp32 rows [M][ld_src] (n_src valid columns) -> bf16 rows [M][ld_dst], zero padded: lets the adjoin input projection
+// (A = joint logits) run on the direct-to-LDS bf16 GEMM path.
+__global__ __launch_bounds__(256) void cvt_pad_bf16_kernel(const float* __restrict__ src, int64_t ld_src, int n_src, bf16_t* __restrict__ dst,
+                                                           int ld_dst, int64_t rows) {
+    const int groups = ld_dst >> 2;                                   // 4 columns per thread
+    const int64_t total = rows * groups;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / groups;
+        const int c = (int)(i - r * groups) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 3 < n_src) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        *reinterpret_cast<uint2*>(dst + r * ld_dst + c) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+}
+
 }  // namespace
+
+int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream) {
+    AMTX_REQUIRE(src && dst && rows > 0 && n_src % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0 && ld_dst >= n_src, "cvt_pad_bf16: bad argument");
+    int64_t nb = (rows * (ld_dst >> 2) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(cvt_pad_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, rows);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
 
 int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int T, int keys, float threshold, float* out,
                           hipStream_t stream) {

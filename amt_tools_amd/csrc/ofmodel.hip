@@ -153,7 +153,7 @@ int pack_lstm(amtx_of_model* m, const std::string& prefix, int dim_in, std::vect
 }
 
 struct Workspace {
-    char *a1, *a2, *a3, *e, *xp, *l1, *joint, *xp2, *l2, *mp;
+    char *a1, *a2, *a3, *e, *xp, *l1, *joint, *joint16, *xp2, *l2, *mp;
     size_t total;
 };
 
@@ -171,6 +171,7 @@ Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
     w.xp = take(BT * 1024 * es * m->n_rec);
     w.l1 = take(BT * m->dim_lm * es * m->n_rec);
     w.joint = take(BT * m->dim_aj * sizeof(float));
+    w.joint16 = take(BT * (size_t)((m->dim_aj + 63) / 64 * 64) * 2);   // bf16 copy, K padded to the GEMM's 64-deep k-tile
     w.xp2 = take(BT * 1024 * es);
     w.l2 = take(BT * m->dim_lm * es);
     w.mp = take(BT * m->n_out * sizeof(float));
@@ -429,7 +430,15 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     mark();
 
     // adjoin
-    g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
+    if (pl == 1) {
+        // bf16 mode: round the joint logits to bf16 once (zero-padded to a 64-multiple K) and use the direct-to-LDS GEMM
+        const int kp = (m->dim_aj + 63) / 64 * 64;
+        if ((rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s)) != AMTX_OK) return rc;
+        g = gemm_args(w.joint16, kp, AMTX_T_BF16, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
+        g.K = kp;
+    } else {
+        g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
+    }
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     l.xproj = w.xp2; l.whh = (const bf16_t*)m->adj_hh.p; l.out = w.l2; l.groups = 1;
