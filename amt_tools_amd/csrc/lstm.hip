@@ -6,9 +6,10 @@
 // this kernel runs the T dependent steps
 //     gates = xproj_t + W_hh h_{t-1};  c = sig(f) c + sig(i) tanh(g);  h = sig(o) tanh(c)   (gate order i,f,g,o)
 //
-// One 256-thread block = one direction x 16 clips, resident for the whole sequence:
-//   * W_hh (512x128) lives in registers for all T steps: wave w owns hidden units [32w, 32w+32) and their
-//     four gates = 8 MFMA row tiles x 4 k-steps (128 VGPRs in bf16, 256 in x3),
+// One 512-thread block (8 waves, two per SIMD) = one direction x 16 clips, resident for the whole sequence:
+//   * W_hh (512x128) lives in registers for all T steps: wave w owns hidden units [16w, 16w+16) and their
+//     four gates = 4 MFMA row tiles x 4 k-steps (64 VGPRs in bf16, 128 in x3); the two waves of a SIMD
+//     overlap one's MFMAs with the other's gate math, which shortens the per-step dependency chain,
 //   * h_{t-1} (16 clips x 128) is the MFMA B operand, exchanged through a double-buffered 4 KiB LDS tile
 //     (row pitch 272 B -> conflict-free 16-byte fragment reads), one barrier per step,
 //   * computed swapped (D' = W_hh . h^T) so i,f,g,o of one (clip, unit) land in the same lane and the
@@ -23,6 +24,9 @@
 namespace {
 
 constexpr int H = 128;
+constexpr int UB = 1;                        // 16-unit blocks per wave
+constexpr int LWAVES = H / (16 * UB);        // waves per block (8): wave w owns hidden units [16*UB*w, 16*UB*(w+1))
+constexpr int LTHREADS = 64 * LWAVES;
 constexpr int HP = H + 8;                    // bf16 elements per LDS row
 constexpr int HBUF_BYTES = 16 * HP * 2;      // one plane of one buffer
 
@@ -49,9 +53,9 @@ template <int X_TYPE> struct XRaw { typedef float4 type; };
 template <> struct XRaw<AMTX_T_BF16> { typedef uint2 type; };
 
 template <int X_TYPE>
-__device__ __forceinline__ void load_x(const char* xbase, int64_t row_off, typename XRaw<X_TYPE>::type (&dst)[2][4]) {
+__device__ __forceinline__ void load_x(const char* xbase, int64_t row_off, typename XRaw<X_TYPE>::type (&dst)[UB][4]) {
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub)
+    for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t e = row_off + q * 128 + 16 * ub;
@@ -74,9 +78,9 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 template <int NS, int X_TYPE, int OUT_TYPE, bool FAST>
-__device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)[2][4][4][NS], const typename XRaw<X_TYPE>::type (&xcur)[2][4],
-                                          typename XRaw<X_TYPE>::type (&xnext)[2][4], float (&c)[2][4], const char* xbase, char* obase, int t, int tnext,
-                                          bool has_next, int clip, int g, int wave, bool clip_ok) {
+__device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)[UB][4][4][NS], const typename XRaw<X_TYPE>::type (&xcur)[UB][4],
+                                          typename XRaw<X_TYPE>::type (&xnext)[UB][4], float (&c)[UB][4], const char* xbase, char* obase, int t, int tnext,
+                                          int clip, int g, int wave, bool clip_ok) {
     const char* hb = smem + cur * NS * HBUF_BYTES;
     uint4 hf[4][NS];
 #pragma unroll
@@ -85,19 +89,19 @@ __device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)
         for (int p = 0; p < NS; ++p)
             hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBUF_BYTES + (clip * HP + 32 * ks + 8 * g) * 2);
 
-    // unconditional (the last step re-reads its own row): a branch here would make the compiler's waitcnt
-    // pass assume the prefetch may not have been issued and wait for it right away
-    load_x<X_TYPE>(xbase, (int64_t)(has_next ? tnext : t) * 1024, xnext);
+    // unconditional (steps past the end re-read the last row): a branch here would make the compiler's waitcnt pass
+    // assume the prefetch may not have been issued and wait for it right away
+    load_x<X_TYPE>(xbase, (int64_t)tnext * 1024, xnext);
 
-    f32x4_t acc[2][4];
+    f32x4_t acc[UB][4];
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub)
+    for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[ub][q] = unpack_x(xcur[ub][q]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
+        for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 acc[ub][q] = mfma16(wf[ub][q][ks][0], hf[ks][0], acc[ub][q]);
@@ -109,7 +113,7 @@ __device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)
 
     char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub) {
+    for (int ub = 0; ub < UB; ++ub) {
         float h[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -127,7 +131,7 @@ __device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)
         } else {
             hiw = make_uint2(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]));
         }
-        const int hoff = (clip * HP + 32 * wave + 16 * ub + 4 * g) * 2;
+        const int hoff = (clip * HP + 16 * UB * wave + 16 * ub + 4 * g) * 2;
         *reinterpret_cast<uint2*>(hn + hoff) = hiw;
         if (NS == 2) *reinterpret_cast<uint2*>(hn + HBUF_BYTES + hoff) = low;
         if (clip_ok) {
@@ -140,7 +144,7 @@ __device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)
 }
 
 template <int NS, int X_TYPE, int OUT_TYPE>
-__global__ __launch_bounds__(256) void bilstm_kernel(LstmArgs a) {
+__global__ __launch_bounds__(LTHREADS) void bilstm_kernel(LstmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16
     constexpr bool FAST = (NS == 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -151,50 +155,51 @@ __global__ __launch_bounds__(256) void bilstm_kernel(LstmArgs a) {
     const int T = a.T;
 
     // ---- stationary recurrent weights
-    uint4 wf[2][4][4][NS];
+    uint4 wf[UB][4][4][NS];
     {
         const uint4* w = reinterpret_cast<const uint4*>(a.whh + (int64_t)grp * a.w_gs) + lane;
 #pragma unroll
-        for (int ub = 0; ub < 2; ++ub)
+        for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int p = 0; p < NS; ++p)
-                        wf[ub][q][ks][p] = w[((((((dir * 4 + wave) * 2 + ub) * 4 + q) * 4 + ks) * NS) + p) * 64];
+                        wf[ub][q][ks][p] = w[((((((dir * LWAVES + wave) * UB + ub) * 4 + q) * 4 + ks) * NS) + p) * 64];
     }
 
-    for (int i = tid; i < 2 * NS * HBUF_BYTES / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * NS * HBUF_BYTES / 16; i += LTHREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    float c[2][4];
+    float c[UB][4];
 #pragma unroll
-    for (int ub = 0; ub < 2; ++ub)
+    for (int ub = 0; ub < UB; ++ub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) c[ub][r] = 0.f;
 
     const char* xbase = reinterpret_cast<const char*>(a.xproj) +
-                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + 32 * wave + 4 * g) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
+                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + 16 * UB * wave + 4 * g) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
     char* obase = reinterpret_cast<char*>(a.out) +
-                  ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + 32 * wave + 4 * g) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+                  ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + 16 * UB * wave + 4 * g) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
 
-    typename XRaw<X_TYPE>::type xa[2][4], xb[2][4];
-    load_x<X_TYPE>(xbase, (int64_t)(dir == 0 ? 0 : T - 1) * 1024, xa);
+    // x-projection ring: the rows of steps s+1..s+3 are in flight while step s runs (HBM latency is about as long as
+    // one step, so a one-step lookahead stalls every step).  Four steps per iteration so the ring slots are named
+    // registers (no copies, no dynamic indexing).
+    typename XRaw<X_TYPE>::type x0[UB][4], x1[UB][4], x2[UB][4], x3[UB][4];
+    auto tidx = [&](int s) { s = s < T ? s : T - 1; return (int64_t)(dir == 0 ? s : T - 1 - s); };
+    load_x<X_TYPE>(xbase, tidx(0) * 1024, x0);
+    load_x<X_TYPE>(xbase, tidx(1) * 1024, x1);
+    load_x<X_TYPE>(xbase, tidx(2) * 1024, x2);
     __syncthreads();
 
-    // two steps per iteration so the prefetched x-projection registers alternate (xa <-> xb) without a copy:
-    // the wait for a prefetch then sits at its first use, one full step after it was issued.
-    for (int s = 0; s < T; s += 2) {
-        {
-            const int t = dir == 0 ? s : T - 1 - s;
-            const int tn = dir == 0 ? s + 1 : T - 2 - s;
-            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, xa, xb, c, xbase, obase, t, tn, s + 1 < T, clip, g, wave, clip_ok);
-        }
-        if (s + 1 < T) {
-            const int t = dir == 0 ? s + 1 : T - 2 - s;
-            const int tn = dir == 0 ? s + 2 : T - 3 - s;
-            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, xb, xa, c, xbase, obase, t, tn, s + 2 < T, clip, g, wave, clip_ok);
-        }
+    for (int s = 0; s < T; s += 4) {
+        lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), clip, g, wave, clip_ok);
+        if (s + 1 < T)
+            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), clip, g, wave, clip_ok);
+        if (s + 2 < T)
+            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), clip, g, wave, clip_ok);
+        if (s + 3 < T)
+            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), clip, g, wave, clip_ok);
     }
 }
 
@@ -202,7 +207,7 @@ template <int NS, int X_TYPE, int OUT_TYPE>
 int launch(const LstmArgs& a, hipStream_t stream) {
     dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
     const size_t lds = 2 * NS * HBUF_BYTES;
-    hipLaunchKernelGGL((bilstm_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((bilstm_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(LTHREADS), lds, stream, a);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -214,17 +219,17 @@ size_t amtx_bilstm_wfrag_elems(int planes) { return (size_t)2 * 512 * 128 * plan
 void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out) {
     for (int dir = 0; dir < 2; ++dir) {
         const float* W = dir == 0 ? whh_fwd : whh_bwd;   // (512, 128) row-major, gate-major rows i,f,g,o
-        for (int w = 0; w < 4; ++w)
-            for (int ub = 0; ub < 2; ++ub)
+        for (int w = 0; w < LWAVES; ++w)
+            for (int ub = 0; ub < UB; ++ub)
                 for (int q = 0; q < 4; ++q)
                     for (int ks = 0; ks < 4; ++ks)
                         for (int l = 0; l < 64; ++l)
                             for (int j = 0; j < 8; ++j) {
-                                const int row = q * 128 + 32 * w + 16 * ub + (l & 15);
+                                const int row = q * 128 + 16 * UB * w + 16 * ub + (l & 15);
                                 const int k = 32 * ks + 8 * (l >> 4) + j;
                                 const float v = W[(size_t)row * H + k];
                                 const bf16_t hi = f32_to_bf16_rn(v);
-                                const size_t base = ((((((size_t)dir * 4 + w) * 2 + ub) * 4 + q) * 4 + ks) * planes) * 512 + (size_t)l * 8 + j;
+                                const size_t base = ((((((size_t)dir * LWAVES + w) * UB + ub) * 4 + q) * 4 + ks) * planes) * 512 + (size_t)l * 8 + j;
                                 out[base] = hi;
                                 if (planes == 2) out[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
                             }
