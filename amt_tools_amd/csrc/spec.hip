@@ -28,7 +28,7 @@ constexpr int NFFT = 2048;
 constexpr int M = NFFT / 2;          // complex FFT length
 constexpr int XB_PITCH = 68;         // LDS row pitch (complex) of the exchange buffer: conflict-free for both passes
 constexpr int XB_ELEMS = 16 * XB_PITCH;
-constexpr int PB_ELEMS = 1028;       // power row (1025 used)
+constexpr int PB_ELEMS = 1092;       // power row: bin k lives at k + (k >> 4) (1025 bins -> 1089 slots), see pidx()
 constexpr int WAVES = 4;
 constexpr int MAX_MEL_ROUNDS = 8;    // up to 512 output rows
 
@@ -81,6 +81,10 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
     for (int k1 = 0; k1 < 4; ++k1) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
 
+// power-row slot of FFT bin k: one pad word per 16 bins, so the untangling pass (lanes stride 16 bins) and the
+// mel gather (lanes start at arbitrary bins) both spread over all LDS banks instead of two.
+__device__ __forceinline__ int pidx(int k) { return k + (k >> 4); }
+
 __device__ __forceinline__ void wave_lds_sync() {
     // same-wave LDS traffic retires in order; this only stops the compiler from moving LDS accesses
     // of different lanes' data across the exchange point.
@@ -113,7 +117,7 @@ __device__ __forceinline__ void untangle_pair(float2 zk, float2 zp, float2 w, fl
 }
 
 template <int FPW, bool MEL>
-__global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float* __restrict__ audio, int64_t num_samples,
+__global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const float* __restrict__ audio, int64_t num_samples,
                                                          int64_t audio_stride, int64_t num_frames,
                                                          float* __restrict__ power, unsigned* __restrict__ clip_max) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float*
     float2* xb = reinterpret_cast<float2*>(smem) + wave * XB_ELEMS;
     float* pb = reinterpret_cast<float*>(smem + WAVES * XB_ELEMS * sizeof(float2)) + wave * PB_ELEMS;
     float2* twp = reinterpret_cast<float2*>(smem + WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float));
+    float2* tw2l = twp + M;                           // W_64^(b*c), [b][c]: 64 entries
 
     constexpr int FPB = FPW * WAVES;
     const unsigned chunks = (unsigned)((num_frames + FPB - 1) / FPB);
@@ -130,59 +135,61 @@ __global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float*
     const unsigned chunk = logical % chunks;
     const float* clip = audio + (int64_t)clip_idx * audio_stride;
 
-    // block-shared untangling twiddles exp(-2 pi i k / 2048), k < 1024
+    // block-shared tables: untangling twiddles exp(-2 pi i k / 2048), k < 1024, and the pass-B twiddles
     for (int i = threadIdx.x; i < M; i += 256) twp[i] = p.tw_post[i];
+    if (threadIdx.x < 64) tw2l[threadIdx.x] = p.tw_fft[(16 * (threadIdx.x >> 4) * (threadIdx.x & 15)) & (M - 1)];
 
     // per-lane constants, reused by every frame this wave transforms
     float wre[16], wim[16];
-    float2 tw1[16], tw2[16];
+    float2 tw1[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         const int m = n1 * 64 + lane;
         wre[n1] = p.window[2 * m];
         wim[n1] = p.window[2 * m + 1];
         tw1[n1] = p.tw_fft[(lane * n1) & (M - 1)];
-        tw2[n1] = p.tw_fft[(16 * (lane & 3) * n1) & (M - 1)];
     }
-    // mel rows owned by this lane
-    int r_start[MAX_MEL_ROUNDS], r_count[MAX_MEL_ROUNDS], r_off[MAX_MEL_ROUNDS];
     const int rounds = MEL ? (p.n_mels + 63) / 64 : 0;
-    if (MEL) {
-#pragma unroll
-        for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
-            const int row = r * 64 + lane;
-            const bool ok = (r < rounds) && row < p.n_mels;
-            r_start[r] = ok ? p.mel_start[row] : 0;
-            r_count[r] = ok ? p.mel_count[row] : 0;
-            r_off[r] = ok ? p.mel_off[row] : 0;
-        }
-    }
     __syncthreads();
 
     float run_max = 0.0f;
     const int64_t half = p.center ? NFFT / 2 : 0;
 
+    // raw samples of the frame about to be transformed; the NEXT frame's samples are requested right after these are
+    // consumed, so their HBM/L2 latency is covered by a whole FFT + mel pass instead of stalling every frame
+    float xr[16], xi[16];
+#define SPEC_LOAD_FRAME(T_)                                                                              \
+    do {                                                                                                 \
+        const int64_t s0_ = (T_) * p.hop - half;                                                         \
+        if (s0_ >= 0 && s0_ + NFFT <= num_samples) {                                                     \
+            const float* src_ = clip + s0_ + 2 * lane;                                                   \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) { xr[n1] = src_[128 * n1]; xi[n1] = src_[128 * n1 + 1]; } \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) {                                          \
+                const int64_t idx_ = s0_ + 2 * (n1 * 64 + lane);                                         \
+                xr[n1] = fetch_padded(clip, idx_, num_samples, p.pad_mode);                              \
+                xi[n1] = fetch_padded(clip, idx_ + 1, num_samples, p.pad_mode);                          \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+    {
+        const int64_t tfirst = (int64_t)chunk * FPB + wave;
+        if (tfirst < num_frames) SPEC_LOAD_FRAME(tfirst);
+    }
+
 #pragma unroll 1
     for (int i = 0; i < FPW; ++i) {
         const int64_t t = (int64_t)chunk * FPB + i * WAVES + wave;
         if (t >= num_frames) break;
-        const int64_t s0 = t * p.hop - half;
 
-        // ---- load + window: v[n1] = z[64 n1 + lane]
+        // ---- window: v[n1] = z[64 n1 + lane]
         float2 v[16];
-        if (s0 >= 0 && s0 + NFFT <= num_samples) {
-            const float* src = clip + s0 + 2 * lane;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                v[n1] = make_float2(src[128 * n1] * wre[n1], src[128 * n1 + 1] * wim[n1]);
-            }
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                const int64_t idx = s0 + 2 * (n1 * 64 + lane);
-                v[n1] = make_float2(fetch_padded(clip, idx, num_samples, p.pad_mode) * wre[n1],
-                                    fetch_padded(clip, idx + 1, num_samples, p.pad_mode) * wim[n1]);
-            }
+        for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(xr[n1] * wre[n1], xi[n1] * wim[n1]);
+        {
+            const int64_t tnext = t + WAVES;
+            if (i + 1 < FPW && tnext < num_frames) SPEC_LOAD_FRAME(tnext);
         }
 
         // ---- pass A: DFT-16 over n1, twiddle W_1024^(lane*k1), exchange 1
@@ -204,8 +211,9 @@ __global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float*
         dft16(v);
         {
             float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
+            const float2* t2 = tw2l + (lane & 3) * 16;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) row[4 * c] = cmul(v[4 * (c & 3) + (c >> 2)], tw2[c]);
+            for (int c = 0; c < 16; ++c) row[4 * c] = cmul(v[4 * (c & 3) + (c >> 2)], t2[c]);
         }
         wave_lds_sync();
 
@@ -235,8 +243,8 @@ __global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float*
                 const int k = kbase + 256 * d;
                 float pk, pmk;
                 untangle_pair(za[d], zb[3 - d], twp[k], pk, pmk);
-                pb[k] = pk;
-                pb[M - k] = pmk;
+                pb[pidx(k)] = pk;
+                pb[pidx(M - k)] = pmk;
             }
         }
         wave_lds_sync();
@@ -244,32 +252,33 @@ __global__ __launch_bounds__(256) void spec_power_kernel(SpecDev p, const float*
         float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
         if (MEL) {
             // ---- sparse mel: lane-per-row gather over contiguous bin ranges
-#pragma unroll
-            for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
-                if (r < rounds) {
-                    const float* w = p.mel_w + r_off[r];
-                    const float* src = pb + r_start[r];
-                    float acc = 0.0f;
-                    const int nmax = p.round_max[r];
-                    for (int j = 0; j < nmax; ++j) {
-                        if (j < r_count[r]) acc = fmaf(w[j], src[j], acc);
-                    }
-                    const int row = r * 64 + lane;
-                    if (row < p.n_mels) {
-                        out_row[row] = acc;
-                        run_max = fmaxf(run_max, acc);
-                    }
+#pragma unroll 1
+            for (int r = 0; r < rounds; ++r) {
+                const int row = r * 64 + lane;
+                const bool ok = row < p.n_mels;
+                const int start = ok ? p.mel_start[row] : 0;
+                const int count = ok ? p.mel_count[row] : 0;
+                const float* w = p.mel_w + (ok ? p.mel_off[row] : 0);
+                float acc = 0.0f;
+                const int nmax = p.round_max[r];
+                for (int j = 0; j < nmax; ++j) {
+                    if (j < count) acc = fmaf(w[j], pb[pidx(start + j)], acc);
+                }
+                if (ok) {
+                    out_row[row] = acc;
+                    run_max = fmaxf(run_max, acc);
                 }
             }
         } else {
             for (int k = lane; k < p.n_out; k += 64) {
-                const float val = pb[k];
+                const float val = pb[pidx(k)];
                 out_row[k] = val;
                 run_max = fmaxf(run_max, val);
             }
         }
         wave_lds_sync();   // pb / xb are rewritten by the next frame
     }
+#undef SPEC_LOAD_FRAME
 
     run_max = wave_max_f32(run_max);
     if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));   // values >= 0: uint order == float order
@@ -502,7 +511,7 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const int64_t chunks = (T + FPB - 1) / FPB;
     const int64_t nblocks = chunks * batch;
     AMTX_REQUIRE(nblocks < (1ll << 31), "amtx_spec_power: grid too large");
-    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + M * sizeof(float2);
+    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M + 64) * sizeof(float2);
     if (plan->n_mels > 0)
         hipLaunchKernelGGL((spec_power_kernel<FPW, true>), dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio,
                            num_samples, audio_stride, T, power, (unsigned*)clip_max);
