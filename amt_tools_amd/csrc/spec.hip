@@ -506,7 +506,7 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const int64_t T = amtx_spec_num_frames(plan, num_samples);
     AMTX_REQUIRE(T > 0, "amtx_spec_power: clip too short for one frame");
     AMTX_CHECK_HIP(hipMemsetAsync(clip_max, 0, sizeof(float) * batch, stream));
-    constexpr int FPW = 4;
+    constexpr int FPW = 8;
     constexpr int FPB = FPW * WAVES;
     const int64_t chunks = (T + FPB - 1) / FPB;
     const int64_t nblocks = chunks * batch;
