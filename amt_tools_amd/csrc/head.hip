@@ -68,3 +68,72 @@ int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int 
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Root-mean-square normalisation of a batch of clips on the device: tools.rms_norm (amt_tools/tools/utils.py:2789-2814,
+// applied by tools.load_normalize_audio, tools/io.py:80-82): audio / sqrt(mean(audio^2)), untouched when the clip is
+// all zeros.  Deterministic two-level reduction (fixed summation order), then a division like the reference's.
+namespace {
+
+constexpr int RMS_CHUNK = 8192;
+
+__global__ __launch_bounds__(256) void rms_partial_kernel(const float* __restrict__ audio, int64_t n, int64_t stride, int nchunks,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const float* src = audio + (int64_t)b * stride;
+    const int64_t i0 = (int64_t)ch * RMS_CHUNK;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < RMS_CHUNK; i += 256) {
+        const int64_t j = i0 + i;
+        const float v = j < n ? src[j] : 0.f;
+        s = fmaf(v, v, s);
+    }
+    s = wave_sum_f32(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)b * nchunks + ch] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void rms_final_kernel(const float* __restrict__ partial, int nchunks, int64_t n, float* __restrict__ rms) {
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nchunks; i += 64) s += partial[(int64_t)b * nchunks + i];
+    s = wave_sum_f32(s);
+    if (threadIdx.x == 0) rms[b] = sqrtf(s / (float)n);
+}
+
+__global__ __launch_bounds__(256) void rms_scale_kernel(const float* __restrict__ audio, int64_t n, int64_t stride, const float* __restrict__ rms,
+                                                        float* __restrict__ out, int64_t out_stride) {
+    const int b = blockIdx.y;
+    const float r = rms[b];
+    const float* src = audio + (int64_t)b * stride;
+    float* dst = out + (int64_t)b * out_stride;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = r > 0.f ? src[i] / r : src[i];
+}
+
+}  // namespace
+
+extern "C" size_t amtx_rms_norm_workspace_bytes(int batch, int64_t num_samples) {
+    if (batch <= 0 || num_samples <= 0) return 0;
+    const int64_t nchunks = (num_samples + RMS_CHUNK - 1) / RMS_CHUNK;
+    return (size_t)batch * (nchunks + 1) * sizeof(float);
+}
+
+extern "C" int amtx_rms_norm(const float* audio, int64_t num_samples, int64_t audio_stride, int batch, float* out, int64_t out_stride,
+                             void* workspace, size_t workspace_bytes, void* stream_) {
+    AMTX_REQUIRE(audio && out && workspace, "amtx_rms_norm: null pointer");
+    AMTX_REQUIRE(batch > 0 && batch < 65536 && num_samples > 0 && audio_stride >= num_samples && out_stride >= num_samples, "amtx_rms_norm: bad sizes");
+    AMTX_REQUIRE(workspace_bytes >= amtx_rms_norm_workspace_bytes(batch, num_samples), "amtx_rms_norm: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const int nchunks = (int)((num_samples + RMS_CHUNK - 1) / RMS_CHUNK);
+    float* partial = (float*)workspace;
+    float* rms = partial + (size_t)batch * nchunks;
+    hipLaunchKernelGGL(rms_partial_kernel, dim3(nchunks, batch), dim3(256), 0, s, audio, num_samples, audio_stride, nchunks, partial);
+    AMTX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rms_final_kernel, dim3(batch), dim3(64), 0, s, (const float*)partial, nchunks, num_samples, rms);
+    AMTX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rms_scale_kernel, dim3(64, batch), dim3(256), 0, s, audio, num_samples, audio_stride, (const float*)rms, out, out_stride);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}

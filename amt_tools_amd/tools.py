@@ -154,6 +154,21 @@ def rms_norm(audio):
     return audio
 
 
+def rms_norm_batch(audio):
+    """rms_norm for a (B, N) float32 CUDA tensor of clips, on the device (amtx_rms_norm)."""
+    from . import _lib
+    assert audio.is_cuda and audio.dim() == 2 and audio.dtype == torch.float32
+    audio = audio.contiguous()
+    B, N = audio.shape
+    L = _lib.lib()
+    ws = torch.empty(int(L.amtx_rms_norm_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
+    out = torch.empty_like(audio)
+    with torch.cuda.device(audio.device):
+        _lib.check(L.amtx_rms_norm(_lib.ptr(audio), N, audio.stride(0), B, _lib.ptr(out), out.stride(0), _lib.ptr(ws), ws.numel(),
+                                   _lib.current_stream(audio.device)), 'amtx_rms_norm')
+    return out
+
+
 def seed_everything(seed):
     import random
     random.seed(seed)

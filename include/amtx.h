@@ -152,6 +152,12 @@ size_t amtx_cqt_workspace_bytes(const amtx_cqt_plan* plan, int batch, int64_t nu
 int amtx_cqt_forward(const amtx_cqt_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
                      void* workspace, size_t workspace_bytes, float* out, void* stream);
 
+/* RMS normalisation of a batch of clips: tools.rms_norm (tools/utils.py:2789-2814) as applied by
+ * tools.load_normalize_audio (tools/io.py:80-82): clip / sqrt(mean(clip^2)), all-zero clips untouched. */
+size_t amtx_rms_norm_workspace_bytes(int batch, int64_t num_samples);
+int amtx_rms_norm(const float* audio, int64_t num_samples, int64_t audio_stride, int batch, float* out, int64_t out_stride,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* Note decoding: binary piano rolls (B, keys, T) fp32 -> per (clip, key) row the list of (onset frame, offset frame)
  * events, `capacity` int32 pairs per row in DESCENDING frame order, and counts[B*keys].  onsets may be null (onsets are
  * then the positive first difference of multi_pitch).  Replaces the event walk of tools.multi_pitch_to_notes

@@ -128,3 +128,15 @@ def test_full_size_clip_properties():
     assert power.shape == (2, 625, 229)
     assert torch.equal(power[1], 16.0 * power[0])
     assert torch.equal(cmax, power.amax(dim=(1, 2)))
+
+
+def test_rms_norm_batch_matches_reference_formula():
+    from amt_tools_amd import tools
+    rng = np.random.default_rng(3)
+    clips = (rng.standard_normal((4, 100001)) * np.array([[0.01], [1.0], [30.0], [0.0]])).astype(np.float32)
+    got = tools.rms_norm_batch(torch.from_numpy(clips).cuda()).cpu().numpy()
+    for b in range(4):
+        ref = tools.rms_norm(clips[b].astype(np.float64)).astype(np.float32)     # tools/utils.py:2789-2814
+        assert np.abs(got[b] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    assert np.all(got[3] == 0)
+    assert abs(np.sqrt(np.mean(got[1].astype(np.float64) ** 2)) - 1.0) < 1e-5
