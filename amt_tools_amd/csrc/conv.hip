@@ -72,7 +72,8 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int 
 // Persistent blocks: each block keeps its (folded) weights in registers and walks tiles blockIdx.x, +gridDim.x, ...
 // For bf16 inputs the NEXT tile's 14 x 16 B per thread are already in flight (registers) while the current tile is
 // on the matrix cores, so the HBM/L2 latency of staging is hidden behind ~3300 MFMA cycles per wave.
-template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1>
+// KS: compile-time bound of the fused first conv's K steps (1 for c_in = 1, 4 otherwise; 0 when not fused)
+template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS>
 __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int COUT = NT * 16;
@@ -93,15 +94,10 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
 #pragma unroll
                 for (int p = 0; p < NS; ++p) wf[tap][nt][p] = w[((tap * NT + nt) * NS + p) * 64];
     }
-    // folded BN shift for this lane's 4*NT consecutive channels
-    float sh[NT][4];
-    {
-        const float* sp = a.shift + (int64_t)grp * a.shift_gs + g * 4 * NT;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sh[nt][r] = sp[4 * nt + r];
-    }
+    // folded BN shift: a C_out-float table at the end of LDS; the accumulators of every column pair are initialised
+    // from it (lane -> its 4*NT consecutive channels), so the epilogue is max3(y0, y1, 0) only
+    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PLANE_BYTES + (FUSE1 ? a.c_in * FROWS * FW * 4 : 0)) + g * NT;
+    if (tid < COUT) reinterpret_cast<float*>(smem + NS * PLANE_BYTES + (FUSE1 ? a.c_in * FROWS * FW * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
 
     const int cols = ft + 2;
     const int npos = ROWS * cols;
@@ -114,20 +110,21 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     const int fcols = ft + 4;
     const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
     const bool fprefetch = FUSE1 && fitems <= FPRE * 256;
-    int koff[4][4];
-    uint2 w1[4][2][NS];
+    constexpr int KSA = KS > 0 ? KS : 1;
+    int koff[KSA][4];
+    uint2 w1[KSA][2][NS];
     float sh1[2][4];
     int ksteps = 0;
     if constexpr (FUSE1) {
         const int kvalid = 9 * a.c_in;
         ksteps = (kvalid + 15) >> 4;                    // K = 16 per MFMA step, <= 4 steps
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = 16 * ks + 4 * g + j;
                 const int ci = k / 9, tap = k - ci * 9, kh = tap / 3, kw = tap - kh * 3;
-                koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : -1;
+                koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : 0;   // padded k: zero weights, any finite value
             }
             const uint2* wp = reinterpret_cast<const uint2*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
 #pragma unroll
@@ -207,40 +204,63 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             __syncthreads();
             if (fprefetch && has_next) CONV_ISSUE_FEAT_LOADS(tn);
             const int ngroups = (npos + 15) >> 4;
-            // two position groups per iteration: independent gather -> MFMA -> epilogue chains the scheduler can overlap
+            // Two position groups per iteration.  The im2col gathers of the NEXT iteration are issued (unconditionally:
+            // positions are clamped, padded k slots read slot 0 against zero weights) before this iteration's epilogue, so
+            // the LDS latency of the gathers is hidden behind the MFMAs + bias/ReLU/pack of the current groups.
+            float pv[2][KSA][4];
+            int ti[2], tj[2];
+#define CONV1_GATHER(GI0)                                                                                  \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                \
+                const int pc = min(((GI0) + 4 * u) * 16 + (lane & 15), npos - 1);                          \
+                ti[u] = __mul24(pc, inv_cols) >> 16;                                                       \
+                tj[u] = pc - __mul24(ti[u], cols);                                                         \
+                const float* fbase = ftile + __mul24(ti[u], FW) + tj[u];                                   \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                          \
+                    if (ks < ksteps) {                                                                     \
+                        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) pv[u][ks][jj] = fbase[koff[ks][jj]]; \
+                    }                                                                                      \
+            }
+            if (wave < ngroups) { CONV1_GATHER(wave) }
             for (int gi0 = wave; gi0 < ngroups; gi0 += 8) {
-                int pos[2], ti[2], tj[2];
+                uint2 ph[2][KSA], pl[2][KSA];
+                int cti[2], ctj[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    cti[u] = ti[u];
+                    ctj[u] = tj[u];
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        pl[u][ks] = make_uint2(0, 0);
+                        if (ks < ksteps) {
+                            if (NS == 2) {
+                                split_bf16x2(pv[u][ks][0], pv[u][ks][1], ph[u][ks].x, pl[u][ks].x);
+                                split_bf16x2(pv[u][ks][2], pv[u][ks][3], ph[u][ks].y, pl[u][ks].y);
+                            } else {
+                                ph[u][ks] = make_uint2(pack_bf16x2(pv[u][ks][0], pv[u][ks][1]), pack_bf16x2(pv[u][ks][2], pv[u][ks][3]));
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                { CONV1_GATHER(gi0 + 8) }
+                __builtin_amdgcn_sched_barrier(0);
                 f32x4_t acc1[2][2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    pos[u] = (gi0 + 4 * u) * 16 + (lane & 15);
-                    ti[u] = (pos[u] * inv_cols) >> 16;
-                    tj[u] = pos[u] - ti[u] * cols;
-                    acc1[u][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    acc1[u][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    acc1[u][0] = (f32x4_t){sh1[0][0], sh1[0][1], sh1[0][2], sh1[0][3]};
+                    acc1[u][1] = (f32x4_t){sh1[1][0], sh1[1][1], sh1[1][2], sh1[1][3]};
                 }
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < KS; ++ks) {
                     if (ks < ksteps) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const int base = ti[u] * FW + tj[u];
-                            float pv[4];
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) pv[jj] = (koff[ks][jj] >= 0 && pos[u] < npos) ? ftile[base + koff[ks][jj]] : 0.f;
-                            uint2 ph, pl = make_uint2(0, 0);
-                            if (NS == 2) {
-                                split_bf16x2(pv[0], pv[1], ph.x, pl.x);
-                                split_bf16x2(pv[2], pv[3], ph.y, pl.y);
-                            } else {
-                                ph = make_uint2(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]));
-                            }
 #pragma unroll
                             for (int nt = 0; nt < 2; ++nt) {
-                                acc1[u][nt] = mfma16k16(w1[ks][nt][0], ph, acc1[u][nt]);
+                                acc1[u][nt] = mfma16k16(w1[ks][nt][0], ph[u][ks], acc1[u][nt]);
                                 if (NS == 2) {
-                                    acc1[u][nt] = mfma16k16(w1[ks][nt][0], pl, acc1[u][nt]);
-                                    acc1[u][nt] = mfma16k16(w1[ks][nt][1], ph, acc1[u][nt]);
+                                    acc1[u][nt] = mfma16k16(w1[ks][nt][0], pl[u][ks], acc1[u][nt]);
+                                    acc1[u][nt] = mfma16k16(w1[ks][nt][1], ph[u][ks], acc1[u][nt]);
                                 }
                             }
                         }
@@ -248,22 +268,23 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if (pos[u] < npos) {
-                        const int t = t0 - 1 + ti[u], f = f0 - 1 + tj[u];
+                    if ((gi0 + 4 * u) * 16 + (lane & 15) < npos) {
+                        const int t = t0 - 1 + cti[u], f = f0 - 1 + ctj[u];
                         const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
                         float y[8];
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[u][nt][r] + sh1[nt][r], 0.f) : 0.f;
+                            for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[u][nt][r], 0.f) : 0.f;
                         uint4 hi, lo;
                         cvt8(y, NS == 2, hi, lo);
-                        const int off = tile_off(ti[u], tj[u], g);
+                        const int off = tile_off(cti[u], ctj[u], g);
                         *reinterpret_cast<uint4*>(smem + off) = hi;
                         if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
                     }
                 }
             }
+#undef CONV1_GATHER
         } else if constexpr (PREFETCH) {
             // ---- the tile was fetched while the previous one was computed: registers -> LDS
 #pragma unroll
@@ -278,13 +299,17 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             // LDS store)
             const char* in = in_grp + (int64_t)tc.b * a.T * a.F * CIN * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
             constexpr int BATCH = ITEMS / 2;
+            // opaque copy of the thread index: keeps the compiler from hoisting the 14 tile-invariant (row, column, LDS offset)
+            // triples out of the persistent loop, where they would sit in registers next to the stationary weights and spill
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 uint4 v0[BATCH], v1[BATCH];
                 int off[BATCH];
 #pragma unroll
                 for (int n = 0; n < BATCH; ++n) {
-                    const int pos = (tid >> 2) + 64 * (half * BATCH + n);
+                    const int pos = (tid_o >> 2) + 64 * (half * BATCH + n);
                     const int i = (pos * inv_cols) >> 16;
                     const int j = pos - i * cols;
                     const int t = t0 - 1 + i, f = f0 - 1 + j;
@@ -323,21 +348,37 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
 
         const int t = t0 + trow;
         char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)tc.b * a.T + t) * Fo * COUT) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
-        for (int jp = wave; jp < (ft >> 1); jp += 4) {
+        // Fragment reads are software-pipelined by tap row: while the MFMAs of row kh run, the ds_reads of the same
+        // row of this wave's NEXT column pair are already in flight (x[kh] is refilled right after its last use), so the
+        // LDS latency never sits between two MFMA groups and the epilogue overlaps the next pair's reads.
+        const int npairs = ft >> 1;
+        int rbase[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) rbase[kh] = tile_off(trow + kh, 0, g);
+        uint4 x[3][4][NS];
+#define CONV_LOAD_ROW(KH, JP)                                                                              \
+        _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) {                                                 \
+            const int off = rbase[KH] + (2 * (JP) + cc) * 64;                                              \
+            x[KH][cc][0] = *reinterpret_cast<const uint4*>(smem + off);                                    \
+            if (NS == 2) x[KH][cc][1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);         \
+        }
+        if (wave < npairs) {
+            CONV_LOAD_ROW(0, wave)
+            CONV_LOAD_ROW(1, wave)
+            CONV_LOAD_ROW(2, wave)
+        }
+        for (int jp = wave; jp < npairs; jp += 4) {
+            const int jn = min(jp + 4, npairs - 1);     // past the end: re-read a valid pair, never used
             f32x4_t acc[2][NT];
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = shl[nt];
 
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    uint4 x[NS];
-                    const int off = tile_off(trow + kh, 2 * jp + cc, g);
-                    x[0] = *reinterpret_cast<const uint4*>(smem + off);
-                    if (NS == 2) x[1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int kw = cc - e;
@@ -345,14 +386,17 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                         const int tap = kh * 3 + kw;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            acc[e][nt] = mfma16(wf[tap][nt][0], x[0], acc[e][nt]);
+                            acc[e][nt] = mfma16(wf[tap][nt][0], x[kh][cc][0], acc[e][nt]);
                             if (NS == 2) {
-                                acc[e][nt] = mfma16(wf[tap][nt][0], x[1], acc[e][nt]);
-                                acc[e][nt] = mfma16(wf[tap][nt][1], x[0], acc[e][nt]);
+                                acc[e][nt] = mfma16(wf[tap][nt][0], x[kh][cc][1], acc[e][nt]);
+                                acc[e][nt] = mfma16(wf[tap][nt][1], x[kh][cc][0], acc[e][nt]);
                             }
                         }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kh == 0) { CONV_LOAD_ROW(0, jn) } else if (kh == 1) { CONV_LOAD_ROW(1, jn) } else { CONV_LOAD_ROW(2, jn) }
+                __builtin_amdgcn_sched_barrier(0);
             }
 
             // ---- + shift, ReLU, MaxPool(1,2) over the (f, f+1) pair, channels-last store
@@ -363,9 +407,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float y0 = fmaxf(acc[0][nt][r] + sh[nt][r], 0.f);
-                        const float y1 = fmaxf(acc[1][nt][r] + sh[nt][r], 0.f);
-                        v[nt * 4 + r] = fmaxf(y0, y1);
+                        v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
                     }
                 if (OUT_TYPE == AMTX_T_BF16) {
                     uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
@@ -380,13 +422,14 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 }
             }
         }
+#undef CONV_LOAD_ROW
         __syncthreads();   // every wave is done with this LDS tile before the next one is staged
     }
 #undef CONV_ISSUE_TILE_LOADS
 #undef CONV_ISSUE_FEAT_LOADS
 }
 
-template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1>
+template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS = 0>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int fe = (a.F + 1) & ~1;
     const int ntf = (fe + FT_MAX - 1) / FT_MAX;
@@ -394,8 +437,8 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int ntt = (a.T + TT - 1) / TT;
     const int64_t nblocks = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
-    const size_t lds = (size_t)NS * PLANE_BYTES + (FUSE1 ? (size_t)a.c_in * FROWS * FW * sizeof(float) : 0);
-    auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1>;
+    const size_t lds = (size_t)NS * PLANE_BYTES + (FUSE1 ? (size_t)a.c_in * FROWS * FW * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
+    auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1, KS>;
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
         if (!done) {
@@ -426,8 +469,12 @@ int dispatch_types(const ConvArgs& a, hipStream_t s) {
             amtx_set_error("conv3x3: the fused first conv feeds a 32 -> 32 layer only");
             return AMTX_ERR_UNSUPPORTED;
         }
-        if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true>(a, s);
-        return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true>(a, s);
+        if (a.c_in * 9 <= 16) {
+            if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true, 1>(a, s);
+            return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true, 1>(a, s);
+        }
+        if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true, 4>(a, s);
+        return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true, 4>(a, s);
     }
     if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16, false>(a, s);
     if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32, false>(a, s);

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument('--clips', type=int, default=512, help='clips per GPU per step')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3'])
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time budget of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only for the "
+                                                      "single-GPU smoke test of the multi-process path)")
+    ap.add_argument('--share-device', action='store_true', help='test only: every rank uses cuda:0')
     return ap.parse_args()
 
 
@@ -117,12 +120,18 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend)
 
     from amt_tools_amd import _lib, tools
     from amt_tools_amd.synth import synth_clip
@@ -159,7 +168,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
