@@ -54,10 +54,17 @@ __device__ __forceinline__ void cvt8(const float (&f)[8], bool split, uint4& hi,
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// Makes the compiler finish the loads that produced v before the persistent loop: otherwise the first use inside the
+// loop carries an s_waitcnt vmcnt(0) that also drains the next tile's prefetch loads every iteration.
+__device__ __forceinline__ void settle(const uint4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+__device__ __forceinline__ void settle(const uint2& v) { asm volatile("" ::"v"(v.x), "v"(v.y)); }
+__device__ __forceinline__ void settle(float v) { asm volatile("" ::"v"(v)); }
+
 constexpr int FROWS = ROWS + 2;      // feature tile rows of the fused first conv
 constexpr int FW = FT_MAX + 6;       // feature tile row pitch (floats)
 
 constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 16-byte staging items per thread (14)
+constexpr int FSLACK = 16;          // floats after the feature tile: gathers of columns past the tile stay in LDS we own
 constexpr int FPRE = 4;                                        // prefetched feature values per thread (c_in = 1)
 
 struct TileCoord { int b, t0, f0; };
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     // next-tile register prefetch only where the register budget keeps 2 waves per SIMD (C_out = 32)
     constexpr bool PREFETCH = (IN_TYPE == AMTX_T_BF16) && !FUSE1 && NT <= 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the same value, provably uniform: scalar loop counters
     const int grp = blockIdx.y;
     const int g = lane >> 4, trow = lane & 15;
 
@@ -96,8 +104,8 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     }
     // folded BN shift: a C_out-float table at the end of LDS; the accumulators of every column pair are initialised
     // from it (lane -> its 4*NT consecutive channels), so the epilogue is max3(y0, y1, 0) only
-    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PLANE_BYTES + (FUSE1 ? a.c_in * FROWS * FW * 4 : 0)) + g * NT;
-    if (tid < COUT) reinterpret_cast<float*>(smem + NS * PLANE_BYTES + (FUSE1 ? a.c_in * FROWS * FW * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
+    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PLANE_BYTES + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + g * NT;
+    if (tid < COUT) reinterpret_cast<float*>(smem + NS * PLANE_BYTES + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
 
     const int cols = ft + 2;
     const int npos = ROWS * cols;
@@ -115,6 +123,8 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     uint2 w1[KSA][2][NS];
     float sh1[2][4];
     int ksteps = 0;
+    int kaddr[KSA][4];                                  // koff + the lane's column inside a 16-column block
+    const int wlane0 = (lane & 15) * 64 + g * 16, wlane1 = (lane & 15) * 64 + (g ^ 2) * 16;   // tile_off lane parts (row swizzle 0 / 1)
     if constexpr (FUSE1) {
         const int kvalid = 9 * a.c_in;
         ksteps = (kvalid + 15) >> 4;                    // K = 16 per MFMA step, <= 4 steps
@@ -125,6 +135,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 const int k = 16 * ks + 4 * g + j;
                 const int ci = k / 9, tap = k - ci * 9, kh = tap / 3, kw = tap - kh * 3;
                 koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : 0;   // padded k: zero weights, any finite value
+                kaddr[ks][j] = koff[ks][j] + (lane & 15);
             }
             const uint2* wp = reinterpret_cast<const uint2*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
 #pragma unroll
@@ -141,6 +152,24 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     uint4 pre[PREFETCH ? ITEMS : 1];
     float fpre[FPRE];
     int tile = blockIdx.x;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) settle(wf[tap][nt][p]);
+    if constexpr (FUSE1) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) settle(w1[ks][nt][p]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) settle(sh1[nt][r]);
+    }
 
 #define CONV_ISSUE_TILE_LOADS(TC)                                                                          \
     do {                                                                                                   \
@@ -203,35 +232,34 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             }
             __syncthreads();
             if (fprefetch && has_next) CONV_ISSUE_FEAT_LOADS(tn);
-            const int ngroups = (npos + 15) >> 4;
-            // Two position groups per iteration.  The im2col gathers of the NEXT iteration are issued (unconditionally:
-            // positions are clamped, padded k slots read slot 0 against zero weights) before this iteration's epilogue, so
-            // the LDS latency of the gathers is hidden behind the MFMAs + bias/ReLU/pack of the current groups.
+            // Position groups are (tile row i, 16-column block jb): row and block are wave-uniform (scalar registers), only
+            // the column inside the block is per lane, so the position arithmetic costs no vector instructions.
+            // Two groups per iteration; the im2col gathers of the NEXT iteration are issued (unconditionally: padded k slots
+            // read slot 0 against zero weights, columns past the tile read finite slack) before this iteration's epilogue,
+            // so the LDS latency of the gathers hides behind the MFMAs + ReLU/pack of the current groups.
+            const int nblk = (cols + 15) >> 4;
+            const int ngroups = ROWS * nblk;
+            const int inv_nblk = 65536 / nblk + 1;               // exact for gq < 1024 (ROWS * nblk <= 72)
             float pv[2][KSA][4];
-            int ti[2], tj[2];
 #define CONV1_GATHER(GI0)                                                                                  \
             _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                \
-                const int pc = min(((GI0) + 4 * u) * 16 + (lane & 15), npos - 1);                          \
-                ti[u] = __mul24(pc, inv_cols) >> 16;                                                       \
-                tj[u] = pc - __mul24(ti[u], cols);                                                         \
-                const float* fbase = ftile + __mul24(ti[u], FW) + tj[u];                                   \
+                const int gq = min((GI0) + 4 * u, ngroups - 1);                                            \
+                const int gi = (gq * inv_nblk) >> 16, gb = gq - gi * nblk;                                 \
+                const float* fbase = ftile + (gi * FW + gb * 16);                                          \
                 _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                          \
-                    if (ks < ksteps) {                                                                     \
-                        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) pv[u][ks][jj] = fbase[koff[ks][jj]]; \
+                    if (KS == 1 || ks < ksteps) {                                                          \
+                        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) pv[u][ks][jj] = fbase[kaddr[ks][jj]]; \
                     }                                                                                      \
             }
-            if (wave < ngroups) { CONV1_GATHER(wave) }
-            for (int gi0 = wave; gi0 < ngroups; gi0 += 8) {
+            if (wave_u < ngroups) { CONV1_GATHER(wave_u) }
+            for (int gi0 = wave_u; gi0 < ngroups; gi0 += 8) {
                 uint2 ph[2][KSA], pl[2][KSA];
-                int cti[2], ctj[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    cti[u] = ti[u];
-                    ctj[u] = tj[u];
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
                         pl[u][ks] = make_uint2(0, 0);
-                        if (ks < ksteps) {
+                        if (KS == 1 || ks < ksteps) {
                             if (NS == 2) {
                                 split_bf16x2(pv[u][ks][0], pv[u][ks][1], ph[u][ks].x, pl[u][ks].x);
                                 split_bf16x2(pv[u][ks][2], pv[u][ks][3], ph[u][ks].y, pl[u][ks].y);
@@ -252,7 +280,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks < ksteps) {
+                    if (KS == 1 || ks < ksteps) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -268,19 +296,26 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    if ((gi0 + 4 * u) * 16 + (lane & 15) < npos) {
-                        const int t = t0 - 1 + cti[u], f = f0 - 1 + ctj[u];
-                        const bool inside = t >= 0 && t < a.T && f >= 0 && f < a.F;
-                        float y[8];
+                    const int gq = gi0 + 4 * u;
+                    if (gq < ngroups) {
+                        const int gi = (gq * inv_nblk) >> 16, gb = gq - gi * nblk;          // scalar
+                        const int t = t0 - 1 + gi;
+                        const int cj = gb * 16 + (lane & 15);
+                        const int f = f0 - 1 + cj;
+                        if (cj < cols) {
+                            // ReLU and the zero padding of the 32-channel map in one v_med3: clamp to [0, inf) inside, [0, 0] outside
+                            const float lim = (t >= 0 && t < a.T && f >= 0 && f < a.F) ? __builtin_inff() : 0.f;
+                            float y[8];
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
+                            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) y[nt * 4 + r] = inside ? fmaxf(acc1[u][nt][r], 0.f) : 0.f;
-                        uint4 hi, lo;
-                        cvt8(y, NS == 2, hi, lo);
-                        const int off = tile_off(cti[u], ctj[u], g);
-                        *reinterpret_cast<uint4*>(smem + off) = hi;
-                        if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+                                for (int r = 0; r < 4; ++r) y[nt * 4 + r] = __builtin_amdgcn_fmed3f(acc1[u][nt][r], 0.f, lim);
+                            uint4 hi, lo;
+                            cvt8(y, NS == 2, hi, lo);
+                            const int off = (gi * PITCH + gb * 16) * 64 + (((gi >> 2) & 1) ? wlane1 : wlane0);
+                            *reinterpret_cast<uint4*>(smem + off) = hi;
+                            if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+                        }
                     }
                 }
             }
@@ -362,12 +397,12 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             x[KH][cc][0] = *reinterpret_cast<const uint4*>(smem + off);                                    \
             if (NS == 2) x[KH][cc][1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);         \
         }
-        if (wave < npairs) {
-            CONV_LOAD_ROW(0, wave)
-            CONV_LOAD_ROW(1, wave)
-            CONV_LOAD_ROW(2, wave)
+        if (wave_u < npairs) {
+            CONV_LOAD_ROW(0, wave_u)
+            CONV_LOAD_ROW(1, wave_u)
+            CONV_LOAD_ROW(2, wave_u)
         }
-        for (int jp = wave; jp < npairs; jp += 4) {
+        for (int jp = wave_u; jp < npairs; jp += 4) {
             const int jn = min(jp + 4, npairs - 1);     // past the end: re-read a valid pair, never used
             f32x4_t acc[2][NT];
 #pragma unroll
@@ -437,7 +472,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int ntt = (a.T + TT - 1) / TT;
     const int64_t nblocks = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
-    const size_t lds = (size_t)NS * PLANE_BYTES + (FUSE1 ? (size_t)a.c_in * FROWS * FW * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
+    const size_t lds = (size_t)NS * PLANE_BYTES + (FUSE1 ? ((size_t)a.c_in * FROWS * FW + FSLACK) * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
     auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1, KS>;
     if (lds > 64 * 1024) {
         static bool done = false;   // per instantiation
