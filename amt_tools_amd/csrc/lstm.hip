@@ -203,11 +203,135 @@ __global__ __launch_bounds__(LTHREADS) void bilstm_kernel(LstmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Four clips per block.  With 16 clips per block a batch of 512 clips is only 64 blocks: a quarter of the chip
+// works, and each of those CUs is bound by the quarter-rate v_exp/v_rcp of 2048 cell updates per step.  Here the
+// product is NOT swapped (D = h . W_hh^T): the four clips sit in rows 0, 4, 8, 12 of the 16-row h tile (the other
+// rows stay zero), so accumulator register 0 of lane (unit = lane & 15, clip = lane >> 4) holds that cell's gate
+// and every lane updates exactly ONE cell per step -- a quarter of the vector work per block and four times as
+// many blocks.  Operand packing (W_hh fragments, h tile) and the k order are those of the 16-clip kernel, so
+// both produce the same bits.
+template <int X_TYPE> struct XScalar { typedef float type; };
+template <> struct XScalar<AMTX_T_BF16> { typedef unsigned short type; };
+__device__ __forceinline__ float unpack_xs(float v) { return v; }
+__device__ __forceinline__ float unpack_xs(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+
+template <int X_TYPE>
+__device__ __forceinline__ void load_x4(const char* xbase, int64_t row_off, typename XScalar<X_TYPE>::type (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        dst[q] = *reinterpret_cast<const typename XScalar<X_TYPE>::type*>(xbase + (row_off + q * 128) * (X_TYPE == AMTX_T_F32 ? 4 : 2));
+}
+
+template <int NS, int X_TYPE, int OUT_TYPE, bool FAST>
+__device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf)[4][4][NS], const typename XScalar<X_TYPE>::type (&xcur)[4],
+                                           typename XScalar<X_TYPE>::type (&xnext)[4], float& c, const char* xbase, char* obase, int t, int tnext,
+                                           int lane, int hwoff, bool clip_ok) {
+    const char* hb = smem + cur * NS * HBUF_BYTES;
+    uint4 hf[4][NS];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int p = 0; p < NS; ++p)
+            hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBUF_BYTES + ((lane & 15) * HP + 32 * ks + 8 * (lane >> 4)) * 2);
+
+    load_x4<X_TYPE>(xbase, (int64_t)tnext * 1024, xnext);     // unconditional, see lstm_step
+
+    f32x4_t acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){unpack_xs(xcur[q]), 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[q] = mfma16(hf[ks][0], wf[q][ks][0], acc[q]);
+            if (NS == 2) {
+                acc[q] = mfma16(hf[ks][1], wf[q][ks][0], acc[q]);
+                acc[q] = mfma16(hf[ks][0], wf[q][ks][1], acc[q]);
+            }
+        }
+
+    const float ig = sigmoid_f<FAST>(acc[0][0]);
+    const float fg = sigmoid_f<FAST>(acc[1][0]);
+    const float gg = tanh_f<FAST>(acc[2][0]);
+    const float og = sigmoid_f<FAST>(acc[3][0]);
+    c = fg * c + ig * gg;
+    const float h = og * tanh_f<FAST>(c);
+
+    char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
+    uint32_t hiw, low = 0;
+    if (NS == 2) split_bf16x2(h, 0.f, hiw, low);
+    else hiw = pack_bf16x2(h, 0.f);
+    *reinterpret_cast<unsigned short*>(hn + hwoff) = (unsigned short)hiw;
+    if (NS == 2) *reinterpret_cast<unsigned short*>(hn + HBUF_BYTES + hwoff) = (unsigned short)low;
+    if (clip_ok) {
+        if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<unsigned short*>(obase + (int64_t)t * 256 * 2) = (unsigned short)hiw;
+        else *reinterpret_cast<float*>(obase + (int64_t)t * 256 * 4) = h;
+    }
+    lds_barrier();
+}
+
+template <int NS, int X_TYPE, int OUT_TYPE>
+__global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16, rows 0/4/8/12 used
+    constexpr bool FAST = (NS == 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = 16 * wave + (lane & 15), cg = lane >> 4;
+    const int dir = blockIdx.y, grp = blockIdx.z;
+    const int b = blockIdx.x * 4 + cg;
+    const bool clip_ok = b < a.B;
+    const int T = a.T;
+
+    uint4 wf[4][4][NS];
+    {
+        const uint4* w = reinterpret_cast<const uint4*>(a.whh + (int64_t)grp * a.w_gs) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) wf[q][ks][p] = w[(((((dir * LWAVES + wave) * 4 + q) * 4 + ks) * NS) + p) * 64];
+    }
+    for (int i = tid; i < 2 * NS * HBUF_BYTES / 16; i += LTHREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    float c = 0.f;
+    const char* xbase = reinterpret_cast<const char*>(a.xproj) +
+                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + unit) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
+    char* obase = reinterpret_cast<char*>(a.out) +
+                  ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + unit) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+    const int hwoff = (4 * cg * HP + unit) * 2;
+
+    typename XScalar<X_TYPE>::type x0[4], x1[4], x2[4], x3[4];
+    auto tidx = [&](int s) { s = s < T ? s : T - 1; return (int64_t)(dir == 0 ? s : T - 1 - s); };
+    load_x4<X_TYPE>(xbase, tidx(0) * 1024, x0);
+    load_x4<X_TYPE>(xbase, tidx(1) * 1024, x1);
+    load_x4<X_TYPE>(xbase, tidx(2) * 1024, x2);
+    __syncthreads();
+
+    for (int s = 0; s < T; s += 4) {
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), lane, hwoff, clip_ok);
+        if (s + 1 < T)
+            lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, clip_ok);
+        if (s + 2 < T)
+            lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, clip_ok);
+        if (s + 3 < T)
+            lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, clip_ok);
+    }
+}
+
+// clips per block: 4 while that still leaves fewer blocks than ~4 per CU, else 16 (a quarter of the total wave-steps)
+inline bool use_four_clip_blocks(const LstmArgs& a) { return (int64_t)((a.B + 3) / 4) * 2 * a.groups <= 1024; }
+
 template <int NS, int X_TYPE, int OUT_TYPE>
 int launch(const LstmArgs& a, hipStream_t stream) {
-    dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
     const size_t lds = 2 * NS * HBUF_BYTES;
-    hipLaunchKernelGGL((bilstm_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(LTHREADS), lds, stream, a);
+    if (use_four_clip_blocks(a)) {
+        dim3 grid((unsigned)((a.B + 3) / 4), 2, (unsigned)a.groups);
+        hipLaunchKernelGGL((bilstm4_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(LTHREADS), lds, stream, a);
+    } else {
+        dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
+        hipLaunchKernelGGL((bilstm_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(LTHREADS), lds, stream, a);
+    }
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

@@ -128,7 +128,8 @@ def _lstm_ref(xproj, whh_f, whh_b):
 
 
 @pytest.mark.parametrize('planes', [1, 2])
-@pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (32, 200)])
+# b <= 2048 runs the four-clips-per-block kernel, larger batches the sixteen-clip one (lstm.hip: use_four_clip_blocks)
+@pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (32, 200), (2049, 7), (2063, 3)])
 def test_bilstm(planes, b, t):
     L = _lib.lib()
     g = torch.Generator().manual_seed(b * 100 + t)
