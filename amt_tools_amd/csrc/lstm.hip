@@ -193,13 +193,13 @@ __global__ __launch_bounds__(LTHREADS) void bilstm_kernel(LstmArgs a) {
     __syncthreads();
 
     for (int s = 0; s < T; s += 4) {
+        // straight-line body: the (up to three) steps past T run on clamped rows with their stores masked.  Branching
+        // around them would give the loop header several predecessor states and hipcc answers that with a full
+        // s_waitcnt vmcnt(0) per iteration, which drains the x-projection ring.
         lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), clip, g, wave, clip_ok);
-        if (s + 1 < T)
-            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), clip, g, wave, clip_ok);
-        if (s + 2 < T)
-            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), clip, g, wave, clip_ok);
-        if (s + 3 < T)
-            lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), clip, g, wave, clip_ok);
+        lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), clip, g, wave, clip_ok && s + 1 < T);
+        lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), clip, g, wave, clip_ok && s + 2 < T);
+        lstm_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), clip, g, wave, clip_ok && s + 3 < T);
     }
 }
 
@@ -212,15 +212,20 @@ __global__ __launch_bounds__(LTHREADS) void bilstm_kernel(LstmArgs a) {
 // many blocks.  Operand packing (W_hh fragments, h tile) and the k order are those of the 16-clip kernel, so
 // both produce the same bits.
 template <int X_TYPE> struct XScalar { typedef float type; };
-template <> struct XScalar<AMTX_T_BF16> { typedef unsigned short type; };
-__device__ __forceinline__ float unpack_xs(float v) { return v; }
-__device__ __forceinline__ float unpack_xs(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+// bf16: the aligned dword that contains the element, untouched until its use one step later (a 16-bit load gets a
+// zero-extension / pair-packing instruction right behind it, which drags the wait for the prefetch to the load)
+template <> struct XScalar<AMTX_T_BF16> { typedef unsigned int type; };
+__device__ __forceinline__ float unpack_xs(float v, bool) { return v; }
+__device__ __forceinline__ float unpack_xs(unsigned int v, bool odd) { return __uint_as_float(odd ? (v & 0xffff0000u) : (v << 16)); }
 
 template <int X_TYPE>
 __device__ __forceinline__ void load_x4(const char* xbase, int64_t row_off, typename XScalar<X_TYPE>::type (&dst)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        dst[q] = *reinterpret_cast<const typename XScalar<X_TYPE>::type*>(xbase + (row_off + q * 128) * (X_TYPE == AMTX_T_F32 ? 4 : 2));
+    {
+        if (X_TYPE == AMTX_T_F32) dst[q] = *reinterpret_cast<const typename XScalar<X_TYPE>::type*>(xbase + (row_off + q * 128) * 4);
+        else dst[q] = *reinterpret_cast<const unsigned int*>(xbase + (row_off + q * 128) * 2);   // xbase is rounded down to the dword
+    }
 }
 
 template <int NS, int X_TYPE, int OUT_TYPE, bool FAST>
@@ -239,7 +244,7 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
 
     f32x4_t acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){unpack_xs(xcur[q]), 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){unpack_xs(xcur[q], lane & 1), 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -296,7 +301,8 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
 
     float c = 0.f;
     const char* xbase = reinterpret_cast<const char*>(a.xproj) +
-                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + unit) * (X_TYPE == AMTX_T_BF16 ? 2 : 4);
+                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + (X_TYPE == AMTX_T_BF16 ? (unit & ~1) : unit)) *
+                            (X_TYPE == AMTX_T_BF16 ? 2 : 4);
     char* obase = reinterpret_cast<char*>(a.out) +
                   ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + unit) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
     const int hwoff = (4 * cg * HP + unit) * 2;
@@ -309,13 +315,11 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
     __syncthreads();
 
     for (int s = 0; s < T; s += 4) {
+        // straight-line body, stores of the steps past T masked (see bilstm_kernel)
         lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), lane, hwoff, clip_ok);
-        if (s + 1 < T)
-            lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, clip_ok);
-        if (s + 2 < T)
-            lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, clip_ok);
-        if (s + 3 < T)
-            lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, clip_ok);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, clip_ok && s + 1 < T);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, clip_ok && s + 2 < T);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, clip_ok && s + 3 < T);
     }
 }
 
