@@ -12,6 +12,8 @@
 
 #include "amtx_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
@@ -203,11 +205,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
                  : "memory");
 }
 
+// Chunk swizzle of the W tile.  MFMA row tile t of a wave takes the W rows 16*(i >> 2) + 4*t + (i & 3), i = 0..15 (not 16
+// consecutive rows), so that a lane ends up with 16 CONSECUTIVE output columns of one C row (acc[0..3][.][0..3]) and
+// the epilogue writes 32/64 contiguous bytes per lane, 128/256 per row and wave, instead of 8-byte pieces.  For that row
+// set the XOR below keeps every ds_read_b128 lane group on 16 distinct 16-byte slots.
+__device__ __forceinline__ int wswz(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
+
 // TB = tile edge (128: 4 waves as 2x2, 256: 8 waves as 2x4); every wave owns (TB/2) x 64 outputs.
 // A 256x256 tile moves 64 KiB per 4.2 M MACs (64 MAC/B); the 128x128 tile's 32 MAC/B sits right at the
 // ~64 B/clk/CU the L2 can deliver, so the big tile is used whenever N is a multiple of 256.
 template <int C_TYPE, int TB>
-__global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g) {
+__global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][A tile | W tile]
     constexpr int TILE = TB * GBK * 2;                            // bytes per operand per buffer
     constexpr int WAVES = TB / 32;                                // 4 or 8
@@ -217,25 +225,30 @@ __global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g) {
     const int wm = wave / WN, wn = wave % WN;
     const int grp = blockIdx.z;
     const unsigned nbn = g.n_pad / TB;
-    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int n0 = (logical % nbn) * TB;
-    const int64_t m0 = (int64_t)(logical / nbn) * TB;
 
     const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)grp * g.a_gs;
     const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
+    const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
+    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
 
     // this wave DMAs rows [32*wave, 32*wave+32) of both tiles: 4 instructions x 8 rows each
     const bf16_t* a_src[4];
     const bf16_t* w_src[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int row = (wave * 4 + n) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        int64_t mr = m0 + row;
-        if (mr >= g.M) mr = g.M - 1;                      // rows past M are never stored; keep the read in bounds
-        a_src[n] = Abase + mr * g.lda + c * 8;
-        w_src[n] = Wbase + (int64_t)(n0 + row) * g.k_pad + c * 8;
-    }
+#define GLDS_SET_TILE(TILE_ID)                                                                                \
+    do {                                                                                                      \
+        const unsigned lg = xcd_remap((unsigned)(TILE_ID), (unsigned)ntiles);                                 \
+        const int tn0 = (lg % nbn) * TB;                                                                      \
+        const int64_t tm0 = (int64_t)(lg / nbn) * TB;                                                         \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                       \
+            const int row = (wave * 4 + n) * 8 + (lane >> 3);                                                 \
+            const int c = (lane & 7) ^ ((row >> 1) & 7);                                                      \
+            const int cw = (lane & 7) ^ wswz(row);                                                            \
+            int64_t mr = tm0 + row;                                                                           \
+            if (mr >= g.M) mr = g.M - 1; /* rows past M are never stored; keep the read in bounds */          \
+            a_src[n] = Abase + mr * g.lda + c * 8;                                                            \
+            w_src[n] = Wbase + (int64_t)(tn0 + row) * g.k_pad + cw * 8;                                       \
+        }                                                                                                     \
+    } while (0)
     // The DMA is issued from inline asm on purpose: with the builtin, hipcc treats every later ds_read as a possible
     // reader of the in-flight LDS write and puts `s_waitcnt vmcnt(0)` in front of the fragment reads, which
     // serialises load and compute.  Hidden from the compiler, the next tile streams in while this one is on the
@@ -249,84 +262,129 @@ __global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g) {
             glds16(w_src[n] + (k0), sb + TILE + n * 1024);                                                    \
         }                                                                                                     \
     } while (0)
-
-    f32x4_t acc[4][MT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#define GLDS_COMPUTE(buf)                                                                                     \
+    do {                                                                                                      \
+        const char* b = smem + (buf) * 2 * TILE;                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                    \
+            uint4 af[MT], wf[4];                                                                              \
+            _Pragma("unroll") for (int t = 0; t < MT; ++t) {                                                  \
+                const int ar = wm * (TB / 2) + t * 16 + frow;                                                 \
+                af[t] = *reinterpret_cast<const uint4*>(b + ar * 128 + (((kk * 4 + fchunk) ^ ((ar >> 1) & 7)) << 4)); \
+            }                                                                                                 \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+                const int wr = wn * 64 + 16 * (frow >> 2) + 4 * t + (frow & 3);   /* see the epilogue */      \
+                wf[t] = *reinterpret_cast<const uint4*>(b + TILE + wr * 128 + (((kk * 4 + fchunk) ^ wswz(wr)) << 4)); \
+            }                                                                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                  \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]); \
+        }                                                                                                     \
+    } while (0)
+#define GLDS_SYNC()                                                                                           \
+    do {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        __syncthreads();                                                                                      \
+    } while (0)
 
     const int nk = g.k_pad / GBK;
-    GLDS_ISSUE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) GLDS_ISSUE((kt + 1) * GBK, cur ^ 1);
-        const char* b = smem + cur * 2 * TILE;
+
+    // Persistent over output tiles (blockIdx.x, + gridDim.x, ...): the first k-tile of the NEXT output tile is already
+    // streaming into the free LDS buffer while this tile's last k-tile is on the matrix cores and its C tile is
+    // written, so short-K problems (the LSTM input projections, K = 512 / 192) do not pay a cold DMA round trip and an
+    // un-overlapped epilogue per 128x128 of output.
+    int tile = blockIdx.x;
+    GLDS_SET_TILE(tile);
+    GLDS_ISSUE(0, 0);
+    GLDS_SYNC();
+    int cur = 0;
+    for (;;) {
+        const unsigned lg = xcd_remap((unsigned)tile, (unsigned)ntiles);
+        const int n0 = (lg % nbn) * TB;
+        const int64_t m0 = (int64_t)(lg / nbn) * TB;
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+
+        f32x4_t acc[4][MT];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint4 af[MT], wf[4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int ar = wm * (TB / 2) + t * 16 + frow;
-                af[t] = *reinterpret_cast<const uint4*>(b + ar * 128 + (((kk * 4 + fchunk) ^ ((ar >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int wr = wn * 64 + t * 16 + frow;
-                wf[t] = *reinterpret_cast<const uint4*>(b + TILE + wr * 128 + (((kk * 4 + fchunk) ^ ((wr >> 1) & 7)) << 4));
-            }
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            GLDS_ISSUE((kt + 1) * GBK, cur ^ 1);
+            GLDS_COMPUTE(cur);
+            GLDS_SYNC();
+            cur ^= 1;
+        }
+        if (has_next) {
+            GLDS_SET_TILE(next);
+            GLDS_ISSUE(0, cur ^ 1);
+        }
+        GLDS_COMPUTE(cur);
+
+        // ---- epilogue (the next tile's DMA is in flight underneath): lane (g, m) holds columns nb .. nb+15 of row m
+        {
+            const int nb = n0 + wn * 64 + 16 * (lane >> 4);
+            float bv[4][4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-#undef GLDS_ISSUE
-
-    const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
-    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+                for (int r = 0; r < 4; ++r) bv[nt][r] = (bias && nb + 4 * nt < g.N) ? bias[nb + 4 * nt + r] : 0.f;
+            constexpr int ES = (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+            const bool wide = nb + 16 <= g.N && ((g.ldc * ES) % 16) == 0;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
-        if (n >= g.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
+            for (int mt = 0; mt < MT; ++mt) {
+                const int64_t m = m0 + wm * (TB / 2) + mt * 16 + (lane & 15);
+                if (m >= g.M) continue;
+                char* dst = Cbase + (m * g.ldc + nb) * ES;
+                float o[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
-        }
+                for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int64_t m = m0 + wm * (TB / 2) + mt * 16 + (lane & 15);
-            if (m >= g.M) continue;
-            const f32x4_t v = acc[nt][mt];
-            const float o0 = v[0] + bv[0], o1 = v[1] + bv[1], o2 = v[2] + bv[2], o3 = v[3] + bv[3];
-            if (C_TYPE == AMTX_T_F32) {
-                *reinterpret_cast<float4*>(Cbase + (m * g.ldc + n) * 4) = make_float4(o0, o1, o2, o3);
-            } else {
-                *reinterpret_cast<uint2*>(Cbase + (m * g.ldc + n) * 2) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                    for (int r = 0; r < 4; ++r) o[nt][r] = acc[nt][mt][r] + bv[nt][r];
+                if (C_TYPE == AMTX_T_F32) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        if (wide || nb + 4 * nt < g.N) reinterpret_cast<float4*>(dst)[nt] = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+                } else if (wide) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        reinterpret_cast<uint4*>(dst)[h] = make_uint4(pack_bf16x2(o[2 * h][0], o[2 * h][1]), pack_bf16x2(o[2 * h][2], o[2 * h][3]),
+                                                                     pack_bf16x2(o[2 * h + 1][0], o[2 * h + 1][1]), pack_bf16x2(o[2 * h + 1][2], o[2 * h + 1][3]));
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        if (nb + 4 * nt < g.N) reinterpret_cast<uint2*>(dst)[nt] = make_uint2(pack_bf16x2(o[nt][0], o[nt][1]), pack_bf16x2(o[nt][2], o[nt][3]));
+                }
             }
         }
+        if (!has_next) break;
+        GLDS_SYNC();
+        cur ^= 1;
+        tile = next;
     }
+#undef GLDS_SET_TILE
+#undef GLDS_ISSUE
+#undef GLDS_COMPUTE
+#undef GLDS_SYNC
 }
-
 template <int C_TYPE, int TB>
 int launch_glds(const GemmArgs& g, hipStream_t stream) {
-    const int64_t nblocks = ((g.M + TB - 1) / TB) * (g.n_pad / TB);
-    AMTX_REQUIRE(nblocks < (1ll << 31), "gemm: grid too large");
+    const int64_t ntiles = ((g.M + TB - 1) / TB) * (g.n_pad / TB);
+    AMTX_REQUIRE(ntiles < (1ll << 31), "gemm: too many output tiles");
     const size_t lds = 4 * (size_t)TB * GBK * 2;
+    // persistent grid: every CU full (two 64 KiB blocks or one 128 KiB block), a multiple of 8 so that a block's tiles stay
+    // on its XCD (tile ids advance by gridDim.x)
+    int64_t gx = (TB == 128 ? 512 : 256) / std::max(1, g.groups);
+    gx = std::max<int64_t>(8, gx / 8 * 8);
+    if (gx > ntiles) gx = ntiles;
     auto kern = gemm_glds_kernel<C_TYPE, TB>;
     static bool attr_done = false;
     if (!attr_done) {
         AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, 1, (unsigned)g.groups), dim3(TB * 2), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(TB * 2), lds, stream, g, (int)ntiles);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
