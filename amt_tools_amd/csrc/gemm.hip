@@ -13,6 +13,7 @@
 #include "amtx_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -215,7 +216,7 @@ __device__ __forceinline__ int wswz(int row) { return ((row >> 1) & 1) | (((row 
 // A 256x256 tile moves 64 KiB per 4.2 M MACs (64 MAC/B); the 128x128 tile's 32 MAC/B sits right at the
 // ~64 B/clk/CU the L2 can deliver, so the big tile is used whenever N is a multiple of 256.
 template <int C_TYPE, int TB>
-__global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g, int ntiles) {
+__global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(GemmArgs g, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][A tile | W tile]
     constexpr int TILE = TB * GBK * 2;                            // bytes per operand per buffer
     constexpr int WAVES = TB / 32;                                // 4 or 8
@@ -368,6 +369,186 @@ __global__ __launch_bounds__(TB * 2) void gemm_glds_kernel(GemmArgs g, int ntile
 #undef GLDS_COMPUTE
 #undef GLDS_SYNC
 }
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, 32-deep k-stages in a FOUR-buffer LDS ring (3 stages = 96 KiB per CU in flight).  With two 64-deep
+// buffers only one stage is in flight while the other is on the matrix cores, and the loaded HBM latency (~2 us)
+// is twice the ~1 us a stage computes: the k-loop then runs at the latency, not at the MFMA rate.  Here the waits are
+// counted (`s_waitcnt vmcnt(8)`: the two newest stages stay in flight), never 0, and one LDS-only barrier per stage
+// both publishes the landed stage and frees the buffer the next DMA overwrites.  The stage stream is flattened across
+// this block's output tiles, so the ring never drains at a tile boundary; the C stores of a finished tile are counted
+// exactly (every store instruction always issues: rows past M go to a scratch line) so that the vmcnt arithmetic
+// stays valid while they are in flight.  bias sits in LDS: a global load in the epilogue would wait in order behind
+// the whole ring.
+constexpr int RBK = 32, RST = 4, RTB = 256;
+constexpr int RING_MAX_NPAD = 4096;          // bias table: 16 KiB next to the 128 KiB ring
+constexpr int ROP = RTB * RBK * 2;          // bytes per operand per stage (16 KiB)
+constexpr int RSTAGE = 2 * ROP;
+__device__ uint4 g_gemm_trash[4];
+
+__device__ __forceinline__ int rswz(int q) { return (0x78 >> (q * 2)) & 3; }   // [0,2,3,1][q], see lds_off
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int C_TYPE>
+__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [RST][A 16K | W 16K] | bias[n_pad]
+    constexpr int MT = 8;
+    constexpr int ES = (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+    constexpr int NSTORE = MT * (C_TYPE == AMTX_T_BF16 ? 2 : 4);   // store instructions of one epilogue, per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int grp = blockIdx.z;
+    const unsigned nbn = g.n_pad / RTB;
+    const int nk = g.k_pad / RBK;
+
+    const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)grp * g.a_gs;
+    const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
+    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * ES;
+    float* bias_l = reinterpret_cast<float*>(smem + RST * RSTAGE);
+    for (int i = tid; i < g.n_pad; i += 512) bias_l[i] = (g.bias && i < g.N) ? g.bias[(int64_t)grp * g.bias_gs + i] : 0.f;
+
+    // DMA: this wave moves rows [32*wave, 32*wave + 32) of both operand tiles, 2 instructions x 16 rows (64 B each)
+    const bf16_t* a_src[2];
+    const bf16_t* w_src[2];
+#define RING_SET_TILE(TILE_ID)                                                                                \
+    do {                                                                                                      \
+        const unsigned lg = xcd_remap((unsigned)(TILE_ID), (unsigned)ntiles);                                 \
+        const int tn0 = (lg % nbn) * RTB;                                                                     \
+        const int64_t tm0 = (int64_t)(lg / nbn) * RTB;                                                        \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                       \
+            const int row = wave * 32 + n * 16 + (lane >> 2);                                                 \
+            int64_t mr = tm0 + row;                                                                           \
+            if (mr >= g.M) mr = g.M - 1;                                                                      \
+            a_src[n] = Abase + mr * g.lda + ((lane & 3) ^ rswz((row >> 2) & 3)) * 8;                          \
+            w_src[n] = Wbase + (int64_t)(tn0 + row) * g.k_pad + ((lane & 3) ^ rswz((row >> 4) & 3)) * 8;      \
+        }                                                                                                     \
+    } while (0)
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem) + wave * 2048;
+
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * nk;                         // stages this block streams
+    int is = 0, ikt = 0, itile = blockIdx.x;
+#define RING_ISSUE_NEXT()                                                                                     \
+    do {                                                                                                      \
+        if (is < S) {                                                                                         \
+            const unsigned sb = lds_base + (is & (RST - 1)) * RSTAGE;                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
+                glds16(a_src[n] + ikt * RBK, sb + n * 1024);                                                  \
+                glds16(w_src[n] + ikt * RBK, sb + ROP + n * 1024);                                            \
+            }                                                                                                 \
+            ++is;                                                                                             \
+            if (++ikt == nk) {                                                                                \
+                ikt = 0;                                                                                      \
+                itile += (int)gridDim.x;                                                                      \
+                if (is < S) RING_SET_TILE(itile);                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+
+    RING_SET_TILE(itile);
+    RING_ISSUE_NEXT();
+    RING_ISSUE_NEXT();
+    RING_ISSUE_NEXT();
+    __syncthreads();                                     // bias_l visible (compiler-visible traffic only: no DMA drain)
+
+    // fragment read offsets inside a stage: lane constants + immediates
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int a_off = (wm * 128 + frow) * 64 + ((fchunk ^ rswz((frow >> 2) & 3)) << 4);
+    const int w_off = ROP + (wn * 64 + 16 * (frow >> 2) + (frow & 3)) * 64 + ((fchunk ^ rswz(frow >> 2)) << 4);
+
+    f32x4_t acc[4][MT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    int ckt = 0, ctile = blockIdx.x;
+    bool stores_pending = false;                         // an epilogue ran in one of the last three iterations
+    int since_epi = 0;
+    for (int cs = 0; cs < S; ++cs) {
+        // ---- wait until stage cs has landed: everything older than the (<= 2) newer stages [+ the counted stores]
+        const int newer = min(S - 1 - cs, 2);
+        if (!stores_pending) {
+            if (newer == 2) wait_vm<8>(); else if (newer == 1) wait_vm<4>(); else wait_vm<0>();
+        } else {
+            if (newer == 2) wait_vm<8 + NSTORE>(); else if (newer == 1) wait_vm<4 + NSTORE>(); else wait_vm<NSTORE>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        RING_ISSUE_NEXT();                               // stage cs+3 -> the buffer stage cs-1 just vacated
+        if (stores_pending && ++since_epi == 3) stores_pending = false;
+
+        const char* b = smem + (cs & (RST - 1)) * RSTAGE;
+        uint4 af[MT], wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const uint4*>(b + w_off + t * 256);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const uint4*>(b + a_off + t * 1024);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]);
+
+        if (++ckt == nk) {
+            // ---- epilogue: lane (g, m) holds columns nb .. nb+15 of row m; exactly NSTORE store instructions
+            const unsigned lg = xcd_remap((unsigned)ctile, (unsigned)ntiles);
+            const int n0 = (lg % nbn) * RTB;
+            const int64_t m0 = (int64_t)(lg / nbn) * RTB;
+            const int nb = n0 + wn * 64 + 16 * (lane >> 4);
+            f32x4_t bv[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const f32x4_t*>(bias_l + nb + 4 * nt);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int64_t m = m0 + wm * 128 + mt * 16 + (lane & 15);
+                char* dst = m < g.M ? Cbase + (m * g.ldc + nb) * ES : reinterpret_cast<char*>(g_gemm_trash);
+                float o[4][4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[nt][r] = acc[nt][mt][r] + bv[nt][r];
+                if (C_TYPE == AMTX_T_F32) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) reinterpret_cast<float4*>(dst)[nt] = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        reinterpret_cast<uint4*>(dst)[h] = make_uint4(pack_bf16x2(o[2 * h][0], o[2 * h][1]), pack_bf16x2(o[2 * h][2], o[2 * h][3]),
+                                                                     pack_bf16x2(o[2 * h + 1][0], o[2 * h + 1][1]), pack_bf16x2(o[2 * h + 1][2], o[2 * h + 1][3]));
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            ckt = 0;
+            ctile += (int)gridDim.x;
+            stores_pending = true;
+            since_epi = 0;
+        }
+    }
+#undef RING_SET_TILE
+#undef RING_ISSUE_NEXT
+}
+
+template <int C_TYPE>
+int launch_ring(const GemmArgs& g, hipStream_t stream) {
+    const int64_t ntiles = ((g.M + RTB - 1) / RTB) * (g.n_pad / RTB);
+    AMTX_REQUIRE(ntiles < (1ll << 31), "gemm: too many output tiles");
+    const size_t lds = (size_t)RST * RSTAGE + (size_t)g.n_pad * sizeof(float);
+    auto kern = gemm_ring_kernel<C_TYPE>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RST * RSTAGE + RING_MAX_NPAD * sizeof(float))));
+        attr_done = true;
+    }
+    int64_t gx = 256 / std::max(1, g.groups);
+    gx = std::max<int64_t>(8, gx / 8 * 8);
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(512), lds, stream, g, (int)ntiles);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
 template <int C_TYPE, int TB>
 int launch_glds(const GemmArgs& g, hipStream_t stream) {
     const int64_t ntiles = ((g.M + TB - 1) / TB) * (g.n_pad / TB);
@@ -428,6 +609,12 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {
+        static const bool no_ring = getenv("AMTX_GEMM_NO_RING") != nullptr;   // A/B switch for tools/bench_gemm.py
+        // measured on MI355X (tools/bench_gemm.py, M = 320000): the ring wins for short K (K = 512: 0.516 vs 0.544 ms, K = 192:
+        // 0.283 vs 0.317 ms), the two-buffer 64-deep loop for long K (K = 3648: 1.20 vs 1.31 ms)
+        if (!no_ring && g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.n_pad <= RING_MAX_NPAD && g.K >= 3 * RBK && g.K <= 1024 &&
+            (g.ldc * amtx_tsize(g.c_type)) % 16 == 0)
+            return g.c_type == AMTX_T_BF16 ? launch_ring<AMTX_T_BF16>(g, stream) : launch_ring<AMTX_T_F32>(g, stream);
         if (g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256)
             return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 256>(g, stream) : launch_glds<AMTX_T_F32, 256>(g, stream);
         return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 128>(g, stream) : launch_glds<AMTX_T_F32, 128>(g, stream);
