@@ -28,7 +28,9 @@ constexpr int NFFT = 2048;
 constexpr int M = NFFT / 2;          // complex FFT length
 constexpr int XB_PITCH = 68;         // LDS row pitch (complex) of the exchange buffer: conflict-free for both passes
 constexpr int XB_ELEMS = 16 * XB_PITCH;
-constexpr int PB_ELEMS = 1092;       // power row: bin k lives at k + (k >> 4) (1025 bins -> 1089 slots), see pidx()
+constexpr int PB_BINS = 1025 + 128;  // bins a padded mel row may touch: the last real bin is 1024, the rest stays zero
+constexpr int PB_ELEMS = 1232;       // power row: bin k lives at k + (k >> 4) (PB_BINS bins -> 1225 slots), see pidx()
+constexpr int MEL_UNROLL = 8;        // taps per batch of the mel gather (loads in flight per lane)
 constexpr int WAVES = 4;
 constexpr int MAX_MEL_ROUNDS = 8;    // up to 512 output rows
 
@@ -36,11 +38,10 @@ struct SpecDev {
     const float* window;     // [NFFT]
     const float2* tw_fft;    // [M]   exp(-2 pi i k / M)
     const float2* tw_post;   // [M]   exp(-2 pi i k / NFFT), k < M
-    const int* mel_start;    // [n_mels] first bin of the row's support
-    const int* mel_count;    // [n_mels] number of taps
-    const int* mel_off;      // [n_mels] offset of the row's weights in mel_w
-    const float* mel_w;      // concatenated row weights
-    int round_max[MAX_MEL_ROUNDS];   // max tap count of rows [64r, 64r+64)
+    const int* mel_start;    // [64 * rounds] first bin of the row's support (0 for rows past n_mels)
+    const float* mel_wt;     // tap-major weights of round r at round_off[r]*64: [tap j][lane] = weight j of row 64r + lane, zero padded
+    int round_max[MAX_MEL_ROUNDS];   // taps of round r = max tap count of rows [64r, 64r+64), rounded up to a multiple of MEL_UNROLL
+    int round_off[MAX_MEL_ROUNDS];   // first tap slot of round r in mel_wt
     int hop, n_out, n_mels, center, pad_mode;
 };
 
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     float* pb = reinterpret_cast<float*>(smem + WAVES * XB_ELEMS * sizeof(float2)) + wave * PB_ELEMS;
     float2* twp = reinterpret_cast<float2*>(smem + WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float));
     float2* tw2l = twp + M;                           // W_64^(b*c), [b][c]: 64 entries
+    int* mstart = reinterpret_cast<int*>(tw2l + 64);  // first bin of every mel row, [64 * rounds]
 
     constexpr int FPB = FPW * WAVES;
     const unsigned chunks = (unsigned)((num_frames + FPB - 1) / FPB);
@@ -150,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         tw1[n1] = p.tw_fft[(lane * n1) & (M - 1)];
     }
     const int rounds = MEL ? (p.n_mels + 63) / 64 : 0;
+    for (int i = threadIdx.x; i < 64 * rounds; i += 256) mstart[i] = p.mel_start[i];
+    for (int i = pidx(M + 1) + lane; i < PB_ELEMS; i += 64) pb[i] = 0.0f;   // bins past 1024: read (times 0) by padded mel taps, never written
     __syncthreads();
 
     float run_max = 0.0f;
@@ -251,22 +255,43 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
 
         float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
         if (MEL) {
-            // ---- sparse mel: lane-per-row gather over contiguous bin ranges
+            // ---- sparse mel: lane-per-row gather over contiguous bin ranges.  Weights are tap-major and zero padded to
+            // the round's tap count, so every access is unconditional: MEL_UNROLL coalesced weight loads (L1/L2 hits, the
+            // table is shared by all waves) and LDS power reads are in flight per batch instead of one waited-for load per
+            // tap.  Rows past their support multiply finite power values (the row is zero beyond bin 1024) by 0.
+            // The stores wait until every round is done: vmcnt retires in order, a store between two rounds would make
+            // the next round's first weight wait for the store's acknowledgement.
+            float res[MAX_MEL_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
+                res[r] = 0.0f;
+                if (r < rounds) {
+                    const int start = mstart[r * 64 + lane];
+                    const float* wt = p.mel_wt + (int64_t)p.round_off[r] * 64 + lane;
+                    const int nmax = p.round_max[r];
+                    float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll 1
-            for (int r = 0; r < rounds; ++r) {
-                const int row = r * 64 + lane;
-                const bool ok = row < p.n_mels;
-                const int start = ok ? p.mel_start[row] : 0;
-                const int count = ok ? p.mel_count[row] : 0;
-                const float* w = p.mel_w + (ok ? p.mel_off[row] : 0);
-                float acc = 0.0f;
-                const int nmax = p.round_max[r];
-                for (int j = 0; j < nmax; ++j) {
-                    if (j < count) acc = fmaf(w[j], pb[pidx(start + j)], acc);
+                    for (int j = 0; j < nmax; j += MEL_UNROLL) {
+                        float wv[MEL_UNROLL], xv[MEL_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < MEL_UNROLL; ++u) wv[u] = wt[(j + u) * 64];
+#pragma unroll
+                        for (int u = 0; u < MEL_UNROLL; ++u) xv[u] = pb[pidx(start + j + u)];
+#pragma unroll
+                        for (int u = 0; u < MEL_UNROLL; u += 2) {
+                            acc0 = fmaf(wv[u], xv[u], acc0);
+                            acc1 = fmaf(wv[u + 1], xv[u + 1], acc1);
+                        }
+                    }
+                    res[r] = acc0 + acc1;
                 }
-                if (ok) {
-                    out_row[row] = acc;
-                    run_max = fmaxf(run_max, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
+                const int row = r * 64 + lane;
+                if (r < rounds && row < p.n_mels) {
+                    out_row[row] = res[r];
+                    run_max = fmaxf(run_max, res[r]);
                 }
             }
         } else {
@@ -396,9 +421,11 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
         tw_post[k] = make_float2((float)cos(2.0 * PI * k / n_fft), (float)(-sin(2.0 * PI * k / n_fft)));
     }
     // librosa.filters.mel (norm='slaney', fmin=0, fmax=sr/2), rounded to float32 like librosa does
-    std::vector<int> m_start(n_mels > 0 ? n_mels : 1, 0), m_count(n_mels > 0 ? n_mels : 1, 0), m_off(n_mels > 0 ? n_mels : 1, 0);
+    const int mel_rounds = n_mels > 0 ? (n_mels + 63) / 64 : 0;
+    std::vector<int> m_start(mel_rounds > 0 ? 64 * mel_rounds : 1, 0), m_count(n_mels > 0 ? n_mels : 1, 0);
     std::vector<float> m_w;
     memset(pl->dev.round_max, 0, sizeof(pl->dev.round_max));
+    memset(pl->dev.round_off, 0, sizeof(pl->dev.round_off));
     if (n_mels > 0) {
         const int nb = pl->n_bins_fft;
         pl->fb_dense.assign((size_t)n_mels * nb, 0.0f);
@@ -421,13 +448,26 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
                 pl->fb_dense[(size_t)i * nb + k] = wf;
                 if (wf != 0.0f) { if (first < 0) first = k; last = k; }
             }
-            m_off[i] = (int)m_w.size();
-            if (first >= 0) {
-                m_start[i] = first; m_count[i] = last - first + 1;
-                for (int k = first; k <= last; ++k) m_w.push_back(pl->fb_dense[(size_t)i * nb + k]);
-            }
+            if (first >= 0) { m_start[i] = first; m_count[i] = last - first + 1; }
             const int r = i / 64;
             if (m_count[i] > pl->dev.round_max[r]) pl->dev.round_max[r] = m_count[i];
+        }
+        // tap-major, zero-padded weight table per round of 64 rows
+        int slots = 0;
+        for (int r = 0; r < mel_rounds; ++r) {
+            pl->dev.round_max[r] = (pl->dev.round_max[r] + MEL_UNROLL - 1) / MEL_UNROLL * MEL_UNROLL;
+            pl->dev.round_off[r] = slots;
+            slots += pl->dev.round_max[r];
+        }
+        m_w.assign((size_t)slots * 64, 0.0f);
+        for (int i = 0; i < n_mels; ++i) {
+            const int r = i / 64, l = i % 64;
+            if (m_start[i] + pl->dev.round_max[r] > PB_BINS) {
+                amtx_set_error("amtx_spec_plan_create: mel row %d (%d taps from bin %d) does not fit the padded power row", i, m_count[i], m_start[i]);
+                delete pl;
+                return AMTX_ERR_UNSUPPORTED;
+            }
+            for (int j = 0; j < m_count[i]; ++j) m_w[((size_t)pl->dev.round_off[r] + j) * 64 + l] = pl->fb_dense[(size_t)i * nb + m_start[i] + j];
         }
     }
     if (m_w.empty()) m_w.push_back(0.0f);
@@ -435,16 +475,13 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
     // one device blob for all tables
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t o_win = 0, o_twf = align16(o_win + window.size() * 4), o_twp = align16(o_twf + tw_fft.size() * 8);
-    size_t o_ms = align16(o_twp + tw_post.size() * 8), o_mc = align16(o_ms + m_start.size() * 4);
-    size_t o_mo = align16(o_mc + m_count.size() * 4), o_mw = align16(o_mo + m_off.size() * 4);
+    size_t o_ms = align16(o_twp + tw_post.size() * 8), o_mw = align16(o_ms + m_start.size() * 4);
     size_t total = align16(o_mw + m_w.size() * 4);
     std::vector<char> host(total, 0);
     memcpy(host.data() + o_win, window.data(), window.size() * 4);
     memcpy(host.data() + o_twf, tw_fft.data(), tw_fft.size() * 8);
     memcpy(host.data() + o_twp, tw_post.data(), tw_post.size() * 8);
     memcpy(host.data() + o_ms, m_start.data(), m_start.size() * 4);
-    memcpy(host.data() + o_mc, m_count.data(), m_count.size() * 4);
-    memcpy(host.data() + o_mo, m_off.data(), m_off.size() * 4);
     memcpy(host.data() + o_mw, m_w.data(), m_w.size() * 4);
     hipError_t e = hipMalloc(&pl->d_blob, total);
     if (e == hipSuccess) e = hipMemcpy(pl->d_blob, host.data(), total, hipMemcpyHostToDevice);
@@ -459,9 +496,7 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
     pl->dev.tw_fft = (const float2*)(d + o_twf);
     pl->dev.tw_post = (const float2*)(d + o_twp);
     pl->dev.mel_start = (const int*)(d + o_ms);
-    pl->dev.mel_count = (const int*)(d + o_mc);
-    pl->dev.mel_off = (const int*)(d + o_mo);
-    pl->dev.mel_w = (const float*)(d + o_mw);
+    pl->dev.mel_wt = (const float*)(d + o_mw);
     pl->dev.hop = hop_length; pl->dev.n_out = pl->n_out; pl->dev.n_mels = n_mels;
     pl->dev.center = center; pl->dev.pad_mode = pad_mode;
     *out = pl;
@@ -511,7 +546,7 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const int64_t chunks = (T + FPB - 1) / FPB;
     const int64_t nblocks = chunks * batch;
     AMTX_REQUIRE(nblocks < (1ll << 31), "amtx_spec_power: grid too large");
-    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M + 64) * sizeof(float2);
+    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M + 64) * sizeof(float2) + 64 * MAX_MEL_ROUNDS * sizeof(int);
     if (plan->n_mels > 0)
         hipLaunchKernelGGL((spec_power_kernel<FPW, true>), dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio,
                            num_samples, audio_stride, T, power, (unsigned*)clip_max);
