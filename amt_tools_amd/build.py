@@ -12,7 +12,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(CSRC, 'libamtx.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + os.environ.get('AMTX_EXTRA_FLAGS', '').split()
 
 
 def _sources():

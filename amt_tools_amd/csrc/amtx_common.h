@@ -97,6 +97,31 @@ static __device__ __forceinline__ float wave_sum_f32(float v) {
     return v;
 }
 
+// ---- LDS-DMA helpers ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// 16 bytes per lane HBM/L2 -> LDS without a VGPR round trip: LDS address = M0 (wave-uniform) + lane*16.
+// Issued from inline asm on purpose: with the builtin, hipcc treats every later ds_read as a possible reader of the
+// in-flight LDS write and puts `s_waitcnt vmcnt(0)` in front of it.  Ordering is the caller's job: a counted
+// s_waitcnt vmcnt by the issuing wave, then a workgroup barrier, before anybody reads the data.
+static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // provably wave-uniform for the "s" constraint
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int N>
+static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// workgroup barrier that waits for this wave's LDS traffic only (not for global loads/stores/DMA in flight)
+static __device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // observed (speed only, never correctness): block b runs on XCD b % 8.  Remap so consecutive logical
 // work items share an XCD (and its L2).  Bijective for any grid size.
 static __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblocks) {

@@ -15,6 +15,7 @@
 #include "amtx_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -60,6 +61,21 @@ __device__ __forceinline__ void settle(const uint4& v) { asm volatile("" ::"v"(v
 __device__ __forceinline__ void settle(const uint2& v) { asm volatile("" ::"v"(v.x), "v"(v.y)); }
 __device__ __forceinline__ void settle(float v) { asm volatile("" ::"v"(v)); }
 
+#ifdef AMTX_CONV_TIMING
+// Debug build only (AMTX_EXTRA_FLAGS=-DAMTX_CONV_TIMING): cycles wave 0 of every block spends per phase of the persistent loop,
+// summed over blocks: [0] staging / feature store, [1] barrier after it, [2] first-conv phase, [3] barrier, [4] conv phase,
+// [5] trailing barrier, [6] tiles.  Read with amtxdbg_conv_prof().
+__device__ unsigned long long g_conv_prof[16];   // [0..7] fused first conv + conv2, [8..15] plain conv
+#define CONV_TICK(SLOT)                                                    \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        prof_acc[SLOT] += now_ - prof_t;                                   \
+        prof_t = now_;                                                     \
+    } while (0)
+#else
+#define CONV_TICK(SLOT) do {} while (0)
+#endif
+
 constexpr int FROWS = ROWS + 2;      // feature tile rows of the fused first conv
 constexpr int FW = FT_MAX + 6;       // feature tile row pitch (floats)
 
@@ -68,7 +84,11 @@ constexpr int FSLACK = 16;          // floats after the feature tile: gathers of
 constexpr int FPRE = 4;                                        // prefetched feature values per thread (c_in = 1)
 
 struct TileCoord { int b, t0, f0; };
-__device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int ft) {
+// `tile` is the virtual id blockIdx.x + k * gridDim.x.  Blocks whose ids agree mod 8 share an XCD (and its L2): xcd_remap
+// hands each XCD one contiguous range of tiles, so the tiles in flight on an XCD are spatial neighbours (same clip, adjacent
+// frequency / time tiles) and the halo rows and columns they share are read from HBM once instead of once per XCD.
+__device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int ft, int ntiles) {
+    tile = (int)xcd_remap((unsigned)tile, (unsigned)ntiles);
     TileCoord c;
     const int tf = tile % ntf; tile /= ntf;
     const int tt = tile % ntt; tile /= ntt;
@@ -197,16 +217,24 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     } while (0)
 
     if (tile < ntiles) {
-        const TileCoord tc0 = tile_coord(tile, ntf, ntt, ft);
+        const TileCoord tc0 = tile_coord(tile, ntf, ntt, ft, ntiles);
         if constexpr (PREFETCH) CONV_ISSUE_TILE_LOADS(tc0);
         if (fprefetch) CONV_ISSUE_FEAT_LOADS(tc0);
     }
 
+#ifdef AMTX_CONV_TIMING
+    unsigned long long prof_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
-        const TileCoord tc = tile_coord(tile, ntf, ntt, ft);
+        CONV_TICK(5);
+#ifdef AMTX_CONV_TIMING
+        prof_acc[6] += 1;
+#endif
+        const TileCoord tc = tile_coord(tile, ntf, ntt, ft, ntiles);
         const int t0 = tc.t0, f0 = tc.f0;
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const TileCoord tn = tile_coord(has_next ? tile + (int)gridDim.x : tile, ntf, ntt, ft);
+        const TileCoord tn = tile_coord(has_next ? tile + (int)gridDim.x : tile, ntf, ntt, ft, ntiles);
 
         if constexpr (FUSE1) {
             // ---- fused first conv: features (c_in, 20 x (ft+4)) -> LDS, then Conv(c_in->32)+BN+ReLU on the matrix cores
@@ -230,7 +258,9 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                     ftile[(ci * FROWS + fi) * FW + fj] = v;
                 }
             }
+            CONV_TICK(0);
             __syncthreads();
+            CONV_TICK(1);
             if (fprefetch && has_next) CONV_ISSUE_FEAT_LOADS(tn);
             // Position groups are (tile row i, 16-column block jb): row and block are wave-uniform (scalar registers), only
             // the column inside the block is per lane, so the position arithmetic costs no vector instructions.
@@ -320,6 +350,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 }
             }
 #undef CONV1_GATHER
+            CONV_TICK(2);
         } else if constexpr (PREFETCH) {
             // ---- the tile was fetched while the previous one was computed: registers -> LDS
 #pragma unroll
@@ -376,7 +407,9 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 }
             }
         }
+        if constexpr (!FUSE1) CONV_TICK(0);
         __syncthreads();
+        CONV_TICK(3);
         if constexpr (PREFETCH) {
             if (has_next) CONV_ISSUE_TILE_LOADS(tn);
         }
@@ -458,10 +491,206 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             }
         }
 #undef CONV_LOAD_ROW
+        CONV_TICK(4);
         __syncthreads();   // every wave is done with this LDS tile before the next one is staged
     }
+#ifdef AMTX_CONV_TIMING
+    if (tid == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_conv_prof[(FUSE1 ? 0 : 8) + i], prof_acc[i]);
+        atomicAdd(&g_conv_prof[(FUSE1 ? 0 : 8) + 7], 1ull);
+    }
+#endif
 #undef CONV_ISSUE_TILE_LOADS
 #undef CONV_ISSUE_FEAT_LOADS
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 -> bf16 layers that read their input from HBM (conv3, and conv2 when the first conv is not fused): the input
+// tile goes HBM/L2 -> LDS by DMA (global_load_lds_dwordx4) into the second of two LDS planes while the current plane is
+// on the matrix cores.  No staging registers, no staging instructions, no exposed load latency: in the register-staged
+// kernel above a C_out = 64 block spends as long waiting for its tile (two dependent batches of loads, ~4 us) as
+// computing on it.  Planes are sized to the tile (row pitch = columns + 1 or + 3, always 1 mod 4, so tile_off's
+// swizzle argument holds): with <= 30 output columns two blocks x two planes fit one CU's 160 KiB.
+// The DMA writes 16 consecutive tile positions (4 chunks each) per instruction; the chunk XOR and the zero padding
+// (out-of-image positions read a 16-byte zero line) live on the SOURCE address.  Ordering: the issuing wave waits with
+// an exact vmcnt (its own C stores issued since are counted: every store instruction always issues, masked
+// positions go to a scratch line), then the LDS-only barrier publishes the plane.
+constexpr int DMA_FT_MAX = 30;
+__device__ uint4 g_conv_zero16;              // zero-initialised: source of padded positions
+__device__ uint4 g_conv_trash[4];            // sink of masked stores
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft, int ntf, int ntt, int pitch, int inv_pitch, int plane_bytes,
+                                                             int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 planes][plane_bytes] | shift[C_out]
+    constexpr int COUT = NT * 16;
+    constexpr int SPP = NT / 2;                                    // 16-byte store instructions per column pair
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = blockIdx.y;
+    const int g = lane >> 4, trow = lane & 15;
+
+    uint4 wf[9][NT];
+    {
+        const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[tap][nt] = w[(tap * NT + nt) * 64];
+    }
+    float* sh_w = reinterpret_cast<float*>(smem + 2 * plane_bytes);
+    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(sh_w) + g * NT;
+    if (tid < COUT) sh_w[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) settle(wf[tap][nt]);
+
+    const int cols = ft + 2;
+    const int npairs = ft >> 1;
+    const int my_pairs = (npairs - wave_u + 3) >> 2;               // column pairs this wave owns (wave_u, +4, ...)
+    const int Fo = a.F >> 1;
+    const int ninstr = plane_bytes >> 10;                          // DMA instructions per plane (16 positions each)
+    const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * 2;
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem);
+
+#define CONV_DMA_ISSUE(TC, BUF)                                                                            \
+    do {                                                                                                   \
+        const char* inb = in_grp + (int64_t)(TC).b * a.T * a.F * CIN * 2;                                  \
+        int lane_o = lane;                                                                                 \
+        asm volatile("" : "+v"(lane_o)); /* keep the per-instruction index math out of the live ranges */ \
+        for (int n = wave_u; n < ninstr; n += 4) {                                                         \
+            const int q = n * 16 + (lane_o >> 2);                                                          \
+            const int i = (q * inv_pitch) >> 16;                                                           \
+            const int j = q - i * pitch;                                                                   \
+            const int t = (TC).t0 - 1 + i, f = (TC).f0 - 1 + j;                                            \
+            const int ch = (lane_o & 3) ^ (((i >> 2) & 1) << 1);                                           \
+            const bool ok = i < ROWS && j < cols && t >= 0 && t < a.T && f >= 0 && f < a.F;                \
+            const void* src = ok ? static_cast<const void*>(inb + (((int64_t)t * a.F + f) * CIN + ch * 8) * 2) \
+                                 : static_cast<const void*>(&g_conv_zero16);                               \
+            glds16(src, lds_base + (BUF) * plane_bytes + n * 1024);                                        \
+        }                                                                                                  \
+    } while (0)
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    {
+        const TileCoord tc0 = tile_coord(tile, ntf, ntt, ft, ntiles);
+        CONV_DMA_ISSUE(tc0, 0);
+    }
+    wait_vm<0>();
+    __syncthreads();                                               // first plane + shift table visible
+
+    int cur = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const TileCoord tc = tile_coord(tile, ntf, ntt, ft, ntiles);
+        const bool has_next = tile + (int)gridDim.x < ntiles;
+        if (has_next) {
+            const TileCoord tn = tile_coord(tile + (int)gridDim.x, ntf, ntt, ft, ntiles);
+            CONV_DMA_ISSUE(tn, cur ^ 1);
+        }
+
+        const char* plane = smem + cur * plane_bytes;
+        const int t = tc.t0 + trow;
+        char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)tc.b * a.T + t) * Fo * COUT) * 2;
+        int rbase[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) rbase[kh] = (((trow + kh) * pitch) * 4 + (g ^ ((((trow + kh) >> 2) & 1) << 1))) * 16;
+        uint4 x[3][4];
+#define CONV_DMA_LOAD_ROW(KH, JP)                                                                          \
+        _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                                   \
+            x[KH][cc] = *reinterpret_cast<const uint4*>(plane + rbase[KH] + (2 * (JP) + cc) * 64);
+        if (wave_u < npairs) {
+            CONV_DMA_LOAD_ROW(0, wave_u)
+            CONV_DMA_LOAD_ROW(1, wave_u)
+            CONV_DMA_LOAD_ROW(2, wave_u)
+        }
+        for (int jp = wave_u; jp < npairs; jp += 4) {
+            const int jn = min(jp + 4, npairs - 1);
+            f32x4_t acc[2][NT];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = shl[nt];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int kw = cc - e;
+                        if (kw < 0 || kw > 2) continue;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[e][nt] = mfma16(wf[kh * 3 + kw][nt], x[kh][cc], acc[e][nt]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (kh == 0) { CONV_DMA_LOAD_ROW(0, jn) } else if (kh == 1) { CONV_DMA_LOAD_ROW(1, jn) } else { CONV_DMA_LOAD_ROW(2, jn) }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- ReLU + MaxPool(1,2) over the (f, f+1) pair (shift is in the accumulator), channels-last store
+            const int fo = (tc.f0 >> 1) + jp;
+            float v[NT * 4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
+            uint4* dst = (t < a.T && fo < Fo) ? reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2) : g_conv_trash;
+#pragma unroll
+            for (int q = 0; q < SPP; ++q)
+                dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                                    pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
+        }
+#undef CONV_DMA_LOAD_ROW
+        // ---- the next plane must have landed: everything older than this tile's my_pairs * SPP stores
+        if (has_next) {
+            switch (my_pairs * SPP) {
+                case 0: wait_vm<0>(); break;
+                case 1: wait_vm<1>(); break;
+                case 2: wait_vm<2>(); break;
+                case 3: wait_vm<3>(); break;
+                case 4: wait_vm<4>(); break;
+                case 6: wait_vm<6>(); break;
+                case 8: wait_vm<8>(); break;
+                default: wait_vm<0>(); break;          // DMA_FT_MAX = 30 -> at most 4 pairs per wave
+            }
+        }
+        lds_only_barrier();
+        cur ^= 1;
+    }
+#undef CONV_DMA_ISSUE
+}
+
+template <int NT>
+int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
+    const int fe = (a.F + 1) & ~1;
+    const int ntf = (fe + DMA_FT_MAX - 1) / DMA_FT_MAX;
+    const int ft = 2 * (((fe >> 1) + ntf - 1) / ntf);
+    const int ntt = (a.T + TT - 1) / TT;
+    const int64_t ntiles = (int64_t)ntf * ntt * a.B;
+    AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
+    const int cols = ft + 2;
+    const int pitch = cols + ((cols & 3) == 0 ? 1 : 3);            // cols is even: pitch = 1 (mod 4)
+    const int plane_bytes = ((ROWS * pitch + 15) / 16) * 1024;
+    const size_t lds = 2 * (size_t)plane_bytes + (size_t)NT * 16 * sizeof(float);
+    const int inv_pitch = 65536 / pitch + 1;
+    for (int q = 0; q < plane_bytes / 64; ++q)
+        if (((q * inv_pitch) >> 16) != q / pitch) {
+            amtx_set_error("conv3x3: internal: reciprocal division inexact for pitch=%d", pitch);
+            return AMTX_ERR_ARG;
+        }
+    auto kern = conv3x3_dma_kernel<NT>;
+    static bool done = false;   // per instantiation
+    if (!done) {
+        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        done = true;
+    }
+    int64_t gx = ntiles;
+    const int64_t per_group = std::max<int64_t>(1, 512 / std::max(1, a.groups));
+    if (gx > per_group) gx = per_group;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt, pitch, inv_pitch, plane_bytes, (int)ntiles);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
 }
 
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS = 0>
@@ -511,7 +740,15 @@ int dispatch_types(const ConvArgs& a, hipStream_t s) {
         if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true, 4>(a, s);
         return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true, 4>(a, s);
     }
-    if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16, false>(a, s);
+    if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) {
+        // Measured on MI355X (conv3 of the bench workload): DMA staging 2.28 ms, register staging 2.19 ms.  The layer moves
+        // ~10.9 GB per launch (4.7 in + halo re-reads, 4.7 out), i.e. it already runs at ~5 TB/s of HBM traffic, so hiding the
+        // staging latency buys nothing and the narrower DMA tiles re-read more halo.  Kept as an opt-in for layers that are not
+        // HBM-bound (AMTX_CONV_DMA=1).
+        static const bool use_dma = getenv("AMTX_CONV_DMA") != nullptr;
+        if (NS == 1 && use_dma) return launch_conv_dma<NT>(a, s);
+        return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16, false>(a, s);
+    }
     if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32, false>(a, s);
     amtx_set_error("conv3x3: in/out element types must match (bf16/bf16 or f32/f32)");
     return AMTX_ERR_UNSUPPORTED;
@@ -653,3 +890,14 @@ int amtx_launch_conv1(const Conv1Args& a, hipStream_t stream) {
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
+
+#ifdef AMTX_CONV_TIMING
+extern "C" int amtxdbg_conv_prof(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_conv_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -194,18 +194,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // Block ids are remapped so the n-tiles that share an A panel run back to back on one XCD (A is then read
 // from HBM once and re-read from that XCD's L2).
 constexpr int GBK = 64;
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// 16 bytes per lane HBM/L2 -> LDS without a VGPR round trip: LDS address = M0 (wave-uniform) + lane*16.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
-    unsigned keep;
-    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // provably wave-uniform for the "s" constraint
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_addr)
-                 : "memory");
-}
-
 // Chunk swizzle of the W tile.  MFMA row tile t of a wave takes the W rows 16*(i >> 2) + 4*t + (i & 3), i = 0..15 (not 16
 // consecutive rows), so that a lane ends up with 16 CONSECUTIVE output columns of one C row (acc[0..3][.][0..3]) and
 // the epilogue writes 32/64 contiguous bytes per lane, 128/256 per row and wave, instead of 8-byte pieces.  For that row
@@ -386,9 +374,6 @@ constexpr int RSTAGE = 2 * ROP;
 __device__ uint4 g_gemm_trash[4];
 
 __device__ __forceinline__ int rswz(int q) { return (0x78 >> (q * 2)) & 3; }   // [0,2,3,1][q], see lds_off
-
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int C_TYPE>
 __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) {
