@@ -200,6 +200,13 @@ constexpr int GBK = 64;
 // set the XOR below keeps every ds_read_b128 lane group on 16 distinct 16-byte slots.
 __device__ __forceinline__ int wswz(int row) { return ((row >> 1) & 1) | (((row >> 4) & 3) << 1); }
 
+// Measured and rejected on MI355X (fc1 shape, M = 320000, N = 512, K = 3648; this kernel: 1.20 ms = 994 TFLOP/s):
+//   * v_mfma_f32_32x32x16_bf16 with a lane owning 32 consecutive C columns: 1.34 ms;
+//   * spreading the 8 DMA instructions over the k-steps instead of issuing them at the top of the iteration: the time moves
+//     from the issue phase into the vmcnt(0) wait (two buffers leave no slack for a later issue);
+//   * the four-buffer ring below for long K: 1.31 ms (wins for K <= 1024 only).
+// With A fully cache-resident the same loop reaches 1211 TFLOP/s: ~20 % of its time is HBM/L2 latency, the rest is the
+// one-barrier-per-k-tile structure (wave 0 of a block: 41 % fragment reads + MFMAs, 17 % DMA issue, 8 % vmcnt, 34 % barrier).
 // TB = tile edge (128: 4 waves as 2x2, 256: 8 waves as 2x4); every wave owns (TB/2) x 64 outputs.
 // A 256x256 tile moves 64 KiB per 4.2 M MACs (64 MAC/B); the 128x128 tile's 32 MAC/B sits right at the
 // ~64 B/clk/CU the L2 can deliver, so the big tile is used whenever N is a multiple of 256.
