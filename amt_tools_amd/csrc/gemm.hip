@@ -575,7 +575,7 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 
 void amtx_gemm_pack_dims(int N, int K, int* n_pad, int* k_pad) {
     *n_pad = ((N + BN - 1) / BN) * BN;
-    *k_pad = ((K + BK - 1) / BK) * BK;
+    *k_pad = ((K + GBK - 1) / GBK) * GBK;   // 64: a zero-padded K also fits the direct-to-LDS kernels' k-tile
 }
 
 void amtx_gemm_pack_host(const float* W, int64_t ldw, int N, int K, int planes, bf16_t* out) {

@@ -187,9 +187,9 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     *out = nullptr;
     AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3, "amtx_of_model_create: bad precision");
     AMTX_REQUIRE(dim_in >= 4 && in_channels >= 1 && n_out > 0 && n_out % 4 == 0, "amtx_of_model_create: bad dims");
-    if (model_complexity != 2 || has_offsets) {
-        amtx_set_error("amtx_of_model_create: only OnsetsFrames with model_complexity=2 (C_in 32 convs, LSTM hidden 128) is implemented "
-                       "(got model_complexity=%d, offsets=%d)", model_complexity, has_offsets);
+    if (model_complexity != 2) {
+        amtx_set_error("amtx_of_model_create: only model_complexity=2 (C_in 32 convs, LSTM hidden 128) is implemented, with or without "
+                       "the OnsetsFrames2 offset head (got model_complexity=%d)", model_complexity);
         return AMTX_ERR_UNSUPPORTED;
     }
     amtx_of_model* m = new amtx_of_model();
@@ -462,6 +462,26 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
                                         hipMemcpyDeviceToDevice, s));
     if (logits_multi_pitch)
         AMTX_CHECK_HIP(hipMemcpyAsync(logits_multi_pitch, w.mp, row * BT, hipMemcpyDeviceToDevice, s));
+    return AMTX_OK;
+}
+
+// OnsetsFrames2: the offset head's LogisticBank output of the LAST amtx_of_forward on this workspace
+// (onsetsframes.py:256-261,323-325: finalize_output without a threshold = sigmoid probabilities, (B, n_out, T)).
+extern "C" int amtx_of_offsets(const amtx_of_model* m, void* workspace, size_t workspace_bytes, int batch, int num_frames, float* out_offsets,
+                               float* logits_offsets, void* stream_) {
+    AMTX_REQUIRE(m && m->finalized, "amtx_of_offsets: model not finalized");
+    AMTX_REQUIRE(m->has_offsets, "amtx_of_offsets: the model has no offset head");
+    AMTX_REQUIRE(workspace && batch > 0 && num_frames > 0, "amtx_of_offsets: bad argument");
+    Workspace w = carve(m, batch, num_frames, (char*)workspace);
+    AMTX_REQUIRE(workspace_bytes >= w.total, "amtx_of_offsets: workspace too small");
+    hipStream_t s = (hipStream_t)stream_;
+    const int64_t BT = (int64_t)batch * num_frames;
+    int rc;
+    if (out_offsets && (rc = amtx_launch_pianoroll((const float*)w.joint, m->dim_aj, m->n_out, batch, num_frames, m->n_out, -1.0f, out_offsets, s)) != AMTX_OK)
+        return rc;
+    const size_t row = (size_t)m->n_out * sizeof(float);
+    if (logits_offsets)
+        AMTX_CHECK_HIP(hipMemcpy2DAsync(logits_offsets, row, w.joint + row, (size_t)m->dim_aj * 4, row, BT, hipMemcpyDeviceToDevice, s));
     return AMTX_OK;
 }
 

@@ -237,7 +237,20 @@ class _OFEngine(object):
             _lib.check(L.amtx_of_forward(self.handle, _lib.ptr(feats), sb, sc, st, sf, B, T, _lib.ptr(self.workspace),
                                          self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch), _lib.ptr(lo),
                                          _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)), 'amtx_of_forward')
+        self._last = (B, T)
         return onsets, multi_pitch, lo, lm, lp
+
+    def offsets(self, device, want_logits=True):
+        """OnsetsFrames2: offset probabilities (B,O,T) [+ raw logits (B,T,O)] of the last forward."""
+        L = _lib.lib()
+        B, T = self._last
+        opts = dict(dtype=torch.float32, device=device)
+        prob = torch.empty((B, self.n_out, T), **opts)
+        logits = torch.empty((B, T, self.n_out), **opts) if want_logits else None
+        with torch.cuda.device(device):
+            _lib.check(L.amtx_of_offsets(self.handle, _lib.ptr(self.workspace), self.workspace.numel(), B, T, _lib.ptr(prob),
+                                         _lib.ptr(logits), _lib.current_stream(device)), 'amtx_of_offsets')
+        return prob, logits
 
     def __del__(self):
         try:
@@ -272,6 +285,7 @@ class OnsetsFrames(TranscriptionModel):
         state = dict(self.__dict__)
         state.pop('_engine', None)
         state.pop('_engine_out', None)
+        state.pop('_engine_offsets', None)
         return state
 
     def _get_engine(self, device):
@@ -299,15 +313,25 @@ class OnsetsFrames(TranscriptionModel):
             output = {tools.KEY_ONSETS: lo, tools.KEY_MULTIPITCH: lm}
             # piano rolls already thresholded on the device; post_proc picks them up for these logits
             self.__dict__['_engine_out'] = (lo, lm, onsets_bin, mp_bin, lp)
+            if self.has_offsets:
+                prob, logits = eng.offsets(feats.device)
+                output[tools.KEY_OFFSETS] = logits
+                self.__dict__['_engine_offsets'] = (logits, prob)
             return output
         self.__dict__.pop('_engine_out', None)
+        self.__dict__.pop('_engine_offsets', None)
         output = dict()
         multi_pitch = self.pitch_head(feats)
         onsets = self.onset_head(feats)
         output[tools.KEY_ONSETS] = onsets
+        heads = [onsets]
+        if self.has_offsets:
+            offsets = self.offset_head(feats)
+            output[tools.KEY_OFFSETS] = offsets
+            heads.append(offsets)
         if self.detach_heads:
-            onsets = onsets.clone().detach()
-        joint = torch.cat((onsets, multi_pitch), -1)
+            heads = [h.clone().detach() for h in heads]
+        joint = torch.cat(heads + [multi_pitch], -1)
         output[tools.KEY_MULTIPITCH] = self.adjoin(joint)
         return output
 
@@ -343,3 +367,46 @@ class OnsetsFrames(TranscriptionModel):
         eng = self._get_engine(feats.device)
         onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats.float())
         return {'onsets': lo, 'multi_pitch': lm, 'pitch_head': lp, 'onsets_bin': onsets_bin, 'multi_pitch_bin': mp_bin}
+
+
+class OnsetsFrames2(OnsetsFrames):
+    """Onsets & Frames V2 (amt_tools/models/onsetsframes.py:199-327): adds an offset detector head whose logits join the
+    refinement stage; `offsets` are returned as probabilities.  The HIP engine runs it for model_complexity=2; other
+    complexities raise from `amtx_of_model_create` in eval mode on a GPU (training / CPU use ATen for any complexity)."""
+
+    has_offsets = True
+
+    def __init__(self, dim_in, profile, in_channels=1, model_complexity=3, detach_heads=True, device='cpu', precision='bf16'):
+        super().__init__(dim_in, profile, in_channels, model_complexity, detach_heads, device, precision)
+        dim_out = self.profile.get_range_len()
+        self.offset_head = nn.Sequential(AcousticModel(self.dim_in, self.dim_am, self.in_channels, self.model_complexity),
+                                         LanguageModel(self.dim_am, self.dim_lm), LogisticBank(self.dim_lm, dim_out))
+        self.dim_aj += dim_out
+        self.adjoin[0] = LanguageModel(self.dim_aj, self.dim_lm)
+
+    def post_proc(self, batch):
+        output = super().post_proc(batch)
+        offset_layer = self.offset_head[-1]
+        offsets_est = output[tools.KEY_OFFSETS]
+        if tools.KEY_LOSS in output.keys():
+            if tools.KEY_OFFSETS in batch.keys():
+                offsets_ref = batch[tools.KEY_OFFSETS]
+            else:
+                offsets_ref = tools.multi_pitch_to_offsets(batch[tools.KEY_MULTIPITCH])
+            loss = output[tools.KEY_LOSS]
+            offsets_loss = offset_layer.get_loss(offsets_est, offsets_ref)
+            loss[tools.KEY_LOSS_OFFSETS] = offsets_loss
+            loss[tools.KEY_LOSS_TOTAL] += offsets_loss
+            output[tools.KEY_LOSS] = loss
+        cached = self.__dict__.pop('_engine_offsets', None)
+        if cached is not None and cached[0] is offsets_est:
+            output[tools.KEY_OFFSETS] = cached[1]
+        else:
+            output[tools.KEY_OFFSETS] = offset_layer.finalize_output(offsets_est)
+        return output
+
+    def engine_logits(self, feats_bcft):
+        out = super().engine_logits(feats_bcft)
+        prob, logits = self._get_engine(feats_bcft.device).offsets(feats_bcft.device)
+        out['offsets'], out['offsets_prob'] = logits, prob
+        return out

@@ -146,6 +146,17 @@ def multi_pitch_to_onsets(multi_pitch):
     return onsets
 
 
+def multi_pitch_to_offsets(multi_pitch):
+    """Where activity ceases; pitches active in the last frame count (amt_tools/tools/utils.py:2555-2589).
+    Accepts ndarray or tensor; returns the same kind."""
+    if torch is not None and isinstance(multi_pitch, torch.Tensor):
+        offsets = torch.cat([multi_pitch[..., :-1] - multi_pitch[..., 1:], multi_pitch[..., -1:]], dim=-1)
+        return torch.clamp(offsets, min=0)
+    offsets = np.concatenate([multi_pitch[..., :-1] - multi_pitch[..., 1:], multi_pitch[..., -1:]], axis=-1)
+    offsets[offsets <= 0] = 0
+    return offsets
+
+
 def rms_norm(audio):
     """Root-mean-square normalisation (amt_tools/tools/utils.py:2789-2814)."""
     rms = np.sqrt(np.mean(audio ** 2))

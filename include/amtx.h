@@ -97,6 +97,12 @@ int amtx_of_forward(const amtx_of_model* model, const float* feats, int64_t stri
                     float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                     float* logits_pitch_head, void* stream);
 
+/* OnsetsFrames2 (has_offsets = 1; amt_tools/models/onsetsframes.py:199-327): the offset head's output of the last amtx_of_forward
+ * that used this workspace: out_offsets (B, n_out, T) sigmoid probabilities (finalize_output without threshold, :323-325),
+ * logits_offsets optional (B, T, n_out). */
+int amtx_of_offsets(const amtx_of_model* model, void* workspace, size_t workspace_bytes, int batch, int num_frames, float* out_offsets,
+                    float* logits_offsets, void* stream);
+
 /* Per-stage timing of amtx_of_forward with HIP events recorded on the launch stream (used by bench.py for the
  * live roofline figure; no reference counterpart -- the reference has no profiling). */
 int amtx_of_num_stages(void);

@@ -56,6 +56,41 @@ def test_engine_matches_reference_golden(name, precision):
     assert tools.KEY_FEATS in batch and batch[tools.KEY_FEATS].device.type == 'cpu'    # caller's batch untouched
 
 
+@pytest.mark.parametrize('precision', ['x3', 'bf16'])
+def test_onsetsframes2_engine_matches_reference_golden(precision):
+    """OnsetsFrames2 (offset head) at model_complexity 2 through the HIP engine vs the real reference's vectors."""
+    from amt_tools_amd.models import OnsetsFrames2
+    g = load_golden('of2_mc2_eval.npz')
+    sd = synth_state_dict(int(g['seed']), dim_in=229, in_channels=1, model_complexity=2, offsets=True)
+    model = OnsetsFrames2(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    tol = TOL[precision]
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_TIMES: torch.from_numpy(g['out_times'])})
+        logits = model.engine_logits(torch.from_numpy(g['feats']).cuda())
+    for key in ('onsets', 'offsets', 'multi_pitch', 'pitch_head'):
+        err = np.abs(logits[key].cpu().numpy() - g['logits_' + key]).max()
+        assert err < tol, (key, err)
+    assert set(out.keys()) == {tools.KEY_ONSETS, tools.KEY_OFFSETS, tools.KEY_MULTIPITCH, tools.KEY_TIMES}
+    assert np.abs(out[tools.KEY_OFFSETS].cpu().numpy() - g['out_offsets']).max() < (1e-4 if precision == 'x3' else 2e-2)
+    for key in ('onsets', 'multi_pitch'):
+        got = out[key].cpu().numpy()
+        near = np.abs(np.swapaxes(g['logits_' + key], -1, -2)) < tol
+        assert np.all((got == g['out_' + key]) | near)
+
+
+def test_model_complexity_3_is_rejected_loudly_by_the_engine():
+    from amt_tools_amd.models import OnsetsFrames2
+    from amt_tools_amd._lib import AmtxError
+    model = OnsetsFrames2(229, tools.PianoProfile(), 1, 3, device='cuda:0')
+    model.change_device()
+    model.eval()
+    with pytest.raises(AmtxError), torch.no_grad():
+        model.run_on_batch({tools.KEY_FEATS: torch.zeros(1, 1, 229, 8)})
+
+
 def test_engine_ragged_batch_and_single_frame():
     from oracle import model_ref
     g = load_golden('of1_eval.npz')

@@ -171,6 +171,7 @@ if __name__ == '__main__':
     gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
     gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
+    gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
     gen_of_train('of1_train.npz', seed=21, dim_in=229, mc=2, B=2, T=24)
     gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
