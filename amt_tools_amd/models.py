@@ -410,3 +410,91 @@ class OnsetsFrames2(OnsetsFrames):
         prob, logits = self._get_engine(feats_bcft.device).offsets(feats_bcft.device)
         out['offsets'], out['offsets_prob'] = logits, prob
         return out
+
+
+class SoftmaxGroups(OutputLayer):
+    """One softmax per degree of freedom (amt_tools/models/common.py:305-483)."""
+
+    def __init__(self, dim_in, num_groups, num_classes, weights=None):
+        self.num_groups = num_groups
+        self.num_classes = num_classes
+        super().__init__(dim_in, num_groups * num_classes, weights)
+        self.output_layer = nn.Linear(self.dim_in, self.dim_out)
+
+    def forward(self, feats):
+        return self.output_layer(feats)
+
+    def get_loss(self, estimated, reference):
+        estimated = estimated.clone()
+        reference = reference.clone()
+        batch_size = estimated.size(0)
+        if self.weights is None:
+            estimated = estimated.view(-1, self.num_classes)
+            reference = reference.transpose(-2, -1)
+            reference[reference == -1] = self.num_classes - 1
+            reference = reference.flatten().long()
+            loss = F.cross_entropy(estimated.float(), reference, reduction='none')
+            loss = torch.sum(loss.view(batch_size, -1, self.num_groups), dim=-1)
+        else:
+            loss = 0
+            estimated = estimated.view(-1, self.num_groups, self.num_classes).float()
+            reference[reference == -1] = self.num_classes - 1
+            weight = self.weights.view(self.num_groups, -1)
+            for smax in range(self.num_groups):
+                loss += F.cross_entropy(estimated[:, smax], reference[:, smax].flatten().long(), weight=weight[smax], reduction='none')
+            loss = loss.view(batch_size, -1)
+        return torch.mean(torch.mean(loss, dim=-1))
+
+    def finalize_output(self, raw_output, last_negative=True):
+        final = raw_output.clone().detach()
+        batch_size = final.size(0)
+        final = final.view(batch_size, -1, self.num_groups, self.num_classes)
+        final = torch.argmax(torch.softmax(final, dim=-1), dim=-1)
+        if last_negative:
+            final[final == self.num_classes - 1] = -1
+        return final.transpose(-2, -1)
+
+
+class TabCNN(TranscriptionModel):
+    """TabCNN (amt_tools/models/tabcnn.py:17-221), BASELINE config 1: CPU plumbing on stock torch ops -- there is no HIP kernel
+    work for this model; it exists so that the reference's CQT + TabCNN experiment runs against this
+    package's FeatureModule / TranscriptionModel objects unchanged."""
+
+    def __init__(self, dim_in, profile, in_channels=1, model_complexity=1, device='cpu'):
+        super().__init__(dim_in, profile, in_channels, model_complexity, 9, device)
+        self.online = False
+        nf1 = 32 * self.model_complexity
+        nf2 = nf3 = 64 * self.model_complexity
+        self.conv = nn.Sequential(nn.Conv2d(self.in_channels, nf1, (3, 3)), nn.ReLU(), nn.Conv2d(nf1, nf2, (3, 3)), nn.ReLU(),
+                                  nn.Conv2d(nf2, nf3, (3, 3)), nn.ReLU(), nn.MaxPool2d((2, 2)), nn.Dropout(0.25))
+        self.conv_embedding_size = nf3 * ((self.dim_in - 6) // 2) * ((self.frame_width - 6) // 2)
+        self.fc_embedding_size = 128 * self.model_complexity
+        self.dense = nn.Sequential(nn.Linear(self.conv_embedding_size, self.fc_embedding_size), nn.ReLU(), nn.Dropout(0.50),
+                                   SoftmaxGroups(self.fc_embedding_size, self.profile.get_num_dofs(), self.profile.num_pitches + 1))
+
+    def toggle_online(self):
+        self.online = not self.online
+
+    def pre_proc(self, batch):
+        batch = super().pre_proc(batch)
+        feats = tools.tensor_to_array(batch[tools.KEY_FEATS])
+        feats = tools.framify_activations(feats, self.frame_width, pad=(not self.online))      # (B,C,F,T,W)
+        feats = tools.array_to_tensor(feats, self.device)
+        batch[tools.KEY_FEATS] = feats.transpose(-2, -3).transpose(-3, -4)                      # (B,T,C,F,W)
+        return batch
+
+    def forward(self, feats):
+        batch_size = feats.size(0)
+        feats = feats.reshape(-1, self.in_channels, self.dim_in, self.frame_width)
+        embeddings = self.conv(feats).flatten(1)
+        embeddings = embeddings.view(batch_size, -1, embeddings.size(-1))
+        return {tools.KEY_TABLATURE: self.dense(embeddings)}
+
+    def post_proc(self, batch):
+        output = batch[tools.KEY_OUTPUT]
+        layer = self.dense[-1]
+        tablature_est = output[tools.KEY_TABLATURE]
+        if tools.KEY_TABLATURE in batch.keys():
+            output[tools.KEY_LOSS] = {tools.KEY_LOSS_TOTAL: layer.get_loss(tablature_est, batch[tools.KEY_TABLATURE])}
+        output[tools.KEY_TABLATURE] = layer.finalize_output(tablature_est)
+        return output

@@ -14,7 +14,8 @@ from collections import OrderedDict
 
 import numpy as np
 
-__all__ = ['synth_clip', 'synth_batch', 'synth_labels', 'of_state_dict_shapes', 'synth_state_dict',
+__all__ = ['synth_clip', 'synth_batch', 'synth_labels', 'of_state_dict_shapes', 'synth_state_dict', 'tabcnn_state_dict_shapes',
+           'synth_tabcnn_state_dict',
            'CLIP_SAMPLES', 'CLIP_FRAMES']
 
 CLIP_SAMPLES = 319999   # max(get_sample_range(625)) -- amt_tools/datasets/common.py:116
@@ -138,6 +139,35 @@ def synth_state_dict(seed=0, **kwargs):
             bound = np.sqrt(3.0 / fan_in)                    # unit-gain uniform
             if key.endswith('output_layer.weight'):
                 bound *= 4.0                                 # spread the logits away from 0
+            val = rng.uniform(-bound, bound, shape).astype(np.float32)
+        sd[key] = val
+    return OrderedDict((k, sd[k]) for k in shapes)
+
+
+def tabcnn_state_dict_shapes(dim_in=192, in_channels=1, model_complexity=1, num_groups=6, num_classes=21):
+    """Names/shapes of TabCNN.state_dict() -- amt_tools/models/tabcnn.py:47-87 (frame width 9)."""
+    nf1, nf2 = 32 * model_complexity, 64 * model_complexity
+    emb = nf2 * ((dim_in - 6) // 2) * ((9 - 6) // 2)
+    fc = 128 * model_complexity
+    return OrderedDict([('conv.0.weight', (nf1, in_channels, 3, 3)), ('conv.0.bias', (nf1,)),
+                        ('conv.2.weight', (nf2, nf1, 3, 3)), ('conv.2.bias', (nf2,)),
+                        ('conv.4.weight', (nf2, nf2, 3, 3)), ('conv.4.bias', (nf2,)),
+                        ('dense.0.weight', (fc, emb)), ('dense.0.bias', (fc,)),
+                        ('dense.3.output_layer.weight', (num_groups * num_classes, fc)),
+                        ('dense.3.output_layer.bias', (num_groups * num_classes,))])
+
+
+def synth_tabcnn_state_dict(seed=0, **kwargs):
+    """Deterministic TabCNN weights (same recipe as synth_state_dict)."""
+    shapes = tabcnn_state_dict_shapes(**kwargs)
+    rng = np.random.default_rng(seed)
+    sd = OrderedDict()
+    for key in sorted(shapes):
+        shape = shapes[key]
+        if len(shape) == 1:
+            val = rng.normal(0.0, 0.05, shape).astype(np.float32)
+        else:
+            bound = np.sqrt(3.0 / int(np.prod(shape[1:]))) * (4.0 if key.endswith('output_layer.weight') else 1.0)
             val = rng.uniform(-bound, bound, shape).astype(np.float32)
         sd[key] = val
     return OrderedDict((k, sd[k]) for k in shapes)

@@ -23,6 +23,7 @@ KEY_PITCHLIST = 'pitch_list'
 KEY_ONSETS = 'onsets'
 KEY_OFFSETS = 'offsets'
 KEY_TIMES = 'times'
+KEY_TABLATURE = 'tablature'
 KEY_NOTES = 'notes'
 KEY_OUTPUT = 'model_output'
 KEY_LOSS = 'loss'
@@ -32,6 +33,9 @@ KEY_LOSS_OFFSETS = 'loss_offsets'
 KEY_LOSS_PITCH = 'loss_pitch'
 DEFAULT_PIANO_LOWEST_PITCH = 21
 DEFAULT_PIANO_HIGHEST_PITCH = 108
+DEFAULT_GUITAR_LABELS = ['E', 'A', 'D', 'G', 'B', 'e']
+DEFAULT_GUITAR_TUNING = ['E2', 'A2', 'D3', 'G3', 'B3', 'E4']
+DEFAULT_GUITAR_NUM_FRETS = 19
 FLOAT32 = 'float32'
 FLOAT64 = 'float64'
 PYT_MODEL = 'model'
@@ -62,6 +66,60 @@ class PianoProfile(InstrumentProfile):
         return 1
 
 
+def note_to_midi(note):
+    """'E2' -> 40, 'A#3' / 'Bb3' -> 58 (scientific pitch notation, C4 = 60): what librosa.note_to_midi returns for the plain
+    note names the instrument profiles use (amt_tools/tools/instrument.py:148-160)."""
+    if isinstance(note, (list, tuple)):
+        return [note_to_midi(n) for n in note]
+    pc = {'C': 0, 'D': 2, 'E': 4, 'F': 5, 'G': 7, 'A': 9, 'B': 11}[note[0].upper()]
+    i = 1
+    while i < len(note) and note[i] in '#b':
+        pc += 1 if note[i] == '#' else -1
+        i += 1
+    octave = int(note[i:]) if i < len(note) else 0
+    return 12 * (octave + 1) + pc
+
+
+class TablatureProfile(InstrumentProfile):
+    """Instruments with several degrees of freedom, e.g. strings (amt_tools/tools/instrument.py:103-260)."""
+
+    def __init__(self, tuning, num_pitches):
+        self.tuning = tuning
+        self.num_pitches = num_pitches
+        midi_tuning = self.get_midi_tuning()
+        super().__init__(midi_tuning[0], midi_tuning[-1] - 1 + self.num_pitches)
+
+    def get_num_dofs(self):
+        return len(self.tuning)
+
+    def get_midi_tuning(self):
+        return note_to_midi(list(self.tuning))
+
+    def get_dof_midi_range(self):
+        tuning = self.get_midi_tuning()
+        return np.array([np.arange(tuning[i], tuning[i] + self.num_pitches) for i in range(self.get_num_dofs())])
+
+    def get_fret(self, midi_pitch, string):
+        return midi_pitch - self.get_midi_tuning()[string]
+
+    def get_pitch(self, string, fret):
+        return self.get_midi_tuning()[string] + fret
+
+
+class GuitarProfile(TablatureProfile):
+    """Six strings in standard tuning, 19 frets by default (amt_tools/tools/instrument.py:263-305)."""
+
+    def __init__(self, tuning=None, num_frets=None):
+        if tuning is None:
+            tuning = DEFAULT_GUITAR_TUNING
+        if num_frets is None:
+            num_frets = DEFAULT_GUITAR_NUM_FRETS
+        super().__init__(tuning, num_frets + 1)
+
+    def get_num_frets(self):
+        return self.num_pitches - 1
+
+
 # ---- dict plumbing ---------------------------------------------------------------------------------
 def unpack_dict(data, key):
     """Entry for `key`, or None (amt_tools/tools/utils.py:3823-3853)."""
@@ -90,6 +148,29 @@ def dict_to_dtype(track, dtype):
 
 def dict_to_tensor(track):
     return _map_dict(track, lambda v: torch.from_numpy(v) if isinstance(v, np.ndarray) else v)
+
+
+def array_to_tensor(data, device=None):
+    """amt_tools/tools/utils.py:3438-3465."""
+    if isinstance(data, np.ndarray):
+        data = torch.from_numpy(data)
+        if device is not None:
+            data = data.to(device)
+    return data
+
+
+def framify_activations(activations, win_length, hop_length=1, pad=True):
+    """Overlapping windows along the last axis: (..., T) -> (..., T', win_length), centre zero padding by win_length // 2 when
+    `pad` (amt_tools/tools/utils.py:2922-2984; librosa.util.pad_center = symmetric zero padding, extra sample on the right)."""
+    num_frames = activations.shape[-1]
+    pad_length = win_length // 2
+    num_frames_ = num_frames + 2 * pad_length if pad else max(win_length, num_frames)
+    lpad = (num_frames_ - num_frames) // 2
+    widths = [(0, 0)] * (activations.ndim - 1) + [(lpad, num_frames_ - num_frames - lpad)]
+    activations = np.pad(activations, widths, mode='constant')
+    num_hops = (num_frames_ - 2 * pad_length) // hop_length
+    chunks = [np.expand_dims(activations[..., i: i + win_length], axis=-2) for i in np.arange(0, num_hops) * hop_length]
+    return np.concatenate(chunks, axis=-2)
 
 
 def tensor_to_array(data):

@@ -75,3 +75,37 @@ def test_batch_and_full_size_clip_properties():
     a = lin.process_batch(x[:1])
     b = lin.process_batch(4.0 * x[:1])
     assert torch.allclose(b, 4.0 * a, rtol=1e-5, atol=0)          # power-of-two gain: linear in amplitude
+
+
+def test_config1_cqt_into_tabcnn_end_to_end():
+    """BASELINE config 1 on the build's objects: one GuitarSet-shape clip -> CQT(192 bins, 24 per octave) on the GPU (HIP) ->
+    TabCNN (stock torch ops) -> tablature (6 strings x T).  Against the oracle's CQT features through the same model on the
+    CPU: identical tablature except where the two best classes of a string are within the feature tolerance of each other."""
+    torch = pytest.importorskip('torch')
+    from amt_tools_amd import tools
+    from amt_tools_amd.features import CQT
+    from amt_tools_amd.models import TabCNN
+    from amt_tools_amd.synth import synth_tabcnn_state_dict
+    y = synth_clip(5, num_samples=4 * 22050)
+    mod = CQT(sample_rate=22050, hop_length=512, n_bins=192, bins_per_octave=24)
+    feats = mod.process_audio(y)                                                   # (1, 192, T) from the HIP kernels
+    ref_feats = cq.cqt_process_audio(y, sample_rate=22050, hop_length=512, n_bins=192, bins_per_octave=24).astype(np.float32)
+    assert feats.shape == ref_feats.shape == (1, 192, mod.get_expected_frames(y))
+    profile = tools.GuitarProfile(num_frets=19)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth_tabcnn_state_dict(3, dim_in=192).items()}
+    outs, logits = [], []
+    for f, dev in ((feats, 'cuda:0'), (ref_feats, 'cpu')):
+        model = TabCNN(192, profile, 1, 1, device=dev)
+        model.load_state_dict(sd)
+        model.change_device()
+        model.eval()
+        with torch.no_grad():
+            batch = {tools.KEY_FEATS: torch.from_numpy(f[None])}
+            raw = model(model.pre_proc(dict(batch))[tools.KEY_FEATS])[tools.KEY_TABLATURE]
+            outs.append(model.run_on_batch(batch)[tools.KEY_TABLATURE].cpu().numpy())
+            logits.append(raw.cpu().numpy())
+    assert outs[0].shape == (1, 6, feats.shape[-1]) and outs[0].min() >= -1 and outs[0].max() <= 19
+    assert np.abs(logits[0] - logits[1]).max() < 5e-2
+    top2 = np.sort(logits[1].reshape(1, -1, 6, 21), axis=-1)[..., -2:]
+    decided = np.swapaxes(top2[..., 1] - top2[..., 0], -1, -2) > 0.1               # (1, 6, T): argmax not a near-tie
+    assert np.all((outs[0] == outs[1]) | ~decided) and decided.mean() > 0.5

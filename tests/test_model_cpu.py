@@ -148,3 +148,35 @@ def test_run_offline_contract_on_cpu():
     res1 = run_offline_batched(g['feats'], model, batch_size=1, rank=1, world=2)
     assert sorted(res0) == [0] and sorted(res1) == [1]
     np.testing.assert_array_equal(res0[0][tools.KEY_ONSETS], pred[tools.KEY_ONSETS])
+
+
+def test_config1_tabcnn_matches_reference_on_cpu():
+    """BASELINE config 1 (TabCNN on CQT-shaped features, CPU plumbing): the mirror reproduces the REAL reference's framing,
+    logits, tablature and loss (tests/golden/tabcnn_eval.npz) and the GuitarProfile geometry."""
+    from amt_tools_amd.models import TabCNN
+    from amt_tools_amd.synth import synth_tabcnn_state_dict
+    g = load_golden('tabcnn_eval.npz')
+    profile = tools.GuitarProfile(num_frets=19)
+    assert (profile.low, profile.high, profile.get_num_dofs(), profile.num_pitches) == (int(g['midi_low']), int(g['midi_high']), 6, 20)
+    np.testing.assert_array_equal(profile.get_dof_midi_range(), g['dof_range'])
+    model = TabCNN(int(g['dim_in']), profile, 1, 1)
+    sd = synth_tabcnn_state_dict(int(g['seed']), dim_in=int(g['dim_in']))
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.eval()
+    assert model.frame_width == 9 and model.model_name() == 'TabCNN'
+    feats = torch.from_numpy(g['feats'])
+    with torch.no_grad():
+        pre = model.pre_proc({tools.KEY_FEATS: feats})
+        assert tuple(pre[tools.KEY_FEATS].shape) == tuple(g['framed_shape'])          # (B, T, C, F, 9)
+        raw = model(pre[tools.KEY_FEATS])[tools.KEY_TABLATURE]
+        out = model.run_on_batch({tools.KEY_FEATS: feats, tools.KEY_TABLATURE: torch.from_numpy(g['tablature_ref'])})
+    assert np.abs(raw.numpy() - g['logits']).max() < 2e-5
+    np.testing.assert_array_equal(out[tools.KEY_TABLATURE].numpy(), g['out_tablature'])
+    assert abs(out[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].item() - float(g['loss_total'])) < 1e-4
+    # framing helper: centre zero padding, one window per frame
+    x = np.arange(5, dtype=np.float32)[None]
+    fr = tools.framify_activations(x, 3)
+    np.testing.assert_array_equal(fr[0], [[0, 0, 1], [0, 1, 2], [1, 2, 3], [2, 3, 4], [3, 4, 0]])
+    assert tools.framify_activations(x, 9, pad=False).shape == (1, 1, 9)
+    assert tools.note_to_midi(['E2', 'A2', 'D3', 'G3', 'B3', 'E4']) == [40, 45, 50, 55, 59, 64] and tools.note_to_midi('Bb3') == 58

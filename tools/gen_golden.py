@@ -41,12 +41,37 @@ for m in ['librosa', 'librosa.util', 'librosa.core', 'librosa.core.constantq', '
     s.__path__ = []
     sys.modules[m] = s
 
+# two librosa helpers the TabCNN path calls are one-liners whose documented behaviour is restated here so that the
+# reference's own code runs (the stub would hand back MagicMocks): symmetric zero padding and note names -> MIDI numbers
+def _pad_center(data, size, axis=-1, **kw):
+    n = data.shape[axis]
+    lpad = (size - n) // 2
+    widths = [(0, 0)] * data.ndim
+    widths[axis] = (lpad, size - n - lpad)
+    return np.pad(data, widths, mode='constant')
+
+
+def _note_to_midi(note):
+    if isinstance(note, (list, tuple)):
+        return [_note_to_midi(n) for n in note]
+    pc = {'C': 0, 'D': 2, 'E': 4, 'F': 5, 'G': 7, 'A': 9, 'B': 11}[note[0].upper()]
+    rest = note[1:]
+    while rest and rest[0] in '#b':
+        pc += 1 if rest[0] == '#' else -1
+        rest = rest[1:]
+    return 12 * (int(rest) + 1) + pc
+
+
+sys.modules['librosa'].note_to_midi = _note_to_midi
+sys.modules['librosa.util'].pad_center = _pad_center
+sys.modules['librosa'].util = sys.modules['librosa.util']
+
 import amt_tools                                    # noqa: E402  (the reference)
 from amt_tools import tools as rtools               # noqa: E402
-from amt_tools.models import OnsetsFrames, OnsetsFrames2   # noqa: E402
+from amt_tools.models import OnsetsFrames, OnsetsFrames2, TabCNN   # noqa: E402
 from amt_tools.transcribe import NoteTranscriber   # noqa: E402
 
-from amt_tools_amd.synth import synth_state_dict, of_state_dict_shapes   # noqa: E402
+from amt_tools_amd.synth import synth_state_dict, of_state_dict_shapes, synth_tabcnn_state_dict   # noqa: E402
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 os.makedirs(OUT, exist_ok=True)
@@ -143,6 +168,33 @@ def gen_of_train(name, seed, dim_in, mc, B, T):
     print(name, 'losses', rec['loss_pitch'], rec['loss_onsets'], rec['loss_total'])
 
 
+def gen_tabcnn(name, seed, dim_in, B, T):
+    """BASELINE config 1 (TabCNN + CQT features, CPU): eval output and training loss of the reference's TabCNN with a
+    GuitarProfile(num_frets=19) on seed features of a GuitarSet-shape CQT (192 bins)."""
+    profile = rtools.GuitarProfile(num_frets=19)
+    model = TabCNN(dim_in, profile, 1, 1)
+    sd_np = synth_tabcnn_state_dict(seed, dim_in=dim_in, in_channels=1, model_complexity=1, num_groups=6, num_classes=21)
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(sd_np.keys()), (list(ref_sd.keys()), list(sd_np.keys()))
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(sd_np[k].shape), (k, v.shape, sd_np[k].shape)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    model.eval()
+    feats = features(seed + 100, B, 1, dim_in, T)
+    rng = np.random.default_rng(seed + 200)
+    tab = rng.integers(-1, 20, size=(B, 6, T)).astype(np.int64)
+    with torch.no_grad():
+        pre = model.pre_proc({rtools.KEY_FEATS: torch.from_numpy(feats)})
+        raw = model(pre[rtools.KEY_FEATS])[rtools.KEY_TABLATURE]
+        out = model.run_on_batch({rtools.KEY_FEATS: torch.from_numpy(feats), rtools.KEY_TABLATURE: torch.from_numpy(tab)})
+    rec = dict(seed=seed, dim_in=dim_in, feats=feats, tablature_ref=tab, wsum=weight_checksum(sd_np),
+               framed_shape=np.array(pre[rtools.KEY_FEATS].shape), logits=raw.numpy(),
+               out_tablature=out[rtools.KEY_TABLATURE].numpy(), loss_total=out[rtools.KEY_LOSS][rtools.KEY_LOSS_TOTAL].item(),
+               midi_low=profile.low, midi_high=profile.high, dof_range=profile.get_dof_midi_range())
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, 'logits', rec['logits'].shape, 'loss', rec['loss_total'], 'range', profile.low, profile.high)
+
+
 def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
     rng = np.random.default_rng(seed)
     profile = rtools.PianoProfile()
@@ -173,6 +225,7 @@ if __name__ == '__main__':
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
     gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
     gen_of_train('of1_train.npz', seed=21, dim_in=229, mc=2, B=2, T=24)
+    gen_tabcnn('tabcnn_eval.npz', seed=41, dim_in=192, B=2, T=30)
     gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
     gen_notes('notes_noonsets.npz', 33, 200, 0.0, 0.06, False)
