@@ -195,6 +195,30 @@ def gen_tabcnn(name, seed, dim_in, B, T):
     print(name, 'logits', rec['logits'].shape, 'loss', rec['loss_total'], 'range', profile.low, profile.high)
 
 
+def gen_labels_and_cache(name, cache_name, seed, T, n_notes, hop=512, sr=22050):
+    """Ground-truth rasterisation (tools/utils.py:1665-1737,2329-2378,2508-2552) of random notes -- some out of the piano's
+    range or outside the time grid -- and a feature cache file written by the reference's own save_dict_npz
+    (datasets/common.py:259-266)."""
+    rng = np.random.default_rng(seed)
+    profile = rtools.PianoProfile()
+    times = np.arange(T) * hop / float(sr)
+    pitches = rng.uniform(15, 115, n_notes)                       # a few below 21 / above 108
+    onsets = rng.uniform(-0.5, times[-1] + 0.5, n_notes)
+    intervals = np.stack([onsets, onsets + rng.uniform(0.01, 1.5, n_notes)], axis=-1)
+    rec = dict(pitches=pitches, intervals=intervals, times=times,
+               multi_pitch=rtools.notes_to_multi_pitch(pitches.copy(), intervals.copy(), times, profile),
+               multi_pitch_no_off=rtools.notes_to_multi_pitch(pitches.copy(), intervals.copy(), times, profile, include_offsets=False),
+               onsets=rtools.notes_to_onsets(pitches.copy(), intervals.copy(), times, profile),
+               onsets_amb=rtools.notes_to_onsets(pitches.copy(), intervals.copy(), times, profile, ambiguity=0.05),
+               offsets=rtools.notes_to_offsets(pitches.copy(), intervals.copy(), times, profile),
+               offsets_amb=rtools.notes_to_offsets(pitches.copy(), intervals.copy(), times, profile, ambiguity=0.05))
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    feats = features(seed + 1, 1, 1, 40, 12)[0]
+    rtools.save_dict_npz(os.path.join(OUT, cache_name), {rtools.KEY_FS: sr, rtools.KEY_HOP: hop, rtools.KEY_FEATS: feats})
+    rtools.save_dict_npz(os.path.join(OUT, cache_name.replace('.npz', '_none.npz')), {rtools.KEY_FS: sr, rtools.KEY_HOP: hop, rtools.KEY_FEATS: None})
+    print(name, {k: v.shape for k, v in rec.items()}, 'active cells', int(rec['multi_pitch'].sum()))
+
+
 def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
     rng = np.random.default_rng(seed)
     profile = rtools.PianoProfile()
@@ -226,6 +250,7 @@ if __name__ == '__main__':
     gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
     gen_of_train('of1_train.npz', seed=21, dim_in=229, mc=2, B=2, T=24)
     gen_tabcnn('tabcnn_eval.npz', seed=41, dim_in=192, B=2, T=30)
+    gen_labels_and_cache('labels.npz', 'feature_cache_ref.npz', seed=51, T=200, n_notes=60)
     gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
     gen_notes('notes_noonsets.npz', 33, 200, 0.0, 0.06, False)
