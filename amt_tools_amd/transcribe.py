@@ -43,9 +43,16 @@ def _sort_by_onset(batched):
     return batched[np.argsort(batched[..., 0])]
 
 
-def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low):
-    """(key, onset frame, offset frame) events in np.nonzero order -> (K,3) rows ordered like the reference."""
-    times_ext = np.append(times, times[-1] + estimate_hop_length(times))
+def _extend_times(times):
+    """The frame grid plus one more frame (tools/utils.py:441-442): offsets may point one past the last frame."""
+    return np.append(times, times[-1] + estimate_hop_length(times))
+
+
+def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low, times_ext=None):
+    """(key, onset frame, offset frame) events in np.nonzero order -> (K,3) rows ordered like the reference.
+    `times_ext` = _extend_times(times) when the caller already has it (one grid shared by a whole batch)."""
+    if times_ext is None:
+        times_ext = _extend_times(times)
     if len(pitch_idcs) == 0:
         return np.empty([0, 3])
     batched = np.stack([times_ext[on_frames], times_ext[off_frames], (pitch_idcs + low).astype(np.float64)], axis=-1)
@@ -74,9 +81,38 @@ def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITC
     return _events_to_notes(pitch_idcs, frame_idcs, after[pitch_idcs, frame_idcs], np.asarray(times), low)
 
 
-def decode_notes_batch(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH):
-    """Device path: (B,88,T) fp32 CUDA tensors (onsets may be None) -> list of B (K,3) float64 arrays.
-    `times` is one (T,) grid shared by the batch or a (B,T) array."""
+class _PendingNotes(object):
+    """Device half of the decoder already enqueued; `result()` brings the compacted events to the host and assembles the
+    reference-ordered note arrays.  Lets a caller enqueue the next batch's kernels before paying for this batch's host work."""
+
+    def __init__(self, ev, counts, B, K, times, low):
+        self._ev, self._counts, self._B, self._K, self._times, self._low = ev, counts, B, K, np.asarray(times), low
+        import torch
+        self._done = torch.cuda.Event()
+        self._done.record(torch.cuda.current_stream(ev.device))
+
+    def result(self):
+        self._done.synchronize()
+        B, K, times, low = self._B, self._K, self._times, self._low
+        ev_h = self._ev.cpu().numpy()
+        counts_h = self._counts.cpu().numpy().reshape(B, K)
+        keys_h = np.repeat(np.tile(np.arange(K), B), counts_h.reshape(-1))             # key of every event
+        bounds = np.concatenate([[0], np.cumsum(counts_h.sum(axis=1))])
+        shared_ext = _extend_times(times) if times.ndim == 1 else None
+        out = []
+        for b in range(B):
+            lo, hi = bounds[b], bounds[b + 1]
+            if hi > lo:
+                t = times if shared_ext is not None else times[b]
+                out.append(_events_to_notes(keys_h[lo:hi], ev_h[lo:hi, 0], ev_h[lo:hi, 1], t, low, shared_ext))
+            else:
+                out.append(np.empty([0, 3]))
+        return out
+
+
+def decode_notes_batch_async(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH):
+    """Enqueue the device decoder (amtx_notes_decode + compaction) and return a handle; `handle.result()` -> list of B (K,3)
+    float64 arrays.  (B,88,T) fp32 CUDA tensors (onsets may be None); `times` is one (T,) grid or a (B,T) array."""
     import torch
     assert multi_pitch.is_cuda and multi_pitch.dim() == 3
     B, K, T = multi_pitch.shape
@@ -89,23 +125,20 @@ def decode_notes_batch(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWES
     with torch.cuda.device(multi_pitch.device):
         _lib.check(_lib.lib().amtx_notes_decode(_lib.ptr(onsets), _lib.ptr(multi_pitch), B, K, T, cap, _lib.ptr(pairs), _lib.ptr(counts),
                                                 _lib.current_stream(multi_pitch.device)), 'amtx_notes_decode')
-    counts_h = counts.cpu().numpy().reshape(B, K)
-    pairs_h = pairs.cpu().numpy().reshape(B, K, cap, 2)
-    times = np.asarray(times)
-    out = []
-    for b in range(B):
-        ks, ons, offs = [], [], []
-        for k in np.nonzero(counts_h[b])[0]:
-            ev = pairs_h[b, k, :counts_h[b, k]][::-1]                 # kernel emits descending frames
-            ks.append(np.full(len(ev), k))
-            ons.append(ev[:, 0])
-            offs.append(ev[:, 1])
-        t = times[b] if times.ndim == 2 else times
-        if ks:
-            out.append(_events_to_notes(np.concatenate(ks), np.concatenate(ons), np.concatenate(offs), t, low))
-        else:
-            out.append(np.empty([0, 3]))
-    return out
+        # compact on the device: only the emitted (onset, offset) pairs cross PCIe (a few MB instead of the padded
+        # B*K*cap*8 bytes), per key in ascending frame order (the kernel emits descending frames) = np.nonzero order
+        counts64 = counts.long()
+        j = torch.arange(cap, device=counts.device)[None, :]
+        valid = j < counts64[:, None]
+        rev = (counts64[:, None] - 1 - j).clamp_(min=0)
+        ev = torch.gather(pairs, 1, rev[..., None].expand(-1, -1, 2))[valid]     # (E, 2), (clip, key)-major
+        return _PendingNotes(ev, counts, B, K, times, low)
+
+
+def decode_notes_batch(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH):
+    """Device path: (B,88,T) fp32 CUDA tensors (onsets may be None) -> list of B (K,3) float64 arrays.
+    `times` is one (T,) grid shared by the batch or a (B,T) array."""
+    return decode_notes_batch_async(onsets, multi_pitch, times, low).result()
 
 
 class NoteTranscriber(object):
