@@ -28,27 +28,94 @@ def run_offline(track_data, model, estimator=None):
 
 
 @torch.no_grad()
-def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=1, decode_notes=False):
+def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=1, decode_notes=False, keep=None):
     """clips: (num_clips, N) float32 array / CPU tensor of equally long clips (the model needs a front-end in
     `model.frontend`) or (num_clips, C, F, T) features.  Returns {clip index: predictions dict} for the clips
-    this rank owns.  With decode_notes=True the note lists are decoded on the device (amtx_notes_decode)."""
+    this rank owns.  With decode_notes=True the note lists are decoded on the device (amtx_notes_decode).
+    `keep`: keys of the model output to bring back to the host (default: every array; () = notes only).
+
+    On a GPU model the loop is a three-stage pipeline: batch i+1 is uploaded on a copy stream (from pinned memory) while batch
+    i's kernels run, and batch i-1's results are brought to the host / assembled into note arrays while the GPU is busy."""
     clips = torch.as_tensor(np.asarray(clips) if not torch.is_tensor(clips) else clips)
     mine = shard_indices(clips.shape[0], rank, world)
     key = tools.KEY_AUDIO if clips.dim() == 2 else tools.KEY_FEATS
+    device = torch.device(f'cuda:{model.device}' if isinstance(model.device, int) else model.device)
+    on_gpu = device.type == 'cuda' and torch.cuda.is_available()
     out = {}
-    for s in range(0, len(mine), batch_size):
-        idx = mine[s:s + batch_size]
-        batch = {key: clips[idx].float()}
-        preds = model.run_on_batch(batch)
-        notes = None
-        if decode_notes:
-            from .transcribe import decode_notes_batch
-            T = preds[tools.KEY_MULTIPITCH].shape[-1]
-            t = times if times is not None else np.arange(T) * 512 / 22050.0
-            notes = decode_notes_batch(preds[tools.KEY_ONSETS], preds[tools.KEY_MULTIPITCH], t, model.profile.low)
-        host = tools.dict_to_array(preds)
+
+    def finish(pending):
+        idx, preds, handle = pending
+        notes = handle.result() if handle is not None else None
+        host = tools.dict_to_array({k: v for k, v in preds.items() if keep is None or k in keep})
         for j, i in enumerate(idx):
             out[i] = {k: v[j] for k, v in host.items() if isinstance(v, np.ndarray)}
             if notes is not None:
                 out[i][tools.KEY_NOTES] = notes[j]
+
+    staging = [None, None]            # pinned staging buffers (ring of two) + the event of the copy that last read them
+    stage_count = [0]
+
+    def stage(idx):
+        lo, hi = int(idx[0]), int(idx[-1]) + 1
+        contiguous = hi - lo == len(idx)
+        if not on_gpu:
+            return (clips[lo:hi] if contiguous else clips[torch.as_tensor(idx)]).float(), None
+        with torch.cuda.stream(copy_stream):
+            if contiguous and clips.is_pinned() and clips.dtype == torch.float32:
+                src = clips[lo:hi]                                # zero-copy: the caller's pinned memory is the DMA source
+            else:
+                slot = stage_count[0] % 2
+                stage_count[0] += 1
+                if staging[slot] is None:
+                    staging[slot] = [torch.empty((batch_size,) + tuple(clips.shape[1:]), dtype=torch.float32).pin_memory(), None]
+                buf, last = staging[slot]
+                if last is not None:
+                    last.synchronize()                            # the copy that read this buffer two batches ago is done
+                src = buf[:len(idx)]
+                if contiguous:
+                    src.copy_(clips[lo:hi])
+                else:
+                    torch.index_select(clips.float() if clips.dtype != torch.float32 else clips, 0, torch.as_tensor(idx), out=src)
+            dev = src.to(device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy_stream)
+            if not (contiguous and clips.is_pinned() and clips.dtype == torch.float32):
+                staging[slot][1] = ev
+        return dev, (ev, src)
+
+    copy_stream = torch.cuda.Stream(device) if on_gpu else None
+    starts = list(range(0, len(mine), batch_size))
+    nxt = stage(mine[starts[0]:starts[0] + batch_size]) if starts else None
+    pending = None
+    for n, s in enumerate(starts):
+        idx = mine[s:s + batch_size]
+        data, sync = nxt
+        if sync is not None:
+            torch.cuda.current_stream(device).wait_event(sync[0])
+        if n + 1 < len(starts):
+            nxt = stage(mine[starts[n + 1]:starts[n + 1] + batch_size])
+        preds = model.run_on_batch({key: data})
+        handle = None
+        if decode_notes:
+            T = preds[tools.KEY_MULTIPITCH].shape[-1]
+            t = times if times is not None else np.arange(T) * 512 / 22050.0
+            if preds[tools.KEY_MULTIPITCH].is_cuda:
+                from .transcribe import decode_notes_batch_async
+                handle = decode_notes_batch_async(preds[tools.KEY_ONSETS], preds[tools.KEY_MULTIPITCH], t, model.profile.low)
+            else:
+                from .transcribe import multi_pitch_to_notes
+
+                class _Host(object):
+                    def __init__(self, p):
+                        self.p = p
+
+                    def result(self):
+                        mp, on = self.p[tools.KEY_MULTIPITCH].numpy(), self.p[tools.KEY_ONSETS].numpy()
+                        return [multi_pitch_to_notes(mp[b], t if np.ndim(t) == 1 else t[b], model.profile.low, on[b]) for b in range(mp.shape[0])]
+                handle = _Host(preds)
+        if pending is not None:
+            finish(pending)                                       # the GPU is busy with this batch meanwhile
+        pending = (idx, preds, handle)
+    if pending is not None:
+        finish(pending)
     return out

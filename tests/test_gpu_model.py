@@ -187,3 +187,28 @@ def test_config3_hcqt_frontend_fused_into_the_model():
         near = np.abs(ref['logits'][key].transpose(-1, -2).numpy()) < 5e-3      # CQT feature tolerance (1e-3) through the model
         assert np.all((out[key].cpu().numpy() == ref[key].numpy()) | near)
         assert (out[key].cpu().numpy() != ref[key].numpy()).mean() < 5e-3
+
+
+def test_run_offline_batched_pipeline_equals_per_clip_runs():
+    """BASELINE config 5 driver: the three-stage pipeline (upload on a copy stream / kernels / host assembly of the previous
+    batch) returns, per clip, exactly what one-clip-at-a-time `run_offline` + the host NoteTranscriber return; shards by rank
+    partition the clips."""
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.inference import run_offline, run_offline_batched
+    from amt_tools_amd.transcribe import NoteTranscriber
+    g = load_golden('of1_eval.npz')
+    model = _model(g, 'x3')
+    model.frontend = torch.nn.Sequential(MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048).frontend())
+    clips = np.stack([synth_clip(i, num_samples=512 * 40 - 1) for i in range(7)])
+    times = (np.arange(40) * 512 / 22050.0).astype(np.float32)      # run_offline casts every array of the track to float32
+    res = run_offline_batched(clips, model, times=times, batch_size=3, decode_notes=True)          # batches of 3, 3, 1
+    assert sorted(res) == list(range(7))
+    est = NoteTranscriber(tools.PianoProfile())
+    for i in (0, 3, 6):
+        single = run_offline({tools.KEY_AUDIO: clips[i], tools.KEY_TIMES: times}, model, est)
+        np.testing.assert_array_equal(res[i][tools.KEY_ONSETS], single[tools.KEY_ONSETS])
+        np.testing.assert_array_equal(res[i][tools.KEY_MULTIPITCH], single[tools.KEY_MULTIPITCH])
+        np.testing.assert_array_equal(res[i][tools.KEY_NOTES], single[tools.KEY_NOTES])
+    shard = run_offline_batched(clips, model, times=times, batch_size=2, rank=1, world=2, decode_notes=True, keep=())
+    assert sorted(shard) == [1, 3, 5] and set(shard[1]) == {tools.KEY_NOTES}
+    np.testing.assert_array_equal(shard[3][tools.KEY_NOTES], res[3][tools.KEY_NOTES])

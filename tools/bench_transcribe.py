@@ -10,7 +10,6 @@ import numpy as np, torch
 import bench
 from amt_tools_amd import tools
 from amt_tools_amd.synth import synth_clip, CLIP_FRAMES
-from amt_tools_amd.transcribe import decode_notes_batch_async
 
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 N = int(args[0]) if args else 2048
@@ -20,42 +19,15 @@ model, mel, sd = bench.build_model('cuda:0', 'bf16')
 base = np.stack([synth_clip(i) for i in range(8)])
 host = torch.from_numpy(np.tile(base, ((N + 7) // 8, 1))[:N]).pin_memory()
 times = np.arange(CLIP_FRAMES) * 512 / 22050.0
-copy_stream = torch.cuda.Stream()
-
-
-def upload(i):
-    with torch.cuda.stream(copy_stream):
-        d = host[i:i + B].to('cuda:0', non_blocking=True)
-        ev = torch.cuda.Event(); ev.record(copy_stream)
-    return d, ev
+model.frontend = torch.nn.Sequential(mel.frontend())
+from amt_tools_amd.inference import run_offline_batched
+keep = (tools.KEY_ONSETS, tools.KEY_MULTIPITCH) if rolls else ()
 
 
 def run():
-    notes_total, pending = 0, None
-    nxt = upload(0)
-
-    def finish(p):
-        handle, rolls_dev = p
-        n = sum(len(x) for x in handle.result())
-        if rolls_dev is not None:
-            _ = [r.cpu() for r in rolls_dev]
-        return n
-
-    with torch.no_grad():
-        for i in range(0, N, B):
-            audio, ev = nxt
-            torch.cuda.current_stream().wait_event(ev)
-            if i + B < N:
-                nxt = upload(i + B)
-            preds = model.run_on_batch({tools.KEY_AUDIO: audio})
-            handle = decode_notes_batch_async(preds[tools.KEY_ONSETS], preds[tools.KEY_MULTIPITCH], times, 21)
-            # this batch's kernels are enqueued; the host now assembles the PREVIOUS batch's notes while the GPU works
-            if pending is not None:
-                notes_total += finish(pending)
-            pending = (handle, (preds[tools.KEY_ONSETS], preds[tools.KEY_MULTIPITCH]) if rolls else None)
-        notes_total += finish(pending)
+    res = run_offline_batched(host, model, times=times, batch_size=B, decode_notes=True, keep=keep)
     torch.cuda.synchronize()
-    return notes_total
+    return sum(len(r[tools.KEY_NOTES]) for r in res.values())
 
 
 run()
