@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line (contract in the task description) with two extra ob
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -167,12 +168,18 @@ def main():
     _lib.check(L.amtx_of_profile_enable(eng.handle, 1))
     mel._prof_events = []
 
+    # a generation-2 garbage collection of the interpreter (tens of ms with torch + numpy loaded) that lands in the first
+    # steps of the timed loop stalls the enqueueing thread long enough for the GPU queue to run dry: seen as 15 instead of
+    # 11.4 ms/step with identical per-kernel times.  Collect now, keep the collector off while timing.
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
