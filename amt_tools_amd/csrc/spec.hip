@@ -84,7 +84,7 @@ __device__ __forceinline__ void dft16(float2 (&v)[16]) {
 
 // power-row slot of FFT bin k: one pad word per 16 bins, so the untangling pass (lanes stride 16 bins) and the
 // mel gather (lanes start at arbitrary bins) both spread over all LDS banks instead of two.
-__device__ __forceinline__ int pidx(int k) { return k + (k >> 4); }
+__device__ __forceinline__ int pidx(int k) { return k; }
 
 __device__ __forceinline__ void wave_lds_sync() {
     // same-wave LDS traffic retires in order; this only stops the compiler from moving LDS accesses
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
 #pragma unroll 1
         for (int q = lane; q < 129; q += 64) {
             int k1, c;
-            if (q < 112) { k1 = 1 + (q >> 4); c = q & 15; }
+            if (q < 112) { c = (q * 9363) >> 16; k1 = 1 + q - 7 * c; }   // c = q / 7 (exact for q < 112), k1 = 1 + q % 7: k1-major lanes
             else if (q < 120) { k1 = 8; c = q - 112; }
             else { k1 = 0; c = q - 120; }
             const int pk1 = (16 - k1) & 15;
