@@ -221,15 +221,20 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         }
         wave_lds_sync();
 
-        // ---- radix-4 tail merged with the real-FFT untangling: 129 (group, partner-group) tasks
+        // ---- radix-4 tail merged with the real-FFT untangling: 128 tasks = exactly two full-wave iterations.
+        // A task takes a 4-point group (k1, c) and its partner group ((16 - k1) & 15, 15 - c), runs the two DFT-4s and
+        // untangles the four bin pairs (k, M - k), k = k1 + 16 c + 256 d.  The two self-paired groups (0,0) and (0,8) would be
+        // a 129th task (and a third, one-lane iteration): they are merged into ONE task (q = 127) whose four untangle slots
+        // are (Z0,Z0) -> bins 0 / 1024, (Z1,Z3) -> 256 / 768 of group (0,0) and (Z0,Z3) -> 128 / 896, (Z1,Z2) -> 384 / 640 of
+        // group (0,8); the one bin left over, 512, is its own partner: X[512] = conj(Z[512]), power |Z2|^2.
 #pragma unroll 1
-        for (int q = lane; q < 129; q += 64) {
-            int k1, c;
-            if (q < 112) { c = (q * 9363) >> 16; k1 = 1 + q - 7 * c; }   // c = q / 7 (exact for q < 112), k1 = 1 + q % 7: k1-major lanes
-            else if (q < 120) { k1 = 8; c = q - 112; }
-            else { k1 = 0; c = q - 120; }
-            const int pk1 = (16 - k1) & 15;
-            const int pc = (k1 == 0) ? ((16 - c) & 15) : (15 - c);
+        for (int q = lane; q < 128; q += 64) {
+            int k1, c, pk1, pc;
+            const bool sp = q == 127;
+            if (q < 112) { c = (q * 9363) >> 16; k1 = 1 + q - 7 * c; pk1 = 16 - k1; pc = 15 - c; }   // c = q / 7, k1 = 1 + q % 7: k1-major lanes
+            else if (q < 120) { k1 = 8; c = q - 112; pk1 = 8; pc = 15 - c; }
+            else if (q < 127) { k1 = 0; c = q - 119; pk1 = 0; pc = 16 - c; }                          // c = 1..7 with 15..9
+            else { k1 = 0; c = 0; pk1 = 0; pc = 8; }
             const float4* ga = reinterpret_cast<const float4*>(xb + k1 * XB_PITCH + 4 * c);
             const float4* gb = reinterpret_cast<const float4*>(xb + pk1 * XB_PITCH + 4 * pc);
             float4 a01 = ga[0], a23 = ga[1], b01 = gb[0], b23 = gb[1];
@@ -237,19 +242,19 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
             float2 zb[4] = {make_float2(b01.x, b01.y), make_float2(b01.z, b01.w), make_float2(b23.x, b23.y), make_float2(b23.z, b23.w)};
             dft4(za[0], za[1], za[2], za[3]);
             dft4(zb[0], zb[1], zb[2], zb[3]);
-            const bool is00 = (k1 == 0) && (c == 0);
-            if (is00) {   // partner of k = 256 d inside the same group: Z[(4-d)&3]
-                zb[0] = za[1]; zb[1] = za[2]; zb[2] = za[3]; zb[3] = za[0];
-            }
             const int kbase = k1 + 16 * c;
+            // slot d untangles (A[d], P[d]) into bins (ks[d], M - ks[d]); the merged task re-routes slots by select
+            const float2 A[4] = {za[0], za[1], sp ? zb[0] : za[2], sp ? zb[1] : za[3]};
+            const float2 P[4] = {sp ? za[0] : zb[3], sp ? za[3] : zb[2], sp ? zb[3] : zb[1], sp ? zb[2] : zb[0]};
+            const int ks[4] = {kbase, kbase + 256, sp ? 128 : kbase + 512, sp ? 384 : kbase + 768};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const int k = kbase + 256 * d;
                 float pk, pmk;
-                untangle_pair(za[d], zb[3 - d], twp[k], pk, pmk);
-                pb[pidx(k)] = pk;
-                pb[pidx(M - k)] = pmk;
+                untangle_pair(A[d], P[d], twp[ks[d]], pk, pmk);
+                pb[pidx(ks[d])] = pk;
+                pb[pidx(M - ks[d])] = pmk;
             }
+            if (sp) pb[pidx(M / 2)] = za[2].x * za[2].x + za[2].y * za[2].y;
         }
         wave_lds_sync();
 
