@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
 
     // ---- constants of the fused first conv
     float* ftile = reinterpret_cast<float*>(smem + NS * PLANE_BYTES);
-    const int fcols = ft + 4;
+    const int fcols = ft + 4 + (KS == 1 ? 1 : 0);       // KS == 1: one more column for the zero-weight fourth slot of a lane's row segment
     const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
     const bool fprefetch = FUSE1 && fitems <= FPRE * 256;
     constexpr int KSA = KS > 0 ? KS : 1;
@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                 const int k = 16 * ks + 4 * g + j;
                 const int ci = k / 9, tap = k - ci * 9, kh = tap / 3, kw = tap - kh * 3;
                 koff[ks][j] = k < kvalid ? (ci * FROWS + kh) * FW + kw : 0;   // padded k: zero weights, any finite value
+                // c_in = 1: slot (g, j) = tap (kh = g, kw = j), see the packing; the zero-weight slots (g = 3, j = 3) read initialised
+                // cells too (row 2 again; one feature column more is staged): uninitialised LDS may hold NaN, and NaN x 0 is not 0
+                if (KS == 1) koff[ks][j] = min(g, 2) * FW + j;
                 kaddr[ks][j] = koff[ks][j] + (lane & 15);
             }
             const uint2* wp = reinterpret_cast<const uint2*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
@@ -853,7 +856,11 @@ void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int plan
                 const int row = l & 15;
                 const int co = (row >> 2) * 8 + 4 * nt + (row & 3);
                 for (int j = 0; j < 4; ++j) {
-                    const int k = 16 * ks + 4 * (l >> 4) + j;
+                    // c_in = 1: K slot (g, j) of the single 16-deep step is tap (kh = g, kw = j), g, j < 3 (the other 7 slots are
+                    // zero), so a lane's four im2col values are one LDS row segment: one address, immediate offsets.
+                    // Otherwise k runs over (ci, kh, kw) in the weight tensor's own order.
+                    int k = 16 * ks + 4 * (l >> 4) + j;
+                    if (c_in == 1) k = ((l >> 4) < 3 && j < 3) ? 3 * (l >> 4) + j : kvalid;
                     const float v = k < kvalid ? w[(size_t)co * kvalid + k] * (scale ? scale[co] : 1.0f) : 0.0f;
                     const bf16_t hi = f32_to_bf16_rn(v);
                     const size_t base = ((size_t)(ks * 2 + nt) * planes) * 64 * 4 + (size_t)l * 4 + j;
