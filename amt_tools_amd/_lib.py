@@ -64,6 +64,9 @@ _SIGNATURES = {
     'amtx_bilstm_packed_elems': (_L, [_I]),
     'amtx_bilstm_pack': (_I, [_P, _P, _I, _P]),
     'amtx_bilstm_fwd': (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
+    'amtx_bilstm_pack_device': (_I, [_P, _P, _I, _P, _P, _P]),
+    'amtx_bilstm_train_fwd': (_I, [_P, _P, _I, _P, _P, _I, _I, _P]),
+    'amtx_bilstm_train_bwd': (_I, [_P, _P, _P, _I, _P, _I, _I, _P]),
     'amtx_cqt_plan_create': (_I, [C.POINTER(_P), _I, _I, C.c_double, _I, _I, C.c_double, C.POINTER(C.c_double), _I, _I, _I]),
     'amtx_cqt_plan_destroy': (_I, [_P]),
     'amtx_cqt_num_harmonics': (_I, [_P]),

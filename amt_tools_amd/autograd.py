@@ -1,0 +1,81 @@
+"""
+Training-mode BiLSTM on the HIP kernels (autograd.Function).
+
+The reference trains through nn.LSTM (amt_tools/models/onsetsframes.py:498-529 inside amt_tools/train.py:126-141).  On
+ROCm that is MIOpen's per-time-step LSTM: thousands of tiny launches per step, 46 of the 61 ms of GPU time of a training
+step at 8 clips x 625 frames, and it keeps the host launch-bound.  Here the T dependent steps of both directions are ONE
+persistent kernel forward (amtx_bilstm_train_fwd, gates and cell states saved) and ONE backward (amtx_bilstm_train_bwd ->
+dL/d(xproj)); the input projection and every parameter gradient are plain GEMMs over B*T (torch.matmul = hipBLASLt:
+plumbing).  Arithmetic: fp32 with split-bf16 (3-MFMA) products for the recurrent mat-vecs -- fp32-class accuracy.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ['bilstm', 'BiLSTMFunction']
+
+H = 128
+
+
+def _pack(w_hh_f, w_hh_b):
+    L = _lib.lib()
+    n = int(L.amtx_bilstm_packed_elems(2))
+    fwd = torch.empty(n, dtype=torch.int16, device=w_hh_f.device)
+    bwd = torch.empty(n, dtype=torch.int16, device=w_hh_f.device)
+    wf, wb = w_hh_f.detach().contiguous().float(), w_hh_b.detach().contiguous().float()
+    _lib.check(L.amtx_bilstm_pack_device(_lib.ptr(wf), _lib.ptr(wb), 2, _lib.ptr(fwd), _lib.ptr(bwd), _lib.current_stream(wf.device)),
+               'amtx_bilstm_pack_device')
+    return fwd, bwd
+
+
+class BiLSTMFunction(torch.autograd.Function):
+    """y = BiLSTM(x) with PyTorch's parameter layout (gate order i, f, g, o; weight_ih (512, I), weight_hh (512, 128), two biases
+    per direction), zero initial state, batch_first.  x (B, T, I) fp32 CUDA -> y (B, T, 256)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b):
+        B, T, I = x.shape
+        L = _lib.lib()
+        x2 = x.reshape(B * T, I)
+        w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                      # (1024, I)
+        bias = torch.cat([b_ih_f + b_hh_f, b_ih_b + b_hh_b], dim=0)
+        xproj = torch.addmm(bias, x2, w_ih.t()).contiguous()                           # (B*T, 2*512) = [B][T][2][512]
+        frag_fwd, frag_bwd = _pack(w_hh_f, w_hh_b)
+        out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
+        save = torch.empty((B, T, 2, 5, H), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.amtx_bilstm_train_fwd(_lib.ptr(xproj), _lib.ptr(frag_fwd), 2, _lib.ptr(out), _lib.ptr(save), B, T,
+                                               _lib.current_stream(x.device)), 'amtx_bilstm_train_fwd')
+        ctx.save_for_backward(x2, w_ih, w_hh_f, w_hh_b, out, save, frag_bwd)
+        ctx.dims = (B, T, I)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, w_ih, w_hh_f, w_hh_b, out, save, frag_bwd = ctx.saved_tensors
+        B, T, I = ctx.dims
+        L = _lib.lib()
+        dout = dout.contiguous().float()
+        dxproj = torch.empty((B * T, 4 * 2 * H), dtype=torch.float32, device=dout.device)
+        with torch.cuda.device(dout.device):
+            _lib.check(L.amtx_bilstm_train_bwd(_lib.ptr(dout), _lib.ptr(save), _lib.ptr(frag_bwd), 2, _lib.ptr(dxproj), B, T,
+                                               _lib.current_stream(dout.device)), 'amtx_bilstm_train_bwd')
+        dx = (dxproj @ w_ih).reshape(B, T, I) if ctx.needs_input_grad[0] else None
+        dw_ih = dxproj.t() @ x2                                                       # (1024, I)
+        db = dxproj.sum(dim=0)
+        # h_{t-1} of the forward direction / h_{t+1} of the backward direction (zero initial state)
+        hp_f = torch.zeros((B, T, H), dtype=torch.float32, device=out.device)
+        hp_f[:, 1:] = out[:, :-1, :H]
+        hp_b = torch.zeros((B, T, H), dtype=torch.float32, device=out.device)
+        hp_b[:, :-1] = out[:, 1:, H:]
+        dg = dxproj.reshape(B * T, 2, 4 * H)
+        dw_hh_f = dg[:, 0].t() @ hp_f.reshape(B * T, H)
+        dw_hh_b = dg[:, 1].t() @ hp_b.reshape(B * T, H)
+        n = 4 * H
+        return (dx, dw_ih[:n], dw_hh_f, db[:n], db[:n], dw_ih[n:], dw_hh_b, db[n:], db[n:])
+
+
+def bilstm(x, lstm):
+    """Run `lstm` (an nn.LSTM(batch_first, bidirectional, hidden 128, one layer)) on x through the HIP kernels, differentiably."""
+    return BiLSTMFunction.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+                                lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)

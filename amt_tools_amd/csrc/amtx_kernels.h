@@ -63,8 +63,12 @@ struct LstmArgs {
     void* out; int out_type;                             // [B][T][256] = h_fwd | h_bwd
     int B, T;
     int groups; int64_t x_gs, w_gs, out_gs;
+    float* save = nullptr;                               // training only: [groups][B][T][2][5][128] post-activation i,f,g,o and c (4-clip kernel)
 };
 int amtx_launch_bilstm(const LstmArgs& l, hipStream_t stream);
+// training: device-side packing of fp32 W_hh into forward + transposed (backward) fragments; backward recurrence -> dL/d(xproj)
+int amtx_launch_bilstm_pack_dev(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream);
+int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* whh_t, int planes, float* dxproj, int B, int T, hipStream_t stream);
 size_t amtx_bilstm_wfrag_elems(int planes);              // per LSTM (both directions)
 void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out);   // each (512,128)
 

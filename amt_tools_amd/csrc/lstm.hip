@@ -231,7 +231,7 @@ __device__ __forceinline__ void load_x4(const char* xbase, int64_t row_off, type
 template <int NS, int X_TYPE, int OUT_TYPE, bool FAST>
 __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf)[4][4][NS], const typename XScalar<X_TYPE>::type (&xcur)[4],
                                            typename XScalar<X_TYPE>::type (&xnext)[4], float& c, const char* xbase, char* obase, int t, int tnext,
-                                           int lane, int hwoff, bool clip_ok) {
+                                           int lane, int hwoff, bool clip_ok, float* save) {
     const char* hb = smem + cur * NS * HBUF_BYTES;
     uint4 hf[4][NS];
 #pragma unroll
@@ -262,6 +262,10 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
     const float og = sigmoid_f<FAST>(acc[3][0]);
     c = fg * c + ig * gg;
     const float h = og * tanh_f<FAST>(c);
+    if (save && clip_ok) {     // training: post-activation gates and the new cell state, [b][t][dir][5][128] (save points at [b][0][dir][0][unit])
+        float* sv = save + (int64_t)t * (2 * 5 * H);
+        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
+    }
 
     char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
     uint32_t hiw, low = 0;
@@ -306,6 +310,7 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
     char* obase = reinterpret_cast<char*>(a.out) +
                   ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + unit) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
     const int hwoff = (4 * cg * HP + unit) * 2;
+    float* save = a.save ? a.save + (((int64_t)grp * a.B + (clip_ok ? b : 0)) * T * 2 + dir) * (5 * H) + unit : nullptr;
 
     typename XScalar<X_TYPE>::type x0[4], x1[4], x2[4], x3[4];
     auto tidx = [&](int s) { s = s < T ? s : T - 1; return (int64_t)(dir == 0 ? s : T - 1 - s); };
@@ -316,10 +321,146 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
 
     for (int s = 0; s < T; s += 4) {
         // straight-line body, stores of the steps past T masked (see bilstm_kernel)
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), lane, hwoff, clip_ok);
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, clip_ok && s + 1 < T);
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, clip_ok && s + 2 < T);
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, clip_ok && s + 3 < T);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), lane, hwoff, clip_ok, save);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, clip_ok && s + 1 < T, save);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, clip_ok && s + 2 < T, save);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, clip_ok && s + 3 < T, save);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training: backward recurrence of the BiLSTM (the reference trains with nn.LSTM, amt_tools/train.py:126-141; MIOpen's
+// LSTM takes 46 of the 61 ms of GPU time of a training step at 8 clips x 625 frames and keeps the host launch-bound).
+// Given dL/dh for every step and the saved post-activation gates / cell states of the forward pass, one persistent
+// block (1 direction x 4 clips, same lane = one cell mapping as bilstm4_kernel) walks the steps in reverse:
+//     dh   = dout_t + W_hh^T dgates_{next}          (MFMA: dgates tile (4 clips in rows 0/4/8/12) x W_hh as the B operand)
+//     do   = dh tanh(c) o(1-o);  dc = dc_next f_next + dh o (1 - tanh(c)^2)
+//     di   = dc g i(1-i);  dg = dc i (1-g^2);  df = dc c_prev f(1-f)
+// and writes dgates = dL/d(xproj).  The parameter gradients are plain GEMMs over (B*T) on the host side
+// (dW_ih = dG^T X, dW_hh = dG^T H_prev, db = sum dG, dX = dG W_ih) -- amt_tools_amd/autograd.py.
+constexpr int GP = 4 * H + 8;                     // bf16 elements per row of the dgates LDS tile
+constexpr int GBUF_BYTES = 16 * GP * 2;           // one plane of one buffer
+
+struct LstmBwdArgs {
+    const float* dout;        // [B][T][256]
+    const float* save;        // [B][T][2][5][128]: i, f, g, o (post-activation), c
+    const bf16_t* whh_t;      // transposed fragments, see bilstm_pack_dev_kernel
+    int planes;
+    float* dxproj;            // [B][T][2][512]
+    int B, T;
+};
+
+template <int NS>
+__global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][GP] bf16, rows 0/4/8/12 used
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int unit = 16 * wave + (lane & 15), cg = lane >> 4;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * 4 + cg;
+    const bool clip_ok = b < a.B;
+    const int T = a.T;
+
+    // W_hh as the MFMA B operand: column = this wave's unit 16 w + (lane & 15), k = gate row 32 ks + 8 (lane >> 4) + j
+    uint4 wt[16][NS];
+    {
+        const uint4* w = reinterpret_cast<const uint4*>(a.whh_t) + lane;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) wt[ks][p] = w[((((dir * LWAVES + wave) * 16 + ks) * NS) + p) * 64];
+    }
+    for (int i = tid; i < 2 * NS * GBUF_BYTES / 16; i += LTHREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+
+    const int64_t bb = clip_ok ? b : 0;
+    const float* sv0 = a.save + ((bb * T) * 2 + dir) * (5 * H) + unit;          // + t * (2*5*H)
+    const float* do0 = a.dout + (bb * T) * 256 + dir * H + unit;                 // + t * 256
+    float* dx0 = a.dxproj + (bb * T) * 1024 + dir * 512 + unit;                  // + t * 1024 + q * 128
+    const int gwoff = (4 * cg * GP + unit) * 2;                                   // byte offset of (slot, gate 0) in a tile plane
+
+    float dh_rec = 0.f, dc_rec = 0.f;
+    for (int s = 0; s < T; ++s) {
+        // the forward pass of direction 0 ran t = 0..T-1, of direction 1 t = T-1..0: walk them backwards
+        const int t = dir == 0 ? T - 1 - s : s;
+        const int tp = dir == 0 ? t - 1 : t + 1;                                  // the step BEFORE t in forward order
+        const float* sv = sv0 + (int64_t)t * (2 * 5 * H);
+        const float ig = sv[0], fg = sv[H], gg = sv[2 * H], og = sv[3 * H], ct = sv[4 * H];
+        const float cp = (tp >= 0 && tp < T) ? sv0[(int64_t)tp * (2 * 5 * H) + 4 * H] : 0.f;
+        const float dh = do0[(int64_t)t * 256] + dh_rec;
+        const float tc = tanhf(ct);
+        const float d_o = dh * tc * og * (1.f - og);
+        const float dc = dc_rec + dh * og * (1.f - tc * tc);
+        const float d_i = dc * gg * ig * (1.f - ig);
+        const float d_g = dc * ig * (1.f - gg * gg);
+        const float d_f = dc * cp * fg * (1.f - fg);
+        dc_rec = dc * fg;
+        const float dgv[4] = {d_i, d_f, d_g, d_o};
+        char* gt = smem + (s & 1) * NS * GBUF_BYTES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (clip_ok) dx0[(int64_t)t * 1024 + q * H] = dgv[q];
+            uint32_t hiw, low = 0;
+            if (NS == 2) split_bf16x2(dgv[q], 0.f, hiw, low);
+            else hiw = pack_bf16x2(dgv[q], 0.f);
+            *reinterpret_cast<unsigned short*>(gt + gwoff + q * H * 2) = (unsigned short)hiw;
+            if (NS == 2) *reinterpret_cast<unsigned short*>(gt + GBUF_BYTES + gwoff + q * H * 2) = (unsigned short)low;
+        }
+        lds_barrier();
+        // dh_{prev} = dgates . W_hh: 16 k-steps over the 512 gate rows
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            uint4 gf[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                gf[p] = *reinterpret_cast<const uint4*>(gt + p * GBUF_BYTES + ((lane & 15) * GP + 32 * ks + 8 * (lane >> 4)) * 2);
+            acc = mfma16(gf[0], wt[ks][0], acc);
+            if (NS == 2) {
+                acc = mfma16(gf[1], wt[ks][0], acc);
+                acc = mfma16(gf[0], wt[ks][1], acc);
+            }
+        }
+        dh_rec = acc[0];
+    }
+}
+
+// fp32 W_hh (512 x 128, both directions) on the DEVICE -> forward fragments (amtx_bilstm_pack_host's layout) and transposed
+// fragments for the backward kernel, hi/lo planes: training repacks after every optimizer step without a host round trip.
+__global__ void bilstm_pack_dev_kernel(const float* __restrict__ whh_fwd, const float* __restrict__ whh_bwd, int planes,
+                                       bf16_t* __restrict__ frag_fwd, bf16_t* __restrict__ frag_bwd) {
+    const int n = 2 * 4 * H * H;                                   // elements per plane set (both directions)
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        // forward fragment element: [dir][w][q][ks][l][j]
+        {
+            int r = idx;
+            const int j = r & 7; r >>= 3;
+            const int l = r & 63; r >>= 6;
+            const int ks = r & 3; r >>= 2;
+            const int q = r & 3; r >>= 2;
+            const int w = r & 7; r >>= 3;
+            const int dir = r;
+            const float* W = dir == 0 ? whh_fwd : whh_bwd;
+            const float v = W[(q * H + 16 * w + (l & 15)) * H + 32 * ks + 8 * (l >> 4) + j];
+            const bf16_t hi = f32_to_bf16_rn(v);
+            const size_t base = ((size_t)((((dir * LWAVES + w) * 4 + q) * 4 + ks) * planes)) * 512 + (size_t)l * 8 + j;
+            frag_fwd[base] = hi;
+            if (planes == 2) frag_fwd[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+        }
+        // transposed fragment element: [dir][w][ks(16)][l][j]: W[row k = 32 ks + 8 (l >> 4) + j][unit 16 w + (l & 15)]
+        {
+            int r = idx;
+            const int j = r & 7; r >>= 3;
+            const int l = r & 63; r >>= 6;
+            const int ks = r & 15; r >>= 4;
+            const int w = r & 7; r >>= 3;
+            const int dir = r;
+            const float* W = dir == 0 ? whh_fwd : whh_bwd;
+            const float v = W[(32 * ks + 8 * (l >> 4) + j) * H + 16 * w + (l & 15)];
+            const bf16_t hi = f32_to_bf16_rn(v);
+            const size_t base = ((size_t)(((dir * LWAVES + w) * 16 + ks) * planes)) * 512 + (size_t)l * 8 + j;
+            frag_bwd[base] = hi;
+            if (planes == 2) frag_bwd[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+        }
     }
 }
 
@@ -329,7 +470,7 @@ inline bool use_four_clip_blocks(const LstmArgs& a) { return (int64_t)((a.B + 3)
 template <int NS, int X_TYPE, int OUT_TYPE>
 int launch(const LstmArgs& a, hipStream_t stream) {
     const size_t lds = 2 * NS * HBUF_BYTES;
-    if (use_four_clip_blocks(a)) {
+    if (use_four_clip_blocks(a) || a.save) {     // the training forward (save != null) exists for the 4-clip mapping only
         dim3 grid((unsigned)((a.B + 3) / 4), 2, (unsigned)a.groups);
         hipLaunchKernelGGL((bilstm4_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(LTHREADS), lds, stream, a);
     } else {
@@ -373,4 +514,32 @@ int amtx_launch_bilstm(const LstmArgs& a, hipStream_t stream) {
     if (a.planes == 2 && a.x_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch<2, AMTX_T_F32, AMTX_T_F32>(a, stream);
     amtx_set_error("bilstm: unsupported precision/type combination");
     return AMTX_ERR_UNSUPPORTED;
+}
+
+int amtx_launch_bilstm_pack_dev(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream) {
+    AMTX_REQUIRE(whh_fwd && whh_bwd && frag_fwd && frag_bwd && (planes == 1 || planes == 2), "bilstm pack: bad argument");
+    hipLaunchKernelGGL(bilstm_pack_dev_kernel, dim3(128), dim3(256), 0, stream, whh_fwd, whh_bwd, planes, frag_fwd, frag_bwd);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* whh_t, int planes, float* dxproj, int B, int T, hipStream_t stream) {
+    AMTX_REQUIRE(dout && save && whh_t && dxproj, "bilstm backward: null pointer");
+    AMTX_REQUIRE(B > 0 && T > 0 && (planes == 1 || planes == 2), "bilstm backward: bad sizes");
+    LstmBwdArgs a;
+    a.dout = dout; a.save = save; a.whh_t = whh_t; a.planes = planes; a.dxproj = dxproj; a.B = B; a.T = T;
+    dim3 grid((unsigned)((B + 3) / 4), 2);
+    const size_t lds = 2 * (size_t)planes * GBUF_BYTES;
+    if (planes == 2) {
+        static bool done = false;
+        if (!done) {
+            AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm4_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+        hipLaunchKernelGGL(bilstm4_bwd_kernel<2>, grid, dim3(LTHREADS), lds, stream, a);
+    } else {
+        hipLaunchKernelGGL(bilstm4_bwd_kernel<1>, grid, dim3(LTHREADS), lds, stream, a);
+    }
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
 }

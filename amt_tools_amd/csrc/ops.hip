@@ -71,3 +71,23 @@ extern "C" int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int
                                   float* out, void* stream) {
     return amtx_launch_pianoroll(logits, ld, col0, batch, num_frames, keys, threshold, out, (hipStream_t)stream);
 }
+
+// ---- training entry points of the BiLSTM (amt_tools_amd/autograd.py)
+extern "C" int amtx_bilstm_pack_device(const float* whh_fwd, const float* whh_bwd, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd, void* stream) {
+    return amtx_launch_bilstm_pack_dev(whh_fwd, whh_bwd, planes, (bf16_t*)frag_fwd, (bf16_t*)frag_bwd, (hipStream_t)stream);
+}
+
+extern "C" int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int planes, float* out, float* save, int batch, int num_frames,
+                                     void* stream) {
+    AMTX_REQUIRE(xproj && whh_packed && out && save, "amtx_bilstm_train_fwd: null pointer");
+    LstmArgs l;
+    l.xproj = xproj; l.x_type = AMTX_T_F32; l.whh = (const bf16_t*)whh_packed; l.planes = planes; l.out = out; l.out_type = AMTX_T_F32;
+    l.B = batch; l.T = num_frames; l.groups = 1; l.x_gs = l.w_gs = l.out_gs = 0; l.save = save;
+    AMTX_REQUIRE(planes == 2, "amtx_bilstm_train_fwd: training runs in the fp32-class (two-plane) precision");
+    return amtx_launch_bilstm(l, (hipStream_t)stream);
+}
+
+extern "C" int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
+                                     int num_frames, void* stream) {
+    return amtx_launch_bilstm_bwd(dout, save, (const bf16_t*)whh_t_packed, planes, dxproj, batch, num_frames, (hipStream_t)stream);
+}

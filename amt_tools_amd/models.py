@@ -162,8 +162,15 @@ class LanguageModel(nn.Module):
         self.num_directions = int(bidirectional) + 1
         self.hidden_size = self.dim_out // self.num_directions
         self.mlm = nn.LSTM(input_size=self.dim_in, hidden_size=self.hidden_size, batch_first=True, bidirectional=bidirectional)
+        self.use_hip_autograd = True      # False: stock nn.LSTM (ATen / MIOpen) also on the GPU
 
     def forward(self, in_feats):
+        # differentiable path on a GPU (training, or eval outside the engine): both directions' recurrence is one persistent HIP
+        # kernel forward and one backward (amt_tools_amd/autograd.py) instead of MIOpen's per-time-step LSTM
+        if (in_feats.is_cuda and in_feats.dtype == torch.float32 and self.num_directions == 2 and self.hidden_size == 128
+                and self.mlm.num_layers == 1 and self.use_hip_autograd):
+            from .autograd import bilstm
+            return bilstm(in_feats, self.mlm)
         return self.mlm(in_feats)[0]
 
 

@@ -134,6 +134,17 @@ int64_t amtx_bilstm_packed_elems(int planes);
 int amtx_bilstm_pack(const float* host_whh_fwd, const float* host_whh_bwd /* (512,128) each */, int planes, uint16_t* host_out);
 int amtx_bilstm_fwd(const void* xproj /*(B,T,2,512)*/, const uint16_t* whh_packed, int planes, int elem_type, void* out /*(B,T,256)*/,
                     int batch, int num_frames, void* stream);
+/* Training (amt_tools/train.py:126-141 drives nn.LSTM's forward + backward through autograd): the same recurrence with the
+ * post-activation gates and cell states saved ([B][T][2][5][128] fp32: i, f, g, o, c), and its backward recurrence
+ *   dout [B][T][256] -> dxproj [B][T][2][512] = dL/d(W_ih x + b).
+ * Parameter gradients are GEMMs over B*T on the caller's side.  W_hh (fp32, DEVICE pointers, (512,128) per direction) is
+ * repacked on the device into forward fragments (amtx_bilstm_packed_elems(planes) elements) and transposed fragments (same
+ * size) after every optimizer step.  Two-plane (fp32-class) precision only. */
+int amtx_bilstm_pack_device(const float* whh_fwd, const float* whh_bwd, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd, void* stream);
+int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int planes, float* out, float* save, int batch, int num_frames,
+                          void* stream);
+int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
+                          int num_frames, void* stream);
 /* LogisticBank.finalize_output: sigmoid -> (B,keys,T) -> threshold (< 0: keep probabilities)  (models/common.py:586-620) */
 int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold, float* out,
                        void* stream);
