@@ -146,7 +146,7 @@ __device__ __forceinline__ void lstm_step(char* smem, int cur, const uint4 (&wf)
 template <int NS, int X_TYPE, int OUT_TYPE>
 __global__ __launch_bounds__(LTHREADS) void bilstm_kernel(LstmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16
-    constexpr bool FAST = (NS == 1);
+    constexpr bool FAST = true;   // v_exp_f32 / v_rcp_f32 are ~1 ulp: also fine for the fp32-class (two-plane) mode, checked at 1e-4 / 2e-4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int clip = lane & 15, g = lane >> 4;
     const int b0 = blockIdx.x * 16, dir = blockIdx.y, grp = blockIdx.z;
@@ -283,7 +283,7 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
 template <int NS, int X_TYPE, int OUT_TYPE>
 __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16, rows 0/4/8/12 used
-    constexpr bool FAST = (NS == 1);
+    constexpr bool FAST = true;   // v_exp_f32 / v_rcp_f32 are ~1 ulp: also fine for the fp32-class (two-plane) mode, checked at 1e-4 / 2e-4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = 16 * wave + (lane & 15), cg = lane >> 4;
     const int dir = blockIdx.y, grp = blockIdx.z;
@@ -379,15 +379,29 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
     const int gwoff = (4 * cg * GP + unit) * 2;                                   // byte offset of (slot, gate 0) in a tile plane
 
     float dh_rec = 0.f, dc_rec = 0.f;
+    // the forward pass of direction 0 ran t = 0..T-1, of direction 1 t = T-1..0: walk them backwards.  Step s reads the saved
+    // values of frame t(s) and the cell state of the step BEFORE it in forward order, which is frame t(s+1): the seven values of
+    // step s+1 are requested (unconditionally, clamped) before step s's mat-vec, so their latency is off the dependency chain.
+    auto frame = [&](int s_) { s_ = s_ < T ? s_ : T - 1; return dir == 0 ? T - 1 - s_ : s_; };
+    float n_i, n_f, n_g, n_o, n_c, n_do;
+    {
+        const float* sv = sv0 + (int64_t)frame(0) * (2 * 5 * H);
+        n_i = sv[0]; n_f = sv[H]; n_g = sv[2 * H]; n_o = sv[3 * H]; n_c = sv[4 * H];
+        n_do = do0[(int64_t)frame(0) * 256];
+    }
     for (int s = 0; s < T; ++s) {
-        // the forward pass of direction 0 ran t = 0..T-1, of direction 1 t = T-1..0: walk them backwards
-        const int t = dir == 0 ? T - 1 - s : s;
-        const int tp = dir == 0 ? t - 1 : t + 1;                                  // the step BEFORE t in forward order
-        const float* sv = sv0 + (int64_t)t * (2 * 5 * H);
-        const float ig = sv[0], fg = sv[H], gg = sv[2 * H], og = sv[3 * H], ct = sv[4 * H];
-        const float cp = (tp >= 0 && tp < T) ? sv0[(int64_t)tp * (2 * 5 * H) + 4 * H] : 0.f;
-        const float dh = do0[(int64_t)t * 256] + dh_rec;
-        const float tc = tanhf(ct);
+        const int t = frame(s);
+        const float ig = n_i, fg = n_f, gg = n_g, og = n_o, ct = n_c, dout_t = n_do;
+        {
+            const int tn = frame(s + 1);
+            const float* sv = sv0 + (int64_t)tn * (2 * 5 * H);
+            n_i = sv[0]; n_f = sv[H]; n_g = sv[2 * H]; n_o = sv[3 * H]; n_c = sv[4 * H];
+            n_do = do0[(int64_t)tn * 256];
+        }
+        asm volatile("" : "+v"(n_c));                      // n_c is consumed below as c_prev: keep it a plain register read
+        const float cp = s + 1 < T ? n_c : 0.f;             // cell state before step t in forward order (zero initial state)
+        const float dh = dout_t + dh_rec;
+        const float tc = tanh_f<true>(ct);
         const float d_o = dh * tc * og * (1.f - og);
         const float dc = dc_rec + dh * og * (1.f - tc * tc);
         const float d_i = dc * gg * ig * (1.f - ig);
