@@ -54,32 +54,71 @@ __global__ __launch_bounds__(256) void cqt_level0_kernel(const float* __restrict
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in)
+// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in).
+// Register-blocked FIR: a thread owns DEC_OPT = 8 consecutive outputs, i.e. the input window e[p] = in[2 m0 + p - DEC_HALF],
+// p = 0 .. 2*8 - 2 + DEC_TAPS - 1.  For tap k output i needs e[2 i + k]: every loaded sample feeds 8 FMAs (one per output, with a
+// different tap), so the loop is 16 LDS reads per 128 FMAs; the taps are wave-uniform and come in through scalar loads (an SGPR
+// operand of v_fma), not through LDS.  The LDS tile is stored with one pad word per 16 samples so that the threads' windows
+// (16 samples apart) start in distinct banks.  k ascends per output exactly as in a plain loop: same rounding.
+constexpr int DEC_OPT = 8;                          // outputs per thread
+constexpr int DEC_CH = 256 * DEC_OPT;               // outputs per block
+constexpr int DEC_TAPS_PAD = 304;                   // 19 chunks of 16 taps, zero padded
+constexpr int DEC_XS = 2 * DEC_CH + DEC_TAPS_PAD + 16;
+__device__ __forceinline__ int dec_pidx(int p) { return p + (p >> 4); }
+
 __global__ __launch_bounds__(256) void cqt_decimate_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
                                                            int64_t n_out, int64_t out_stride, int pad, const float* __restrict__ taps) {
-    constexpr int CH = 1024;                        // outputs per block
-    __shared__ float xs[2 * CH + DEC_TAPS + 3];
-    __shared__ float hs[DEC_TAPS + 3];
+    __shared__ float xs[DEC_XS + (DEC_XS >> 4) + 1];
     const int b = blockIdx.y;
-    const int64_t m0 = (int64_t)blockIdx.x * CH;
+    const int64_t m0 = (int64_t)blockIdx.x * DEC_CH;
     const float* src = in + (int64_t)b * in_stride + pad;
-    for (int i = threadIdx.x; i < DEC_TAPS; i += 256) hs[i] = taps[i];
     const int64_t base = 2 * m0 - DEC_HALF;
-    for (int i = threadIdx.x; i < 2 * CH + DEC_TAPS; i += 256) {
+    for (int i = threadIdx.x; i < DEC_XS; i += 256) {
         const int64_t g = base + i;
-        xs[i] = (g >= 0 && g < n_in) ? src[g] : 0.f;
+        xs[dec_pidx(i)] = (g >= 0 && g < n_in) ? src[g] : 0.f;
     }
     __syncthreads();
+    const int j = threadIdx.x;
+    const float* e = xs + 17 * j;                                   // dec_pidx(16 j + p) = 17 j + p + (p >> 4)
+    float acc[DEC_OPT];
+#pragma unroll
+    for (int i = 0; i < DEC_OPT; ++i) acc[i] = 0.f;
+    float w0[16], w1[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) w0[p] = e[p];                      // p >> 4 = 0
+#pragma unroll 1
+    for (int kb = 0; kb < DEC_TAPS_PAD; kb += 32) {
+        // two 16-tap chunks per iteration so the two register windows swap roles by name
+#pragma unroll
+        for (int p = 0; p < 16; ++p) w1[p] = e[kb + 16 + p + ((kb + 16 + p) >> 4)];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float h = taps[kb + kk];                          // uniform: scalar load
+#pragma unroll
+            for (int i = 0; i < DEC_OPT; ++i) {
+                const int idx = 2 * i + kk;
+                acc[i] = fmaf(h, idx < 16 ? w0[idx] : w1[idx - 16], acc[i]);
+            }
+        }
+        if (kb + 16 < DEC_TAPS_PAD) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) w0[p] = e[kb + 32 + p + ((kb + 32 + p) >> 4)];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float h = taps[kb + 16 + kk];
+#pragma unroll
+                for (int i = 0; i < DEC_OPT; ++i) {
+                    const int idx = 2 * i + kk;
+                    acc[i] = fmaf(h, idx < 16 ? w1[idx] : w0[idx - 16], acc[i]);
+                }
+            }
+        }
+    }
     float* dst = out + (int64_t)b * out_stride + pad;
 #pragma unroll
-    for (int r = 0; r < CH / 256; ++r) {
-        const int j = threadIdx.x + 256 * r;
-        if (m0 + j >= n_out) continue;
-        float acc = 0.f;
-        const float* x = xs + 2 * j;
-#pragma unroll 4
-        for (int k = 0; k < DEC_TAPS; ++k) acc = fmaf(hs[k], x[k], acc);
-        dst[m0 + j] = 1.41421356237309505f * acc;
+    for (int i = 0; i < DEC_OPT; ++i) {
+        const int64_t m = m0 + (int64_t)DEC_OPT * j + i;
+        if (m < n_out) dst[m] = 1.41421356237309505f * acc[i];
     }
 }
 
@@ -354,7 +393,7 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
     }
     p->pad = (p->pad + 3) & ~3;
     // decimator taps
-    std::vector<float> taps(DEC_TAPS);
+    std::vector<float> taps(DEC_TAPS_PAD + 16, 0.0f);      // zero padded: the kernel walks whole 16-tap chunks
     {
         std::vector<double> h(DEC_TAPS);
         double sum = 0;
@@ -367,8 +406,8 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
         }
         for (int i = 0; i < DEC_TAPS; ++i) taps[i] = (float)(h[i] / sum);
     }
-    hipError_t e = hipMalloc(&p->d_taps, DEC_TAPS * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), DEC_TAPS * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = hipMalloc(&p->d_taps, taps.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         amtx_set_error("amtx_cqt_plan_create: device allocation failed: %s", hipGetErrorString(e));
         amtx_cqt_plan_destroy(p);
@@ -484,7 +523,7 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
             const unsigned nb = (unsigned)std::min<int64_t>((num_samples + 255) / 256, 4096);
             hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad);
         } else {
-            const unsigned nb = (unsigned)((d.len[l] + 1023) / 1024);
+            const unsigned nb = (unsigned)((d.len[l] + DEC_CH - 1) / DEC_CH);
             hipLaunchKernelGGL(cqt_decimate_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
                                d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps);
         }
