@@ -141,21 +141,42 @@ __global__ __launch_bounds__(256) void cqt_pad_kernel(float* __restrict__ pyr, i
     }
 }
 
-// |R| of every bank of one level -> mag[b][h][bin][t] for t < frames(bank)
+// |R| of every bank of one level -> mag[b][h][bin][t] for t < frames(bank): a (time x filter) -> (filter x time) transpose,
+// staged through a 32 x 33 LDS tile so that both the reads (filters contiguous in R) and the writes (frames contiguous in
+// mag) are coalesced.  grid = (time tiles, banks, clips); a block walks the bank's filter tiles.
 __global__ __launch_bounds__(256) void cqt_mag_kernel(const float* __restrict__ R, LevelDev lv, int64_t t_level, int n_harm, int n_bins,
                                                       int64_t t_buf, float* __restrict__ mag) {
+    __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int bank = blockIdx.y;
     if (bank >= lv.nbanks) return;
     const BankDev bk = lv.b[bank];
-    const int64_t total = (int64_t)bk.nf * bk.frames;
     const float* Rb = R + (int64_t)b * t_level * lv.ncols;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int k = (int)(i / bk.frames);
-        const int64_t t = i - (int64_t)k * bk.frames;
-        const float re = Rb[t * lv.ncols + bk.col0 + k];
-        const float im = Rb[t * lv.ncols + bk.col0 + bk.nf + k];
-        mag[(((int64_t)b * n_harm + bk.harm) * n_bins + bk.bin0 + k) * t_buf + t] = sqrtf(re * re + im * im);
+    float* mb = mag + (((int64_t)b * n_harm + bk.harm) * n_bins + bk.bin0) * t_buf;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
+    for (int64_t t0 = (int64_t)blockIdx.x * 32; t0 < bk.frames; t0 += (int64_t)gridDim.x * 32) {
+        for (int k0 = 0; k0 < bk.nf; k0 += 32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t t = t0 + ty + 8 * r;
+                const int k = k0 + tx;
+                float v = 0.f;
+                if (t < bk.frames && k < bk.nf) {
+                    const float re = Rb[t * lv.ncols + bk.col0 + k];
+                    const float im = Rb[t * lv.ncols + bk.col0 + bk.nf + k];
+                    v = sqrtf(re * re + im * im);
+                }
+                tile[ty + 8 * r][tx] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + ty + 8 * r;
+                const int64_t t = t0 + tx;
+                if (t < bk.frames && k < bk.nf) mb[(int64_t)k * t_buf + t] = tile[tx][ty + 8 * r];
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -548,7 +569,7 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
         LevelDev lv;
         lv.nbanks = (int)L.banks.size(); lv.ncols = L.ncols;
         for (int i = 0; i < lv.nbanks; ++i) { lv.b[i] = L.banks[i]; lv.b[i].frames = d.frames_h[L.banks[i].harm]; }
-        hipLaunchKernelGGL(cqt_mag_kernel, dim3(16, lv.nbanks, B), dim3(256), 0, s, (const float*)R, lv, d.frames[l], p->n_harm, p->n_bins,
+        hipLaunchKernelGGL(cqt_mag_kernel, dim3((unsigned)std::min<int64_t>(64, (d.frames[l] + 31) / 32), lv.nbanks, B), dim3(256), 0, s, (const float*)R, lv, d.frames[l], p->n_harm, p->n_bins,
                            d.t_buf, mag);
         AMTX_CHECK_LAUNCH();
     }
