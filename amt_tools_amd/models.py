@@ -55,6 +55,10 @@ class TranscriptionModel(nn.Module):
             device = torch.device(f'cuda:{device}' if torch.cuda.is_available() else 'cpu')
         self.device = device
         self.to(self.device)
+        if torch.device(self.device).type == 'cuda':
+            # the autograd (training) path runs its convolutions / BatchNorms through MIOpen: channels-last weights and
+            # activations pick its faster kernels (train step 18.9 -> 15.5 ms); values, shapes and state_dict are unchanged
+            self.to(memory_format=torch.channels_last)
 
     def pre_proc(self, batch):
         """To-device copy (the caller's dict is not modified) + optional front-end on the raw audio
