@@ -27,4 +27,9 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(3): step()
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=22, max_name_column_width=70))
+rows = [(e.key, e.self_device_time_total / 3e3, e.count // 3) for e in prof.key_averages() if e.self_device_time_total > 0]
+rows.sort(key=lambda r: -r[1])
+print('per training step: device-time ms, launches, kernel / op')
+for k, ms, n in rows[:28]:
+    print(f'{ms:8.3f} {n:5d}  {k[:110]}')
+print(f'{sum(r[1] for r in rows):8.3f}        total')
