@@ -117,3 +117,28 @@ def test_stft_agrees_with_scipy_an_independent_implementation():
     X = sft.stft(ypad, p0=(n_fft // 2) // hop, p1=(n_fft // 2) // hop + S.shape[1])
     assert X.shape == S.shape
     np.testing.assert_allclose(np.abs(X) ** 2, S, rtol=1e-9, atol=1e-9)
+
+
+def test_mel_front_end_agrees_with_hf_transformers_audio_utils():
+    """transformers.audio_utils is a third, unrelated code base whose mel filterbank and spectrogram are written to match librosa
+    (it is what the Whisper / CLAP feature extractors use instead of librosa).  The oracle agrees with it on the filterbank
+    (Slaney and HTK scales, Slaney area norm) to float32 rounding and on the whole log-mel chain (periodic Hann, zero centre
+    padding, power spectrum, mel projection, 10 log10 relative to the clip maximum, -80 dB floor) -- still not librosa itself,
+    so the header keeps saying PARITY UNPINNED, but the conventions it could differ in are pinned twice over."""
+    au = pytest.importorskip('transformers.audio_utils')
+    for sr, htk in ((16000, False), (22050, True)):
+        theirs = au.mel_filter_bank(num_frequency_bins=1025, num_mel_filters=229, min_frequency=0.0, max_frequency=sr / 2.0, sampling_rate=sr,
+                                    norm='slaney', mel_scale='htk' if htk else 'slaney')
+        np.testing.assert_allclose(fe.mel_filterbank(sr, 2048, 229, htk=htk), theirs.T, rtol=0, atol=1e-7)
+    rng = np.random.default_rng(7)
+    y = (rng.standard_normal(30000) * np.hanning(30000)).astype(np.float32)
+    fb = au.mel_filter_bank(num_frequency_bins=1025, num_mel_filters=229, min_frequency=0.0, max_frequency=8000.0, sampling_rate=16000,
+                            norm='slaney', mel_scale='slaney')
+    win = au.window_function(2048, 'hann', periodic=True)
+    mel = au.spectrogram(y.astype(np.float64), win, frame_length=2048, hop_length=512, fft_length=2048, power=2.0, center=True,
+                         pad_mode='constant', mel_filters=fb, mel_floor=0.0, dtype=np.float64)                    # (229, T)
+    db = au.power_to_db(mel, reference=float(mel.max()), min_value=1e-10, db_range=80.0)
+    theirs = db / 80.0 + 1.0
+    ours = fe.melspec_process_audio(y, 16000)[0]
+    assert ours.shape == theirs.shape
+    assert np.abs(ours - theirs).max() < 1e-5
