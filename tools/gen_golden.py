@@ -219,6 +219,47 @@ def gen_labels_and_cache(name, cache_name, seed, T, n_notes, hop=512, sr=22050):
     print(name, {k: v.shape for k, v in rec.items()}, 'active cells', int(rec['multi_pitch'].sum()))
 
 
+def gen_feature_bookkeeping(name):
+    """Frame / sample bookkeeping of the reference's STFT and MelSpec FeatureModules (features/common.py:41-150,232-321,
+    stft.py, mel.py; waveform.py for the non-centred framing) -- pure arithmetic, runs under the librosa stub -- and their
+    dB post-processing on a fixed array with the documented librosa.amplitude_to_db / power_to_db formulas plugged into the stub."""
+    from amt_tools.features import STFT, MelSpec
+
+    def _to_db(S, ref, amin, top_db, mult):
+        S = np.asarray(S)
+        ref_v = ref(S) if callable(ref) else ref
+        log = mult * np.log10(np.maximum(amin, S)) - mult * np.log10(np.maximum(amin, ref_v))
+        return np.maximum(log, log.max() - top_db)
+
+    sys.modules['librosa.core'].amplitude_to_db = lambda S, ref=1.0, amin=1e-5, top_db=80.0: _to_db(np.abs(S) ** 2, (lambda P: ref(np.sqrt(P)) ** 2) if callable(ref) else ref ** 2, amin ** 2, top_db, 10.0)
+    sys.modules['librosa.core'].power_to_db = lambda S, ref=1.0, amin=1e-10, top_db=80.0: _to_db(S, ref, amin, top_db, 10.0)
+    sys.modules['librosa'].core = sys.modules['librosa.core']
+    sys.modules['librosa'].frames_to_time = lambda frames, sr=22050, hop_length=512, n_fft=None: (np.asarray(frames) * hop_length + (n_fft // 2 if n_fft else 0)) / float(sr)
+    lengths = np.array([0, 1, 2, 511, 512, 513, 1023, 1024, 2047, 2048, 2049, 4095, 4096, 22050, 319999, 320000])
+    frames = np.array([0, 1, 2, 3, 10, 625])
+    rec = dict(lengths=lengths, frames=frames)
+    mods = {'stft_c': STFT(sample_rate=22050, hop_length=512, n_fft=2048), 'stft_nc': STFT(sample_rate=16000, hop_length=256, n_fft=1024, win_length=800, center=False),
+            'mel_c': MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048), 'mel_nc': MelSpec(sample_rate=16000, hop_length=512, n_mels=64, n_fft=2048, center=False)}
+    for key, m in mods.items():
+        rec[key + '_expected_frames'] = np.array([m.get_expected_frames(np.zeros(int(n))) for n in lengths])
+        sr_ = [m.get_sample_range(int(f)) for f in frames]
+        rec[key + '_sample_range_min'] = np.array([int(np.min(r)) for r in sr_])
+        rec[key + '_sample_range_max'] = np.array([int(np.max(r)) for r in sr_])
+        rec[key + '_sample_range_len'] = np.array([len(r) for r in sr_])
+        rec[key + '_num_samples_required'] = np.array(m.get_num_samples_required())
+        rec[key + '_feature_size'] = np.array(m.get_feature_size())
+        rec[key + '_num_channels'] = np.array(m.get_num_channels())
+        rec[key + '_times'] = np.asarray(m.get_times(np.zeros(5000)), dtype=np.float64)
+        rec[key + '_name'] = np.array(m.features_name())
+    rng = np.random.default_rng(3)
+    S = np.abs(rng.standard_normal((5, 12))) ** 3 * 10.0
+    rec['db_in'] = S
+    rec['stft_post'] = mods['stft_c'].post_proc(S.copy())                  # magnitude -> dB -> scaled, channel axis
+    rec['mel_post'] = mods['mel_c'].post_proc(S.copy())                    # power -> dB -> scaled
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, {k: (v.tolist() if v.size < 20 else v.shape) for k, v in rec.items() if 'mel_c' in k})
+
+
 def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
     rng = np.random.default_rng(seed)
     profile = rtools.PianoProfile()
@@ -251,6 +292,7 @@ if __name__ == '__main__':
     gen_of_train('of1_train.npz', seed=21, dim_in=229, mc=2, B=2, T=24)
     gen_tabcnn('tabcnn_eval.npz', seed=41, dim_in=192, B=2, T=30)
     gen_labels_and_cache('labels.npz', 'feature_cache_ref.npz', seed=51, T=200, n_notes=60)
+    gen_feature_bookkeeping('feature_bookkeeping.npz')
     gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
     gen_notes('notes_noonsets.npz', 33, 200, 0.0, 0.06, False)
