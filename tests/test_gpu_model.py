@@ -212,3 +212,20 @@ def test_run_offline_batched_pipeline_equals_per_clip_runs():
     shard = run_offline_batched(clips, model, times=times, batch_size=2, rank=1, world=2, decode_notes=True, keep=())
     assert sorted(shard) == [1, 3, 5] and set(shard[1]) == {tools.KEY_NOTES}
     np.testing.assert_array_equal(shard[3][tools.KEY_NOTES], res[3][tools.KEY_NOTES])
+
+
+def test_engine_long_single_clip():
+    """One long track (T = 1500 frames, not a multiple of the 16-frame conv tile, of 4, or of the reference's 512-frame LSTM
+    chunk): the whole-sequence recurrence and the tiled convolutions against the oracle (fp32-class mode)."""
+    from oracle import model_ref
+    g = load_golden('of1_eval.npz')
+    model = _model(g, 'x3')
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(11)
+    feats = torch.from_numpy(rng.random((1, 1, 229, 1500)).astype(np.float32))
+    with torch.no_grad():
+        ref = model_ref.run_on_batch(feats, sd)
+        got = model.engine_logits(feats.cuda())
+    for key in ('onsets', 'multi_pitch'):
+        assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
+        assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
