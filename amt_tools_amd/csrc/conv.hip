@@ -127,6 +127,20 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PLANE_BYTES + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + g * NT;
     if (tid < COUT) reinterpret_cast<float*>(smem + NS * PLANE_BYTES + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
 
+    // C_out = 32: the shift also sits in 8 registers and is the C operand of each pair's first MFMAs directly (the LDS table read
+    // at the top of every column pair put ~100 cycles of LDS latency in front of the first MFMA); C_out = 64 has no registers left
+    constexpr bool SH_REGS = (NT == 2 && NS == 1);
+    f32x4_t shr[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) shr[nt][r] = SH_REGS ? a.shift[(int64_t)grp * a.shift_gs + (g * NT + nt) * 4 + r] : 0.f;
+    if (SH_REGS) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) settle(shr[nt][r]);
+    }
     const int cols = ft + 2;
     const int npos = ROWS * cols;
     const int Fo = a.F >> 1;
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = shl[nt];
+                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = SH_REGS ? shr[nt] : shl[nt];
 
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
