@@ -314,20 +314,35 @@ class OnsetsFrames(TranscriptionModel):
         batch[tools.KEY_FEATS] = batch[tools.KEY_FEATS].transpose(-1, -2)
         return batch
 
+    def run_on_batch(self, batch):
+        # Without ground truth nothing downstream reads the raw logits (post_proc only thresholds them,
+        # onsetsframes.py:186-194, and the engine has done that on the device): they stay in the engine's workspace
+        # instead of being copied out into three (B,T,O) tensors.  forward() called on its own always returns logits.
+        labelled = any(tools.query_dict(batch, k) for k in (tools.KEY_MULTIPITCH, tools.KEY_ONSETS, tools.KEY_OFFSETS))
+        self.__dict__['_logits_wanted'] = labelled
+        try:
+            return super().run_on_batch(batch)
+        finally:
+            self.__dict__.pop('_logits_wanted', None)
+
     def forward(self, feats):
         """feats (B,C,T,F) -> dict of raw logits (B,T,O) under 'onsets' and 'multi_pitch'."""
         if feats.is_cuda and not self.training:
             eng = self._get_engine(feats.device)
             if feats.dtype != torch.float32:
                 feats = feats.float()
-            onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats.detach())
+            want = self.__dict__.get('_logits_wanted', True)
+            onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats.detach(), want_logits=want)
+            if not want:
+                # label-free run_on_batch: the entries are the final piano rolls already (post_proc passes them through)
+                lo, lm = onsets_bin, mp_bin
             output = {tools.KEY_ONSETS: lo, tools.KEY_MULTIPITCH: lm}
             # piano rolls already thresholded on the device; post_proc picks them up for these logits
             self.__dict__['_engine_out'] = (lo, lm, onsets_bin, mp_bin, lp)
             if self.has_offsets:
-                prob, logits = eng.offsets(feats.device)
-                output[tools.KEY_OFFSETS] = logits
-                self.__dict__['_engine_offsets'] = (logits, prob)
+                prob, logits = eng.offsets(feats.device, want_logits=want)
+                output[tools.KEY_OFFSETS] = logits if want else prob
+                self.__dict__['_engine_offsets'] = (output[tools.KEY_OFFSETS], prob)
             return output
         self.__dict__.pop('_engine_out', None)
         self.__dict__.pop('_engine_offsets', None)
