@@ -25,6 +25,15 @@ constexpr int FT_MAX = 46;          // frequency columns per block tile (even)
 constexpr int PITCH = FT_MAX + 3;   // LDS positions per tile row: 49 = 1 (mod 4), see tile_off
 constexpr int ROWS = TT + 2;
 constexpr int PLANE_BYTES = ROWS * PITCH * 64;
+// The fused first conv writes its 32-channel map CHUNK-major: 16-byte chunk c of position (i, j) sits at
+// c * CM_PLANE + (i * PITCH + j) * 16.  Its lanes hold (chunk = lane >> 4, column = lane & 15), so every 8-lane group of a
+// ds_write_b128 covers 128 contiguous bytes; in the position-major layout of tile_off the same store put 8 lanes on two
+// 16-byte bank groups (4-way conflict, 32 LDS cycles per store instead of 13: 39 % of that kernel's LDS cycles were conflict
+// cycles, PMC SQ_LDS_BANK_CONFLICT).  Fragment reads stay conflict-free without any XOR: rows are PITCH = 1 (mod 16) slots
+// apart and CM_PLANE is a multiple of 256 bytes, so a ds_read_b128 lane group (8 rows of chunk c, the other 8 rows of chunk
+// c + 1) lands on 16 distinct slots.
+constexpr int CM_PLANE = (ROWS * PITCH * 16 + 255) / 256 * 256;
+constexpr int CM_BYTES = 3 * CM_PLANE + ROWS * PITCH * 16;   // the last chunk plane needs no tail padding
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
@@ -77,7 +86,10 @@ __device__ unsigned long long g_conv_prof[16];   // [0..7] fused first conv + co
 #endif
 
 constexpr int FROWS = ROWS + 2;      // feature tile rows of the fused first conv
-constexpr int FW = FT_MAX + 6;       // feature tile row pitch (floats)
+// Feature tile row pitch (floats).  c_in = 1 (KS = 1): the im2col gather of lane (g, column) reads row min(g, 2), so lanes
+// 0-31 of a ds_read_b32 take 16 consecutive floats of two rows: a pitch of 16 (mod 32) puts them on disjoint banks (lanes
+// 32-63 share one row and broadcast).  c_in > 1 (KS = 4): the tightest pitch, so that two blocks still fit one CU's LDS.
+constexpr int fw_pitch(int ks) { return ks == 1 ? 80 : FT_MAX + 4; }
 
 constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 16-byte staging items per thread (14)
 constexpr int FSLACK = 16;          // floats after the feature tile: gathers of columns past the tile stay in LDS we own
@@ -104,6 +116,8 @@ template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS>
 __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int COUT = NT * 16;
+    constexpr int PB = FUSE1 ? CM_BYTES : PLANE_BYTES;      // bytes of one input-tile plane in LDS
+    constexpr int FW = fw_pitch(KS);
     // next-tile register prefetch only where the register budget keeps 2 waves per SIMD (C_out = 32)
     constexpr bool PREFETCH = (IN_TYPE == AMTX_T_BF16) && !FUSE1 && NT <= 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,8 +138,8 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     }
     // folded BN shift: a C_out-float table at the end of LDS; the accumulators of every column pair are initialised
     // from it (lane -> its 4*NT consecutive channels), so the epilogue is max3(y0, y1, 0) only
-    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PLANE_BYTES + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + g * NT;
-    if (tid < COUT) reinterpret_cast<float*>(smem + NS * PLANE_BYTES + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
+    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + g * NT;
+    if (tid < COUT) reinterpret_cast<float*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
 
     // C_out = 32: the shift also sits in 8 registers and is the C operand of each pair's first MFMAs directly (the LDS table read
     // at the top of every column pair put ~100 cycles of LDS latency in front of the first MFMA); C_out = 64 has no registers left
@@ -148,7 +162,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
 
     // ---- constants of the fused first conv
-    float* ftile = reinterpret_cast<float*>(smem + NS * PLANE_BYTES);
+    float* ftile = reinterpret_cast<float*>(smem + NS * PB);
     const int fcols = ft + 4 + (KS == 1 ? 1 : 0);       // KS == 1: one more column for the zero-weight fourth slot of a lane's row segment
     const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
     const bool fprefetch = FUSE1 && fitems <= FPRE * 256;
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     float sh1[2][4];
     int ksteps = 0;
     int kaddr[KSA][4];                                  // koff + the lane's column inside a 16-column block
-    const int wlane0 = (lane & 15) * 64 + g * 16, wlane1 = (lane & 15) * 64 + (g ^ 2) * 16;   // tile_off lane parts (row swizzle 0 / 1)
+    const int wlane = g * CM_PLANE + (lane & 15) * 16;   // lane part of the chunk-major store address
     if constexpr (FUSE1) {
         const int kvalid = 9 * a.c_in;
         ksteps = (kvalid + 15) >> 4;                    // K = 16 per MFMA step, <= 4 steps
@@ -364,9 +378,9 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                                 for (int r = 0; r < 4; ++r) y[nt * 4 + r] = __builtin_amdgcn_fmed3f(acc1[u][nt][r], 0.f, lim);
                             uint4 hi, lo;
                             cvt8(y, NS == 2, hi, lo);
-                            const int off = (gi * PITCH + gb * 16) * 64 + (((gi >> 2) & 1) ? wlane1 : wlane0);
+                            const int off = (gi * PITCH + gb * 16) * 16 + wlane;
                             *reinterpret_cast<uint4*>(smem + off) = hi;
-                            if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off) = lo;
+                            if (NS == 2) *reinterpret_cast<uint4*>(smem + PB + off) = lo;
                         }
                     }
                 }
@@ -426,7 +440,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                         cvt8(fv, NS == 2, hi, lo);
                     }
                     *reinterpret_cast<uint4*>(smem + off[n]) = hi;
-                    if (NS == 2) *reinterpret_cast<uint4*>(smem + PLANE_BYTES + off[n]) = lo;
+                    if (NS == 2) *reinterpret_cast<uint4*>(smem + PB + off[n]) = lo;
                 }
             }
         }
@@ -445,13 +459,14 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
         const int npairs = ft >> 1;
         int rbase[3];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) rbase[kh] = tile_off(trow + kh, 0, g);
+        for (int kh = 0; kh < 3; ++kh) rbase[kh] = FUSE1 ? g * CM_PLANE + (trow + kh) * PITCH * 16 : tile_off(trow + kh, 0, g);
+        constexpr int CSTEP = FUSE1 ? 16 : 64;              // bytes between neighbouring columns of one chunk
         uint4 x[3][4][NS];
 #define CONV_LOAD_ROW(KH, JP)                                                                              \
         _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) {                                                 \
-            const int off = rbase[KH] + (2 * (JP) + cc) * 64;                                              \
+            const int off = rbase[KH] + (2 * (JP) + cc) * CSTEP;                                             \
             x[KH][cc][0] = *reinterpret_cast<const uint4*>(smem + off);                                    \
-            if (NS == 2) x[KH][cc][1] = *reinterpret_cast<const uint4*>(smem + PLANE_BYTES + off);         \
+            if (NS == 2) x[KH][cc][1] = *reinterpret_cast<const uint4*>(smem + PB + off);         \
         }
         if (wave_u < npairs) {
             CONV_LOAD_ROW(0, wave_u)
@@ -724,13 +739,13 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int ntt = (a.T + TT - 1) / TT;
     const int64_t nblocks = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
-    const size_t lds = (size_t)NS * PLANE_BYTES + (FUSE1 ? ((size_t)a.c_in * FROWS * FW + FSLACK) * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
+    const size_t lds = (size_t)NS * (FUSE1 ? CM_BYTES : PLANE_BYTES) + (FUSE1 ? ((size_t)a.c_in * FROWS * fw_pitch(KS) + FSLACK) * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
     auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1, KS>;
     if (lds > 64 * 1024) {
-        static bool done = false;   // per instantiation
-        if (!done) {
+        static size_t granted = 0;   // per instantiation; the size grows with c_in
+        if (lds > granted) {
             AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done = true;
+            granted = lds;
         }
     }
     const int cols = ft + 2;
