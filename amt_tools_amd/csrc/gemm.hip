@@ -204,7 +204,8 @@ __device__ __forceinline__ int wswz(int row) { return ((row >> 1) & 1) | (((row 
 //   * v_mfma_f32_32x32x16_bf16 with a lane owning 32 consecutive C columns: 1.34 ms;
 //   * spreading the 8 DMA instructions over the k-steps instead of issuing them at the top of the iteration: the time moves
 //     from the issue phase into the vmcnt(0) wait (two buffers leave no slack for a later issue);
-//   * the four-buffer ring below for long K: 1.31 ms (wins for K <= 1024 only).
+//   * the four-buffer two-group ring below for long K: 1.21 ms, and 1212 vs 1237 TFLOP/s with A cache-resident (it wins for
+//     K <= 1024 only, where the epilogue and the cold start of a tile weigh more).
 // With A fully cache-resident the same loop reaches 1211 TFLOP/s: ~20 % of its time is HBM/L2 latency, the rest is the
 // one-barrier-per-k-tile structure (wave 0 of a block: 41 % fragment reads + MFMAs, 17 % DMA issue, 8 % vmcnt, 34 % barrier).
 // TB = tile edge (128: 4 waves as 2x2, 256: 8 waves as 2x4); every wave owns (TB/2) x 64 outputs.
@@ -365,15 +366,12 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
 #undef GLDS_SYNC
 }
 // ------------------------------------------------------------------------------------------------
-// 256x256 tile, 32-deep k-stages in a FOUR-buffer LDS ring (3 stages = 96 KiB per CU in flight).  With two 64-deep
-// buffers only one stage is in flight while the other is on the matrix cores, and the loaded HBM latency (~2 us)
-// is twice the ~1 us a stage computes: the k-loop then runs at the latency, not at the MFMA rate.  Here the waits are
-// counted (`s_waitcnt vmcnt(8)`: the two newest stages stay in flight), never 0, and one LDS-only barrier per stage
-// both publishes the landed stage and frees the buffer the next DMA overwrites.  The stage stream is flattened across
-// this block's output tiles, so the ring never drains at a tile boundary; the C stores of a finished tile are counted
-// exactly (every store instruction always issues: rows past M go to a scratch line) so that the vmcnt arithmetic
-// stays valid while they are in flight.  bias sits in LDS: a global load in the epilogue would wait in order behind
-// the whole ring.
+// Short-K problems (the LSTM input projections, K = 512 / 192): 256x256 tile, 32-deep k-stages in a FOUR-buffer LDS ring.
+// With two 64-deep buffers only one stage is in flight while the other is on the matrix cores; here the waits are counted
+// (`s_waitcnt vmcnt(4)`: the newest stage stays in flight), never 0.  The stage stream is flattened across this block's output
+// tiles, so the ring never drains at a tile boundary; the C stores of a finished tile are counted exactly (every store
+// instruction always issues: rows past M go to a scratch line) so that the vmcnt arithmetic stays valid while they are in
+// flight.  bias sits in LDS: a global load in the epilogue would wait in order behind the whole ring.
 constexpr int RBK = 32, RST = 4, RTB = 256;
 constexpr int RING_MAX_NPAD = 4096;          // bias table: 16 KiB next to the 128 KiB ring
 constexpr int ROP = RTB * RBK * 2;          // bytes per operand per stage (16 KiB)
@@ -382,12 +380,40 @@ __device__ uint4 g_gemm_trash[4];
 
 __device__ __forceinline__ int rswz(int q) { return (0x78 >> (q * 2)) & 3; }   // [0,2,3,1][q], see lds_off
 
+// ------------------------------------------------------------------------------------------------
+// The eight waves are split into two groups (wm = 0 / wm = 1) that run ONE barrier interval apart: while one
+// group is on the matrix cores (16 MFMAs of one half of its 128 x 64 block) the other issues its fragment reads and its share
+// of the DMA, then they swap -- every SIMD holds one wave of each group, so its matrix pipe always has a wave whose operands
+// are already in registers.  A 32-deep stage is two such phases (rows 0-63, rows 64-127 of the wave's block):
+//     L1: read W (4) + A rows 0-63 (4) of stage s            | barrier | lgkmcnt(0), 16 MFMA | barrier |
+//     L2: vmcnt: my part of stage s+1 landed; read A rows 64-127 (4); DMA stage s+3 -> buffer of stage s-1
+//                                                             | barrier | lgkmcnt(0), 16 MFMA [epilogue] | barrier |
+// Hazards, by barrier count (group 1 lags group 0 by one interval; interval 4s is group 0's L1 of stage s):
+//   * stage s+1 is first read in interval 4s+4; every wave's vmcnt for it sits in its L2 of stage s (intervals 4s+2 / 4s+3),
+//     at least one barrier earlier;
+//   * the buffer of stage s-1 is last read in group 1's L2 of stage s-1 (interval 4s-1, retired by its lgkmcnt(0) in interval
+//     4s); the DMA that overwrites it is issued in L2 of stage s (intervals 4s+2 / 4s+3).
+// In flight per wave at the vmcnt: stage s+2 (4 DMAs) [+ the counted C stores when the previous stage ended a tile].
+#ifdef AMTX_GEMM_TIMING
+// Debug build only (AMTX_EXTRA_FLAGS=-DAMTX_GEMM_TIMING): cycles waves 0 (group 0) and 4 (group 1) of every block spend per section of the
+// two-group loop, summed over blocks; read with amtxdbg_gemm_prof().
+__device__ unsigned long long g_gemm_prof[2][16];
+#define PP_TICK(SLOT)                                                      \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        prof_acc[SLOT] += now_ - prof_t;                                   \
+        prof_t = now_;                                                     \
+    } while (0)
+#else
+#define PP_TICK(SLOT) do {} while (0)
+#endif
+
 template <int C_TYPE>
-__global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [RST][A 16K | W 16K] | bias[n_pad]
     constexpr int MT = 8;
     constexpr int ES = (C_TYPE == AMTX_T_BF16 ? 2 : 4);
-    constexpr int NSTORE = MT * (C_TYPE == AMTX_T_BF16 ? 2 : 4);   // store instructions of one epilogue, per wave
+    constexpr int NSTORE = MT * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int grp = blockIdx.z;
@@ -400,10 +426,9 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) 
     float* bias_l = reinterpret_cast<float*>(smem + RST * RSTAGE);
     for (int i = tid; i < g.n_pad; i += 512) bias_l[i] = (g.bias && i < g.N) ? g.bias[(int64_t)grp * g.bias_gs + i] : 0.f;
 
-    // DMA: this wave moves rows [32*wave, 32*wave + 32) of both operand tiles, 2 instructions x 16 rows (64 B each)
     const bf16_t* a_src[2];
     const bf16_t* w_src[2];
-#define RING_SET_TILE(TILE_ID)                                                                                \
+#define PP_SET_TILE(TILE_ID)                                                                                  \
     do {                                                                                                      \
         const unsigned lg = xcd_remap((unsigned)(TILE_ID), (unsigned)ntiles);                                 \
         const int tn0 = (lg % nbn) * RTB;                                                                     \
@@ -419,32 +444,51 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) 
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem) + wave * 2048;
 
     const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int S = my_tiles * nk;                         // stages this block streams
+    const int S = my_tiles * nk;
     int is = 0, ikt = 0, itile = blockIdx.x;
-#define RING_ISSUE_NEXT()                                                                                     \
+    bool pending_w = false;
+// The DMA of a stage is issued in two halves so that both load phases carry the same VMEM work (the texture path moves 64 B/clk:
+// four 1-KiB instructions per wave in one phase made that phase longer than the other group's 16 MFMAs): the A half of stage X
+// in L2 of stage X-3, the W half in L1 of stage X-2.
+#define PP_ISSUE_A()                                                                                          \
     do {                                                                                                      \
         if (is < S) {                                                                                         \
             const unsigned sb = lds_base + (is & (RST - 1)) * RSTAGE;                                         \
-            _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
-                glds16(a_src[n] + ikt * RBK, sb + n * 1024);                                                  \
-                glds16(w_src[n] + ikt * RBK, sb + ROP + n * 1024);                                            \
-            }                                                                                                 \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) glds16(a_src[n] + ikt * RBK, sb + n * 1024);        \
+            pending_w = true;                                                                                 \
+        }                                                                                                     \
+    } while (0)
+#define PP_ISSUE_W()                                                                                          \
+    do {                                                                                                      \
+        if (pending_w) {                                                                                      \
+            const unsigned sb = lds_base + (is & (RST - 1)) * RSTAGE;                                         \
+            _Pragma("unroll") for (int n = 0; n < 2; ++n) glds16(w_src[n] + ikt * RBK, sb + ROP + n * 1024);  \
+            pending_w = false;                                                                                \
             ++is;                                                                                             \
             if (++ikt == nk) {                                                                                \
                 ikt = 0;                                                                                      \
                 itile += (int)gridDim.x;                                                                      \
-                if (is < S) RING_SET_TILE(itile);                                                             \
+                if (is < S) PP_SET_TILE(itile);                                                               \
             }                                                                                                 \
         }                                                                                                     \
     } while (0)
+#define PP_BARRIER()                                                                                          \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        asm volatile("s_barrier" ::: "memory");                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
 
-    RING_SET_TILE(itile);
-    RING_ISSUE_NEXT();
-    RING_ISSUE_NEXT();
-    RING_ISSUE_NEXT();
-    __syncthreads();                                     // bias_l visible (compiler-visible traffic only: no DMA drain)
+    PP_SET_TILE(itile);
+    PP_ISSUE_A(); PP_ISSUE_W();
+    PP_ISSUE_A(); PP_ISSUE_W();
+    PP_ISSUE_A();
+    // stage 0 landed everywhere (stage 1 and the A half of stage 2 stay in flight) and bias_l visible
+    if (S >= 3) wait_vm<6>(); else if (S == 2) wait_vm<4>(); else wait_vm<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) PP_BARRIER();                            // group 1 starts one interval late
 
-    // fragment read offsets inside a stage: lane constants + immediates
     const int frow = lane & 15, fchunk = lane >> 4;
     const int a_off = (wm * 128 + frow) * 64 + ((fchunk ^ rswz((frow >> 2) & 3)) << 4);
     const int w_off = ROP + (wn * 64 + 16 * (frow >> 2) + (frow & 3)) * 64 + ((fchunk ^ rswz(frow >> 2)) << 4);
@@ -455,32 +499,65 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) 
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+#ifdef AMTX_GEMM_TIMING
+    unsigned long long prof_acc[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
     int ckt = 0, ctile = blockIdx.x;
-    bool stores_pending = false;                         // an epilogue ran in one of the last three iterations
-    int since_epi = 0;
+    bool stores_recent = false;                           // the previous stage ended with an epilogue: its C stores are younger than
+                                                          // stage cs+1's DMA but older than the W half of stage cs+2
     for (int cs = 0; cs < S; ++cs) {
-        // ---- wait until stage cs has landed: everything older than the (<= 2) newer stages [+ the counted stores]
-        const int newer = min(S - 1 - cs, 2);
-        if (!stores_pending) {
-            if (newer == 2) wait_vm<8>(); else if (newer == 1) wait_vm<4>(); else wait_vm<0>();
-        } else {
-            if (newer == 2) wait_vm<8 + NSTORE>(); else if (newer == 1) wait_vm<4 + NSTORE>(); else wait_vm<NSTORE>();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        RING_ISSUE_NEXT();                               // stage cs+3 -> the buffer stage cs-1 just vacated
-        if (stores_pending && ++since_epi == 3) stores_pending = false;
-
         const char* b = smem + (cs & (RST - 1)) * RSTAGE;
-        uint4 af[MT], wf[4];
+        uint4 af[4], wf[4];
+        // ---- phase 1
 #pragma unroll
         for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const uint4*>(b + w_off + t * 256);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const uint4*>(b + a_off + t * 1024);
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const uint4*>(b + a_off + t * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_ISSUE_W();                                     // W half of stage cs+2
+        PP_TICK(0);
+        PP_BARRIER();
+        PP_TICK(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_TICK(2);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], af[mt], acc[nt][mt]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_TICK(3);
+        PP_BARRIER();
+        PP_TICK(4);
+        // ---- phase 2
+        {
+            const int newer = min(S - 2 - cs, 1);         // stages newer than cs+1 already issued (cs+2), if they exist
+            if (newer >= 0) {                             // stage cs+1 exists
+                // issue order: ... W(cs+1) | A(cs+2) | [stores of stage cs-1's epilogue] | W(cs+2) | <- now
+                if (!stores_recent) { if (newer == 1) wait_vm<4>(); else wait_vm<0>(); }
+                else { if (newer == 1) wait_vm<4 + NSTORE>(); else wait_vm<NSTORE>(); }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PP_TICK(5);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const uint4*>(b + a_off + (4 + t) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        PP_ISSUE_A();                                     // A half of stage cs+3 -> the buffer stage cs-1 vacated two intervals ago
+        stores_recent = false;
+        PP_TICK(6);
+        PP_BARRIER();
+        PP_TICK(7);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PP_TICK(8);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt][4 + mt] = mfma16(wf[nt], af[mt], acc[nt][4 + mt]);
+        __builtin_amdgcn_s_setprio(0);
+        PP_TICK(9);
 
         if (++ckt == nk) {
             // ---- epilogue: lane (g, m) holds columns nb .. nb+15 of row m; exactly NSTORE store instructions
@@ -494,7 +571,11 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int64_t m = m0 + wm * 128 + mt * 16 + (lane & 15);
+#ifdef AMTX_PP_NOSTORE
+                char* dst = reinterpret_cast<char*>(g_gemm_trash);
+#else
                 char* dst = m < g.M ? Cbase + (m * g.ldc + nb) * ES : reinterpret_cast<char*>(g_gemm_trash);
+#endif
                 float o[4][4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
@@ -514,20 +595,33 @@ __global__ __launch_bounds__(512) void gemm_ring_kernel(GemmArgs g, int ntiles) 
             }
             ckt = 0;
             ctile += (int)gridDim.x;
-            stores_pending = true;
-            since_epi = 0;
+            stores_recent = true;
+            PP_TICK(13);
         }
+        PP_TICK(10);
+        PP_BARRIER();
+        PP_TICK(11);
     }
-#undef RING_SET_TILE
-#undef RING_ISSUE_NEXT
+#ifdef AMTX_GEMM_TIMING
+    if (lane == 0 && (wave & 3) == 0) {
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_gemm_prof[wm][i], prof_acc[i]);
+        atomicAdd(&g_gemm_prof[wm][13], prof_acc[13]);
+        atomicAdd(&g_gemm_prof[wm][12], (unsigned long long)S);
+    }
+#endif
+    if (wm == 0) PP_BARRIER();                            // group 0 meets group 1's last barrier
+#undef PP_SET_TILE
+#undef PP_ISSUE_A
+#undef PP_ISSUE_W
+#undef PP_BARRIER
 }
 
 template <int C_TYPE>
-int launch_ring(const GemmArgs& g, hipStream_t stream) {
+int launch_pp(const GemmArgs& g, hipStream_t stream) {
     const int64_t ntiles = ((g.M + RTB - 1) / RTB) * (g.n_pad / RTB);
     AMTX_REQUIRE(ntiles < (1ll << 31), "gemm: too many output tiles");
     const size_t lds = (size_t)RST * RSTAGE + (size_t)g.n_pad * sizeof(float);
-    auto kern = gemm_ring_kernel<C_TYPE>;
+    auto kern = gemm_pp_kernel<C_TYPE>;
     static bool attr_done = false;
     if (!attr_done) {
         AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RST * RSTAGE + RING_MAX_NPAD * sizeof(float))));
@@ -573,6 +667,15 @@ int launch(const GemmArgs& g, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef AMTX_GEMM_TIMING
+extern "C" void amtxdbg_gemm_prof(unsigned long long* out, int reset) {
+    unsigned long long h[2][16];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_prof), sizeof(h));
+    memcpy(out, h, sizeof(h));
+    if (reset) { memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), h, sizeof(h)); }
+}
+#endif
+
 void amtx_gemm_pack_dims(int N, int K, int* n_pad, int* k_pad) {
     *n_pad = ((N + BN - 1) / BN) * BN;
     *k_pad = ((K + GBK - 1) / GBK) * GBK;   // 64: a zero-padded K also fits the direct-to-LDS kernels' k-tile
@@ -601,12 +704,14 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {
-        static const bool no_ring = getenv("AMTX_GEMM_NO_RING") != nullptr;   // A/B switch for tools/bench_gemm.py
-        // measured on MI355X (tools/bench_gemm.py, M = 320000): the ring wins for short K (K = 512: 0.516 vs 0.544 ms, K = 192:
-        // 0.283 vs 0.317 ms), the two-buffer 64-deep loop for long K (K = 3648: 1.20 vs 1.31 ms)
-        if (!no_ring && g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.n_pad <= RING_MAX_NPAD && g.K >= 3 * RBK && g.K <= 1024 &&
-            (g.ldc * amtx_tsize(g.c_type)) % 16 == 0)
-            return g.c_type == AMTX_T_BF16 ? launch_ring<AMTX_T_BF16>(g, stream) : launch_ring<AMTX_T_F32>(g, stream);
+        // A/B switches for tools/bench_gemm.py / tools/check_gemm_pp.py: AMTX_GEMM_PP=1 forces the two-group ring for any K,
+        // AMTX_GEMM_NO_PP=1 disables it
+        static const bool force_pp = getenv("AMTX_GEMM_PP") != nullptr, no_pp = getenv("AMTX_GEMM_NO_PP") != nullptr;
+        // measured on MI355X (tools/bench_gemm.py, M = 320000, N = 1024): K = 512: 0.49 ms vs 0.53 (two 64-deep buffers);
+        // K = 192: 0.255 vs 0.271 ms; K = 3648 (N = 512): 1.21 vs 1.20 ms
+        if (!no_pp && (force_pp || g.K <= 1024) && g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.n_pad <= RING_MAX_NPAD &&
+            g.K >= 4 * RBK && (g.ldc * amtx_tsize(g.c_type)) % 16 == 0)
+            return g.c_type == AMTX_T_BF16 ? launch_pp<AMTX_T_BF16>(g, stream) : launch_pp<AMTX_T_F32>(g, stream);
         if (g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256)
             return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 256>(g, stream) : launch_glds<AMTX_T_F32, 256>(g, stream);
         return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 128>(g, stream) : launch_glds<AMTX_T_F32, 128>(g, stream);
