@@ -74,7 +74,8 @@ __device__ __forceinline__ void settle(float v) { asm volatile("" ::"v"(v)); }
 // Debug build only (AMTX_EXTRA_FLAGS=-DAMTX_CONV_TIMING): cycles wave 0 of every block spends per phase of the persistent loop,
 // summed over blocks: [0] staging / feature store, [1] barrier after it, [2] first-conv phase, [3] barrier, [4] conv phase,
 // [5] trailing barrier, [6] tiles.  Read with amtxdbg_conv_prof().
-__device__ unsigned long long g_conv_prof[16];   // [0..7] fused first conv + conv2, [8..15] plain conv
+__device__ unsigned long long g_conv_prof[32];   // [16..22]: sections of the first-conv loop (pack, gather issue, MFMA issue, epilogue 0, epilogue 1, -, iterations)
+// layout of the first 16:   // [0..7] fused first conv + conv2, [8..15] plain conv
 #define CONV_TICK(SLOT)                                                    \
     do {                                                                   \
         const unsigned long long now_ = __builtin_readcyclecounter();      \
@@ -112,10 +113,16 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int 
 // For bf16 inputs the NEXT tile's 14 x 16 B per thread are already in flight (registers) while the current tile is
 // on the matrix cores, so the HBM/L2 latency of staging is hidden behind ~3300 MFMA cycles per wave.
 // KS: compile-time bound of the fused first conv's K steps (1 for c_in = 1, 4 otherwise; 0 when not fused)
+// Threads per block.  The fused c_in = 1 bf16 kernel runs EIGHT waves per block (16 per CU, 4 per SIMD; it needs ~100 VGPRs, LDS
+// per block is unchanged): its first-conv phase is a latency chain (gather -> 4 small MFMAs -> clamp/pack -> LDS store) that two
+// waves per SIMD cannot hide, and with four a SIMD almost always has a wave in the MFMA-bound conv phase next to it.
+constexpr int conv_threads(bool fuse1, int ks, int ns) { return 256; }
+
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS>
-__global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
+__global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_threads(FUSE1, KS, NS) / 128 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int COUT = NT * 16;
+    constexpr int NTH = conv_threads(FUSE1, KS, NS), NW = NTH / 64;
     constexpr int PB = FUSE1 ? CM_BYTES : PLANE_BYTES;      // bytes of one input-tile plane in LDS
     constexpr int FW = fw_pitch(KS);
     // next-tile register prefetch only where the register budget keeps 2 waves per SIMD (C_out = 32)
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     float* ftile = reinterpret_cast<float*>(smem + NS * PB);
     const int fcols = ft + 4 + (KS == 1 ? 1 : 0);       // KS == 1: one more column for the zero-weight fourth slot of a lane's row segment
     const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
-    const bool fprefetch = FUSE1 && fitems <= FPRE * 256;
+    const bool fprefetch = FUSE1 && fitems <= FPRE * NTH;
     constexpr int KSA = KS > 0 ? KS : 1;
     int koff[KSA][4];
     uint2 w1[KSA][2][NS];
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     do {                                                                                                   \
         const float* fb = a.feats + (int64_t)(TC).b * a.f_stride_b;                                        \
         _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                                 \
-            const int it = tid + 256 * n;                                                                  \
+            const int it = tid + NTH * n;                                                                  \
             const int fi = it / fcols, fj = it - fi * fcols;                                               \
             const int t = (TC).t0 - 2 + fi, f = (TC).f0 - 2 + fj;                                          \
             fpre[n] = 0.f;                                                                                 \
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
     }
 
 #ifdef AMTX_CONV_TIMING
-    unsigned long long prof_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
     for (; tile < ntiles; tile += gridDim.x) {
@@ -274,13 +281,13 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             if (fprefetch) {
 #pragma unroll
                 for (int n = 0; n < FPRE; ++n) {
-                    const int it = tid + 256 * n;
+                    const int it = tid + NTH * n;
                     const int fi = it / fcols, fj = it - fi * fcols;
                     if (it < fitems) ftile[fi * FW + fj] = fpre[n];
                 }
             } else {
                 const float* fb = a.feats + (int64_t)tc.b * a.f_stride_b;
-                for (int it = tid; it < fitems; it += 256) {
+                for (int it = tid; it < fitems; it += NTH) {
                     const int ci = it / (FROWS * fcols), r = it - ci * (FROWS * fcols);
                     const int fi = r / fcols, fj = r - fi * fcols;
                     const int t = t0 - 2 + fi, f = f0 - 2 + fj;
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             float pv[2][KSA][4];
 #define CONV1_GATHER(GI0)                                                                                  \
             _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                \
-                const int gq = min((GI0) + 4 * u, ngroups - 1);                                            \
+                const int gq = min((GI0) + NW * u, ngroups - 1);                                            \
                 const int gi = (gq * inv_nblk) >> 16, gb = gq - gi * nblk;                                 \
                 const float* fbase = ftile + (gi * FW + gb * 16);                                          \
                 _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                          \
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             // (measured: conv1+conv2 3.16-3.33 -> 3.00 ms; raising the conv phase or its epilogue instead costs time).
             __builtin_amdgcn_s_setprio(2);
             if (wave_u < ngroups) { CONV1_GATHER(wave_u) }
-            for (int gi0 = wave_u; gi0 < ngroups; gi0 += 8) {
+            for (int gi0 = wave_u; gi0 < ngroups; gi0 += 2 * NW) {
                 uint2 ph[2][KSA], pl[2][KSA];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -336,8 +343,10 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                { CONV1_GATHER(gi0 + 8) }
+                CONV_TICK(8);
+                { CONV1_GATHER(gi0 + 2 * NW) }
                 __builtin_amdgcn_sched_barrier(0);
+                CONV_TICK(9);
                 f32x4_t acc1[2][2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -360,30 +369,58 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
                         }
                     }
                 }
+                CONV_TICK(10);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int gq = gi0 + 4 * u;
+                    const int gq = gi0 + NW * u;
+                    if (u == 1) CONV_TICK(11);
                     if (gq < ngroups) {
                         const int gi = (gq * inv_nblk) >> 16, gb = gq - gi * nblk;          // scalar
                         const int t = t0 - 1 + gi;
                         const int cj = gb * 16 + (lane & 15);
                         const int f = f0 - 1 + cj;
                         if (cj < cols) {
-                            // ReLU and the zero padding of the 32-channel map in one v_med3: clamp to [0, inf) inside, [0, 0] outside
-                            const float lim = (t >= 0 && t < a.T && f >= 0 && f < a.F) ? __builtin_inff() : 0.f;
-                            float y[8];
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) y[nt * 4 + r] = __builtin_amdgcn_fmed3f(acc1[u][nt][r], 0.f, lim);
-                            uint4 hi, lo;
-                            cvt8(y, NS == 2, hi, lo);
                             const int off = (gi * PITCH + gb * 16) * 16 + wlane;
-                            *reinterpret_cast<uint4*>(smem + off) = hi;
-                            if (NS == 2) *reinterpret_cast<uint4*>(smem + PB + off) = lo;
+                            if constexpr (NS == 1) {
+                                // bf16 mode: round first, then ReLU on the packed pairs as a signed 16-bit max with 0 (a negative
+                                // bf16 is a negative int16, -0 included) -- 4 + 4 instructions for 8 values instead of 8 + 4.
+                                // The zero padding of the map only exists at the image border: a group whose row and 16 columns
+                                // are all inside (decided on scalars) skips the mask.
+                                typedef short s16x2 __attribute__((ext_vector_type(2)));
+                                uint32_t pk[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const uint32_t v = pack_bf16x2(acc1[u][q >> 1][2 * (q & 1)], acc1[u][q >> 1][2 * (q & 1) + 1]);
+                                    pk[q] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+                                }
+                                const int fb0 = f0 - 1 + gb * 16;                          // scalar
+                                const bool inside = t >= 0 && t < a.T && fb0 >= 0 && fb0 + 15 < a.F;
+                                if (!inside) {
+                                    const uint32_t keep = (t >= 0 && t < a.T && f >= 0 && f < a.F) ? 0xffffffffu : 0u;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) pk[q] &= keep;
+                                }
+                                *reinterpret_cast<uint4*>(smem + off) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                            } else {
+                                // ReLU and the zero padding of the 32-channel map in one v_med3: clamp to [0, inf) inside, [0, 0] outside
+                                const float lim = (t >= 0 && t < a.T && f >= 0 && f < a.F) ? __builtin_inff() : 0.f;
+                                float y[8];
+#pragma unroll
+                                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) y[nt * 4 + r] = __builtin_amdgcn_fmed3f(acc1[u][nt][r], 0.f, lim);
+                                uint4 hi, lo;
+                                cvt8(y, true, hi, lo);
+                                *reinterpret_cast<uint4*>(smem + off) = hi;
+                                *reinterpret_cast<uint4*>(smem + PB + off) = lo;
+                            }
                         }
                     }
                 }
+                CONV_TICK(12);
+#ifdef AMTX_CONV_TIMING
+                prof_acc[14] += 1;
+#endif
             }
 #undef CONV1_GATHER
             __builtin_amdgcn_s_setprio(0);
@@ -473,8 +510,8 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
             CONV_LOAD_ROW(1, wave_u)
             CONV_LOAD_ROW(2, wave_u)
         }
-        for (int jp = wave_u; jp < npairs; jp += 4) {
-            const int jn = min(jp + 4, npairs - 1);     // past the end: re-read a valid pair, never used
+        for (int jp = wave_u; jp < npairs; jp += NW) {
+            const int jn = min(jp + NW, npairs - 1);     // past the end: re-read a valid pair, never used
             f32x4_t acc[2][NT];
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -535,6 +572,7 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void conv3x3_kernel(ConvArg
 #ifdef AMTX_CONV_TIMING
     if (tid == 0) {
         for (int i = 0; i < 7; ++i) atomicAdd(&g_conv_prof[(FUSE1 ? 0 : 8) + i], prof_acc[i]);
+        if (FUSE1) for (int i = 8; i < 15; ++i) atomicAdd(&g_conv_prof[8 + i], prof_acc[i]);
         atomicAdd(&g_conv_prof[(FUSE1 ? 0 : 8) + 7], 1ull);
     }
 #endif
@@ -759,7 +797,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     int64_t gx = nblocks;
     const int64_t per_group = std::max<int64_t>(1, 512 / std::max(1, a.groups));
     if (gx > per_group) gx = per_group;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt, inv_cols, (int)nblocks);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(conv_threads(FUSE1, KS, NS)), lds, stream, a, ft, ntf, ntt, inv_cols, (int)nblocks);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -934,10 +972,10 @@ int amtx_launch_conv1(const Conv1Args& a, hipStream_t stream) {
 }
 
 #ifdef AMTX_CONV_TIMING
-extern "C" int amtxdbg_conv_prof(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_conv_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+extern "C" int amtxdbg_conv_prof(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_conv_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_conv_prof), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

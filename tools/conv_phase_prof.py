@@ -14,7 +14,7 @@ model, mel, sd = bench.build_model('cuda:0', 'bf16')
 base = np.stack([synth_clip(i) for i in range(4)])
 audio = torch.from_numpy(base).cuda().repeat((B + 3) // 4, 1)[:B].contiguous()
 L = C.CDLL(_lib.LIB_PATH)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 with torch.no_grad():
     for _ in range(2):
         model.run_on_batch({tools.KEY_AUDIO: audio})
@@ -33,3 +33,10 @@ for k, title in ((0, 'fused conv1+conv2'), (8, 'conv3')):
     for i, n in enumerate(names):
         print(f'   {n:<22} {buf[k + i] / tiles:9.0f}  ({100.0 * buf[k + i] / tot:4.1f} %)')
     print(f'   total                  {tot / tiles:9.0f}')
+
+it = buf[22]
+if it:
+    secs = ['pack gathered values', 'gather issue (next)', 'acc init + MFMA issue', 'epilogue group 0', 'epilogue group 1']
+    print(f'first-conv loop, cycles per iteration (wave 0, {it} iterations, {it / max(1, buf[6]):.2f} per tile):')
+    for i, n in enumerate(secs):
+        print(f'   {n:<24} {buf[16 + i] / it:8.0f}')
