@@ -117,7 +117,12 @@ __device__ __forceinline__ void untangle_pair(float2 zk, float2 zp, float2 w, fl
     pmk = br * br + bi * bi;
 }
 
-template <int FPW, bool MEL>
+// MELLDS: the tap-major mel table (slots x 64 lanes) is copied into LDS once per block and the gather reads its weights from
+// there: per frame 72 global loads per lane (L1/L2 hits, but nine dependent batches of load latency with only two waves per SIMD
+// to cover them) become conflict-free LDS reads.  Plans whose table does not leave room for two blocks per CU keep it in memory.
+constexpr int MEL_LDS_MAX_SLOTS = 80;
+
+template <int FPW, bool MEL, bool MELLDS>
 __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const float* __restrict__ audio, int64_t num_samples,
                                                          int64_t audio_stride, int64_t num_frames,
                                                          float* __restrict__ power, unsigned* __restrict__ clip_max) {
@@ -127,8 +132,9 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     float2* xb = reinterpret_cast<float2*>(smem) + wave * XB_ELEMS;
     float* pb = reinterpret_cast<float*>(smem + WAVES * XB_ELEMS * sizeof(float2)) + wave * PB_ELEMS;
     float2* twp = reinterpret_cast<float2*>(smem + WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float));
-    float2* tw2l = twp + M;                           // W_64^(b*c), [b][c]: 64 entries
-    int* mstart = reinterpret_cast<int*>(tw2l + 64);  // first bin of every mel row, [64 * rounds]
+    float2* tw2l = twp + M / 2;                       // W_64^(b*c), [b][c]: 64 entries
+    int* mstart = reinterpret_cast<int*>(tw2l + 64);  // first bin of every mel row, [64 * MAX_MEL_ROUNDS]
+    float* melw = reinterpret_cast<float*>(mstart + 64 * MAX_MEL_ROUNDS);   // MELLDS: [slot][lane] weights
 
     constexpr int FPB = FPW * WAVES;
     const unsigned chunks = (unsigned)((num_frames + FPB - 1) / FPB);
@@ -137,8 +143,9 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     const unsigned chunk = logical % chunks;
     const float* clip = audio + (int64_t)clip_idx * audio_stride;
 
-    // block-shared tables: untangling twiddles exp(-2 pi i k / 2048), k < 1024, and the pass-B twiddles
-    for (int i = threadIdx.x; i < M; i += 256) twp[i] = p.tw_post[i];
+    // block-shared tables: untangling twiddles exp(-2 pi i k / 2048) for k < 512 (k + 512 is the same value times -i: a swap and
+    // a sign, applied where it is used) and the pass-B twiddles
+    for (int i = threadIdx.x; i < M / 2; i += 256) twp[i] = p.tw_post[i];
     if (threadIdx.x < 64) tw2l[threadIdx.x] = p.tw_fft[(16 * (threadIdx.x >> 4) * (threadIdx.x & 15)) & (M - 1)];
 
     // per-lane constants, reused by every frame this wave transforms
@@ -153,6 +160,10 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     }
     const int rounds = MEL ? (p.n_mels + 63) / 64 : 0;
     for (int i = threadIdx.x; i < 64 * rounds; i += 256) mstart[i] = p.mel_start[i];
+    if constexpr (MELLDS) {
+        const int nw = 64 * (p.round_off[rounds - 1] + p.round_max[rounds - 1]);
+        for (int i = threadIdx.x; i < nw; i += 256) melw[i] = p.mel_wt[i];
+    }
     for (int i = pidx(M + 1) + lane; i < PB_ELEMS; i += 64) pb[i] = 0.0f;   // bins past 1024: read (times 0) by padded mel taps, never written
     __syncthreads();
 
@@ -250,7 +261,12 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 float pk, pmk;
-                untangle_pair(A[d], P[d], twp[ks[d]], pk, pmk);
+                float2 w = twp[ks[d] & (M / 2 - 1)];
+                if (d >= 2) {                                  // ks >= 512 unless this is the merged task (128, 384)
+                    const float2 wr = make_float2(w.y, -w.x);  // times -i
+                    w = sp ? w : wr;
+                }
+                untangle_pair(A[d], P[d], w, pk, pmk);
                 pb[pidx(ks[d])] = pk;
                 pb[pidx(M - ks[d])] = pmk;
             }
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
                 res[r] = 0.0f;
                 if (r < rounds) {
                     const int start = mstart[r * 64 + lane];
-                    const float* wt = p.mel_wt + (int64_t)p.round_off[r] * 64 + lane;
+                    const float* wt = (MELLDS ? melw : p.mel_wt) + p.round_off[r] * 64 + lane;
                     const int nmax = p.round_max[r];
                     float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll 1
@@ -551,13 +567,27 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const int64_t chunks = (T + FPB - 1) / FPB;
     const int64_t nblocks = chunks * batch;
     AMTX_REQUIRE(nblocks < (1ll << 31), "amtx_spec_power: grid too large");
-    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M + 64) * sizeof(float2) + 64 * MAX_MEL_ROUNDS * sizeof(int);
-    if (plan->n_mels > 0)
-        hipLaunchKernelGGL((spec_power_kernel<FPW, true>), dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio,
-                           num_samples, audio_stride, T, power, (unsigned*)clip_max);
-    else
-        hipLaunchKernelGGL((spec_power_kernel<FPW, false>), dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio,
-                           num_samples, audio_stride, T, power, (unsigned*)clip_max);
+    const int mel_rounds = plan->n_mels > 0 ? (plan->n_mels + 63) / 64 : 0;
+    const int mel_slots = mel_rounds > 0 ? plan->dev.round_off[mel_rounds - 1] + plan->dev.round_max[mel_rounds - 1] : 0;
+    const bool mel_lds = mel_rounds > 0 && mel_slots <= MEL_LDS_MAX_SLOTS;
+    const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M / 2 + 64) * sizeof(float2) +
+                       64 * MAX_MEL_ROUNDS * sizeof(int) + (mel_lds ? (size_t)mel_slots * 64 * sizeof(float) : 0);
+    auto launch = [&](auto kern) -> int {
+        static size_t granted = 64 * 1024;   // per kernel instantiation
+        if (lds > granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { amtx_set_error("amtx_spec_power: %s", hipGetErrorString(e)); return AMTX_ERR_HIP; }
+            granted = lds;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio, num_samples, audio_stride, T, power,
+                           (unsigned*)clip_max);
+        return AMTX_OK;
+    };
+    int rc;
+    if (mel_lds) rc = launch(spec_power_kernel<FPW, true, true>);
+    else if (plan->n_mels > 0) rc = launch(spec_power_kernel<FPW, true, false>);
+    else rc = launch(spec_power_kernel<FPW, false, false>);
+    if (rc != AMTX_OK) return rc;
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
