@@ -150,7 +150,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 
     // C_out = 32: the shift also sits in 8 registers and is the C operand of each pair's first MFMAs directly (the LDS table read
     // at the top of every column pair put ~100 cycles of LDS latency in front of the first MFMA); C_out = 64 has no registers left
-    constexpr bool SH_REGS = (NT == 2 && NS == 1);
+    constexpr bool SH_REGS = (NT == 2 && NS == 1 && KS <= 1);   // not the c_in > 1 variant: it is out of registers already
     f32x4_t shr[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
