@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['bilstm', 'BiLSTMFunction']
+__all__ = ['bilstm', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction']
 
 H = 128
 
@@ -79,3 +79,34 @@ def bilstm(x, lstm):
     """Run `lstm` (an nn.LSTM(batch_first, bidirectional, hidden 128, one layer)) on x through the HIP kernels, differentiably."""
     return BiLSTMFunction.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                                 lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
+
+
+class BCELogitsLossFunction(torch.autograd.Function):
+    """LogisticBank.get_loss (amt_tools/models/common.py:541-584): logits (B,T,K), labels (B,K,T), optional per-key weights ->
+    mean_b sum_k mean_t BCEWithLogits, with d loss / d logits produced by the same kernel pass (amtx_bce_logits_loss)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, weight):
+        B, T, K = logits.shape
+        L = _lib.lib()
+        x = logits.detach().contiguous().float()
+        y = labels.detach().contiguous().float()
+        w = weight.detach().contiguous().float() if weight is not None else None
+        need_grad = logits.requires_grad
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty((B, T, K), dtype=torch.float32, device=x.device) if need_grad else None
+        ws = torch.empty(int(L.amtx_bce_logits_loss_workspace_bytes(B, T, K)), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.amtx_bce_logits_loss(_lib.ptr(x), K, _lib.ptr(y), _lib.ptr(w), B, T, K, _lib.ptr(loss), _lib.ptr(grad),
+                                              _lib.ptr(ws), ws.numel(), _lib.current_stream(x.device)), 'amtx_bce_logits_loss')
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None, None
+
+
+def bce_logits_loss(logits, labels, weight=None):
+    """(B,T,K) fp32 CUDA logits, (B,K,T) labels -> scalar loss attached to the autograd graph of `logits`."""
+    return BCELogitsLossFunction.apply(logits, labels, weight)

@@ -74,6 +74,9 @@ void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int plane
 
 // ---------------------------------------------------------------- logits -> piano roll
 // out[b][k][t] = threshold < 0 ? sigmoid(x) : (sigmoid(x) < threshold ? 0 : 1), x = logits[(b*T+t)*ld + col0 + k]
+size_t amtx_bce_loss_partials(int B, int T, int keys);
+int amtx_launch_bce_loss(const float* logits, int64_t ld, const float* labels, const float* weight, int B, int T, int keys, float* loss,
+                         float* grad, float* partial, hipStream_t stream);
 int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int T, int keys, float threshold, float* out,
                           hipStream_t stream);
 

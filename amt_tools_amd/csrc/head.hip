@@ -70,6 +70,78 @@ int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// LogisticBank.get_loss (amt_tools/models/common.py:541-584) and its gradient in one pass:
+//   loss = mean_b sum_k mean_t  w_k * BCEWithLogits(x[b,t,k], y[b,k,t])          (x: (B,T,K) logits, y: (B,K,T) labels)
+//   grad[b,t,k] = w_k * (sigmoid(x) - y) / (B*T)                                 (d loss / d x)
+// with torch's stable form max(x,0) - x*y + log1p(exp(-|x|)).  The labels arrive key-major, the logits frame-major: a 32x32
+// LDS transpose keeps both streams coalesced.  Deterministic: one partial per block, summed in block order by one wave.
+namespace {
+
+__global__ __launch_bounds__(256) void bce_loss_kernel(const float* __restrict__ logits, int64_t ld, const float* __restrict__ labels,
+                                                       const float* __restrict__ weight, int T, int keys, float inv_bt,
+                                                       float* __restrict__ grad, float* __restrict__ partial) {
+    __shared__ float tile[32][33];
+    __shared__ float red[4];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, t = t0 + tx;
+        tile[ty + 8 * i][tx] = (t < T && k < keys) ? labels[((int64_t)b * keys + k) * T + t] : 0.f;
+    }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i, k = k0 + tx;
+        if (t < T && k < keys) {
+            const float x = logits[((int64_t)b * T + t) * ld + k];
+            const float y = tile[tx][ty + 8 * i];
+            const float w = weight ? weight[k] : 1.0f;
+            const float e = expf(-fabsf(x));
+            acc += w * (fmaxf(x, 0.f) - x * y + log1pf(e));
+            if (grad) {
+                const float sg = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+                grad[((int64_t)b * T + t) * keys + k] = w * (sg - y) * inv_bt;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(64) void bce_loss_reduce_kernel(const float* __restrict__ partial, int64_t n, float inv_bt, float* __restrict__ loss) {
+    // fixed order: lane l sums partial[l], partial[l+64], ... in double, then a fixed butterfly
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 64) a += (double)partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (threadIdx.x == 0) *loss = (float)(a * (double)inv_bt);
+}
+
+}  // namespace
+
+size_t amtx_bce_loss_partials(int B, int T, int keys) { return (size_t)B * ((T + 31) / 32) * ((keys + 31) / 32); }
+
+int amtx_launch_bce_loss(const float* logits, int64_t ld, const float* labels, const float* weight, int B, int T, int keys, float* loss,
+                         float* grad, float* partial, hipStream_t stream) {
+    AMTX_REQUIRE(logits && labels && loss && partial, "bce_loss: null pointer");
+    AMTX_REQUIRE(B > 0 && B < 65536 && T > 0 && keys > 0 && ld >= keys, "bce_loss: bad sizes");
+    const float inv_bt = 1.0f / ((float)B * (float)T);
+    dim3 grid((unsigned)((T + 31) / 32), (unsigned)((keys + 31) / 32), (unsigned)B);
+    hipLaunchKernelGGL(bce_loss_kernel, grid, dim3(256), 0, stream, logits, ld, labels, weight, T, keys, inv_bt, grad, partial);
+    AMTX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_loss_reduce_kernel, dim3(1), dim3(64), 0, stream, partial, (int64_t)amtx_bce_loss_partials(B, T, keys), inv_bt, loss);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Root-mean-square normalisation of a batch of clips on the device: tools.rms_norm (amt_tools/tools/utils.py:2789-2814,
 // applied by tools.load_normalize_audio, tools/io.py:80-82): audio / sqrt(mean(audio^2)), untouched when the clip is
 // all zeros.  Deterministic two-level reduction (fixed summation order), then a division like the reference's.

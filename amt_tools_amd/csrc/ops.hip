@@ -72,6 +72,18 @@ extern "C" int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int
     return amtx_launch_pianoroll(logits, ld, col0, batch, num_frames, keys, threshold, out, (hipStream_t)stream);
 }
 
+extern "C" size_t amtx_bce_logits_loss_workspace_bytes(int batch, int num_frames, int keys) {
+    if (batch <= 0 || num_frames <= 0 || keys <= 0) return 0;
+    return amtx_bce_loss_partials(batch, num_frames, keys) * sizeof(float);
+}
+
+extern "C" int amtx_bce_logits_loss(const float* logits, int64_t ld, const float* labels, const float* weight, int batch, int num_frames,
+                                    int keys, float* loss, float* grad, void* workspace, size_t workspace_bytes, void* stream) {
+    AMTX_REQUIRE(workspace && workspace_bytes >= amtx_bce_logits_loss_workspace_bytes(batch, num_frames, keys),
+                 "amtx_bce_logits_loss: workspace too small");
+    return amtx_launch_bce_loss(logits, ld, labels, weight, batch, num_frames, keys, loss, grad, (float*)workspace, (hipStream_t)stream);
+}
+
 // ---- training entry points of the BiLSTM (amt_tools_amd/autograd.py)
 extern "C" int amtx_bilstm_pack_device(const float* whh_fwd, const float* whh_bwd, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd, void* stream) {
     return amtx_launch_bilstm_pack_dev(whh_fwd, whh_bwd, planes, (bf16_t*)frag_fwd, (bf16_t*)frag_bwd, (hipStream_t)stream);

@@ -119,6 +119,10 @@ class LogisticBank(OutputLayer):
     def get_loss(self, estimated, reference):
         """BCE with logits; mean over frames, sum over keys, mean over the batch (common.py:541-584).
         estimated (B,T,O) logits, reference (B,O,T)."""
+        if (estimated.is_cuda and estimated.dtype == torch.float32 and estimated.dim() == 3 and reference.dim() == 3
+                and reference.shape == (estimated.shape[0], estimated.shape[2], estimated.shape[1])):
+            from .autograd import bce_logits_loss     # one HIP pass: loss + d loss / d logits
+            return bce_logits_loss(estimated, reference, self.weights)
         est = estimated.transpose(-2, -1)
         weight = self.weights.unsqueeze(-1) if self.weights is not None else None
         loss = F.binary_cross_entropy_with_logits(est.float(), reference.float(), weight=weight, reduction='none')

@@ -145,6 +145,13 @@ int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int pl
                           void* stream);
 int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
                           int num_frames, void* stream);
+/* LogisticBank.get_loss (amt_tools/models/common.py:541-584) forward and backward in one pass: logits (B, T, keys) fp32 with row
+ * stride ld, labels (B, keys, T) fp32, weight = optional per-key weights (`OutputLayer.weights`);
+ * *loss = mean_b sum_k mean_t w_k BCEWithLogits, grad (optional, (B, T, keys) contiguous) = d loss / d logits.
+ * Deterministic (fixed summation order).  workspace: amtx_bce_logits_loss_workspace_bytes(batch, num_frames, keys).        */
+size_t amtx_bce_logits_loss_workspace_bytes(int batch, int num_frames, int keys);
+int amtx_bce_logits_loss(const float* logits, int64_t ld, const float* labels, const float* weight, int batch, int num_frames, int keys,
+                         float* loss, float* grad, void* workspace, size_t workspace_bytes, void* stream);
 /* LogisticBank.finalize_output: sigmoid -> (B,keys,T) -> threshold (< 0: keep probabilities)  (models/common.py:586-620) */
 int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold, float* out,
                        void* stream);

@@ -68,3 +68,25 @@ def test_training_step_on_gpu_matches_reference_golden():
     model.zero_grad()
     out2 = model.run_on_batch(batch)
     assert abs(out2[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].item() - loss[tools.KEY_LOSS_TOTAL].item()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T,K,weighted', [(8, 625, 88, False), (3, 70, 88, True), (1, 1, 4, False), (2, 33, 120, True)])
+def test_bce_logits_loss_matches_torch(B, T, K, weighted):
+    """amtx_bce_logits_loss = LogisticBank.get_loss (common.py:541-584) and its gradient, against torch in float64."""
+    import torch.nn.functional as F
+    from amt_tools_amd.autograd import bce_logits_loss
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = (torch.randn(B, T, K, generator=g) * 4).cuda().requires_grad_(True)
+    y = (torch.rand(B, K, T, generator=g) < 0.1).float().cuda()
+    w = (torch.rand(K, generator=g) + 0.5).cuda() if weighted else None
+    loss = bce_logits_loss(x, y, w)
+    (loss * 3.0).backward()
+    x64 = x.detach().double().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(x64.transpose(-2, -1), y.double(), weight=None if w is None else w.double().unsqueeze(-1),
+                                             reduction='none').mean(dim=-1).sum(dim=-1).mean()
+    (ref * 3.0).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item()) + 1e-7          # tolerance: fp32 terms, double reduction
+    assert (x.grad.double() - x64.grad).abs().max().item() <= 1e-6 * x64.grad.abs().max().item() + 1e-9
+    again = bce_logits_loss(x.detach(), y, w)
+    assert again.item() == loss.item()                                             # deterministic
