@@ -33,3 +33,21 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(_lib.AmtxError):
         _lib.check(rc, 'amtx_of_model_create')
     assert os.path.exists(_lib.LIB_PATH)
+
+
+def test_missing_extension_fails_loudly_without_a_cpu_fallback(monkeypatch):
+    """No HIP extension -> the product path raises; nothing quietly computes on the CPU (oracle/ is never imported by the package)."""
+    import sys
+    import numpy as np
+    import pytest
+    from amt_tools_amd.features import MelSpec
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libamtx.so')
+    with pytest.raises(_lib.AmtxError, match='no CPU fallback'):
+        _lib.lib()
+    with pytest.raises(Exception):          # AmtxError (no library) -- never a silently computed spectrogram
+        MelSpec(sample_rate=22050).process_audio(np.zeros(4096, dtype=np.float32))
+    assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules if 'amt_tools_amd' in str(getattr(sys.modules[m], '__file__', '')))
+    import amt_tools_amd, pathlib
+    src = ''.join(p.read_text() for p in pathlib.Path(amt_tools_amd.__file__).parent.glob('*.py'))
+    assert 'import oracle' not in src and 'from oracle' not in src
