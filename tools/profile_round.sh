@@ -6,6 +6,7 @@
 # 3. rocprofv3 --pmc passes (separate runs, kernel-trace only) -> <tag>_pmc_counters.txt
 # 4. secondary benches (HCQT config 3, training step, latency, host-to-host transcription) -> <tag>_secondary_benches.txt
 TAG=${1:-r01x}
+CLIPS=${2:-1024}   # = bench.py's default --clips
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
@@ -17,7 +18,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/${TAG}_stats -o prof -- pytho
 DB=$(ls $O/${TAG}_stats/*.db $O/${TAG}_stats/*/*.db 2>/dev/null | head -1)
 cd $R
 [ -n "$DB" ] && python3 tools/rocpd_summary.py $DB > $O/${TAG}_bench_kernel_stats.txt
-bash tools/pmc_passes.sh $TAG 512 > $O/${TAG}_pmc.log 2>&1
+bash tools/pmc_passes.sh $TAG $CLIPS > $O/${TAG}_pmc.log 2>&1
 python3 tools/pmc_summary.py $O/pmc_${TAG}_* > $O/${TAG}_pmc_counters.txt
 {
   echo "== tools/bench_hcqt.py 512 (BASELINE config 3)"; timeout 300 python3 tools/bench_hcqt.py 512 2>&1 | grep -v amdgpu.ids | tail -3
