@@ -33,6 +33,19 @@ def test_melspec_matches_oracle(lv, htk):
     assert got.max() == 1.0 and got.min() >= 0.0
 
 
+@pytest.mark.parametrize('n_mels,sr', [(40, 16000), (64, 22050), (128, 44100), (300, 22050), (512, 22050)])
+def test_melspec_other_filterbank_sizes(n_mels, sr):
+    """Other row counts / sample rates: one to eight rounds of 64 rows, both homes of the tap table (LDS up to 80 tap slots,
+    device memory beyond: 512 rows)."""
+    MelSpec, _ = _mods()
+    y = synth_clip(11, num_samples=50000)
+    mod = MelSpec(sample_rate=sr, hop_length=512, n_mels=n_mels, n_fft=2048)
+    got = mod.process_audio(y)
+    ref = fe.melspec_process_audio(y, sr, 512, n_mels, 2048)
+    assert got.shape == ref.shape == (1, n_mels, 1 + 50000 // 512)
+    assert np.abs(got - ref).max() < TOL_SCALED
+
+
 def test_melspec_linear_power_and_filterbank():
     MelSpec, _ = _mods()
     y = synth_clip(5, num_samples=40000)
