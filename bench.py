@@ -233,7 +233,10 @@ def main():
                                    'clips of 319999 samples (625 frames), audio resident in HBM -> piano rolls',
                        'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
                        'whole_path_frac_of_mfma_roof': fps / world * 26.70e6 / 2.5e15,
-                       'whole_path_frac_of_compulsory_hbm_roof': fps / world * 2752 / 8.0e12},
+                       'whole_path_frac_of_compulsory_hbm_roof': fps / world * 2752 / 8.0e12,
+                       # a layer-by-layer implementation moves ~125 kB of bf16 activations per frame -> 6.4e7 frames/s
+                       # at 8 TB/s (this build moves ~81 kB: PMC, profiles/pmc_traffic.json + the small kernels)
+                       'whole_path_frac_of_layerwise_hbm_roof': fps / world * 125.0e3 / 8.0e12},
             'roofline': roof,
         }
         if world == 1 and args.cpu_seconds > 0:
