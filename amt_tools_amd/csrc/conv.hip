@@ -113,9 +113,9 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int 
 // For bf16 inputs the NEXT tile's 14 x 16 B per thread are already in flight (registers) while the current tile is
 // on the matrix cores, so the HBM/L2 latency of staging is hidden behind ~3300 MFMA cycles per wave.
 // KS: compile-time bound of the fused first conv's K steps (1 for c_in = 1, 4 otherwise; 0 when not fused)
-// Threads per block.  The fused c_in = 1 bf16 kernel runs EIGHT waves per block (16 per CU, 4 per SIMD; it needs ~100 VGPRs, LDS
-// per block is unchanged): its first-conv phase is a latency chain (gather -> 4 small MFMAs -> clamp/pack -> LDS store) that two
-// waves per SIMD cannot hide, and with four a SIMD almost always has a wave in the MFMA-bound conv phase next to it.
+// Threads per block: four waves everywhere.  The kernel is written for any multiple of 64 (NTH / NW below), but more waves per
+// SIMD do not pay on gfx950: eight per block need <= 128 VGPRs and spill (72 weight + 48 fragment-ring + 16 accumulator registers
+// alone), six (168 VGPRs) leave one block resident per CU (measured 5.9 vs 2.85 ms for the fused c_in = 1 kernel).
 constexpr int conv_threads(bool fuse1, int ks, int ns) { return 256; }
 
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS>
