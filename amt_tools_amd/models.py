@@ -301,6 +301,7 @@ class OnsetsFrames(TranscriptionModel):
         state.pop('_engine', None)
         state.pop('_engine_out', None)
         state.pop('_engine_offsets', None)
+        state.pop('_side_stream', None)
         return state
 
     def _get_engine(self, device):
@@ -351,8 +352,25 @@ class OnsetsFrames(TranscriptionModel):
         self.__dict__.pop('_engine_out', None)
         self.__dict__.pop('_engine_offsets', None)
         output = dict()
-        multi_pitch = self.pitch_head(feats)
-        onsets = self.onset_head(feats)
+        if feats.is_cuda and self.training and self.__dict__.get('overlap_heads', True):
+            # The two heads only meet at the adjoin layer.  The onset head (acoustic model + a 625-step BiLSTM that occupies 4 of
+            # the 256 CUs at 8 clips) runs on a side stream next to the pitch head; autograd replays each op's backward on the
+            # stream of its forward, so the backward passes overlap the same way.
+            main = torch.cuda.current_stream(feats.device)
+            side = self.__dict__.get('_side_stream')
+            if side is None or side.device != feats.device:
+                side = torch.cuda.Stream(device=feats.device)
+                self.__dict__['_side_stream'] = side
+            side.wait_stream(main)
+            feats.record_stream(side)
+            with torch.cuda.stream(side):
+                onsets = self.onset_head(feats)
+            multi_pitch = self.pitch_head(feats)
+            main.wait_stream(side)
+            onsets.record_stream(main)
+        else:
+            multi_pitch = self.pitch_head(feats)
+            onsets = self.onset_head(feats)
         output[tools.KEY_ONSETS] = onsets
         heads = [onsets]
         if self.has_offsets:
