@@ -60,6 +60,12 @@ _SIGNATURES = {
     'amtx_conv3x3_packed_elems': (_L, [_I, _I]),
     'amtx_conv3x3_pack': (_I, [_P, _P, _I, _I, _P]),
     'amtx_conv3x3_fwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),
+    'amtx_conv3x3g_packed_elems': (_L, [_I, _I, _I]),
+    'amtx_conv3x3g_pack': (_I, [_P, _P, _I, _I, _I, _P]),
+    'amtx_conv3x3g_fwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'amtx_bilstm_h_packed_elems': (_L, [_I, _I]),
+    'amtx_bilstm_h_pack': (_I, [_P, _P, _I, _I, _P]),
+    'amtx_bilstm_h_fwd': (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _P]),
     'amtx_conv1_fwd': (_I, [_P, _L, _L, _L, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'amtx_bilstm_packed_elems': (_L, [_I]),
     'amtx_bilstm_pack': (_I, [_P, _P, _I, _P]),

@@ -36,6 +36,7 @@ struct ConvArgs {
     int c_in = 0;
     const bf16_t* w1frag = nullptr; const float* shift1 = nullptr;   // per-group strides: w1_gs, 32
     int64_t w1_gs = 0;
+    int64_t out_ts = 0;                                  // convg.hip only: elements between consecutive (b, t) rows of `out`; 0 = (F/2) * c_out
 };
 int amtx_launch_conv3x3(const ConvArgs& c, hipStream_t stream);
 size_t amtx_conv1_wfrag_elems(int c_in, int planes);
@@ -44,6 +45,12 @@ void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int plan
 size_t amtx_conv3x3_wfrag_elems(int c_out, int planes);
 // host packing: weight (c_out, 32, 3, 3) fp32 * scale[c_out] -> fragment order
 void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int planes, bf16_t* out);
+
+// general channel counts (convg.hip): C_in a multiple of 16, weights staged in LDS per C_out chunk; `a.in` is [B][T][F][c_in]
+int amtx_conv3x3_gen_ntc(int c_in, int c_out);           // 0 = this pair of channel counts is not built
+size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes);
+void amtx_conv3x3_gen_pack_host(const float* w /*(c_out,c_in,3,3)*/, const float* scale, int c_in, int c_out, int planes, bf16_t* out);
+int amtx_launch_conv3x3_gen(const ConvArgs& c, int c_in, hipStream_t stream);
 
 // ---------------------------------------------------------------- first conv (small C_in) + folded BN + ReLU, direct
 struct Conv1Args {
@@ -63,6 +70,7 @@ struct LstmArgs {
     void* out; int out_type;                             // [B][T][256] = h_fwd | h_bwd
     int B, T;
     int groups; int64_t x_gs, w_gs, out_gs;
+    int hidden = 128;                                    // per direction; != 128: xproj [B][T][2][4 hidden], out [B][T][2 hidden]
     float* save = nullptr;                               // training only: [groups][B][T][2][5][128] post-activation i,f,g,o and c (4-clip kernel)
 };
 int amtx_launch_bilstm(const LstmArgs& l, hipStream_t stream);
@@ -71,6 +79,8 @@ int amtx_launch_bilstm_pack_dev(const float* whh_fwd, const float* whh_bwd, int 
 int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* whh_t, int planes, float* dxproj, int B, int T, hipStream_t stream);
 size_t amtx_bilstm_wfrag_elems(int planes);              // per LSTM (both directions)
 void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out);   // each (512,128)
+size_t amtx_bilstm_wfrag_elems_h(int hidden, int planes);
+void amtx_bilstm_pack_host_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* out);   // each (4 hidden, hidden)
 
 // ---------------------------------------------------------------- logits -> piano roll
 // out[b][k][t] = threshold < 0 ? sigmoid(x) : (sigmoid(x) < threshold ? 0 : 1), x = logits[(b*T+t)*ld + col0 + k]

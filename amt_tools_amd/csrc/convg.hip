@@ -1,0 +1,281 @@
+// Conv2d 3x3 pad 1 + folded BatchNorm2d + ReLU + MaxPool(1,2) for the channel counts conv.hip's register-stationary
+// kernel does not cover (amt_tools/models/onsetsframes.py:375-416 at model_complexity != 2; OnsetsFrames2's default
+// model_complexity = 3 has 48 -> 48 and 48 -> 96 channel layers, onsetsframes.py:199-233).
+//
+// Same implicit GEMM as conv.hip (swapped product D' = W . X^T on the matrix cores, one 16-frame column of positions per
+// MFMA N-tile, pooling pair and channels-last store lane-local), but C_in is any multiple of 16 and the folded weights do not
+// fit the register file next to two waves per SIMD, so they are staged in LDS in fragment order, one C_out chunk of NTC
+// 16-channel tiles at a time:
+//   * K per tap = C_in = n32 x 32 (v_mfma_f32_16x16x32_bf16) + (C_in % 32 ? one 16-deep v_mfma_f32_16x16x16_bf16 : none),
+//   * the input tile (18 x (FT+2) positions) is held chunk-major (16-byte chunk c of a position at c * CPLANE + position * 16,
+//     CPLANE = 48 (mod 256) bytes, odd row pitch): the fragment reads of 16 consecutive rows and the staging stores of
+//     consecutive chunks both spread over the banks,
+//   * one wave = four neighbouring output columns (two pooled outputs) x all NTC tiles of the chunk: a weight fragment read
+//     from LDS feeds 4 MFMAs, an input fragment NTC x (up to) 3,
+//   * x3 precision: hi/lo planes of both operands, 3 MFMAs per product (as everywhere else in this library).
+// Algorithmic HBM bytes per output position: C_in in + C_out / 2 out, element size of the mode.
+
+#include "amtx_kernels.h"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int GTT = 16;             // frames per tile
+constexpr int GROWS = GTT + 2;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 g_bf16x8;
+typedef __attribute__((ext_vector_type(4))) short g_s16x4;
+__device__ __forceinline__ f32x4_t gm32(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t gm16(uint2 a, uint2 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(g_s16x4, a), __builtin_bit_cast(g_s16x4, b), c, 0, 0, 0);
+}
+
+constexpr int g_cplane(int ft) {
+    // bytes of one chunk plane: ROWS x PC positions x 16 B, rounded up to 48 (mod 256)
+    const int pc = (ft + 2) | 1;
+    const int raw = GROWS * pc * 16;
+    return (raw + 255 - 48) / 256 * 256 + 48;
+}
+
+// per (tap, tile) weight bytes of one plane in LDS / in the packed global buffer
+constexpr int g_wfrag_bytes(int ci16) { return (ci16 / 2) * 1024 + (ci16 % 2) * 512; }
+
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE>
+__global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks) {
+    constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
+    constexpr int CIN = 16 * CI16;
+    constexpr int NCH = CIN / 8;                 // 16-byte chunks per position
+    constexpr int N32 = CI16 / 2, N16 = CI16 % 2;
+    constexpr int PC = (FT + 2) | 1;             // positions per tile row (odd)
+    constexpr int COLS = FT + 2;
+    constexpr int CPLANE = g_cplane(FT);
+    constexpr int XPLANE = NCH * CPLANE;         // one precision plane of the input tile
+    constexpr int WFRAG = g_wfrag_bytes(CI16);   // one plane of one (tap, tile)
+    constexpr int WCHUNK = 9 * NTC * NS * WFRAG; // all planes of one C_out chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    char* ws = smem + NS * XPLANE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int grp = blockIdx.y;
+    int tile = blockIdx.x;
+    const int tf = tile % ntf; tile /= ntf;
+    const int tt = tile % ntt; tile /= ntt;
+    const int b = tile, t0 = tt * GTT, f0 = tf * FT;
+    const int F = a.F, T = a.T, F2 = F >> 1;
+    constexpr int IES = IN_TYPE == AMTX_T_BF16 ? 2 : 4;
+    const int64_t out_ts = a.out_ts ? a.out_ts : (int64_t)F2 * a.c_out;
+
+    // ---- stage the input tile: rows t0-1 .. t0+16, columns f0-1 .. f0+FT, zero outside the map
+    {
+        const char* in = reinterpret_cast<const char*>(a.in) + ((int64_t)grp * a.in_gs + (int64_t)b * T * F * CIN) * IES;
+        constexpr int NITEMS = GROWS * COLS * NCH;
+        for (int it = tid; it < NITEMS; it += NTH) {
+            const int c = it % NCH, pos = it / NCH;
+            const int i = pos / COLS, j = pos % COLS;
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            const bool ok = t >= 0 && t < T && f >= 0 && f < F;
+            uint4 hi = make_uint4(0, 0, 0, 0), lo = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const char* p = in + (((int64_t)t * F + f) * CIN + c * 8) * IES;
+                if (IN_TYPE == AMTX_T_BF16) {
+                    hi = *reinterpret_cast<const uint4*>(p);
+                } else {
+                    const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
+                    if (NS == 2) {
+                        split_bf16x2(v0.x, v0.y, hi.x, lo.x); split_bf16x2(v0.z, v0.w, hi.y, lo.y);
+                        split_bf16x2(v1.x, v1.y, hi.z, lo.z); split_bf16x2(v1.z, v1.w, hi.w, lo.w);
+                    } else {
+                        hi = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w));
+                    }
+                }
+            }
+            const int off = c * CPLANE + (i * PC + j) * 16;
+            *reinterpret_cast<uint4*>(xs + off) = hi;
+            if (NS == 2) *reinterpret_cast<uint4*>(xs + XPLANE + off) = lo;
+        }
+    }
+
+    const int jb = 4 * wave;                                   // first of this wave's four output columns (tile-relative)
+    const int t_out = t0 + r16;
+    const int xrow = r16 * PC * 16;                            // byte offset of this lane's row (kh = 0) in a chunk plane
+    const int x32 = g * CPLANE;                                // + ks * 4 * CPLANE: chunk 4 ks + g
+    const int x16 = (4 * N32 + (g >> 1)) * CPLANE + (g & 1) * 8;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch > 0) __syncthreads();                           // everybody is done with the previous chunk's weights
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wfrag) + ((int64_t)grp * a.w_gs * 2 + (int64_t)ch * WCHUNK));
+            for (int it = tid; it < WCHUNK / 16; it += NTH) reinterpret_cast<uint4*>(ws)[it] = src[it];
+        }
+        __syncthreads();
+
+        // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
+        f32x4_t acc[4][NTC];
+        {
+            const float* sh = a.shift + (int64_t)grp * a.shift_gs + ch * 16 * NTC + g * 4 * NTC;
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                const float4 s = *reinterpret_cast<const float4*>(sh + 4 * nt);
+#pragma unroll
+                for (int col = 0; col < 4; ++col) acc[col][nt] = (f32x4_t){s.x, s.y, s.z, s.w};
+            }
+        }
+
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            uint4 xa[6][N32 > 0 ? N32 : 1][NS];
+            uint2 xb[6][NS];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int base = xrow + (kh * PC + jb + c) * 16;
+#pragma unroll
+                for (int p = 0; p < NS; ++p) {
+#pragma unroll
+                    for (int ks = 0; ks < N32; ++ks) xa[c][ks][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x32 + ks * 4 * CPLANE);
+                    if (N16) xb[c][p] = *reinterpret_cast<const uint2*>(xs + p * XPLANE + base + x16);
+                }
+            }
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) {
+                    const char* wp = ws + ((kh * 3 + kw) * NTC + nt) * NS * WFRAG;
+#pragma unroll
+                    for (int ks = 0; ks < N32; ++ks) {
+                        uint4 w[NS];
+#pragma unroll
+                        for (int p = 0; p < NS; ++p) w[p] = *reinterpret_cast<const uint4*>(wp + (ks * NS + p) * 1024 + lane * 16);
+#pragma unroll
+                        for (int col = 0; col < 4; ++col) {
+                            acc[col][nt] = gm32(w[0], xa[col + kw][ks][0], acc[col][nt]);
+                            if (NS == 2) {
+                                acc[col][nt] = gm32(w[0], xa[col + kw][ks][1], acc[col][nt]);
+                                acc[col][nt] = gm32(w[1], xa[col + kw][ks][0], acc[col][nt]);
+                            }
+                        }
+                    }
+                    if (N16) {
+                        uint2 w[NS];
+#pragma unroll
+                        for (int p = 0; p < NS; ++p) w[p] = *reinterpret_cast<const uint2*>(wp + N32 * NS * 1024 + p * 512 + lane * 8);
+#pragma unroll
+                        for (int col = 0; col < 4; ++col) {
+                            acc[col][nt] = gm16(w[0], xb[col + kw][0], acc[col][nt]);
+                            if (NS == 2) {
+                                acc[col][nt] = gm16(w[0], xb[col + kw][1], acc[col][nt]);
+                                acc[col][nt] = gm16(w[1], xb[col + kw][0], acc[col][nt]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
+        if (t_out < T) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int fo = (f0 + jb + 2 * pr) >> 1;
+                if (fo >= F2) continue;
+                const int64_t o = (int64_t)grp * a.out_gs + ((int64_t)b * T + t_out) * out_ts + (int64_t)fo * a.c_out + ch * 16 * NTC + g * 4 * NTC;
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(acc[2 * pr][nt][r], acc[2 * pr + 1][nt][r]), 0.f);
+                    if (OUT_TYPE == AMTX_T_BF16)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    else
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4 * nt) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE>
+int launch_gen(const ConvArgs& a, hipStream_t stream) {
+    const int fe = a.F & ~1;                                  // columns that reach a pooled output
+    const int ntf = (fe + FT - 1) / FT;
+    const int ntt = (a.T + GTT - 1) / GTT;
+    const int64_t nblocks = (int64_t)ntf * ntt * a.B;
+    AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
+    const int nchunks = a.c_out / (16 * NTC);
+    const size_t lds = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT) + (size_t)9 * NTC * NS * g_wfrag_bytes(CI16);
+    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+template <int CI16, int NTC>
+int dispatch_gen(const ConvArgs& a, hipStream_t s) {
+    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
+    if (a.planes == 2 && a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32>(a, s);
+    amtx_set_error("conv3x3 (general): unsupported precision/type combination");
+    return AMTX_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// C_out chunk (in 16-channel tiles) the general kernel keeps in LDS at a time
+int amtx_conv3x3_gen_ntc(int c_in, int c_out) {
+    if (c_in == 48 && c_out % 48 == 0) return 3;
+    return 0;
+}
+
+size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes) { return (size_t)9 * (c_out / 16) * planes * g_wfrag_bytes(c_in / 16) / 2; }
+
+// host packing: weight (c_out, c_in, 3, 3) fp32 * scale[c_out] -> [chunk][tap][tile][k-step][plane][lane][8 or 4]
+void amtx_conv3x3_gen_pack_host(const float* w, const float* scale, int c_in, int c_out, int planes, bf16_t* out) {
+    const int ntc = amtx_conv3x3_gen_ntc(c_in, c_out);
+    const int ci16 = c_in / 16, n32 = ci16 / 2, n16 = ci16 % 2;
+    const size_t wfrag = (size_t)g_wfrag_bytes(ci16) / 2;      // elements of one plane of one (tap, tile)
+    const int nchunks = c_out / (16 * ntc);
+    for (int ch = 0; ch < nchunks; ++ch)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int nt = 0; nt < ntc; ++nt) {
+                bf16_t* base = out + (((size_t)ch * 9 + tap) * ntc + nt) * planes * wfrag;
+                for (int l = 0; l < 64; ++l) {
+                    const int row = l & 15, gq = l >> 4;
+                    const int co = ch * 16 * ntc + (row >> 2) * (4 * ntc) + 4 * nt + (row & 3);
+                    const float sc = scale ? scale[co] : 1.0f;
+                    for (int ks = 0; ks < n32; ++ks)
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = 32 * ks + 8 * gq + j;
+                            const float v = w[((size_t)co * c_in + ci) * 9 + tap] * sc;
+                            const bf16_t hi = f32_to_bf16_rn(v);
+                            base[((size_t)ks * planes + 0) * 512 + l * 8 + j] = hi;
+                            if (planes == 2) base[((size_t)ks * planes + 1) * 512 + l * 8 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                        }
+                    if (n16)
+                        for (int j = 0; j < 4; ++j) {
+                            const int ci = 32 * n32 + 4 * gq + j;
+                            const float v = w[((size_t)co * c_in + ci) * 9 + tap] * sc;
+                            const bf16_t hi = f32_to_bf16_rn(v);
+                            bf16_t* b16 = base + (size_t)n32 * planes * 512;
+                            b16[l * 4 + j] = hi;
+                            if (planes == 2) b16[256 + l * 4 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                        }
+                }
+            }
+}
+
+int amtx_launch_conv3x3_gen(const ConvArgs& a, int c_in, hipStream_t stream) {
+    AMTX_REQUIRE(a.in && a.wfrag && a.shift && a.out, "conv3x3 (general): null pointer");
+    AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F >= 2 && a.groups > 0, "conv3x3 (general): bad sizes");
+    AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3 (general): planes must be 1 or 2");
+    if (c_in == 48 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 3) return dispatch_gen<3, 3>(a, stream);
+    amtx_set_error("conv3x3 (general): unsupported channel counts %d -> %d", c_in, a.c_out);
+    return AMTX_ERR_UNSUPPORTED;
+}

@@ -478,6 +478,171 @@ __global__ void bilstm_pack_dev_kernel(const float* __restrict__ whh_fwd, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Any hidden size HH = 128 k (OnsetsFrames at model_complexity 3: 256, onsetsframes.py:57-58 dim_lm = 256 (mc - 1)).
+// 4 HH x HH bf16 recurrent weights of one direction (512 KiB at HH = 256) are as large as a CU's whole register file, so
+// they are NOT stationary here: every step each wave streams the fragments of its unit tiles from L2 (all blocks of a launch
+// read the same <= 2 MiB, which stays cache-resident), double-buffered one (unit tile, gate) group ahead of the MFMAs, the
+// first group of the next step already in flight across the step barrier.  One block = one direction x 16 clips x all T
+// steps, eight waves; product swapped (D' = W_hh . h^T) so the four gates of a (clip, unit) meet in one lane; h_{t-1}
+// exchanged through a double-buffered LDS tile; c in registers.  Per step and block: 8 HH^2 bytes from L2 against
+// 128 HH^2 flops -> the step time is the L2 stream (about 3.4 us at HH = 256), T steps per launch: latency-bound like the
+// register-stationary kernels, only with a longer step.
+template <int HH, int NS, int X_TYPE, int OUT_TYPE>
+__global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
+    constexpr int NU = HH / 16, UPW = NU / 8, KSN = HH / 32;
+    constexpr int SGK = NS == 2 ? 2 : 4;          // k-steps per streamed group: 16 VGPRs per group in either precision
+    constexpr int NSUB = KSN / SGK;               // groups per (unit tile, gate)
+    constexpr int NG = UPW * 4 * NSUB;            // groups per step and wave
+    constexpr int HPG = HH + 8;
+    constexpr int HBG = 16 * HPG * 2;
+    constexpr bool FAST = true;
+    static_assert(NU % 8 == 0 && KSN % SGK == 0 && NG % 4 == 0, "hidden size must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HPG] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int clip = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * 16, dir = blockIdx.y, grp = blockIdx.z;
+    const int b = b0 + clip;
+    const bool clip_ok = b < a.B;
+    const int T = a.T;
+    constexpr int XES = X_TYPE == AMTX_T_BF16 ? 2 : 4, OES = OUT_TYPE == AMTX_T_BF16 ? 2 : 4;
+
+    for (int i = tid; i < 2 * NS * HBG / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // fragment (u, q, ks, p) of direction dir: uint4 index ((((dir * NU + u) * 4 + q) * KSN + ks) * NS + p) * 64 + lane;
+    // a wave's groups of one step are consecutive in memory
+    // wave-uniform base (scalar registers) + one per-lane byte offset: every fragment load is `global_load saddr + voffset`, without
+    // a 64-bit address pair per load held in vector registers across the loop
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* wbase = reinterpret_cast<const char*>(a.whh + (int64_t)grp * a.w_gs) + ((int64_t)(dir * NU + wave_u * UPW) * 4 * KSN * NS) * 1024;
+    const unsigned wlane = lane * 16;
+    const char* xbase = reinterpret_cast<const char*>(a.xproj) +
+                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 8 * HH + dir * 4 * HH + 16 * UPW * wave + 4 * g) * XES;
+    char* obase = reinterpret_cast<char*>(a.out) +
+                  ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 2 * HH + dir * HH + 16 * UPW * wave + 4 * g) * OES;
+
+    float c[UPW][4];
+#pragma unroll
+    for (int ub = 0; ub < UPW; ++ub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[ub][r] = 0.f;
+
+    typedef typename XRaw<X_TYPE>::type xraw_t;
+    auto tidx = [&](int s) { s = s < T ? s : T - 1; return (int64_t)(dir == 0 ? s : T - 1 - s); };
+    auto load_xrow = [&](int64_t t, xraw_t (&dst)[UPW][4]) {
+#pragma unroll
+        for (int ub = 0; ub < UPW; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                dst[ub][q] = *reinterpret_cast<const xraw_t*>(xbase + (t * 8 * HH + q * HH + 16 * ub) * XES);
+    };
+    uint4 w[4][SGK][NS];                          // ring: group gi lives in slot gi & 3, three groups in flight
+    typedef const __attribute__((address_space(1))) char* gchar_p;      // explicitly global: the asm below must not turn the loads into flat ones
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    typedef __attribute__((address_space(1))) u32x4_t gu4_t;
+    gchar_p wb = (gchar_p)wbase;
+    auto load_w = [&](int gi) {
+#pragma unroll
+        for (int k = 0; k < SGK; ++k)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) w[gi & 3][k][p] = __builtin_bit_cast(uint4, *reinterpret_cast<const gu4_t*>(wb + ((gi * SGK + k) * NS + p) * 1024 + wlane));
+    };
+
+    xraw_t xn[UPW][4];
+    load_xrow(tidx(0), xn);
+    load_w(0); load_w(1); load_w(2);
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < T; ++s) {
+        // opaque to the optimiser: otherwise it hoists one 64-bit vector address per fragment load out of the loop (128 VGPRs)
+        wb = (gchar_p)wbase;
+        asm volatile("" : "+s"(wb));
+        const char* hb = smem + cur * NS * HBG;
+        uint4 hf[KSN][NS];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int p = 0; p < NS; ++p) hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBG + (clip * HPG + 32 * ks + 8 * g) * 2);
+
+        f32x4_t acc[UPW][4];
+#pragma unroll
+        for (int ub = 0; ub < UPW; ++ub)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[ub][q] = unpack_x(xn[ub][q]);
+        load_xrow(tidx(s + 1), xn);
+        __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const int ub = gi / (4 * NSUB), q = (gi / NSUB) & 3, sub = gi % NSUB;
+            load_w((gi + 3) % NG);                // behind the last three groups: the first three of the next step
+            f32x4_t d = acc[ub][q];
+#pragma unroll
+            for (int k = 0; k < SGK; ++k) {
+                const int ks = sub * SGK + k;
+                d = mfma16(w[gi & 3][k][0], hf[ks][0], d);
+                if (NS == 2) {
+                    d = mfma16(w[gi & 3][k][0], hf[ks][1], d);
+                    d = mfma16(w[gi & 3][k][1], hf[ks][0], d);
+                }
+            }
+            acc[ub][q] = d;
+            __builtin_amdgcn_sched_barrier(0);   // keep the ring three groups deep: no hoisting of later loads above this group
+        }
+
+        char* hn = smem + (cur ^ 1) * NS * HBG;
+        const int64_t t = tidx(s);
+#pragma unroll
+        for (int ub = 0; ub < UPW; ++ub) {
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ig = sigmoid_f<FAST>(acc[ub][0][r]);
+                const float fg = sigmoid_f<FAST>(acc[ub][1][r]);
+                const float gg = tanh_f<FAST>(acc[ub][2][r]);
+                const float og = sigmoid_f<FAST>(acc[ub][3][r]);
+                c[ub][r] = fg * c[ub][r] + ig * gg;
+                h[r] = og * tanh_f<FAST>(c[ub][r]);
+            }
+            uint2 hiw, low = make_uint2(0, 0);
+            if (NS == 2) {
+                split_bf16x2(h[0], h[1], hiw.x, low.x);
+                split_bf16x2(h[2], h[3], hiw.y, low.y);
+            } else {
+                hiw = make_uint2(pack_bf16x2(h[0], h[1]), pack_bf16x2(h[2], h[3]));
+            }
+            const int hoff = (clip * HPG + 16 * UPW * wave + 16 * ub + 4 * g) * 2;
+            *reinterpret_cast<uint2*>(hn + hoff) = hiw;
+            if (NS == 2) *reinterpret_cast<uint2*>(hn + HBG + hoff) = low;
+            if (clip_ok) {
+                const int64_t e = t * 2 * HH + 16 * ub;
+                if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<uint2*>(obase + e * 2) = hiw;
+                else *reinterpret_cast<float4*>(obase + e * 4) = make_float4(h[0], h[1], h[2], h[3]);
+            }
+        }
+        cur ^= 1;
+        lds_barrier();
+    }
+}
+
+template <int HH, int NS, int X_TYPE, int OUT_TYPE>
+int launch_stream(const LstmArgs& a, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2;
+    dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
+    hipLaunchKernelGGL((bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>), grid, dim3(512), lds, stream, a);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+template <int HH>
+int dispatch_stream(const LstmArgs& a, hipStream_t stream) {
+    if (a.planes == 1 && a.x_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_stream<HH, 1, AMTX_T_BF16, AMTX_T_BF16>(a, stream);
+    if (a.planes == 2 && a.x_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_stream<HH, 2, AMTX_T_F32, AMTX_T_F32>(a, stream);
+    amtx_set_error("bilstm (hidden %d): unsupported precision/type combination", HH);
+    return AMTX_ERR_UNSUPPORTED;
+}
+
 // clips per block: 4 while that still leaves fewer blocks than ~4 per CU, else 16 (a quarter of the total wave-steps)
 inline bool use_four_clip_blocks(const LstmArgs& a) { return (int64_t)((a.B + 3) / 4) * 2 * a.groups <= 1024; }
 
@@ -498,6 +663,30 @@ int launch(const LstmArgs& a, hipStream_t stream) {
 }  // namespace
 
 size_t amtx_bilstm_wfrag_elems(int planes) { return (size_t)2 * 512 * 128 * planes; }
+
+size_t amtx_bilstm_wfrag_elems_h(int hidden, int planes) { return (size_t)2 * 4 * hidden * hidden * planes; }
+
+// hidden != 128: fragment order of bilstm_stream_kernel, [dir][unit tile][gate][k-step][plane][lane][8]
+void amtx_bilstm_pack_host_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* out) {
+    if (hidden == H) { amtx_bilstm_pack_host(whh_fwd, whh_bwd, planes, out); return; }
+    const int nu = hidden / 16, ksn = hidden / 32;
+    for (int dir = 0; dir < 2; ++dir) {
+        const float* W = dir == 0 ? whh_fwd : whh_bwd;   // (4 hidden, hidden) row-major, gate-major rows i,f,g,o
+        for (int u = 0; u < nu; ++u)
+            for (int q = 0; q < 4; ++q)
+                for (int ks = 0; ks < ksn; ++ks)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int row = q * hidden + 16 * u + (l & 15);
+                            const int k = 32 * ks + 8 * (l >> 4) + j;
+                            const float v = W[(size_t)row * hidden + k];
+                            const bf16_t hi = f32_to_bf16_rn(v);
+                            const size_t base = (((((size_t)dir * nu + u) * 4 + q) * ksn + ks) * planes) * 512 + (size_t)l * 8 + j;
+                            out[base] = hi;
+                            if (planes == 2) out[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                        }
+    }
+}
 
 void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out) {
     for (int dir = 0; dir < 2; ++dir) {
@@ -523,6 +712,12 @@ int amtx_launch_bilstm(const LstmArgs& a, hipStream_t stream) {
     AMTX_REQUIRE(a.xproj && a.whh && a.out, "bilstm: null pointer");
     AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.groups > 0, "bilstm: bad sizes");
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "bilstm: planes must be 1 or 2");
+    if (a.hidden != H) {
+        AMTX_REQUIRE(!a.save, "bilstm: the training forward exists for hidden = 128 only");
+        if (a.hidden == 256) return dispatch_stream<256>(a, stream);
+        amtx_set_error("bilstm: unsupported hidden size %d (128 and 256 are built)", a.hidden);
+        return AMTX_ERR_UNSUPPORTED;
+    }
     if (a.planes == 1 && a.x_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch<1, AMTX_T_BF16, AMTX_T_BF16>(a, stream);
     if (a.planes == 1 && a.x_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch<1, AMTX_T_F32, AMTX_T_F32>(a, stream);
     if (a.planes == 2 && a.x_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch<2, AMTX_T_F32, AMTX_T_F32>(a, stream);

@@ -48,6 +48,9 @@ struct amtx_of_model {
     int dim_in, in_channels, mc, n_out, has_offsets, precision;
     int planes, act_type;
     int nf1, nf2, nf3, dim_am, dim_lm, fq, kfc;
+    int kfc_pad;                               // fc1's K rounded up to the DMA GEMM's 64-deep k-tile (rows of a3 are this long)
+    int hid, xw;                               // LSTM hidden size per direction, width of an x-projection row (2 dirs x 4 gates x hid)
+    bool gen_conv = false;                     // channel counts other than 32/32/64: convg.hip (weights in LDS) instead of conv.hip
     int n_heads;                               // acoustic heads: onset, (offset), pitch
     int n_rec;                                 // recurrent heads feeding the joint: onset, (offset)
     std::vector<std::string> head_names;       // state_dict prefixes of the acoustic models, group order
@@ -147,8 +150,8 @@ int pack_lstm(amtx_of_model* m, const std::string& prefix, int dim_in, std::vect
     memcpy(w_ih.data() + (size_t)G * dim_in, wib, sizeof(float) * G * dim_in);
     b.resize(2 * G);
     for (int i = 0; i < G; ++i) { b[i] = bif[i] + bhf[i]; b[G + i] = bib[i] + bhb[i]; }
-    hh.resize(amtx_bilstm_wfrag_elems(m->planes));
-    amtx_bilstm_pack_host(whf, whb, m->planes, hh.data());
+    hh.resize(amtx_bilstm_wfrag_elems_h(H, m->planes));
+    amtx_bilstm_pack_host_h(whf, whb, H, m->planes, hh.data());
     return AMTX_OK;
 }
 
@@ -166,13 +169,13 @@ Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
     w.a1 = take(m->fuse_conv1 ? 256 : BT * F * m->nf1 * es * m->n_heads);
     w.a2 = take(BT * F2 * m->nf2 * es * m->n_heads);
-    w.a3 = take(BT * m->fq * m->nf3 * es * m->n_heads);
+    w.a3 = take(BT * m->kfc_pad * es * m->n_heads);
     w.e = take(BT * m->dim_am * es * m->n_heads);
-    w.xp = take(BT * 1024 * es * m->n_rec);
+    w.xp = take(BT * m->xw * es * m->n_rec);
     w.l1 = take(BT * m->dim_lm * es * m->n_rec);
     w.joint = take(BT * m->dim_aj * sizeof(float));
     w.joint16 = take(BT * (size_t)((m->dim_aj + 63) / 64 * 64) * 2);   // bf16 copy, K padded to the GEMM's 64-deep k-tile
-    w.xp2 = take(BT * 1024 * es);
+    w.xp2 = take(BT * m->xw * es);
     w.l2 = take(BT * m->dim_lm * es);
     w.mp = take(BT * m->n_out * sizeof(float));
     w.total = off;
@@ -187,9 +190,9 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     *out = nullptr;
     AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3, "amtx_of_model_create: bad precision");
     AMTX_REQUIRE(dim_in >= 4 && in_channels >= 1 && n_out > 0 && n_out % 4 == 0, "amtx_of_model_create: bad dims");
-    if (model_complexity != 2) {
-        amtx_set_error("amtx_of_model_create: only model_complexity=2 (C_in 32 convs, LSTM hidden 128) is implemented, with or without "
-                       "the OnsetsFrames2 offset head (got model_complexity=%d)", model_complexity);
+    if (model_complexity != 2 && model_complexity != 3) {
+        amtx_set_error("amtx_of_model_create: model_complexity 2 (32/32/64-channel convolutions, LSTM hidden 128) and 3 (48/48/96, hidden 256) "
+                       "are implemented, with or without the OnsetsFrames2 offset head (got model_complexity=%d)", model_complexity);
         return AMTX_ERR_UNSUPPORTED;
     }
     amtx_of_model* m = new amtx_of_model();
@@ -201,6 +204,9 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->dim_am = 256 * model_complexity; m->dim_lm = 256 * (model_complexity - 1);
     m->fq = dim_in / 4;                      // two MaxPool(1,2): floor(floor(F/2)/2) == F//4
     m->kfc = m->nf3 * m->fq;
+    m->kfc_pad = (m->kfc + 63) / 64 * 64;
+    m->hid = m->dim_lm / 2; m->xw = 8 * m->hid;
+    m->gen_conv = m->nf1 != 32;
     m->head_names = {"onset_head"};
     if (has_offsets) m->head_names.push_back("offset_head");
     m->n_rec = (int)m->head_names.size();
@@ -238,7 +244,13 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     m->fuse_conv1 = (9 * m->in_channels <= 64) && m->nf1 == 32;
     const size_t c1f_per = amtx_conv1_wfrag_elems(m->in_channels, m->planes);
     std::vector<bf16_t> c1f(m->fuse_conv1 ? c1f_per * nh : 0);
-    std::vector<bf16_t> c2w(amtx_conv3x3_wfrag_elems(m->nf2, m->planes) * nh), c3w(amtx_conv3x3_wfrag_elems(m->nf3, m->planes) * nh);
+    const size_t c2w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, m->planes) : amtx_conv3x3_wfrag_elems(m->nf2, m->planes);
+    const size_t c3w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, m->planes) : amtx_conv3x3_wfrag_elems(m->nf3, m->planes);
+    if (m->gen_conv && (!amtx_conv3x3_gen_ntc(m->nf1, m->nf2) || !amtx_conv3x3_gen_ntc(m->nf2, m->nf3))) {
+        amtx_set_error("of_model: no convolution kernel for %d -> %d -> %d channels", m->nf1, m->nf2, m->nf3);
+        return AMTX_ERR_UNSUPPORTED;
+    }
+    std::vector<bf16_t> c2w(c2w_per * nh), c3w(c3w_per * nh);
     std::vector<float> c2s((size_t)nh * m->nf2), c3s((size_t)nh * m->nf3);
     std::vector<std::vector<float>> fcw(nh), fcb(nh);
     for (int h = 0; h < nh; ++h) {
@@ -257,24 +269,26 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
         rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
-        amtx_conv3x3_pack_host(w, scale.data(), m->nf2, m->planes, c2w.data() + amtx_conv3x3_wfrag_elems(m->nf2, m->planes) * h);
+        if (m->gen_conv) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
+        else amtx_conv3x3_pack_host(w, scale.data(), m->nf2, m->planes, c2w.data() + c2w_per * h);
         memcpy(c2s.data() + (size_t)h * m->nf2, shift.data(), sizeof(float) * m->nf2);
 
         rc = fold_bn(m, am + ".layer3.0", am + ".layer3.1", m->nf3, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
-        amtx_conv3x3_pack_host(w, scale.data(), m->nf3, m->planes, c3w.data() + amtx_conv3x3_wfrag_elems(m->nf3, m->planes) * h);
+        if (m->gen_conv) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf2, m->nf3, m->planes, c3w.data() + c3w_per * h);
+        else amtx_conv3x3_pack_host(w, scale.data(), m->nf3, m->planes, c3w.data() + c3w_per * h);
         memcpy(c3s.data() + (size_t)h * m->nf3, shift.data(), sizeof(float) * m->nf3);
 
         // fc1: reference column index c*fq + f  ->  ours f*nf3 + c
         const float* fb;
         NEED(am + ".fc1.0.weight", (size_t)m->dim_am * m->kfc, w);
         NEED(am + ".fc1.0.bias", (size_t)m->dim_am, fb);
-        fcw[h].resize((size_t)m->dim_am * m->kfc);
+        fcw[h].assign((size_t)m->dim_am * m->kfc_pad, 0.0f);     // columns kfc .. kfc_pad stay zero
         for (int n = 0; n < m->dim_am; ++n)
             for (int c = 0; c < m->nf3; ++c)
                 for (int f = 0; f < m->fq; ++f)
-                    fcw[h][(size_t)n * m->kfc + (size_t)f * m->nf3 + c] = w[(size_t)n * m->kfc + (size_t)c * m->fq + f];
+                    fcw[h][(size_t)n * m->kfc_pad + (size_t)f * m->nf3 + c] = w[(size_t)n * m->kfc + (size_t)c * m->fq + f];
         fcb[h].assign(fb, fb + m->dim_am);
     }
     int rc;
@@ -285,7 +299,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     if ((rc = m->conv2_s.upload(c2s.data(), c2s.size() * 4)) != AMTX_OK) return rc;
     if ((rc = m->conv3_w.upload(c3w.data(), c3w.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv3_s.upload(c3s.data(), c3s.size() * 4)) != AMTX_OK) return rc;
-    if ((rc = pack_linear_groups(m, m->fc1, fcw, fcb, m->dim_am, m->kfc)) != AMTX_OK) return rc;
+    if ((rc = pack_linear_groups(m, m->fc1, fcw, fcb, m->dim_am, m->kfc_pad)) != AMTX_OK) return rc;
 
     // ---- recurrent heads (onset, offset): LSTM + LogisticBank
     {
@@ -301,7 +315,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
             wo[r].assign(w, w + (size_t)m->n_out * m->dim_lm);
             bo[r].assign(b, b + m->n_out);
         }
-        if ((rc = pack_linear_groups(m, m->rec_ih, wih, bih, 1024, m->dim_am)) != AMTX_OK) return rc;
+        if ((rc = pack_linear_groups(m, m->rec_ih, wih, bih, m->xw, m->dim_am)) != AMTX_OK) return rc;
         if ((rc = m->rec_hh.upload(hh_all.data(), hh_all.size() * 2)) != AMTX_OK) return rc;
         if ((rc = pack_linear_groups(m, m->rec_out, wo, bo, m->n_out, m->dim_lm)) != AMTX_OK) return rc;
     }
@@ -318,7 +332,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
         std::vector<std::vector<float>> wih(1), bih(1);
         std::vector<bf16_t> hh;
         if ((rc = pack_lstm(m, "adjoin.0", m->dim_aj, wih[0], bih[0], hh)) != AMTX_OK) return rc;
-        if ((rc = pack_linear_groups(m, m->adj_ih, wih, bih, 1024, m->dim_aj)) != AMTX_OK) return rc;
+        if ((rc = pack_linear_groups(m, m->adj_ih, wih, bih, m->xw, m->dim_aj)) != AMTX_OK) return rc;
         if ((rc = m->adj_hh.upload(hh.data(), hh.size() * 2)) != AMTX_OK) return rc;
         const float *w, *b;
         NEED("adjoin.1.output_layer.weight", (size_t)m->n_out * m->dim_lm, w);
@@ -386,7 +400,8 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     ConvArgs c2;
     c2.in = w.a1; c2.in_type = at; c2.wfrag = (const bf16_t*)m->conv2_w.p; c2.planes = pl; c2.shift = (const float*)m->conv2_s.p;
     c2.out = w.a2; c2.out_type = at; c2.B = B; c2.T = T; c2.F = F; c2.c_out = m->nf2;
-    c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf2, pl); c2.shift_gs = m->nf2;
+    c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.shift_gs = m->nf2;
+    c2.w_gs = (int64_t)(m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, pl) : amtx_conv3x3_wfrag_elems(m->nf2, pl));
     c2.out_gs = BT * F2 * m->nf2;
     if (m->fuse_conv1) {   // Conv(c_in->32)+BN+ReLU computed inside the conv2 kernel; a1 is never materialised
         c2.in = nullptr;
@@ -394,29 +409,39 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
         c2.c_in = m->in_channels; c2.w1frag = (const bf16_t*)m->conv1_frag.p; c2.shift1 = (const float*)m->conv1_s.p;
         c2.w1_gs = (int64_t)amtx_conv1_wfrag_elems(m->in_channels, pl);
     }
-    if ((rc = amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
+    if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c3 = c2;
     c3.feats = nullptr; c3.w1frag = nullptr; c3.shift1 = nullptr; c3.c_in = 0;
     c3.in = w.a2; c3.wfrag = (const bf16_t*)m->conv3_w.p; c3.shift = (const float*)m->conv3_s.p; c3.out = w.a3;
-    c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2; c3.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl);
-    c3.shift_gs = m->nf3; c3.out_gs = BT * m->fq * m->nf3;
-    if ((rc = amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
+    c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2;
+    c3.w_gs = (int64_t)(m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, pl) : amtx_conv3x3_wfrag_elems(m->nf3, pl));
+    c3.shift_gs = m->nf3; c3.out_gs = BT * m->kfc_pad;
+    if (m->kfc_pad != m->kfc) {
+        // rows of a3 are padded to the DMA GEMM's k-tile: the pad columns meet zero weights, they only have to be finite
+        AMTX_REQUIRE(m->gen_conv, "amtx_of_forward: internal: padded fc1 rows need the general conv kernel");
+        c3.out_ts = m->kfc_pad;
+        const size_t es = amtx_tsize(at);
+        AMTX_CHECK_HIP(hipMemset2DAsync(w.a3 + (size_t)m->kfc * es, (size_t)m->kfc_pad * es, 0, (size_t)(m->kfc_pad - m->kfc) * es,
+                                        (size_t)BT * m->n_heads, s));
+    }
+    if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
     mark();
 
     // fc1 for every acoustic head
-    GemmArgs g = gemm_args(w.a3, m->kfc, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_heads, BT * m->kfc, BT * m->dim_am);
+    GemmArgs g = gemm_args(w.a3, m->kfc_pad, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_heads, BT * m->kfc_pad, BT * m->dim_am);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
     // recurrent heads: heads 0..n_rec-1 of `e`
-    g = gemm_args(w.e, m->dim_am, at, m->rec_ih, pl, w.xp, 1024, at, BT, m->n_rec, BT * m->dim_am, BT * 1024);
+    g = gemm_args(w.e, m->dim_am, at, m->rec_ih, pl, w.xp, m->xw, at, BT, m->n_rec, BT * m->dim_am, BT * m->xw);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     LstmArgs l;
     l.xproj = w.xp; l.x_type = at; l.whh = (const bf16_t*)m->rec_hh.p; l.planes = pl; l.out = w.l1; l.out_type = at;
-    l.B = B; l.T = T; l.groups = m->n_rec; l.x_gs = BT * 1024; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems(pl); l.out_gs = BT * m->dim_lm;
+    l.B = B; l.T = T; l.groups = m->n_rec; l.x_gs = BT * m->xw; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems_h(m->hid, pl); l.out_gs = BT * m->dim_lm;
+    l.hidden = m->hid;
     if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
     mark();
     // LogisticBank of each recurrent head -> joint[:, r*n_out : (r+1)*n_out]; group stride of C = n_out columns
@@ -434,10 +459,10 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
         // bf16 mode: round the joint logits to bf16 once (zero-padded to a 64-multiple K) and use the direct-to-LDS GEMM
         const int kp = (m->dim_aj + 63) / 64 * 64;
         if ((rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s)) != AMTX_OK) return rc;
-        g = gemm_args(w.joint16, kp, AMTX_T_BF16, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
+        g = gemm_args(w.joint16, kp, AMTX_T_BF16, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
         g.K = kp;
     } else {
-        g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, 1024, at, BT, 1, 0, 0);
+        g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
     }
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();

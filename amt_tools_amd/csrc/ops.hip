@@ -40,6 +40,27 @@ extern "C" int amtx_conv3x3_fwd(const void* in, int elem_type, const uint16_t* w
     return amtx_launch_conv3x3(a, (hipStream_t)stream);
 }
 
+extern "C" int64_t amtx_conv3x3g_packed_elems(int c_in, int c_out, int planes) {
+    if (c_in <= 0 || c_out <= 0 || c_in % 16 || c_out % 16 || !amtx_conv3x3_gen_ntc(c_in, c_out)) return 0;
+    return (int64_t)amtx_conv3x3_gen_wfrag_elems(c_in, c_out, planes);
+}
+
+extern "C" int amtx_conv3x3g_pack(const float* host_w, const float* host_scale, int c_in, int c_out, int planes, uint16_t* host_out) {
+    AMTX_REQUIRE(host_w && host_out && (planes == 1 || planes == 2), "amtx_conv3x3g_pack: bad argument");
+    AMTX_REQUIRE(amtx_conv3x3g_packed_elems(c_in, c_out, planes) > 0, "amtx_conv3x3g_pack: channel counts %d -> %d are not built", c_in, c_out);
+    amtx_conv3x3_gen_pack_host(host_w, host_scale, c_in, c_out, planes, host_out);
+    return AMTX_OK;
+}
+
+extern "C" int amtx_conv3x3g_fwd(const void* in, int elem_type, const uint16_t* w_packed, int planes, const float* shift, void* out,
+                                 int batch, int num_frames, int num_bins, int c_in, int c_out, void* stream) {
+    ConvArgs a;
+    a.in = in; a.in_type = elem_type; a.wfrag = w_packed; a.planes = planes; a.shift = shift; a.out = out; a.out_type = elem_type;
+    a.B = batch; a.T = num_frames; a.F = num_bins; a.c_out = c_out;
+    a.groups = 1; a.in_gs = a.w_gs = a.shift_gs = a.out_gs = 0;
+    return amtx_launch_conv3x3_gen(a, c_in, (hipStream_t)stream);
+}
+
 extern "C" int amtx_conv1_fwd(const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t, int64_t stride_f, const float* w,
                               const float* shift, void* out, int out_type, int batch, int num_frames, int num_bins, int c_in, int c_out,
                               void* stream) {
@@ -64,6 +85,26 @@ extern "C" int amtx_bilstm_fwd(const void* xproj, const uint16_t* whh_packed, in
     LstmArgs l;
     l.xproj = xproj; l.x_type = elem_type; l.whh = whh_packed; l.planes = planes; l.out = out; l.out_type = elem_type;
     l.B = batch; l.T = num_frames; l.groups = 1; l.x_gs = l.w_gs = l.out_gs = 0;
+    return amtx_launch_bilstm(l, (hipStream_t)stream);
+}
+
+extern "C" int64_t amtx_bilstm_h_packed_elems(int hidden, int planes) {
+    if (hidden != 128 && hidden != 256) return 0;
+    return (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes);
+}
+
+extern "C" int amtx_bilstm_h_pack(const float* host_whh_fwd, const float* host_whh_bwd, int hidden, int planes, uint16_t* host_out) {
+    AMTX_REQUIRE(host_whh_fwd && host_whh_bwd && host_out && (planes == 1 || planes == 2), "amtx_bilstm_h_pack: bad argument");
+    AMTX_REQUIRE(hidden == 128 || hidden == 256, "amtx_bilstm_h_pack: hidden size %d is not built (128, 256)", hidden);
+    amtx_bilstm_pack_host_h(host_whh_fwd, host_whh_bwd, hidden, planes, host_out);
+    return AMTX_OK;
+}
+
+extern "C" int amtx_bilstm_h_fwd(const void* xproj, const uint16_t* whh_packed, int hidden, int planes, int elem_type, void* out, int batch,
+                                 int num_frames, void* stream) {
+    LstmArgs l;
+    l.xproj = xproj; l.x_type = elem_type; l.whh = whh_packed; l.planes = planes; l.out = out; l.out_type = elem_type;
+    l.B = batch; l.T = num_frames; l.groups = 1; l.x_gs = l.w_gs = l.out_gs = 0; l.hidden = hidden;
     return amtx_launch_bilstm(l, (hipStream_t)stream);
 }
 

@@ -125,6 +125,14 @@ int amtx_conv3x3_pack(const float* host_w /*(c_out,32,3,3)*/, const float* host_
                       uint16_t* host_out);
 int amtx_conv3x3_fwd(const void* in, int elem_type, const uint16_t* w_packed, int planes, const float* shift, void* out, int batch,
                      int num_frames, int num_bins, int c_out, void* stream);
+/* The same layer for the channel counts of the other model complexities (models/onsetsframes.py:362-364 nf = 16 mc / 16 mc / 32 mc;
+ * built: 48 -> 48 and 48 -> 96 = model_complexity 3, OnsetsFrames2's default).  `in` is [B][T][F][c_in] channels-last.
+ * amtx_conv3x3g_packed_elems returns 0 for a pair of channel counts that is not built. */
+int64_t amtx_conv3x3g_packed_elems(int c_in, int c_out, int planes);
+int amtx_conv3x3g_pack(const float* host_w /*(c_out,c_in,3,3)*/, const float* host_scale /*[c_out] or null*/, int c_in, int c_out, int planes,
+                       uint16_t* host_out);
+int amtx_conv3x3g_fwd(const void* in, int elem_type, const uint16_t* w_packed, int planes, const float* shift, void* out, int batch,
+                      int num_frames, int num_bins, int c_in, int c_out, void* stream);
 /* Conv2d(c_in -> c_out, 3x3, pad 1) + folded BatchNorm + ReLU for the first layer (models/onsetsframes.py:375-384) */
 int amtx_conv1_fwd(const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t, int64_t stride_f, const float* w,
                    const float* shift, void* out, int out_type, int batch, int num_frames, int num_bins, int c_in, int c_out,
@@ -134,6 +142,12 @@ int64_t amtx_bilstm_packed_elems(int planes);
 int amtx_bilstm_pack(const float* host_whh_fwd, const float* host_whh_bwd /* (512,128) each */, int planes, uint16_t* host_out);
 int amtx_bilstm_fwd(const void* xproj /*(B,T,2,512)*/, const uint16_t* whh_packed, int planes, int elem_type, void* out /*(B,T,256)*/,
                     int batch, int num_frames, void* stream);
+/* Any built hidden size (128, 256 = dim_lm / 2 at model_complexity 2, 3; models/onsetsframes.py:57-58, 498-507):
+ * W_hh (4 hidden, hidden) per direction, xproj (B,T,2,4 hidden), out (B,T,2 hidden). */
+int64_t amtx_bilstm_h_packed_elems(int hidden, int planes);
+int amtx_bilstm_h_pack(const float* host_whh_fwd, const float* host_whh_bwd, int hidden, int planes, uint16_t* host_out);
+int amtx_bilstm_h_fwd(const void* xproj, const uint16_t* whh_packed, int hidden, int planes, int elem_type, void* out, int batch,
+                      int num_frames, void* stream);
 /* Training (amt_tools/train.py:126-141 drives nn.LSTM's forward + backward through autograd): the same recurrence with the
  * post-activation gates and cell states saved ([B][T][2][5][128] fp32: i, f, g, o, c), and its backward recurrence
  *   dout [B][T][256] -> dxproj [B][T][2][512] = dL/d(W_ih x + b).

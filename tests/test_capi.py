@@ -21,13 +21,15 @@ def test_host_only_queries():
     assert L.amtx_linear_packed_elems(512, 3648, 2) == 2 * 512 * 3648
     assert L.amtx_conv3x3_packed_elems(64, 1) == 9 * 4 * 512
     assert L.amtx_bilstm_packed_elems(2) == 2 * 2 * 512 * 128
+    assert L.amtx_bilstm_h_packed_elems(256, 1) == 2 * 1024 * 256 and L.amtx_bilstm_h_packed_elems(128, 2) == L.amtx_bilstm_packed_elems(2)
+    assert L.amtx_conv3x3g_packed_elems(48, 96, 1) == 9 * 96 * 48 and L.amtx_conv3x3g_packed_elems(32, 40, 1) == 0
 
 
 def test_errors_are_reported_not_swallowed():
     import ctypes as C
     L = _lib.lib()
     h = C.c_void_p()
-    rc = L.amtx_of_model_create(C.byref(h), 229, 1, 3, 88, 1, 0)    # OnsetsFrames2 shape: not implemented yet
+    rc = L.amtx_of_model_create(C.byref(h), 229, 1, 4, 88, 1, 0)    # model_complexity 4: no kernels for its channel counts
     assert rc < 0 and b'model_complexity' in L.amtx_last_error()
     import pytest
     with pytest.raises(_lib.AmtxError):

@@ -81,10 +81,59 @@ def test_onsetsframes2_engine_matches_reference_golden(precision):
         assert np.all((got == g['out_' + key]) | near)
 
 
-def test_model_complexity_3_is_rejected_loudly_by_the_engine():
+@pytest.mark.parametrize('precision', ['x3', 'bf16'])
+def test_onsetsframes2_default_complexity_3_engine_matches_reference_golden(precision):
+    """OnsetsFrames2 as the reference ships it (model_complexity 3: 48/48/96-channel convolutions, LSTM hidden 256, offset head,
+    onsetsframes.py:199-233) through the HIP engine vs vectors recorded from the real reference classes."""
     from amt_tools_amd.models import OnsetsFrames2
+    g = load_golden('of2_eval.npz')
+    assert int(g['model_complexity']) == 3
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=1, model_complexity=3, offsets=True)
+    model = OnsetsFrames2(int(g['dim_in']), tools.PianoProfile(), 1, device='cuda:0', precision=precision)
+    assert model.model_complexity == 3
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    tol = TOL[precision]
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_TIMES: torch.from_numpy(g['out_times'])})
+        logits = model.engine_logits(torch.from_numpy(g['feats']).cuda())
+    for key in ('onsets', 'offsets', 'multi_pitch', 'pitch_head'):
+        err = np.abs(logits[key].cpu().numpy() - g['logits_' + key]).max()
+        assert err < tol, (key, err)
+    assert np.abs(out[tools.KEY_OFFSETS].cpu().numpy() - g['out_offsets']).max() < (1e-4 if precision == 'x3' else 2e-2)
+    for key in ('onsets', 'multi_pitch'):
+        got = out[key].cpu().numpy()
+        near = np.abs(np.swapaxes(g['logits_' + key], -1, -2)) < tol
+        assert np.all((got == g['out_' + key]) | near)
+
+
+def test_complexity_3_engine_vs_oracle_on_ragged_batches():
+    """OnsetsFrames (no offset head) at model_complexity 3 against the oracle on fresh inputs, batch and frame counts that do not
+    fill the kernels' tiles."""
+    from oracle import model_ref
+    from amt_tools_amd.models import OnsetsFrames
+    sd = synth_state_dict(11, dim_in=229, in_channels=1, model_complexity=3)
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 3, device='cuda:0', precision='x3')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    sdt = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(6)
+    for B, T in ((1, 1), (3, 17), (17, 9), (2, 40)):
+        feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32))
+        with torch.no_grad():
+            ref = model_ref.run_on_batch(feats, sdt)
+            got = model.engine_logits(feats.cuda())
+        for key in ('onsets', 'multi_pitch'):
+            assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
+            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+
+
+def test_unbuilt_model_complexity_is_rejected_loudly_by_the_engine():
+    from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd._lib import AmtxError
-    model = OnsetsFrames2(229, tools.PianoProfile(), 1, 3, device='cuda:0')
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 4, device='cuda:0')
     model.change_device()
     model.eval()
     with pytest.raises(AmtxError), torch.no_grad():

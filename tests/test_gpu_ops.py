@@ -91,6 +91,40 @@ def test_conv3x3_bn_relu_pool(planes, b, t, f, cout):
     assert err < _tol(planes, ref.abs().max().item()) + (1e-2 * ref.abs().max().item() if planes == 1 else 0), err
 
 
+@pytest.mark.parametrize('planes', [1, 2])
+@pytest.mark.parametrize('b,t,f,cin,cout', [(2, 40, 229, 48, 48), (1, 17, 114, 48, 96), (3, 5, 36, 48, 48), (1, 33, 18, 48, 96),
+                                            (1, 1, 2, 48, 48), (2, 16, 33, 48, 96)])
+def test_conv3x3_general_channels(planes, b, t, f, cin, cout):
+    """convg.hip (weights staged in LDS): the 48 -> 48 and 48 -> 96 layers of model_complexity 3."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(b * 1000 + t * 10 + f + cout)
+    x = torch.rand(b, t, f, cin, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9.0 * cin) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    n = L.amtx_conv3x3g_packed_elems(cin, cout, planes)
+    assert n > 0
+    packed = np.zeros(n, dtype=np.uint16)
+    _lib.check(L.amtx_conv3x3g_pack(_lib.ptr(w.numpy()), _lib.ptr(scale.numpy()), cin, cout, planes, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    x_d = _to_act(x, planes)
+    out = torch.full((b, t, f // 2, cout), -7.0, dtype=x_d.dtype, device='cuda')
+    shift_d = shift.cuda()
+    _lib.check(L.amtx_conv3x3g_fwd(_lib.ptr(x_d), BF16 if planes == 1 else F32, _lib.ptr(wp), planes, _lib.ptr(shift_d),
+                                   _lib.ptr(out), b, t, f, cin, cout, _stream()), 'amtx_conv3x3g_fwd')
+    ref = _conv_ref(x_d.float().cpu(), w, scale, shift)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < _tol(planes, ref.abs().max().item()) + (1e-2 * ref.abs().max().item() if planes == 1 else 0), err
+
+
+def test_conv3x3_general_rejects_unbuilt_channel_counts():
+    L = _lib.lib()
+    assert L.amtx_conv3x3g_packed_elems(40, 48, 1) == 0 and L.amtx_conv3x3g_packed_elems(48, 80, 1) == 0
+    dummy = np.zeros(16, dtype=np.float32)
+    assert L.amtx_conv3x3g_pack(_lib.ptr(dummy), None, 40, 48, 1, _lib.ptr(dummy)) < 0
+    assert b'not built' in L.amtx_last_error()
+
+
 @pytest.mark.parametrize('cin,f', [(1, 229), (6, 72)])
 @pytest.mark.parametrize('layout', ['bcft', 'bctf'])
 def test_conv1(cin, f, layout):
@@ -110,21 +144,62 @@ def test_conv1(cin, f, layout):
     assert (out.cpu() - ref).abs().max().item() < 2e-5
 
 
-def _lstm_ref(xproj, whh_f, whh_b):
-    """xproj (B,T,2,512) -> (B,T,256), explicit loop in fp64."""
+def _lstm_ref(xproj, whh_f, whh_b, H=128):
+    """xproj (B,T,2,4H) -> (B,T,2H), explicit loop in fp64."""
     B, T = xproj.shape[:2]
-    out = torch.zeros(B, T, 256, dtype=torch.float64)
+    out = torch.zeros(B, T, 2 * H, dtype=torch.float64)
     for d, whh in enumerate((whh_f.double(), whh_b.double())):
-        h = torch.zeros(B, 128, dtype=torch.float64)
-        c = torch.zeros(B, 128, dtype=torch.float64)
+        h = torch.zeros(B, H, dtype=torch.float64)
+        c = torch.zeros(B, H, dtype=torch.float64)
         for s in range(T):
             t = s if d == 0 else T - 1 - s
             gates = xproj[:, t, d].double() + h @ whh.T
             i, f, g, o = gates.chunk(4, dim=-1)
             c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
             h = torch.sigmoid(o) * torch.tanh(c)
-            out[:, t, 128 * d:128 * (d + 1)] = h
+            out[:, t, H * d:H * (d + 1)] = h
     return out.float()
+
+
+@pytest.mark.parametrize('planes', [1, 2])
+@pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (40, 120)])
+def test_bilstm_hidden_256(planes, b, t):
+    """lstm.hip bilstm_stream_kernel (W_hh streamed from L2): the recurrence of model_complexity 3 (hidden 256 per direction)."""
+    L = _lib.lib()
+    H = 256
+    g = torch.Generator().manual_seed(b * 100 + t)
+    xproj = torch.randn(b, t, 2, 4 * H, generator=g)
+    whh_f = (torch.rand(4 * H, H, generator=g) - 0.5) * 0.2
+    whh_b = (torch.rand(4 * H, H, generator=g) - 0.5) * 0.2
+    packed = np.zeros(L.amtx_bilstm_h_packed_elems(H, planes), dtype=np.uint16)
+    _lib.check(L.amtx_bilstm_h_pack(_lib.ptr(whh_f.numpy()), _lib.ptr(whh_b.numpy()), H, planes, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    x_d = _to_act(xproj, planes)
+    out = torch.full((b, t, 2 * H), 9.0, dtype=x_d.dtype, device='cuda')
+    _lib.check(L.amtx_bilstm_h_fwd(_lib.ptr(x_d), _lib.ptr(wp), H, planes, BF16 if planes == 1 else F32, _lib.ptr(out), b, t, _stream()),
+               'amtx_bilstm_h_fwd')
+    ref = _lstm_ref(x_d.float().cpu(), whh_f, whh_b, H)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < (3e-5 if planes == 2 else 3e-2), err
+
+
+def test_bilstm_h_entry_runs_hidden_128_like_the_fixed_entry():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    b, t = 5, 20
+    xproj = torch.randn(b, t, 2, 512, generator=g)
+    whh_f = (torch.rand(512, 128, generator=g) - 0.5) * 0.3
+    whh_b = (torch.rand(512, 128, generator=g) - 0.5) * 0.3
+    packed = np.zeros(L.amtx_bilstm_h_packed_elems(128, 2), dtype=np.uint16)
+    _lib.check(L.amtx_bilstm_h_pack(_lib.ptr(whh_f.numpy()), _lib.ptr(whh_b.numpy()), 128, 2, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    x_d = xproj.cuda()
+    out_a = torch.zeros(b, t, 256, device='cuda')
+    out_b = torch.zeros(b, t, 256, device='cuda')
+    _lib.check(L.amtx_bilstm_h_fwd(_lib.ptr(x_d), _lib.ptr(wp), 128, 2, F32, _lib.ptr(out_a), b, t, _stream()))
+    _lib.check(L.amtx_bilstm_fwd(_lib.ptr(x_d), _lib.ptr(wp), 2, F32, _lib.ptr(out_b), b, t, _stream()))
+    assert torch.equal(out_a, out_b)
+    assert L.amtx_bilstm_h_packed_elems(192, 1) == 0
 
 
 @pytest.mark.parametrize('planes', [1, 2])
