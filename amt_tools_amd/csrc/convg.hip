@@ -6,7 +6,10 @@
 // MFMA N-tile, pooling pair and channels-last store lane-local), but C_in is any multiple of 16 and the folded weights do not
 // fit the register file next to two waves per SIMD, so they are staged in LDS in fragment order, one C_out chunk of NTC
 // 16-channel tiles at a time:
-//   * K per tap = C_in = n32 x 32 (v_mfma_f32_16x16x32_bf16) + (C_in % 32 ? one 16-deep v_mfma_f32_16x16x16_bf16 : none),
+//   * K per tap = C_in = n32 x 32 (v_mfma_f32_16x16x32_bf16) + (C_in % 32 ? one more 32-deep step whose upper half (lane groups
+//     2, 3) multiplies zero weights : none).  The legacy 16-deep v_mfma_f32_16x16x16_bf16 is NOT used for that tail: mixed into
+//     the 32-deep accumulation chains it gave wrong, run-to-run varying values in the later result registers on MI355X (first
+//     version of this file; hipcc 7.2 schedules it with too few wait states), and it costs the same issue cycles anyway,
 //   * the input tile (18 x (FT+2) positions) is held chunk-major (16-byte chunk c of a position at c * CPLANE + position * 16,
 //     CPLANE = 48 (mod 256) bytes, odd row pitch): the fragment reads of 16 consecutive rows and the staging stores of
 //     consecutive chunks both spread over the banks,
@@ -25,12 +28,8 @@ constexpr int GTT = 16;             // frames per tile
 constexpr int GROWS = GTT + 2;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g_bf16x8;
-typedef __attribute__((ext_vector_type(4))) short g_s16x4;
 __device__ __forceinline__ f32x4_t gm32(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4_t gm16(uint2 a, uint2 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(g_s16x4, a), __builtin_bit_cast(g_s16x4, b), c, 0, 0, 0);
 }
 
 constexpr int g_cplane(int ft) {
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     const int t_out = t0 + r16;
     const int xrow = r16 * PC * 16;                            // byte offset of this lane's row (kh = 0) in a chunk plane
     const int x32 = g * CPLANE;                                // + ks * 4 * CPLANE: chunk 4 ks + g
-    const int x16 = (4 * N32 + (g >> 1)) * CPLANE + (g & 1) * 8;
+    const int x16 = (4 * N32 + (g & 1)) * CPLANE;              // tail step: lane groups 2, 3 re-read the chunks of 0, 1 (their weights are zero)
 
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch > 0) __syncthreads();                           // everybody is done with the previous chunk's weights
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             uint4 xa[6][N32 > 0 ? N32 : 1][NS];
-            uint2 xb[6][NS];
+            uint4 xb[6][NS];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const int base = xrow + (kh * PC + jb + c) * 16;
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                 for (int p = 0; p < NS; ++p) {
 #pragma unroll
                     for (int ks = 0; ks < N32; ++ks) xa[c][ks][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x32 + ks * 4 * CPLANE);
-                    if (N16) xb[c][p] = *reinterpret_cast<const uint2*>(xs + p * XPLANE + base + x16);
+                    if (N16) xb[c][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x16);
                 }
             }
 #pragma unroll
@@ -160,15 +159,18 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                         }
                     }
                     if (N16) {
-                        uint2 w[NS];
+                        uint4 w[NS];
 #pragma unroll
-                        for (int p = 0; p < NS; ++p) w[p] = *reinterpret_cast<const uint2*>(wp + N32 * NS * 1024 + p * 512 + lane * 8);
+                        for (int p = 0; p < NS; ++p) {
+                            w[p] = make_uint4(0, 0, 0, 0);
+                            if (g < 2) w[p] = *reinterpret_cast<const uint4*>(wp + N32 * NS * 1024 + p * 512 + (lane & 31) * 16);
+                        }
 #pragma unroll
                         for (int col = 0; col < 4; ++col) {
-                            acc[col][nt] = gm16(w[0], xb[col + kw][0], acc[col][nt]);
+                            acc[col][nt] = gm32(w[0], xb[col + kw][0], acc[col][nt]);
                             if (NS == 2) {
-                                acc[col][nt] = gm16(w[0], xb[col + kw][1], acc[col][nt]);
-                                acc[col][nt] = gm16(w[1], xb[col + kw][0], acc[col][nt]);
+                                acc[col][nt] = gm32(w[0], xb[col + kw][1], acc[col][nt]);
+                                acc[col][nt] = gm32(w[1], xb[col + kw][0], acc[col][nt]);
                             }
                         }
                     }
@@ -236,7 +238,7 @@ int amtx_conv3x3_gen_ntc(int c_in, int c_out) {
 
 size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes) { return (size_t)9 * (c_out / 16) * planes * g_wfrag_bytes(c_in / 16) / 2; }
 
-// host packing: weight (c_out, c_in, 3, 3) fp32 * scale[c_out] -> [chunk][tap][tile][k-step][plane][lane][8 or 4]
+// host packing: weight (c_out, c_in, 3, 3) fp32 * scale[c_out] -> [chunk][tap][tile][k-step][plane][lane][8] (tail step: 32 lanes)
 void amtx_conv3x3_gen_pack_host(const float* w, const float* scale, int c_in, int c_out, int planes, bf16_t* out) {
     const int ntc = amtx_conv3x3_gen_ntc(c_in, c_out);
     const int ci16 = c_in / 16, n32 = ci16 / 2, n16 = ci16 % 2;
@@ -258,14 +260,14 @@ void amtx_conv3x3_gen_pack_host(const float* w, const float* scale, int c_in, in
                             base[((size_t)ks * planes + 0) * 512 + l * 8 + j] = hi;
                             if (planes == 2) base[((size_t)ks * planes + 1) * 512 + l * 8 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
                         }
-                    if (n16)
-                        for (int j = 0; j < 4; ++j) {
-                            const int ci = 32 * n32 + 4 * gq + j;
+                    if (n16 && gq < 2)                                   // tail: lane groups 0, 1 of a 32-deep step, 8 channels each
+                        for (int j = 0; j < 8; ++j) {
+                            const int ci = 32 * n32 + 8 * gq + j;
                             const float v = w[((size_t)co * c_in + ci) * 9 + tap] * sc;
                             const bf16_t hi = f32_to_bf16_rn(v);
                             bf16_t* b16 = base + (size_t)n32 * planes * 512;
-                            b16[l * 4 + j] = hi;
-                            if (planes == 2) b16[256 + l * 4 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                            b16[l * 8 + j] = hi;
+                            if (planes == 2) b16[256 + l * 8 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
                         }
                 }
             }

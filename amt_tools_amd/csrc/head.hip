@@ -6,6 +6,8 @@
 
 #include "amtx_kernels.h"
 
+#include <algorithm>
+
 namespace {
 
 __global__ __launch_bounds__(256) void pianoroll_kernel(const float* __restrict__ logits, int64_t ld, int col0, int T, int keys,
@@ -49,6 +51,23 @@ __global__ __launch_bounds__(256) void cvt_pad_bf16_kernel(const float* __restri
 }
 
 }  // namespace
+
+// zero `width` bytes (a multiple of 16) at the start of each of `rows` rows that are `pitch` bytes apart
+__global__ __launch_bounds__(256) void zero_cols_kernel(char* __restrict__ base, int64_t pitch, int w16, int64_t rows) {
+    const int64_t n = rows * w16;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        *reinterpret_cast<uint4*>(base + (i / w16) * pitch + (i % w16) * 16) = make_uint4(0, 0, 0, 0);
+}
+
+int amtx_launch_zero_cols(void* base, int64_t pitch_bytes, int width_bytes, int64_t rows, hipStream_t stream) {
+    AMTX_REQUIRE(base && width_bytes > 0 && width_bytes % 16 == 0 && pitch_bytes % 16 == 0 && ((uintptr_t)base % 16) == 0 && rows > 0,
+                 "zero_cols: bad argument");
+    const int64_t n = rows * (width_bytes / 16);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(zero_cols_kernel, dim3(blocks), dim3(256), 0, stream, (char*)base, pitch_bytes, width_bytes / 16, rows);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
 
 int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream) {
     AMTX_REQUIRE(src && dst && rows > 0 && n_src % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0 && ld_dst >= n_src, "cvt_pad_bf16: bad argument");

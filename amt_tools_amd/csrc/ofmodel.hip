@@ -17,6 +17,7 @@
 #include "amtx_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -423,8 +424,8 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
         AMTX_REQUIRE(m->gen_conv, "amtx_of_forward: internal: padded fc1 rows need the general conv kernel");
         c3.out_ts = m->kfc_pad;
         const size_t es = amtx_tsize(at);
-        AMTX_CHECK_HIP(hipMemset2DAsync(w.a3 + (size_t)m->kfc * es, (size_t)m->kfc_pad * es, 0, (size_t)(m->kfc_pad - m->kfc) * es,
-                                        (size_t)BT * m->n_heads, s));
+        if ((rc = amtx_launch_zero_cols(w.a3 + (size_t)m->kfc * es, (int64_t)m->kfc_pad * es, (int)((m->kfc_pad - m->kfc) * es),
+                                        BT * m->n_heads, s)) != AMTX_OK) return rc;
     }
     if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
     mark();

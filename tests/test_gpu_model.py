@@ -130,6 +130,27 @@ def test_complexity_3_engine_vs_oracle_on_ragged_batches():
             assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
 
 
+@pytest.mark.parametrize('mc', [2, 3])
+@pytest.mark.parametrize('precision', ['bf16', 'x3'])
+def test_engine_is_deterministic_run_to_run(mc, precision):
+    """Same input, same workspace contents or not: identical bits.  (The first general-channel conv kernel mixed the legacy 16-deep
+    bf16 MFMA into 32-deep accumulation chains and produced run-to-run varying values; this is the screen for that class of bug.)"""
+    from amt_tools_amd.models import OnsetsFrames2
+    sd = synth_state_dict(5, dim_in=229, in_channels=1, model_complexity=mc, offsets=True)
+    model = OnsetsFrames2(229, tools.PianoProfile(), 1, mc, device='cuda:0', precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    feats = torch.from_numpy(np.random.default_rng(2).random((3, 1, 229, 70)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        first = {k: v.clone() for k, v in model.engine_logits(feats).items()}
+        model._get_engine(feats.device).workspace.fill_(0xFF)      # stale workspace contents (here: NaN bit patterns) must not matter
+        for _ in range(3):
+            again = model.engine_logits(feats)
+            for k in first:
+                assert torch.equal(first[k], again[k]), k
+
+
 def test_unbuilt_model_complexity_is_rejected_loudly_by_the_engine():
     from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd._lib import AmtxError
