@@ -11,8 +11,8 @@
 //     the 32-deep accumulation chains it gave wrong, run-to-run varying values in the later result registers on MI355X (first
 //     version of this file; hipcc 7.2 schedules it with too few wait states), and it costs the same issue cycles anyway,
 //   * the input tile (18 x (FT+2) positions) is held chunk-major (16-byte chunk c of a position at c * CPLANE + position * 16,
-//     CPLANE = 48 (mod 256) bytes, odd row pitch): the fragment reads of 16 consecutive rows and the staging stores of
-//     consecutive chunks both spread over the banks,
+//     CPLANE = 48 (mod 256) bytes, row pitch FT + 2 = 2 (mod 16) positions): the fragment reads of 16 consecutive rows are
+//     conflict-free, the staging stores of consecutive chunks spread over the banks,
 //   * one wave = four neighbouring output columns (two pooled outputs) x all NTC tiles of the chunk: a weight fragment read
 //     from LDS feeds 4 MFMAs, an input fragment NTC x (up to) 3,
 //   * x3 precision: hi/lo planes of both operands, 3 MFMAs per product (as everywhere else in this library).
@@ -21,6 +21,7 @@
 #include "amtx_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -34,7 +35,7 @@ __device__ __forceinline__ f32x4_t gm32(uint4 a, uint4 b, f32x4_t c) {
 
 constexpr int g_cplane(int ft) {
     // bytes of one chunk plane: ROWS x PC positions x 16 B, rounded up to 48 (mod 256)
-    const int pc = (ft + 2) | 1;
+    const int pc = ft + 2;
     const int raw = GROWS * pc * 16;
     return (raw + 255 - 48) / 256 * 256 + 48;
 }
@@ -43,17 +44,23 @@ constexpr int g_cplane(int ft) {
 constexpr int g_wfrag_bytes(int ci16) { return (ci16 / 2) * 1024 + (ci16 % 2) * 512; }
 
 template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE>
-__global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks) {
+__global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
     constexpr int NCH = CIN / 8;                 // 16-byte chunks per position
     constexpr int N32 = CI16 / 2, N16 = CI16 % 2;
-    constexpr int PC = (FT + 2) | 1;             // positions per tile row (odd)
+    constexpr int PC = FT + 2;                   // positions per tile row: FT + 2 = 2 (mod 16) with CPLANE = 48 (mod 256) bytes keeps
+                                                 // every ds_read_b128 lane group on 16 distinct 16-byte slots (tools/lds_swizzle_search.py model)
     constexpr int COLS = FT + 2;
     constexpr int CPLANE = g_cplane(FT);
     constexpr int XPLANE = NCH * CPLANE;         // one precision plane of the input tile
     constexpr int WFRAG = g_wfrag_bytes(CI16);   // one plane of one (tap, tile)
     constexpr int WCHUNK = 9 * NTC * NS * WFRAG; // all planes of one C_out chunk
+    constexpr int IES = IN_TYPE == AMTX_T_BF16 ? 2 : 4;
+    constexpr int NITEMS = GROWS * COLS * NCH;
+    constexpr int NIT = (NITEMS + NTH - 1) / NTH;
+    constexpr int NWIT = (WCHUNK / 16 + NTH - 1) / NTH;
+    constexpr int NRAW = IN_TYPE == AMTX_T_BF16 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     char* ws = smem + NS * XPLANE;
@@ -61,141 +68,205 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int grp = blockIdx.y;
-    int tile = blockIdx.x;
-    const int tf = tile % ntf; tile /= ntf;
-    const int tt = tile % ntt; tile /= ntt;
-    const int b = tile, t0 = tt * GTT, f0 = tf * FT;
     const int F = a.F, T = a.T, F2 = F >> 1;
-    constexpr int IES = IN_TYPE == AMTX_T_BF16 ? 2 : 4;
     const int64_t out_ts = a.out_ts ? a.out_ts : (int64_t)F2 * a.c_out;
+    const char* in_g = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * IES;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wfrag) + (int64_t)grp * a.w_gs * 2);
 
-    // ---- stage the input tile: rows t0-1 .. t0+16, columns f0-1 .. f0+FT, zero outside the map
-    {
-        const char* in = reinterpret_cast<const char*>(a.in) + ((int64_t)grp * a.in_gs + (int64_t)b * T * F * CIN) * IES;
-        constexpr int NITEMS = GROWS * COLS * NCH;
-        for (int it = tid; it < NITEMS; it += NTH) {
+    // tile id -> (clip, first frame, first column); consecutive ids of one XCD are spatial neighbours (halo rows / columns come
+    // from that XCD's L2 instead of HBM)
+    auto coord = [&](int tile, int& b, int& t0, int& f0) {
+        tile = (int)xcd_remap((unsigned)tile, (unsigned)ntiles);
+        const int tf = tile % ntf; tile /= ntf;
+        const int tt = tile % ntt; tile /= ntt;
+        b = tile; t0 = tt * GTT; f0 = tf * FT;
+    };
+    // All loads of a thread are issued before the first LDS store (clamped addresses + a select instead of a branch: a branchy
+    // loop costs one full memory round trip per item).  Rows t0-1 .. t0+16, columns f0-1 .. f0+FT, zero outside the map.
+    auto load_x = [&](int tile, uint4 (&raw)[NIT][NRAW], unsigned& okmask) {
+        int b, t0, f0;
+        coord(tile, b, t0, f0);
+        const char* in = in_g + (int64_t)b * T * F * CIN * IES;
+        okmask = 0;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            int it = tid + k * NTH;
+            it = it < NITEMS ? it : NITEMS - 1;
             const int c = it % NCH, pos = it / NCH;
             const int i = pos / COLS, j = pos % COLS;
             const int t = t0 - 1 + i, f = f0 - 1 + j;
-            const bool ok = t >= 0 && t < T && f >= 0 && f < F;
-            uint4 hi = make_uint4(0, 0, 0, 0), lo = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const char* p = in + (((int64_t)t * F + f) * CIN + c * 8) * IES;
-                if (IN_TYPE == AMTX_T_BF16) {
-                    hi = *reinterpret_cast<const uint4*>(p);
+            if (t >= 0 && t < T && f >= 0 && f < F) okmask |= 1u << k;
+            const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
+            const char* p = in + (((int64_t)tc * F + fc) * CIN + c * 8) * IES;
+            raw[k][0] = *reinterpret_cast<const uint4*>(p);
+            if (NRAW == 2) raw[k][NRAW - 1] = reinterpret_cast<const uint4*>(p)[1];
+        }
+    };
+    auto store_x = [&](const uint4 (&raw)[NIT][NRAW], unsigned okmask) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int it = tid + k * NTH;
+            const int c = it % NCH, pos = it / NCH;
+            uint4 hi = raw[k][0], lo = make_uint4(0, 0, 0, 0);
+            if (NRAW == 2) {
+                const float4 v0 = __builtin_bit_cast(float4, raw[k][0]), v1 = __builtin_bit_cast(float4, raw[k][NRAW - 1]);
+                if (NS == 2) {
+                    split_bf16x2(v0.x, v0.y, hi.x, lo.x); split_bf16x2(v0.z, v0.w, hi.y, lo.y);
+                    split_bf16x2(v1.x, v1.y, hi.z, lo.z); split_bf16x2(v1.z, v1.w, hi.w, lo.w);
                 } else {
-                    const float4 v0 = reinterpret_cast<const float4*>(p)[0], v1 = reinterpret_cast<const float4*>(p)[1];
-                    if (NS == 2) {
-                        split_bf16x2(v0.x, v0.y, hi.x, lo.x); split_bf16x2(v0.z, v0.w, hi.y, lo.y);
-                        split_bf16x2(v1.x, v1.y, hi.z, lo.z); split_bf16x2(v1.z, v1.w, hi.w, lo.w);
-                    } else {
-                        hi = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w));
-                    }
+                    hi = make_uint4(pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w));
                 }
             }
-            const int off = c * CPLANE + (i * PC + j) * 16;
-            *reinterpret_cast<uint4*>(xs + off) = hi;
-            if (NS == 2) *reinterpret_cast<uint4*>(xs + XPLANE + off) = lo;
+            if (!((okmask >> k) & 1)) { hi = make_uint4(0, 0, 0, 0); lo = hi; }
+            if (it < NITEMS) {
+                const int off = c * CPLANE + pos * 16;        // PC == COLS: tile position (i, j) is slot i * COLS + j
+                *reinterpret_cast<uint4*>(xs + off) = hi;
+                if (NS == 2) *reinterpret_cast<uint4*>(xs + XPLANE + off) = lo;
+            }
         }
-    }
+    };
+    auto load_w = [&](int ch, uint4 (&wreg)[NWIT]) {
+#pragma unroll
+        for (int k = 0; k < NWIT; ++k) {
+            const int it = tid + k * NTH;
+            wreg[k] = wsrc[(int64_t)ch * (WCHUNK / 16) + (it < WCHUNK / 16 ? it : 0)];
+        }
+    };
+    auto store_w = [&](const uint4 (&wreg)[NWIT]) {
+#pragma unroll
+        for (int k = 0; k < NWIT; ++k) {
+            const int it = tid + k * NTH;
+            if (it < WCHUNK / 16) reinterpret_cast<uint4*>(ws)[it] = wreg[k];
+        }
+    };
 
     const int jb = 4 * wave;                                   // first of this wave's four output columns (tile-relative)
-    const int t_out = t0 + r16;
     const int xrow = r16 * PC * 16;                            // byte offset of this lane's row (kh = 0) in a chunk plane
     const int x32 = g * CPLANE;                                // + ks * 4 * CPLANE: chunk 4 ks + g
     const int x16 = (4 * N32 + (g & 1)) * CPLANE;              // tail step: lane groups 2, 3 re-read the chunks of 0, 1 (their weights are zero)
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch > 0) __syncthreads();                           // everybody is done with the previous chunk's weights
-        {
-            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wfrag) + ((int64_t)grp * a.w_gs * 2 + (int64_t)ch * WCHUNK));
-            for (int it = tid; it < WCHUNK / 16; it += NTH) reinterpret_cast<uint4*>(ws)[it] = src[it];
-        }
-        __syncthreads();
+    // Persistent blocks (one per CU: the tile and one weight chunk fill most of the LDS): the NEXT tile's input and the NEXT
+    // weight chunk travel HBM/L2 -> registers while the current ones are on the matrix cores, so neither the block start-up nor
+    // a memory round trip is paid per tile.  With a single C_out chunk the weights stay in LDS for the whole launch.
+    uint4 xraw[NIT][NRAW], wreg[NWIT];
+    unsigned xok;
+    int tile = blockIdx.x;
+    load_x(tile, xraw, xok);
+    bool w_resident = false;
+    if (w_all) {                                               // every C_out chunk fits next to the tile: weights stay in LDS for the launch
+        for (int it = tid; it < nchunks * (WCHUNK / 16); it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[it];
+        w_resident = true;
+    } else {
+        load_w(0, wreg);
+    }
 
-        // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
-        f32x4_t acc[4][NTC];
-        {
-            const float* sh = a.shift + (int64_t)grp * a.shift_gs + ch * 16 * NTC + g * 4 * NTC;
-#pragma unroll
-            for (int nt = 0; nt < NTC; ++nt) {
-                const float4 s = *reinterpret_cast<const float4*>(sh + 4 * nt);
-#pragma unroll
-                for (int col = 0; col < 4; ++col) acc[col][nt] = (f32x4_t){s.x, s.y, s.z, s.w};
-            }
-        }
+    for (; tile < ntiles; tile += gridDim.x) {
+        int b, t0, f0;
+        coord(tile, b, t0, f0);
+        const int t_out = t0 + r16;
+        store_x(xraw, xok);
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
 
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            uint4 xa[6][N32 > 0 ? N32 : 1][NS];
-            uint4 xb[6][NS];
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const int base = xrow + (kh * PC + jb + c) * 16;
-#pragma unroll
-                for (int p = 0; p < NS; ++p) {
-#pragma unroll
-                    for (int ks = 0; ks < N32; ++ks) xa[c][ks][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x32 + ks * 4 * CPLANE);
-                    if (N16) xb[c][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x16);
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (!w_resident) store_w(wreg);
+            if (!w_all || ch == 0) __syncthreads();            // tile and weight chunk visible
+            if (ch == 0 && has_next) load_x(next, xraw, xok);  // in flight during the MFMA phase
+            if (!w_all) {
+                if (nchunks > 1) {
+                    if (ch + 1 < nchunks) load_w(ch + 1, wreg);
+                    else if (has_next) load_w(0, wreg);
+                } else {
+                    w_resident = true;
                 }
             }
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
+
+            const char* wsc = ws + (w_all ? ch * WCHUNK : 0);
+            // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
+            f32x4_t acc[4][NTC];
+            {
+                const float* sh = a.shift + (int64_t)grp * a.shift_gs + ch * 16 * NTC + g * 4 * NTC;
 #pragma unroll
                 for (int nt = 0; nt < NTC; ++nt) {
-                    const char* wp = ws + ((kh * 3 + kw) * NTC + nt) * NS * WFRAG;
+                    const float4 s = *reinterpret_cast<const float4*>(sh + 4 * nt);
 #pragma unroll
-                    for (int ks = 0; ks < N32; ++ks) {
-                        uint4 w[NS];
+                    for (int col = 0; col < 4; ++col) acc[col][nt] = (f32x4_t){s.x, s.y, s.z, s.w};
+                }
+            }
+
 #pragma unroll
-                        for (int p = 0; p < NS; ++p) w[p] = *reinterpret_cast<const uint4*>(wp + (ks * NS + p) * 1024 + lane * 16);
+            for (int kh = 0; kh < 3; ++kh) {
+                uint4 xa[6][N32 > 0 ? N32 : 1][NS];
+                uint4 xb[6][NS];
 #pragma unroll
-                        for (int col = 0; col < 4; ++col) {
-                            acc[col][nt] = gm32(w[0], xa[col + kw][ks][0], acc[col][nt]);
-                            if (NS == 2) {
-                                acc[col][nt] = gm32(w[0], xa[col + kw][ks][1], acc[col][nt]);
-                                acc[col][nt] = gm32(w[1], xa[col + kw][ks][0], acc[col][nt]);
+                for (int c = 0; c < 6; ++c) {
+                    const int base = xrow + (kh * PC + jb + c) * 16;
+#pragma unroll
+                    for (int p = 0; p < NS; ++p) {
+#pragma unroll
+                        for (int ks = 0; ks < N32; ++ks) xa[c][ks][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x32 + ks * 4 * CPLANE);
+                        if (N16) xb[c][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x16);
+                    }
+                }
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+#pragma unroll
+                    for (int nt = 0; nt < NTC; ++nt) {
+                        const char* wp = wsc + ((kh * 3 + kw) * NTC + nt) * NS * WFRAG;
+#pragma unroll
+                        for (int ks = 0; ks < N32; ++ks) {
+                            uint4 w[NS];
+#pragma unroll
+                            for (int p = 0; p < NS; ++p) w[p] = *reinterpret_cast<const uint4*>(wp + (ks * NS + p) * 1024 + lane * 16);
+#pragma unroll
+                            for (int col = 0; col < 4; ++col) {
+                                acc[col][nt] = gm32(w[0], xa[col + kw][ks][0], acc[col][nt]);
+                                if (NS == 2) {
+                                    acc[col][nt] = gm32(w[0], xa[col + kw][ks][1], acc[col][nt]);
+                                    acc[col][nt] = gm32(w[1], xa[col + kw][ks][0], acc[col][nt]);
+                                }
+                            }
+                        }
+                        if (N16) {
+                            uint4 w[NS];
+#pragma unroll
+                            for (int p = 0; p < NS; ++p) {
+                                w[p] = make_uint4(0, 0, 0, 0);
+                                if (g < 2) w[p] = *reinterpret_cast<const uint4*>(wp + N32 * NS * 1024 + p * 512 + (lane & 31) * 16);
+                            }
+#pragma unroll
+                            for (int col = 0; col < 4; ++col) {
+                                acc[col][nt] = gm32(w[0], xb[col + kw][0], acc[col][nt]);
+                                if (NS == 2) {
+                                    acc[col][nt] = gm32(w[0], xb[col + kw][1], acc[col][nt]);
+                                    acc[col][nt] = gm32(w[1], xb[col + kw][0], acc[col][nt]);
+                                }
                             }
                         }
                     }
-                    if (N16) {
-                        uint4 w[NS];
+                }
+            }
+
+            // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
+            if (t_out < T) {
 #pragma unroll
-                        for (int p = 0; p < NS; ++p) {
-                            w[p] = make_uint4(0, 0, 0, 0);
-                            if (g < 2) w[p] = *reinterpret_cast<const uint4*>(wp + N32 * NS * 1024 + p * 512 + (lane & 31) * 16);
-                        }
+                for (int pr = 0; pr < 2; ++pr) {
+                    const int fo = (f0 + jb + 2 * pr) >> 1;
+                    if (fo >= F2) continue;
+                    const int64_t o = (int64_t)grp * a.out_gs + ((int64_t)b * T + t_out) * out_ts + (int64_t)fo * a.c_out + ch * 16 * NTC + g * 4 * NTC;
 #pragma unroll
-                        for (int col = 0; col < 4; ++col) {
-                            acc[col][nt] = gm32(w[0], xb[col + kw][0], acc[col][nt]);
-                            if (NS == 2) {
-                                acc[col][nt] = gm32(w[0], xb[col + kw][1], acc[col][nt]);
-                                acc[col][nt] = gm32(w[1], xb[col + kw][0], acc[col][nt]);
-                            }
-                        }
+                    for (int nt = 0; nt < NTC; ++nt) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(acc[2 * pr][nt][r], acc[2 * pr + 1][nt][r]), 0.f);
+                        if (OUT_TYPE == AMTX_T_BF16)
+                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        else
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4 * nt) = make_float4(v[0], v[1], v[2], v[3]);
                     }
                 }
             }
-        }
-
-        // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
-        if (t_out < T) {
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const int fo = (f0 + jb + 2 * pr) >> 1;
-                if (fo >= F2) continue;
-                const int64_t o = (int64_t)grp * a.out_gs + ((int64_t)b * T + t_out) * out_ts + (int64_t)fo * a.c_out + ch * 16 * NTC + g * 4 * NTC;
-#pragma unroll
-                for (int nt = 0; nt < NTC; ++nt) {
-                    float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(acc[2 * pr][nt][r], acc[2 * pr + 1][nt][r]), 0.f);
-                    if (OUT_TYPE == AMTX_T_BF16)
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                    else
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4 * nt) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
+            if (!w_all || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
         }
     }
 }
@@ -205,24 +276,35 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
     const int ntf = (fe + FT - 1) / FT;
     const int ntt = (a.T + GTT - 1) / GTT;
-    const int64_t nblocks = (int64_t)ntf * ntt * a.B;
-    AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
+    const int64_t ntiles = (int64_t)ntf * ntt * a.B;
+    AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
     const int nchunks = a.c_out / (16 * NTC);
-    const size_t lds = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT) + (size_t)9 * NTC * NS * g_wfrag_bytes(CI16);
+    const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)9 * NTC * NS * g_wfrag_bytes(CI16);
+    const int w_all = nchunks > 1 && lds_x + nchunks * wchunk <= 160 * 1024;
+    const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk;
     auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE>;
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
+    static size_t granted = 0;
+    if (lds > granted && lds > 64 * 1024) {
         AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        granted = lds;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks);
+    // persistent grid: as many blocks as fit the chip at once (LDS allows 160 KiB / lds per CU), a multiple of 8 per group so a
+    // block's tiles stay on its XCD
+    const int per_cu = std::max(1, (int)(160 * 1024 / lds));
+    int64_t gx = std::max<int64_t>(8, (256 * per_cu / std::max(1, a.groups)) / 8 * 8);
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
 
 template <int CI16, int NTC>
 int dispatch_gen(const ConvArgs& a, hipStream_t s) {
-    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
+    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) {
+        static const bool narrow = getenv("AMTX_CONVG_FT16") != nullptr;
+        if (narrow) return launch_gen<CI16, NTC, 1, 16, AMTX_T_BF16, AMTX_T_BF16>(a, s);
+        return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
+    }
     if (a.planes == 2 && a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32>(a, s);
     amtx_set_error("conv3x3 (general): unsupported precision/type combination");
     return AMTX_ERR_UNSUPPORTED;
