@@ -51,6 +51,10 @@ int amtx_conv3x3_gen_ntc(int c_in, int c_out);           // 0 = this pair of cha
 size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes);
 void amtx_conv3x3_gen_pack_host(const float* w /*(c_out,c_in,3,3)*/, const float* scale, int c_in, int c_out, int planes, bf16_t* out);
 int amtx_launch_conv3x3_gen(const ConvArgs& c, int c_in, hipStream_t stream);
+// fused first conv of the general kernel (ConvArgs.feats / c_in / w1frag / shift1 as for conv.hip; `c_in` above = its output channels)
+size_t amtx_conv1g_wfrag_elems(int c_in, int c_mid, int planes);
+void amtx_conv1g_pack_host(const float* w /*(c_mid,c_in,3,3)*/, const float* scale, int c_in, int c_mid, int planes, bf16_t* out);
+bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes);
 
 // ---------------------------------------------------------------- first conv (small C_in) + folded BN + ReLU, direct
 struct Conv1Args {

@@ -43,7 +43,11 @@ constexpr int g_cplane(int ft) {
 // per (tap, tile) weight bytes of one plane in LDS / in the packed global buffer
 constexpr int g_wfrag_bytes(int ci16) { return (ci16 / 2) * 1024 + (ci16 % 2) * 512; }
 
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE>
+// KS1 > 0: the first convolution (Conv2d(c_in -> C_in of this layer) + BN + ReLU, models/onsetsframes.py:375-384) is computed
+// inside this kernel, from the fp32 features, straight into the LDS input tile (the C_in-channel map never exists in HBM):
+// K = 9 c_in taps padded to KS1 32-deep steps, im2col gathered per lane from a small feature tile in LDS, D' = W1 . P^T per
+// 16 tile positions, epilogue shift + ReLU + zero outside the map + bf16 (hi/lo) -> 8-byte LDS stores.
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1>
 __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
@@ -61,6 +65,11 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     constexpr int NIT = (NITEMS + NTH - 1) / NTH;
     constexpr int NWIT = (WCHUNK / 16 + NTH - 1) / NTH;
     constexpr int NRAW = IN_TYPE == AMTX_T_BF16 ? 1 : 2;
+    constexpr bool FUSE1 = KS1 > 0;
+    constexpr int FROWS1 = GROWS + 2, FP1 = FT + 4 + 1;      // feature tile: rows t0-2 .. t0+17, columns f0-2 .. f0+FT+1 (+1 pad)
+    constexpr int NPOS = GROWS * COLS;                        // positions of the input tile
+    constexpr int NNT1 = (NPOS + 15) / 16;                    // 16-position groups of the fused first conv
+    constexpr int NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs = smem;
     char* ws = smem + NS * XPLANE;
@@ -70,6 +79,9 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     const int grp = blockIdx.y;
     const int F = a.F, T = a.T, F2 = F >> 1;
     const int64_t out_ts = a.out_ts ? a.out_ts : (int64_t)F2 * a.c_out;
+    float* fs = reinterpret_cast<float*>(ws + (w_all ? nchunks : 1) * WCHUNK);      // FUSE1: [c_in][FROWS1][FP1] fp32 features
+    const int c_in1 = a.c_in;
+    const int nfeat = c_in1 * FROWS1 * (FT + 4);
     const char* in_g = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * IES;
     const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wfrag) + (int64_t)grp * a.w_gs * 2);
 
@@ -148,10 +160,113 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     // Persistent blocks (one per CU: the tile and one weight chunk fill most of the LDS): the NEXT tile's input and the NEXT
     // weight chunk travel HBM/L2 -> registers while the current ones are on the matrix cores, so neither the block start-up nor
     // a memory round trip is paid per tile.  With a single C_out chunk the weights stay in LDS for the whole launch.
-    uint4 xraw[NIT][NRAW], wreg[NWIT];
-    unsigned xok;
+    // ---- fused first conv helpers
+    constexpr int NF1 = FUSE1 ? (7 * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7)
+    auto load_f = [&](int tile, float (&fr)[NF1]) {
+        int b, t0, f0;
+        coord(tile, b, t0, f0);
+        const float* fb = a.feats + (int64_t)b * a.f_stride_b;
+#pragma unroll
+        for (int k = 0; k < NF1; ++k) {
+            const int it = tid + k * NTH;
+            const int itc = it < nfeat ? it : 0;
+            const int j = itc % (FT + 4), rest = itc / (FT + 4);
+            const int i = rest % FROWS1, ci = rest / FROWS1;
+            const int t = t0 - 2 + i, f = f0 - 2 + j;
+            const bool ok = it < nfeat && t >= 0 && t < T && f >= 0 && f < F;
+            const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
+            const float v = fb[(int64_t)ci * a.f_stride_c + (int64_t)tc * a.f_stride_t + (int64_t)fc * a.f_stride_f];
+            fr[k] = ok ? v : 0.f;
+        }
+    };
+    auto store_f = [&](const float (&fr)[NF1]) {
+#pragma unroll
+        for (int k = 0; k < NF1; ++k) {
+            const int it = tid + k * NTH;
+            if (it < nfeat) {
+                const int j = it % (FT + 4), rest = it / (FT + 4);
+                fs[rest * FP1 + j] = fr[k];
+            }
+        }
+    };
+    // per-lane im2col offsets (floats) of the K slots this lane feeds: k = 32 ks + 8 g + jj -> (ci, kh, kw) in the weight
+    // tensor's own order; slots past 9 c_in read a valid address (their weights are zero)
+    int koff[KS1 > 0 ? KS1 : 1][8];
+    if (FUSE1) {
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                int k = 32 * ks + 8 * g + jj;
+                k = k < 9 * c_in1 ? k : 0;
+                const int ci = k / 9, tap = k % 9;
+                koff[ks][jj] = (ci * FROWS1 + tap / 3) * FP1 + tap % 3;
+            }
+    }
+    auto first_conv = [&](int t0, int f0) {
+        const uint4* w1 = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs);   // [tile][ks][plane][lane]
+        const float* sh1 = a.shift1 + (int64_t)grp * CIN;
+        uint4 wf[CI16][KS1 > 0 ? KS1 : 1][NS];
+#pragma unroll
+        for (int nt = 0; nt < CI16; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) wf[nt][ks][p] = w1[((nt * KS1 + ks) * NS + p) * 64 + lane];
+        for (int n = wave; n < NNT1; n += NW) {
+            int pos = n * 16 + r16;
+            const int posc = pos < NPOS ? pos : NPOS - 1;
+            const int i = posc / COLS, j = posc % COLS;
+            const float* fp = fs + i * FP1 + j;
+            uint4 ph[KS1 > 0 ? KS1 : 1], pl[KS1 > 0 ? KS1 : 1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ++ks) {
+                float v[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) v[jj] = fp[koff[ks][jj]];
+                if (NS == 2) {
+                    split_bf16x2(v[0], v[1], ph[ks].x, pl[ks].x); split_bf16x2(v[2], v[3], ph[ks].y, pl[ks].y);
+                    split_bf16x2(v[4], v[5], ph[ks].z, pl[ks].z); split_bf16x2(v[6], v[7], ph[ks].w, pl[ks].w);
+                } else {
+                    ph[ks] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                }
+            }
+            const int t = t0 - 1 + i, f = f0 - 1 + j;
+            const bool inside = t >= 0 && t < T && f >= 0 && f < F;
+#pragma unroll
+            for (int nt = 0; nt < CI16; ++nt) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sh1 + 16 * nt + 4 * g);
+                f32x4_t d = (f32x4_t){s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+                for (int ks = 0; ks < KS1; ++ks) {
+                    d = gm32(wf[nt][ks][0], ph[ks], d);
+                    if (NS == 2) {
+                        d = gm32(wf[nt][ks][0], pl[ks], d);
+                        d = gm32(wf[nt][ks][1], ph[ks], d);
+                    }
+                }
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = inside ? fmaxf(d[r], 0.f) : 0.f;
+                uint2 hi, lo = make_uint2(0, 0);
+                if (NS == 2) { split_bf16x2(o[0], o[1], hi.x, lo.x); split_bf16x2(o[2], o[3], hi.y, lo.y); }
+                else hi = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                if (pos < NPOS) {
+                    // channels 16 nt + 4 g .. + 4 = half (g & 1) of 16-byte chunk 2 nt + (g >> 1)
+                    const int off = (2 * nt + (g >> 1)) * CPLANE + pos * 16 + (g & 1) * 8;
+                    *reinterpret_cast<uint2*>(xs + off) = hi;
+                    if (NS == 2) *reinterpret_cast<uint2*>(xs + XPLANE + off) = lo;
+                }
+            }
+        }
+    };
+
+    uint4 xraw[FUSE1 ? 1 : NIT][NRAW], wreg[NWIT];
+    float fraw[NF1];
+    unsigned xok = 0;
     int tile = blockIdx.x;
-    load_x(tile, xraw, xok);
+    if (FUSE1) load_f(tile, fraw);
+    else load_x(tile, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);
     bool w_resident = false;
     if (w_all) {                                               // every C_out chunk fits next to the tile: weights stay in LDS for the launch
         for (int it = tid; it < nchunks * (WCHUNK / 16); it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[it];
@@ -164,14 +279,21 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
         int b, t0, f0;
         coord(tile, b, t0, f0);
         const int t_out = t0 + r16;
-        store_x(xraw, xok);
         const int next = tile + (int)gridDim.x;
         const bool has_next = next < ntiles;
+        if (FUSE1) {
+            store_f(fraw);
+            __syncthreads();                                   // feature tile visible
+            if (has_next) load_f(next, fraw);
+            first_conv(t0, f0);
+        } else {
+            store_x(reinterpret_cast<const uint4 (&)[NIT][NRAW]>(xraw), xok);
+        }
 
         for (int ch = 0; ch < nchunks; ++ch) {
             if (!w_resident) store_w(wreg);
             if (!w_all || ch == 0) __syncthreads();            // tile and weight chunk visible
-            if (ch == 0 && has_next) load_x(next, xraw, xok);  // in flight during the MFMA phase
+            if (!FUSE1 && ch == 0 && has_next) load_x(next, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);  // in flight during the MFMA phase
             if (!w_all) {
                 if (nchunks > 1) {
                     if (ch + 1 < nchunks) load_w(ch + 1, wreg);
@@ -271,7 +393,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     }
 }
 
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE>
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0>
 int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
     const int ntf = (fe + FT - 1) / FT;
@@ -280,9 +402,11 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
     const int nchunks = a.c_out / (16 * NTC);
     const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)9 * NTC * NS * g_wfrag_bytes(CI16);
-    const int w_all = nchunks > 1 && lds_x + nchunks * wchunk <= 160 * 1024;
-    const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk;
-    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE>;
+    const size_t lds_f = KS1 > 0 ? (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float) : 0;
+    const int w_all = nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
+    const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
+    AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
+    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1>;
     static size_t granted = 0;
     if (lds > granted && lds > 64 * 1024) {
         AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -300,6 +424,19 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
 
 template <int CI16, int NTC>
 int dispatch_gen(const ConvArgs& a, hipStream_t s) {
+    if (a.feats) {                                              // fused first conv
+        const int ks1 = (9 * a.c_in + 31) / 32;
+        if (a.planes == 1 && a.out_type == AMTX_T_BF16) {
+            if (ks1 == 1) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1>(a, s);
+            if (ks1 == 2) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 2>(a, s);
+        }
+        if (a.planes == 2 && a.out_type == AMTX_T_F32) {
+            if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
+            if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);
+        }
+        amtx_set_error("conv3x3 (general): fused first conv: unsupported c_in / precision");
+        return AMTX_ERR_UNSUPPORTED;
+    }
     if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) {
         static const bool narrow = getenv("AMTX_CONVG_FT16") != nullptr;
         if (narrow) return launch_gen<CI16, NTC, 1, 16, AMTX_T_BF16, AMTX_T_BF16>(a, s);
@@ -355,8 +492,37 @@ void amtx_conv3x3_gen_pack_host(const float* w, const float* scale, int c_in, in
             }
 }
 
+// fused first conv (c_in -> c_mid channels, c_mid = this layer's C_in): fragments [tile of 16 channels][k-step][plane][lane][8],
+// k = 32 ks + 8 (lane >> 4) + j over (ci, kh, kw) in the weight tensor's order, zero past 9 c_in
+size_t amtx_conv1g_wfrag_elems(int c_in, int c_mid, int planes) { return (size_t)(c_mid / 16) * ((9 * c_in + 31) / 32) * planes * 512; }
+
+void amtx_conv1g_pack_host(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out) {
+    const int kvalid = 9 * c_in, ks1 = (kvalid + 31) / 32;
+    for (int nt = 0; nt < c_mid / 16; ++nt)
+        for (int ks = 0; ks < ks1; ++ks)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int co = 16 * nt + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+                    const float v = k < kvalid ? w[(size_t)co * kvalid + k] * (scale ? scale[co] : 1.0f) : 0.0f;
+                    const bf16_t hi = f32_to_bf16_rn(v);
+                    const size_t base = ((size_t)(nt * ks1 + ks) * planes) * 512 + (size_t)l * 8 + j;
+                    out[base] = hi;
+                    if (planes == 2) out[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                }
+}
+
+// does the fused-first-conv variant fit the LDS for this layer?
+bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
+    if (c_in < 1 || c_in > 7 || !amtx_conv3x3_gen_ntc(c_mid, c_out)) return false;
+    const int ft = planes == 2 ? 16 : 32, ntc = amtx_conv3x3_gen_ntc(c_mid, c_out);
+    const size_t lds = (size_t)planes * (c_mid / 8) * g_cplane(ft) + (size_t)9 * ntc * planes * g_wfrag_bytes(c_mid / 16) +
+                       (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
+    return lds <= 160 * 1024;
+}
+
 int amtx_launch_conv3x3_gen(const ConvArgs& a, int c_in, hipStream_t stream) {
-    AMTX_REQUIRE(a.in && a.wfrag && a.shift && a.out, "conv3x3 (general): null pointer");
+    AMTX_REQUIRE((a.in || a.feats) && a.wfrag && a.shift && a.out, "conv3x3 (general): null pointer");
+    if (a.feats) AMTX_REQUIRE(a.w1frag && a.shift1 && a.c_in > 0 && a.c_in <= 7, "conv3x3 (general): fused first conv needs w1frag / shift1 and c_in <= 7");
     AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F >= 2 && a.groups > 0, "conv3x3 (general): bad sizes");
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3 (general): planes must be 1 or 2");
     if (c_in == 48 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 3) return dispatch_gen<3, 3>(a, stream);

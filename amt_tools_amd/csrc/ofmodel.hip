@@ -214,7 +214,7 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->head_names.push_back("pitch_head");
     m->n_heads = (int)m->head_names.size();
     m->dim_aj = (m->n_rec + 1) * n_out;
-    m->fuse_conv1 = (9 * in_channels <= 64) && m->nf1 == 32;
+    m->fuse_conv1 = m->gen_conv ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
     *out = m;
     return AMTX_OK;
 }
@@ -242,8 +242,8 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     const int nh = m->n_heads;
     // ---- acoustic heads
     std::vector<float> c1w((size_t)nh * m->nf1 * m->in_channels * 9), c1s((size_t)nh * m->nf1);
-    m->fuse_conv1 = (9 * m->in_channels <= 64) && m->nf1 == 32;
-    const size_t c1f_per = amtx_conv1_wfrag_elems(m->in_channels, m->planes);
+    m->fuse_conv1 = m->gen_conv ? amtx_conv3x3_gen_can_fuse1(m->in_channels, m->nf1, m->nf2, m->planes) : (9 * m->in_channels <= 64);
+    const size_t c1f_per = m->gen_conv ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, m->planes) : amtx_conv1_wfrag_elems(m->in_channels, m->planes);
     std::vector<bf16_t> c1f(m->fuse_conv1 ? c1f_per * nh : 0);
     const size_t c2w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, m->planes) : amtx_conv3x3_wfrag_elems(m->nf2, m->planes);
     const size_t c3w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, m->planes) : amtx_conv3x3_wfrag_elems(m->nf3, m->planes);
@@ -265,7 +265,8 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
             for (int i = 0; i < m->in_channels * 9; ++i)
                 c1w[((size_t)h * m->nf1 + co) * m->in_channels * 9 + i] = w[(size_t)co * m->in_channels * 9 + i] * scale[co];
         memcpy(c1s.data() + (size_t)h * m->nf1, shift.data(), sizeof(float) * m->nf1);
-        if (m->fuse_conv1) amtx_conv1_pack_host(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
+        if (m->fuse_conv1 && m->gen_conv) amtx_conv1g_pack_host(w, scale.data(), m->in_channels, m->nf1, m->planes, c1f.data() + c1f_per * h);
+        else if (m->fuse_conv1) amtx_conv1_pack_host(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
 
         rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
         if (rc != AMTX_OK) return rc;
@@ -408,7 +409,7 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
         c2.in = nullptr;
         c2.feats = feats; c2.f_stride_b = stride_b; c2.f_stride_c = stride_c; c2.f_stride_t = stride_t; c2.f_stride_f = stride_f;
         c2.c_in = m->in_channels; c2.w1frag = (const bf16_t*)m->conv1_frag.p; c2.shift1 = (const float*)m->conv1_s.p;
-        c2.w1_gs = (int64_t)amtx_conv1_wfrag_elems(m->in_channels, pl);
+        c2.w1_gs = (int64_t)(m->gen_conv ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, pl) : amtx_conv1_wfrag_elems(m->in_channels, pl));
     }
     if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
     mark();

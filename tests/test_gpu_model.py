@@ -108,20 +108,21 @@ def test_onsetsframes2_default_complexity_3_engine_matches_reference_golden(prec
         assert np.all((got == g['out_' + key]) | near)
 
 
-def test_complexity_3_engine_vs_oracle_on_ragged_batches():
+@pytest.mark.parametrize('dim_in,in_channels', [(229, 1), (72, 6)])
+def test_complexity_3_engine_vs_oracle_on_ragged_batches(dim_in, in_channels):
     """OnsetsFrames (no offset head) at model_complexity 3 against the oracle on fresh inputs, batch and frame counts that do not
-    fill the kernels' tiles."""
+    fill the kernels' tiles; one-channel mel features and the six-channel HCQT shape (two K steps in the fused first conv)."""
     from oracle import model_ref
     from amt_tools_amd.models import OnsetsFrames
-    sd = synth_state_dict(11, dim_in=229, in_channels=1, model_complexity=3)
-    model = OnsetsFrames(229, tools.PianoProfile(), 1, 3, device='cuda:0', precision='x3')
+    sd = synth_state_dict(11, dim_in=dim_in, in_channels=in_channels, model_complexity=3)
+    model = OnsetsFrames(dim_in, tools.PianoProfile(), in_channels, 3, device='cuda:0', precision='x3')
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model.change_device()
     model.eval()
     sdt = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     rng = np.random.default_rng(6)
     for B, T in ((1, 1), (3, 17), (17, 9), (2, 40)):
-        feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32))
+        feats = torch.from_numpy(rng.random((B, in_channels, dim_in, T)).astype(np.float32))
         with torch.no_grad():
             ref = model_ref.run_on_batch(feats, sdt)
             got = model.engine_logits(feats.cuda())
