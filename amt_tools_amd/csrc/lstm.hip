@@ -21,6 +21,8 @@
 
 #include "amtx_kernels.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int H = 128;
@@ -488,6 +490,16 @@ __global__ void bilstm_pack_dev_kernel(const float* __restrict__ whh_fwd, const 
 // exchanged through a double-buffered LDS tile; c in registers.  Per step and block: 8 HH^2 bytes from L2 against
 // 128 HH^2 flops -> the step time is the L2 stream (about 3.4 us at HH = 256), T steps per launch: latency-bound like the
 // register-stationary kernels, only with a longer step.
+// compile-time loop: the body sees its index as a constant expression (register arrays indexed through it stay in registers;
+// with a plain unrolled loop and computed indices hipcc left the weight arrays in scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int HH, int NS, int X_TYPE, int OUT_TYPE>
 __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     constexpr int NU = HH / 16, UPW = NU / 8, KSN = HH / 32;
@@ -497,7 +509,14 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     constexpr int HPG = HH + 8;
     constexpr int HBG = 16 * HPG * 2;
     constexpr bool FAST = true;
-    static_assert(NU % 8 == 0 && KSN % SGK == 0 && NG % 4 == 0, "hidden size must be a multiple of 128");
+    constexpr int RS = 4;                         // ring slots: RS - 1 streamed groups (4 KiB each per wave) in flight (8 slots: no faster,
+                                                  // the stream is bound by the 64 B/clk a CU's vector memory path takes, not by latency)
+    // Of every four consecutive groups of a wave, group 0 is held in registers and group 1 in LDS for the whole launch (bf16
+    // mode: 64 spare VGPRs, 128 KiB of LDS per block), the other two are streamed: half the bytes per step.
+    constexpr bool PIN = NS == 1;
+    constexpr int NPIN = PIN ? NG / 4 : 0;        // groups pinned per kind (registers, LDS) and wave
+    constexpr int NSG = NG - 2 * NPIN;            // streamed groups per step and wave
+    static_assert(NU % 8 == 0 && KSN % SGK == 0 && NG % 4 == 0 && NSG % RS == 0, "hidden size must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HPG] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int clip = lane & 15, g = lane >> 4;
@@ -536,21 +555,43 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
             for (int q = 0; q < 4; ++q)
                 dst[ub][q] = *reinterpret_cast<const xraw_t*>(xbase + (t * 8 * HH + q * HH + 16 * ub) * XES);
     };
-    uint4 w[4][SGK][NS];                          // ring: group gi lives in slot gi & 3, three groups in flight
+    uint4 w[RS][SGK][NS];                         // ring: streamed group si lives in slot si % RS, RS - 1 groups in flight
+    uint4 wpin[PIN ? NPIN : 1][SGK][NS];          // register-resident groups
+    // group gi -> kind (0 registers, 1 LDS, 2 streamed) and index within its kind: see kind_of / sidx_of / gi_of_sidx below
+    char* wlds = smem + 2 * NS * HBG + wave * (NPIN * SGK * NS * 1024);      // this wave's LDS-resident groups
     typedef const __attribute__((address_space(1))) char* gchar_p;      // explicitly global: the asm below must not turn the loads into flat ones
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
     typedef __attribute__((address_space(1))) u32x4_t gu4_t;
     gchar_p wb = (gchar_p)wbase;
-    auto load_w = [&](int gi) {
-#pragma unroll
-        for (int k = 0; k < SGK; ++k)
-#pragma unroll
-            for (int p = 0; p < NS; ++p) w[gi & 3][k][p] = __builtin_bit_cast(uint4, *reinterpret_cast<const gu4_t*>(wb + ((gi * SGK + k) * NS + p) * 1024 + wlane));
+    auto load_frag = [&](int gi, int k, int p) {
+        return __builtin_bit_cast(uint4, *reinterpret_cast<const gu4_t*>(wb + ((gi * SGK + k) * NS + p) * 1024 + wlane));
     };
+    if constexpr (PIN) {
+        static_for<0, NG>([&](auto ic) {
+            constexpr int gi = decltype(ic)::value;
+            if constexpr ((gi & 3) < 2) {
+                static_for<0, SGK>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    static_for<0, NS>([&](auto pc) {
+                        constexpr int p = decltype(pc)::value;
+                        const uint4 v = load_frag(gi, k, p);
+                        if constexpr ((gi & 3) == 0) wpin[gi >> 2][k][p] = v;
+                        else *reinterpret_cast<uint4*>(wlds + (((gi >> 2) * SGK + k) * NS + p) * 1024 + wlane) = v;
+                    });
+                });
+            }
+        });
+    }
 
     xraw_t xn[UPW][4];
     load_xrow(tidx(0), xn);
-    load_w(0); load_w(1); load_w(2);
+    static_for<0, RS - 1>([&](auto sc) {
+        constexpr int si = decltype(sc)::value;
+        constexpr int gi = PIN ? (si >> 1) * 4 + 2 + (si & 1) : si;
+        static_for<0, SGK>([&](auto kc) {
+            static_for<0, NS>([&](auto pc) { w[si % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
+        });
+    });
     __syncthreads();
 
     int cur = 0;
@@ -573,23 +614,41 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
         load_xrow(tidx(s + 1), xn);
         __builtin_amdgcn_sched_barrier(0);
 
-#pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
-            const int ub = gi / (4 * NSUB), q = (gi / NSUB) & 3, sub = gi % NSUB;
-            load_w((gi + 3) % NG);                // behind the last three groups: the first three of the next step
-            f32x4_t d = acc[ub][q];
-#pragma unroll
-            for (int k = 0; k < SGK; ++k) {
-                const int ks = sub * SGK + k;
-                d = mfma16(w[gi & 3][k][0], hf[ks][0], d);
-                if (NS == 2) {
-                    d = mfma16(w[gi & 3][k][0], hf[ks][1], d);
-                    d = mfma16(w[gi & 3][k][1], hf[ks][0], d);
-                }
+        static_for<0, NG>([&](auto ic) {
+            constexpr int gi = decltype(ic)::value;
+            constexpr int ub = gi / (4 * NSUB), q = (gi / NSUB) & 3, sub = gi % NSUB;
+            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : 2;     // 0 registers, 1 LDS, 2 streamed
+            constexpr int si = PIN ? (gi >> 2) * 2 + (gi & 3) - 2 : gi;                        // index among the streamed groups
+            if constexpr (kind == 2) {
+                // behind the last RS - 1 streamed groups: the first ones of the next step
+                constexpr int sn = (si + RS - 1) % NSG;
+                constexpr int gn = PIN ? (sn >> 1) * 4 + 2 + (sn & 1) : sn;
+                static_for<0, SGK>([&](auto kc) {
+                    static_for<0, NS>([&](auto pc) { w[sn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
+                });
             }
+            f32x4_t d = acc[ub][q];
+            static_for<0, SGK>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int ks = sub * SGK + k;
+                uint4 w0, w1;
+                if constexpr (kind == 0) {
+                    w0 = wpin[gi >> 2][k][0]; w1 = wpin[gi >> 2][k][NS - 1];
+                } else if constexpr (kind == 1) {
+                    w0 = *reinterpret_cast<const uint4*>(wlds + (((gi >> 2) * SGK + k) * NS + 0) * 1024 + wlane);
+                    w1 = w0;
+                } else {
+                    w0 = w[si % RS][k][0]; w1 = w[si % RS][k][NS - 1];
+                }
+                d = mfma16(w0, hf[ks][0], d);
+                if constexpr (NS == 2) {
+                    d = mfma16(w0, hf[ks][1], d);
+                    d = mfma16(w1, hf[ks][0], d);
+                }
+            });
             acc[ub][q] = d;
-            __builtin_amdgcn_sched_barrier(0);   // keep the ring three groups deep: no hoisting of later loads above this group
-        }
+            __builtin_amdgcn_sched_barrier(0);   // keep the ring as deep as written: no hoisting of later loads above this group
+        });
 
         char* hn = smem + (cur ^ 1) * NS * HBG;
         const int64_t t = tidx(s);
@@ -628,9 +687,16 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
 
 template <int HH, int NS, int X_TYPE, int OUT_TYPE>
 int launch_stream(const LstmArgs& a, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2;
+    // h tiles + (bf16 mode) the LDS-resident quarter of W_hh: 8 waves x (groups / 4) x 4 KiB
+    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 ? (size_t)8 * ((HH / 128) * 4 * (HH / 32 / 4) / 4) * 4096 : 0);
+    auto kern = bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
     dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
-    hipLaunchKernelGGL((bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>), grid, dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
