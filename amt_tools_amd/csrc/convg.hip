@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -31,6 +32,15 @@ constexpr int GROWS = GTT + 2;
 typedef __attribute__((ext_vector_type(8))) __bf16 g_bf16x8;
 __device__ __forceinline__ f32x4_t gm32(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
+}
+
+// compile-time loop: the body sees its index as a constant expression, so register arrays indexed through it stay in registers
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 constexpr int g_cplane(int ft) {
@@ -316,58 +326,62 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                 }
             }
 
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                uint4 xa[6][N32 > 0 ? N32 : 1][NS];
-                uint4 xb[6][NS];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
+            // One "item" = one weight fragment (16 B per lane) x the wave's four columns = 4 MFMAs (12 in the two-plane mode).
+            // Items run kh-major; weight fragments are read from LDS WD items ahead of their use (ring of WD + 1 register slots):
+            // without this every item was ds_read -> lgkmcnt(0) -> 4 MFMAs, i.e. a full LDS latency per 64 matrix-core cycles.
+            // The six input columns of a tap row are read at the row boundary (one exposed LDS latency per row; double-buffering
+            // them as well costs 48 more VGPRs and spills).
+            constexpr int STEPS = N32 + N16;                    // 32-deep steps per tap
+            constexpr int IPR = 3 * NTC * STEPS;                // items per tap row
+            constexpr int NITM = 3 * IPR;
+            constexpr int WD = 2;
+            uint4 xa[1][6][STEPS][NS];
+            uint4 wq[WD + 1][NS];
+            auto load_xrow = [&](auto khc) {
+                constexpr int kh = decltype(khc)::value;
+                static_for<0, 6>([&](auto cc) {
+                    constexpr int c = decltype(cc)::value;
                     const int base = xrow + (kh * PC + jb + c) * 16;
-#pragma unroll
-                    for (int p = 0; p < NS; ++p) {
-#pragma unroll
-                        for (int ks = 0; ks < N32; ++ks) xa[c][ks][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x32 + ks * 4 * CPLANE);
-                        if (N16) xb[c][p] = *reinterpret_cast<const uint4*>(xs + p * XPLANE + base + x16);
+                    static_for<0, NS>([&](auto pc) {
+                        constexpr int pl = decltype(pc)::value;
+                        static_for<0, STEPS>([&](auto sc) {
+                            constexpr int st = decltype(sc)::value;
+                            xa[0][c][st][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + base + (st < N32 ? x32 + st * 4 * CPLANE : x16));
+                        });
+                    });
+                });
+            };
+            auto load_witem = [&](auto vc) {
+                constexpr int v = decltype(vc)::value;
+                constexpr int kh = v / IPR, r = v % IPR, kw = r / (NTC * STEPS), nt = (r / STEPS) % NTC, st = r % STEPS;
+                const char* wp = wsc + ((kh * 3 + kw) * NTC + nt) * NS * WFRAG;
+                static_for<0, NS>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    if constexpr (st < N32) {
+                        wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wp + (st * NS + pl) * 1024 + lane * 16);
+                    } else {                                   // tail step: lane groups 2, 3 carry zero weights
+                        wq[v % (WD + 1)][pl] = make_uint4(0, 0, 0, 0);
+                        if (g < 2) wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wp + N32 * NS * 1024 + pl * 512 + (lane & 31) * 16);
                     }
-                }
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-#pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) {
-                        const char* wp = wsc + ((kh * 3 + kw) * NTC + nt) * NS * WFRAG;
-#pragma unroll
-                        for (int ks = 0; ks < N32; ++ks) {
-                            uint4 w[NS];
-#pragma unroll
-                            for (int p = 0; p < NS; ++p) w[p] = *reinterpret_cast<const uint4*>(wp + (ks * NS + p) * 1024 + lane * 16);
-#pragma unroll
-                            for (int col = 0; col < 4; ++col) {
-                                acc[col][nt] = gm32(w[0], xa[col + kw][ks][0], acc[col][nt]);
-                                if (NS == 2) {
-                                    acc[col][nt] = gm32(w[0], xa[col + kw][ks][1], acc[col][nt]);
-                                    acc[col][nt] = gm32(w[1], xa[col + kw][ks][0], acc[col][nt]);
-                                }
-                            }
-                        }
-                        if (N16) {
-                            uint4 w[NS];
-#pragma unroll
-                            for (int p = 0; p < NS; ++p) {
-                                w[p] = make_uint4(0, 0, 0, 0);
-                                if (g < 2) w[p] = *reinterpret_cast<const uint4*>(wp + N32 * NS * 1024 + p * 512 + (lane & 31) * 16);
-                            }
-#pragma unroll
-                            for (int col = 0; col < 4; ++col) {
-                                acc[col][nt] = gm32(w[0], xb[col + kw][0], acc[col][nt]);
-                                if (NS == 2) {
-                                    acc[col][nt] = gm32(w[0], xb[col + kw][1], acc[col][nt]);
-                                    acc[col][nt] = gm32(w[1], xb[col + kw][0], acc[col][nt]);
-                                }
-                            }
-                        }
+                });
+            };
+            load_xrow(std::integral_constant<int, 0>{});
+            static_for<0, WD>([&](auto vc) { load_witem(vc); });
+            static_for<0, NITM>([&](auto vc) {
+                constexpr int v = decltype(vc)::value;
+                constexpr int kh = v / IPR, r = v % IPR, kw = r / (NTC * STEPS), nt = (r / STEPS) % NTC, st = r % STEPS;
+                if constexpr (r == 0 && kh > 0) load_xrow(std::integral_constant<int, kh>{});
+                if constexpr (v + WD < NITM) load_witem(std::integral_constant<int, v + WD>{});
+                static_for<0, 4>([&](auto colc) {
+                    constexpr int col = decltype(colc)::value;
+                    acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[0][col + kw][st][0], acc[col][nt]);
+                    if constexpr (NS == 2) {
+                        acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[0][col + kw][st][NS - 1], acc[col][nt]);
+                        acc[col][nt] = gm32(wq[v % (WD + 1)][NS - 1], xa[0][col + kw][st][0], acc[col][nt]);
                     }
-                }
-            }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
 
             // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
             if (t_out < T) {
