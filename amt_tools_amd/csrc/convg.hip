@@ -51,7 +51,11 @@ constexpr int g_cplane(int ft) {
 }
 
 // per (tap, tile) weight bytes of one plane in LDS / in the packed global buffer
-constexpr int g_wfrag_bytes(int ci16) { return (ci16 / 2) * 1024 + (ci16 % 2) * 512; }
+// Weight fragments (1024 bytes per plane each) of one 16-channel output tile: 9 taps x n32 full 32-deep steps, plus, when C_in has a
+// 16-channel tail, 5 PAIRED tail steps: the two 16-channel tails of two taps share one 32-deep MFMA (lane groups 0, 1 = first tap,
+// 2, 3 = second tap): (kh 0, kh 1) for each kw, then (2,0)+(2,1), then (2,2) alone (upper half zero).  14 MFMAs per output column
+// and channel tile at C_in = 48 instead of 18 with one half-empty tail step per tap.
+constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 2); }
 
 // KS1 > 0: the first convolution (Conv2d(c_in -> C_in of this layer) + BN + ReLU, models/onsetsframes.py:375-384) is computed
 // inside this kernel, from the fp32 features, straight into the LDS input tile (the C_in-channel map never exists in HBM):
@@ -68,8 +72,9 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     constexpr int COLS = FT + 2;
     constexpr int CPLANE = g_cplane(FT);
     constexpr int XPLANE = NCH * CPLANE;         // one precision plane of the input tile
-    constexpr int WFRAG = g_wfrag_bytes(CI16);   // one plane of one (tap, tile)
-    constexpr int WCHUNK = 9 * NTC * NS * WFRAG; // all planes of one C_out chunk
+    constexpr int NMAIN = 9 * NTC * N32;         // full 32-deep (tap, tile, step) fragments of one chunk
+    constexpr int NTAIL = 5 * NTC * N16;         // paired tail fragments
+    constexpr int WCHUNK = (NMAIN + NTAIL) * NS * 1024;   // all planes of one C_out chunk
     constexpr int IES = IN_TYPE == AMTX_T_BF16 ? 2 : 4;
     constexpr int NITEMS = GROWS * COLS * NCH;
     constexpr int NIT = (NITEMS + NTH - 1) / NTH;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     const int jb = 4 * wave;                                   // first of this wave's four output columns (tile-relative)
     const int xrow = r16 * PC * 16;                            // byte offset of this lane's row (kh = 0) in a chunk plane
     const int x32 = g * CPLANE;                                // + ks * 4 * CPLANE: chunk 4 ks + g
-    const int x16 = (4 * N32 + (g & 1)) * CPLANE;              // tail step: lane groups 2, 3 re-read the chunks of 0, 1 (their weights are zero)
+    const int x16 = (4 * N32 + (g & 1)) * CPLANE;              // tail steps: lane groups (0, 1) and (2, 3) each read the two tail chunks
 
     // Persistent blocks (one per CU: the tile and one weight chunk fill most of the LDS): the NEXT tile's input and the NEXT
     // weight chunk travel HBM/L2 -> registers while the current ones are on the matrix cores, so neither the block start-up nor
@@ -327,57 +332,65 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
             }
 
             // One "item" = one weight fragment (16 B per lane) x the wave's four columns = 4 MFMAs (12 in the two-plane mode).
-            // Items run kh-major; weight fragments are read from LDS WD items ahead of their use (ring of WD + 1 register slots):
-            // without this every item was ds_read -> lgkmcnt(0) -> 4 MFMAs, i.e. a full LDS latency per 64 matrix-core cycles.
-            // The six input columns of a tap row are read at the row boundary (one exposed LDS latency per row; double-buffering
-            // them as well costs 48 more VGPRs and spills).
-            constexpr int STEPS = N32 + N16;                    // 32-deep steps per tap
-            constexpr int IPR = 3 * NTC * STEPS;                // items per tap row
-            constexpr int NITM = 3 * IPR;
+            // Items run row-major over five "rows" of six input-column fragments: tap rows kh = 0, 1, 2 (full 32-deep steps), then
+            // row 3 = the channel tails of tap rows 0 | 1 side by side, row 4 = the tails of tap row 2 at columns c | c + 1.
+            // Weight fragments are read from LDS WD items ahead of their use (ring of WD + 1 register slots); the six column
+            // fragments of a row are read at the row boundary (double-buffering them as well costs 48 more VGPRs and spills).
+            constexpr int NROWS = 3 + 2 * N16;
+            constexpr int IPM = 3 * NTC * N32;                   // items of a main row: (kw, tile, step)
+            constexpr int NITM = 3 * IPM + (3 * NTC + 2 * NTC) * N16;
             constexpr int WD = 2;
-            uint4 xa[1][6][STEPS][NS];
+            uint4 xa[6][N32 > 0 ? N32 : 1][NS];
             uint4 wq[WD + 1][NS];
-            auto load_xrow = [&](auto khc) {
-                constexpr int kh = decltype(khc)::value;
+            // item v -> row, kw (column shift of the X fragment), tile, step, index of its weight fragment in the chunk
+            auto load_xrow = [&](auto rowc) {
+                constexpr int row = decltype(rowc)::value;
                 static_for<0, 6>([&](auto cc) {
                     constexpr int c = decltype(cc)::value;
-                    const int base = xrow + (kh * PC + jb + c) * 16;
                     static_for<0, NS>([&](auto pc) {
                         constexpr int pl = decltype(pc)::value;
-                        static_for<0, STEPS>([&](auto sc) {
-                            constexpr int st = decltype(sc)::value;
-                            xa[0][c][st][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + base + (st < N32 ? x32 + st * 4 * CPLANE : x16));
-                        });
+                        if constexpr (row < 3) {
+                            static_for<0, N32>([&](auto sc) {
+                                constexpr int st = decltype(sc)::value;
+                                xa[c][st][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + (row * PC + jb + c) * 16 + x32 + st * 4 * CPLANE);
+                            });
+                        } else if constexpr (row == 3) {           // lane groups 0, 1: tap row 0; 2, 3: tap row 1
+                            xa[c][0][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + ((g >> 1) * PC + jb + c) * 16 + x16);
+                        } else {                                   // tap row 2: lane groups 0, 1: column c; 2, 3: column c + 1
+                            // (columns 4, 5 only meet the lone (2,2) tail, whose upper weights are zero: stay inside the tile)
+                            xa[c][0][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + (2 * PC + jb + c + (c < 4 ? (g >> 1) : 0)) * 16 + x16);
+                        }
                     });
                 });
             };
             auto load_witem = [&](auto vc) {
                 constexpr int v = decltype(vc)::value;
-                constexpr int kh = v / IPR, r = v % IPR, kw = r / (NTC * STEPS), nt = (r / STEPS) % NTC, st = r % STEPS;
-                const char* wp = wsc + ((kh * 3 + kw) * NTC + nt) * NS * WFRAG;
+                constexpr int widx = v < 3 * IPM ? v                                      // main: ((kh * 3 + kw) * NTC + nt) * N32 + st == v
+                                                 : NMAIN + (v - 3 * IPM);                 // tails: A (kw, nt), B (nt), C (nt) in item order
                 static_for<0, NS>([&](auto pc) {
                     constexpr int pl = decltype(pc)::value;
-                    if constexpr (st < N32) {
-                        wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wp + (st * NS + pl) * 1024 + lane * 16);
-                    } else {                                   // tail step: lane groups 2, 3 carry zero weights
-                        wq[v % (WD + 1)][pl] = make_uint4(0, 0, 0, 0);
-                        if (g < 2) wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wp + N32 * NS * 1024 + pl * 512 + (lane & 31) * 16);
-                    }
+                    wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wsc + (widx * NS + pl) * 1024 + lane * 16);
                 });
             };
             load_xrow(std::integral_constant<int, 0>{});
             static_for<0, WD>([&](auto vc) { load_witem(vc); });
             static_for<0, NITM>([&](auto vc) {
                 constexpr int v = decltype(vc)::value;
-                constexpr int kh = v / IPR, r = v % IPR, kw = r / (NTC * STEPS), nt = (r / STEPS) % NTC, st = r % STEPS;
-                if constexpr (r == 0 && kh > 0) load_xrow(std::integral_constant<int, kh>{});
+                constexpr bool is_main = v < 3 * IPM;
+                constexpr int t = v - 3 * IPM;                                            // tail item index
+                constexpr int row = is_main ? v / IPM : (t < 3 * NTC ? 3 : 4);
+                constexpr int kw = is_main ? (v % IPM) / (NTC * N32) : (t < 3 * NTC ? t / NTC : (t < 4 * NTC ? 0 : 2));
+                constexpr int nt = is_main ? ((v % IPM) / N32) % NTC : t % NTC;
+                constexpr int st = is_main ? v % N32 : 0;
+                constexpr bool row_start = is_main ? (v % IPM == 0) : (t == 0 || t == 3 * NTC);
+                if constexpr (row_start && v > 0) load_xrow(std::integral_constant<int, row>{});
                 if constexpr (v + WD < NITM) load_witem(std::integral_constant<int, v + WD>{});
                 static_for<0, 4>([&](auto colc) {
                     constexpr int col = decltype(colc)::value;
-                    acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[0][col + kw][st][0], acc[col][nt]);
+                    acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[col + kw][st][0], acc[col][nt]);
                     if constexpr (NS == 2) {
-                        acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[0][col + kw][st][NS - 1], acc[col][nt]);
-                        acc[col][nt] = gm32(wq[v % (WD + 1)][NS - 1], xa[0][col + kw][st][0], acc[col][nt]);
+                        acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[col + kw][st][NS - 1], acc[col][nt]);
+                        acc[col][nt] = gm32(wq[v % (WD + 1)][NS - 1], xa[col + kw][st][0], acc[col][nt]);
                     }
                 });
                 __builtin_amdgcn_sched_barrier(0);
@@ -415,7 +428,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int64_t ntiles = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
     const int nchunks = a.c_out / (16 * NTC);
-    const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)9 * NTC * NS * g_wfrag_bytes(CI16);
+    const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)NTC * NS * g_wfrags_per_tile(CI16) * 1024;
     const size_t lds_f = KS1 > 0 ? (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float) : 0;
     const int w_all = nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
     const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
@@ -469,41 +482,42 @@ int amtx_conv3x3_gen_ntc(int c_in, int c_out) {
     return 0;
 }
 
-size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes) { return (size_t)9 * (c_out / 16) * planes * g_wfrag_bytes(c_in / 16) / 2; }
+size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes) { return (size_t)(c_out / 16) * planes * g_wfrags_per_tile(c_in / 16) * 512; }
 
-// host packing: weight (c_out, c_in, 3, 3) fp32 * scale[c_out] -> [chunk][tap][tile][k-step][plane][lane][8] (tail step: 32 lanes)
+// host packing: weight (c_out, c_in, 3, 3) fp32 * scale[c_out] -> [chunk][fragment][plane][lane][8]; fragments of a chunk: the full
+// steps in (tap, tile, step) order, then the paired tails A (kw, tile): taps (0,kw) | (1,kw); B (tile): (2,0) | (2,1); C (tile): (2,2) | 0
 void amtx_conv3x3_gen_pack_host(const float* w, const float* scale, int c_in, int c_out, int planes, bf16_t* out) {
     const int ntc = amtx_conv3x3_gen_ntc(c_in, c_out);
     const int ci16 = c_in / 16, n32 = ci16 / 2, n16 = ci16 % 2;
-    const size_t wfrag = (size_t)g_wfrag_bytes(ci16) / 2;      // elements of one plane of one (tap, tile)
+    const int nmain = 9 * ntc * n32, nfrag = nmain + 5 * ntc * n16;
     const int nchunks = c_out / (16 * ntc);
-    for (int ch = 0; ch < nchunks; ++ch)
-        for (int tap = 0; tap < 9; ++tap)
-            for (int nt = 0; nt < ntc; ++nt) {
-                bf16_t* base = out + (((size_t)ch * 9 + tap) * ntc + nt) * planes * wfrag;
-                for (int l = 0; l < 64; ++l) {
-                    const int row = l & 15, gq = l >> 4;
-                    const int co = ch * 16 * ntc + (row >> 2) * (4 * ntc) + 4 * nt + (row & 3);
-                    const float sc = scale ? scale[co] : 1.0f;
+    auto put = [&](bf16_t* frag, int l, int j, float v) {
+        const bf16_t hi = f32_to_bf16_rn(v);
+        frag[l * 8 + j] = hi;
+        if (planes == 2) frag[512 + l * 8 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+    };
+    for (int ch = 0; ch < nchunks; ++ch) {
+        bf16_t* cbase = out + (size_t)ch * nfrag * planes * 512;
+        for (int nt = 0; nt < ntc; ++nt)
+            for (int l = 0; l < 64; ++l) {
+                const int row = l & 15, gq = l >> 4;
+                const int co = ch * 16 * ntc + (row >> 2) * (4 * ntc) + 4 * nt + (row & 3);
+                const float sc = scale ? scale[co] : 1.0f;
+                auto wv = [&](int ci, int tap) { return w[((size_t)co * c_in + ci) * 9 + tap] * sc; };
+                for (int tap = 0; tap < 9; ++tap)
                     for (int ks = 0; ks < n32; ++ks)
-                        for (int j = 0; j < 8; ++j) {
-                            const int ci = 32 * ks + 8 * gq + j;
-                            const float v = w[((size_t)co * c_in + ci) * 9 + tap] * sc;
-                            const bf16_t hi = f32_to_bf16_rn(v);
-                            base[((size_t)ks * planes + 0) * 512 + l * 8 + j] = hi;
-                            if (planes == 2) base[((size_t)ks * planes + 1) * 512 + l * 8 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
-                        }
-                    if (n16 && gq < 2)                                   // tail: lane groups 0, 1 of a 32-deep step, 8 channels each
-                        for (int j = 0; j < 8; ++j) {
-                            const int ci = 32 * n32 + 8 * gq + j;
-                            const float v = w[((size_t)co * c_in + ci) * 9 + tap] * sc;
-                            const bf16_t hi = f32_to_bf16_rn(v);
-                            bf16_t* b16 = base + (size_t)n32 * planes * 512;
-                            b16[l * 8 + j] = hi;
-                            if (planes == 2) b16[256 + l * 8 + j] = f32_to_bf16_rn(v - bf16_to_f32(hi));
-                        }
+                        for (int j = 0; j < 8; ++j)
+                            put(cbase + (size_t)(((tap * ntc + nt) * n32) + ks) * planes * 512, l, j, wv(32 * ks + 8 * gq + j, tap));
+                if (!n16) continue;
+                const int ct = 32 * n32 + 8 * (gq & 1);                // tail channels of this lane group: ct .. ct + 7
+                for (int j = 0; j < 8; ++j) {
+                    for (int kw = 0; kw < 3; ++kw)                   // A: tap rows 0 | 1 at column shift kw
+                        put(cbase + (size_t)(nmain + kw * ntc + nt) * planes * 512, l, j, wv(ct + j, (gq < 2 ? 0 : 3) + kw));
+                    put(cbase + (size_t)(nmain + 3 * ntc + nt) * planes * 512, l, j, wv(ct + j, gq < 2 ? 6 : 7));      // B: (2,0) | (2,1)
+                    put(cbase + (size_t)(nmain + 4 * ntc + nt) * planes * 512, l, j, gq < 2 ? wv(ct + j, 8) : 0.0f);  // C: (2,2) | zero
                 }
             }
+    }
 }
 
 // fused first conv (c_in -> c_mid channels, c_mid = this layer's C_in): fragments [tile of 16 channels][k-step][plane][lane][8],
@@ -529,7 +543,7 @@ void amtx_conv1g_pack_host(const float* w, const float* scale, int c_in, int c_m
 bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
     if (c_in < 1 || c_in > 7 || !amtx_conv3x3_gen_ntc(c_mid, c_out)) return false;
     const int ft = planes == 2 ? 16 : 32, ntc = amtx_conv3x3_gen_ntc(c_mid, c_out);
-    const size_t lds = (size_t)planes * (c_mid / 8) * g_cplane(ft) + (size_t)9 * ntc * planes * g_wfrag_bytes(c_mid / 16) +
+    const size_t lds = (size_t)planes * (c_mid / 8) * g_cplane(ft) + (size_t)ntc * planes * g_wfrags_per_tile(c_mid / 16) * 1024 +
                        (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
     return lds <= 160 * 1024;
 }

@@ -22,7 +22,7 @@ def test_host_only_queries():
     assert L.amtx_conv3x3_packed_elems(64, 1) == 9 * 4 * 512
     assert L.amtx_bilstm_packed_elems(2) == 2 * 2 * 512 * 128
     assert L.amtx_bilstm_h_packed_elems(256, 1) == 2 * 1024 * 256 and L.amtx_bilstm_h_packed_elems(128, 2) == L.amtx_bilstm_packed_elems(2)
-    assert L.amtx_conv3x3g_packed_elems(48, 96, 1) == 9 * 96 * 48 and L.amtx_conv3x3g_packed_elems(32, 40, 1) == 0
+    assert L.amtx_conv3x3g_packed_elems(48, 96, 1) == 6 * 14 * 512 and L.amtx_conv3x3g_packed_elems(32, 40, 1) == 0
 
 
 def test_errors_are_reported_not_swallowed():
