@@ -43,6 +43,21 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+#ifdef AMTX_CONV_TIMING
+// Debug build only (AMTX_EXTRA_FLAGS=-DAMTX_CONV_TIMING): cycles wave 0 of every block spends per phase of the persistent loop, summed
+// over blocks: [0] tile store / feature store + barrier, [1] fused first conv, [2] weight store + barrier, [3] MFMA loop, [4] epilogue
+// stores, [5] trailing barrier, [6] chunk-tiles.  Read with amtxdbg_convg_prof().
+__device__ unsigned long long g_convg_prof[8];
+#define CG_TICK(SLOT)                                                      \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        cg_acc[SLOT] += now_ - cg_t;                                       \
+        cg_t = now_;                                                       \
+    } while (0)
+#else
+#define CG_TICK(SLOT) do {} while (0)
+#endif
+
 constexpr int g_cplane(int ft) {
     // bytes of one chunk plane: ROWS x PC positions x 16 B, rounded up to 48 (mod 256)
     const int pc = ft + 2;
@@ -94,9 +109,18 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     const int grp = blockIdx.y;
     const int F = a.F, T = a.T, F2 = F >> 1;
     const int64_t out_ts = a.out_ts ? a.out_ts : (int64_t)F2 * a.c_out;
-    float* fs = reinterpret_cast<float*>(ws + (w_all ? nchunks : 1) * WCHUNK);      // FUSE1: [c_in][FROWS1][FP1] fp32 features
+    // FUSE1: first-conv weight fragments [tile][ks][plane][lane] + shift [CIN] (copied once: a global load per tile would put an
+    // L2 round trip in front of every tile's first MFMA), then [c_in][FROWS1][FP1] fp32 features
+    constexpr int W1BYTES = FUSE1 ? CI16 * KS1 * NS * 1024 + CIN * 4 : 0;
+    char* w1s = ws + (w_all ? nchunks : 1) * WCHUNK;
+    float* fs = reinterpret_cast<float*>(w1s + W1BYTES);
     const int c_in1 = a.c_in;
     const int nfeat = c_in1 * FROWS1 * (FT + 4);
+    if (FUSE1) {
+        const uint4* w1g = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs);
+        for (int it = tid; it < CI16 * KS1 * NS * 64; it += NTH) reinterpret_cast<uint4*>(w1s)[it] = w1g[it];
+        if (tid < CIN) reinterpret_cast<float*>(w1s + CI16 * KS1 * NS * 1024)[tid] = a.shift1[(int64_t)grp * CIN + tid];
+    }
     const char* in_g = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * IES;
     const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wfrag) + (int64_t)grp * a.w_gs * 2);
 
@@ -177,30 +201,41 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     // a memory round trip is paid per tile.  With a single C_out chunk the weights stay in LDS for the whole launch.
     // ---- fused first conv helpers
     constexpr int NF1 = FUSE1 ? (7 * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7)
-    auto load_f = [&](int tile, float (&fr)[NF1]) {
+    // A thread's feature items are the same tile-relative (channel, row, column) for every tile: decoded once (the div / mod chains
+    // per item and tile were a sixth of the kernel), bit 31 = item exists.  The zeroing of values outside the map waits for
+    // store_f: a select right behind the load would wait for the load here.
+    unsigned fdesc[NF1];
+#pragma unroll
+    for (int k = 0; k < NF1; ++k) {
+        const int it = tid + k * NTH;
+        const int itc = it < nfeat ? it : 0;
+        const int j = itc % (FT + 4), rest = itc / (FT + 4);
+        fdesc[k] = (it < nfeat ? 0x80000000u : 0u) | ((unsigned)(rest / FROWS1) << 16) | ((unsigned)(rest % FROWS1) << 8) | (unsigned)j;
+    }
+    const int nfk = (nfeat + NTH - 1) / NTH;                   // items per thread that exist for this c_in (uniform)
+    auto load_f = [&](int tile, float (&fr)[NF1], unsigned& okmask) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
         const float* fb = a.feats + (int64_t)b * a.f_stride_b;
+        okmask = 0;
 #pragma unroll
         for (int k = 0; k < NF1; ++k) {
-            const int it = tid + k * NTH;
-            const int itc = it < nfeat ? it : 0;
-            const int j = itc % (FT + 4), rest = itc / (FT + 4);
-            const int i = rest % FROWS1, ci = rest / FROWS1;
+            if (k >= nfk) break;
+            const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
             const int t = t0 - 2 + i, f = f0 - 2 + j;
-            const bool ok = it < nfeat && t >= 0 && t < T && f >= 0 && f < F;
+            const bool ok = (fdesc[k] >> 31) && t >= 0 && t < T && f >= 0 && f < F;
             const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
-            const float v = fb[(int64_t)ci * a.f_stride_c + (int64_t)tc * a.f_stride_t + (int64_t)fc * a.f_stride_f];
-            fr[k] = ok ? v : 0.f;
+            fr[k] = fb[(int64_t)ci * a.f_stride_c + (int64_t)tc * a.f_stride_t + (int64_t)fc * a.f_stride_f];
+            if (ok) okmask |= 1u << k;
         }
     };
-    auto store_f = [&](const float (&fr)[NF1]) {
+    auto store_f = [&](const float (&fr)[NF1], unsigned okmask) {
 #pragma unroll
         for (int k = 0; k < NF1; ++k) {
-            const int it = tid + k * NTH;
-            if (it < nfeat) {
-                const int j = it % (FT + 4), rest = it / (FT + 4);
-                fs[rest * FP1 + j] = fr[k];
+            if (k >= nfk) break;
+            if (fdesc[k] >> 31) {
+                const int j = fdesc[k] & 0xff, rest = ((fdesc[k] >> 16) & 0xff) * FROWS1 + ((fdesc[k] >> 8) & 0xff);
+                fs[rest * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
             }
         }
     };
@@ -219,8 +254,8 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
             }
     }
     auto first_conv = [&](int t0, int f0) {
-        const uint4* w1 = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs);   // [tile][ks][plane][lane]
-        const float* sh1 = a.shift1 + (int64_t)grp * CIN;
+        const uint4* w1 = reinterpret_cast<const uint4*>(w1s);                                   // [tile][ks][plane][lane]
+        const float* sh1 = reinterpret_cast<const float*>(w1s + CI16 * KS1 * NS * 1024);
         uint4 wf[CI16][KS1 > 0 ? KS1 : 1][NS];
 #pragma unroll
         for (int nt = 0; nt < CI16; ++nt)
@@ -228,59 +263,84 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
             for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
                 for (int p = 0; p < NS; ++p) wf[nt][ks][p] = w1[((nt * KS1 + ks) * NS + p) * 64 + lane];
-        for (int n = wave; n < NNT1; n += NW) {
-            int pos = n * 16 + r16;
-            const int posc = pos < NPOS ? pos : NPOS - 1;
-            const int i = posc / COLS, j = posc % COLS;
-            const float* fp = fs + i * FP1 + j;
-            uint4 ph[KS1 > 0 ? KS1 : 1], pl[KS1 > 0 ? KS1 : 1];
+        // Straight-line code, two 16-position groups at a time: their gathers, then their MFMAs, then their epilogues, so that no
+        // instruction waits on the one right before it (a loop of gather -> MFMA -> epilogue per channel tile ran at ~1500 cycles per
+        // group, a third of the conv2 kernel).
+        float4 s4[CI16];
 #pragma unroll
-            for (int ks = 0; ks < KS1; ++ks) {
-                float v[8];
+        for (int nt = 0; nt < CI16; ++nt) s4[nt] = *reinterpret_cast<const float4*>(sh1 + 16 * nt + 4 * g);
+        constexpr int NIT1 = (NNT1 + NW - 1) / NW, GP = (KS1 * NS > 2) ? 1 : 2;
+        static_for<0, (NIT1 + GP - 1) / GP>([&](auto gc) {
+            constexpr int it0 = decltype(gc)::value * GP;
+            constexpr int cnt = it0 + GP <= NIT1 ? GP : NIT1 - it0;
+            int pos[GP];
+            bool inside[GP];
+            uint4 ph[GP][KS1 > 0 ? KS1 : 1], pl[GP][KS1 > 0 ? KS1 : 1];
+            static_for<0, cnt>([&](auto ic) {
+                constexpr int i_ = decltype(ic)::value;
+                pos[i_] = (wave + (it0 + i_) * NW) * 16 + r16;
+                const int posc = pos[i_] < NPOS ? pos[i_] : NPOS - 1;
+                const int i = posc / COLS, j = posc % COLS;
+                const float* fp = fs + i * FP1 + j;
+                const int t = t0 - 1 + i, f = f0 - 1 + j;
+                inside[i_] = t >= 0 && t < T && f >= 0 && f < F;
+                static_for<0, KS1>([&](auto kc) {
+                    constexpr int ks = decltype(kc)::value;
+                    float v[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) v[jj] = fp[koff[ks][jj]];
-                if (NS == 2) {
-                    split_bf16x2(v[0], v[1], ph[ks].x, pl[ks].x); split_bf16x2(v[2], v[3], ph[ks].y, pl[ks].y);
-                    split_bf16x2(v[4], v[5], ph[ks].z, pl[ks].z); split_bf16x2(v[6], v[7], ph[ks].w, pl[ks].w);
-                } else {
-                    ph[ks] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-                }
-            }
-            const int t = t0 - 1 + i, f = f0 - 1 + j;
-            const bool inside = t >= 0 && t < T && f >= 0 && f < F;
-#pragma unroll
-            for (int nt = 0; nt < CI16; ++nt) {
-                const float4 s4 = *reinterpret_cast<const float4*>(sh1 + 16 * nt + 4 * g);
-                f32x4_t d = (f32x4_t){s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-                for (int ks = 0; ks < KS1; ++ks) {
-                    d = gm32(wf[nt][ks][0], ph[ks], d);
+                    for (int jj = 0; jj < 8; ++jj) v[jj] = fp[koff[ks][jj]];
                     if (NS == 2) {
-                        d = gm32(wf[nt][ks][0], pl[ks], d);
-                        d = gm32(wf[nt][ks][1], ph[ks], d);
+                        split_bf16x2(v[0], v[1], ph[i_][ks].x, pl[i_][ks].x); split_bf16x2(v[2], v[3], ph[i_][ks].y, pl[i_][ks].y);
+                        split_bf16x2(v[4], v[5], ph[i_][ks].z, pl[i_][ks].z); split_bf16x2(v[6], v[7], ph[i_][ks].w, pl[i_][ks].w);
+                    } else {
+                        ph[i_][ks] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
                     }
-                }
-                float o[4];
+                });
+            });
+            f32x4_t d[GP][CI16];
+            static_for<0, cnt>([&](auto ic) {
+                constexpr int i_ = decltype(ic)::value;
+                static_for<0, CI16>([&](auto nc) {
+                    constexpr int nt = decltype(nc)::value;
+                    f32x4_t dd = (f32x4_t){s4[nt].x, s4[nt].y, s4[nt].z, s4[nt].w};
+                    static_for<0, KS1>([&](auto kc) {
+                        constexpr int ks = decltype(kc)::value;
+                        dd = gm32(wf[nt][ks][0], ph[i_][ks], dd);
+                        if constexpr (NS == 2) {
+                            dd = gm32(wf[nt][ks][0], pl[i_][ks], dd);
+                            dd = gm32(wf[nt][ks][NS - 1], ph[i_][ks], dd);
+                        }
+                    });
+                    d[i_][nt] = dd;
+                });
+            });
+            static_for<0, cnt>([&](auto ic) {
+                constexpr int i_ = decltype(ic)::value;
+                static_for<0, CI16>([&](auto nc) {
+                    constexpr int nt = decltype(nc)::value;
+                    float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = inside ? fmaxf(d[r], 0.f) : 0.f;
-                uint2 hi, lo = make_uint2(0, 0);
-                if (NS == 2) { split_bf16x2(o[0], o[1], hi.x, lo.x); split_bf16x2(o[2], o[3], hi.y, lo.y); }
-                else hi = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-                if (pos < NPOS) {
-                    // channels 16 nt + 4 g .. + 4 = half (g & 1) of 16-byte chunk 2 nt + (g >> 1)
-                    const int off = (2 * nt + (g >> 1)) * CPLANE + pos * 16 + (g & 1) * 8;
-                    *reinterpret_cast<uint2*>(xs + off) = hi;
-                    if (NS == 2) *reinterpret_cast<uint2*>(xs + XPLANE + off) = lo;
-                }
-            }
-        }
+                    for (int r = 0; r < 4; ++r) o[r] = inside[i_] ? fmaxf(d[i_][nt][r], 0.f) : 0.f;
+                    uint2 hi, lo = make_uint2(0, 0);
+                    if (NS == 2) { split_bf16x2(o[0], o[1], hi.x, lo.x); split_bf16x2(o[2], o[3], hi.y, lo.y); }
+                    else hi = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                    if (pos[i_] < NPOS) {
+                        // channels 16 nt + 4 g .. + 4 = half (g & 1) of 16-byte chunk 2 nt + (g >> 1)
+                        const int off = (2 * nt + (g >> 1)) * CPLANE + pos[i_] * 16 + (g & 1) * 8;
+                        *reinterpret_cast<uint2*>(xs + off) = hi;
+                        if (NS == 2) *reinterpret_cast<uint2*>(xs + XPLANE + off) = lo;
+                    }
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);                 // one pair at a time: hoisting every pair's gathers to the top spills
+        });
     };
 
     uint4 xraw[FUSE1 ? 1 : NIT][NRAW], wreg[NWIT];
     float fraw[NF1];
     unsigned xok = 0;
     int tile = blockIdx.x;
-    if (FUSE1) load_f(tile, fraw);
+    if (FUSE1) load_f(tile, fraw, xok);
     else load_x(tile, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);
     bool w_resident = false;
     if (w_all) {                                               // every C_out chunk fits next to the tile: weights stay in LDS for the launch
@@ -290,24 +350,32 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
         load_w(0, wreg);
     }
 
+#ifdef AMTX_CONV_TIMING
+    unsigned long long cg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cg_t = __builtin_readcyclecounter();
+#endif
     for (; tile < ntiles; tile += gridDim.x) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
         const int t_out = t0 + r16;
+        CG_TICK(7);
         const int next = tile + (int)gridDim.x;
         const bool has_next = next < ntiles;
         if (FUSE1) {
-            store_f(fraw);
+            store_f(fraw, xok);
             __syncthreads();                                   // feature tile visible
-            if (has_next) load_f(next, fraw);
+            CG_TICK(0);
+            if (has_next) load_f(next, fraw, xok);
             first_conv(t0, f0);
+            CG_TICK(1);
         } else {
             store_x(reinterpret_cast<const uint4 (&)[NIT][NRAW]>(xraw), xok);
+            CG_TICK(0);
         }
 
         for (int ch = 0; ch < nchunks; ++ch) {
             if (!w_resident) store_w(wreg);
             if (!w_all || ch == 0) __syncthreads();            // tile and weight chunk visible
+            CG_TICK(2);
             if (!FUSE1 && ch == 0 && has_next) load_x(next, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);  // in flight during the MFMA phase
             if (!w_all) {
                 if (nchunks > 1) {
@@ -396,6 +464,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                 __builtin_amdgcn_sched_barrier(0);
             });
 
+            CG_TICK(3);
             // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
             if (t_out < T) {
 #pragma unroll
@@ -415,10 +484,30 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                     }
                 }
             }
+            CG_TICK(4);
             if (!w_all || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
+            CG_TICK(5);
+#ifdef AMTX_CONV_TIMING
+            cg_acc[6] += 1;
+#endif
         }
     }
+#ifdef AMTX_CONV_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_convg_prof[i], cg_acc[i]);
+#endif
 }
+
+#ifdef AMTX_CONV_TIMING
+extern "C" int amtxdbg_convg_prof(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_convg_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_convg_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0>
 int launch_gen(const ConvArgs& a, hipStream_t stream) {
@@ -429,7 +518,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
     const int nchunks = a.c_out / (16 * NTC);
     const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)NTC * NS * g_wfrags_per_tile(CI16) * 1024;
-    const size_t lds_f = KS1 > 0 ? (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float) : 0;
+    const size_t lds_f = KS1 > 0 ? (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float) + (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
     const int w_all = nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
     const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
@@ -464,11 +553,9 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
         amtx_set_error("conv3x3 (general): fused first conv: unsupported c_in / precision");
         return AMTX_ERR_UNSUPPORTED;
     }
-    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) {
-        static const bool narrow = getenv("AMTX_CONVG_FT16") != nullptr;
-        if (narrow) return launch_gen<CI16, NTC, 1, 16, AMTX_T_BF16, AMTX_T_BF16>(a, s);
-        return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
-    }
+    // (16-column tiles = two 256-thread blocks per CU were measured too: 22.5 vs 15.9 ms for conv2 at mc 3, the kernels need more
+    // than 256 VGPRs so only one of the two blocks is resident)
+    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
     if (a.planes == 2 && a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32>(a, s);
     amtx_set_error("conv3x3 (general): unsupported precision/type combination");
     return AMTX_ERR_UNSUPPORTED;
@@ -544,7 +631,7 @@ bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
     if (c_in < 1 || c_in > 7 || !amtx_conv3x3_gen_ntc(c_mid, c_out)) return false;
     const int ft = planes == 2 ? 16 : 32, ntc = amtx_conv3x3_gen_ntc(c_mid, c_out);
     const size_t lds = (size_t)planes * (c_mid / 8) * g_cplane(ft) + (size_t)ntc * planes * g_wfrags_per_tile(c_mid / 16) * 1024 +
-                       (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
+                       (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float) + (size_t)(c_mid / 16) * ((9 * c_in + 31) / 32) * planes * 1024 + c_mid * 4;
     return lds <= 160 * 1024;
 }
 
