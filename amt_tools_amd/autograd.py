@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['bilstm', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction']
+__all__ = ['bilstm', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction']
 
 H = 128
 
@@ -110,3 +110,57 @@ class BCELogitsLossFunction(torch.autograd.Function):
 def bce_logits_loss(logits, labels, weight=None):
     """(B,T,K) fp32 CUDA logits, (B,K,T) labels -> scalar loss attached to the autograd graph of `logits`."""
     return BCELogitsLossFunction.apply(logits, labels, weight)
+
+
+class BNReLUPoolFunction(torch.autograd.Function):
+    """BatchNorm2d with batch statistics + ReLU (+ MaxPool2d((1, 2))) of the acoustic model's conv stages
+    (amt_tools/models/onsetsframes.py:375-416) as two HIP passes forward and two backward (amtx_bn_relu_pool_train_fwd / _bwd)
+    instead of MIOpen BatchNorm + elementwise ReLU / pooling kernels.  x (B, C, T, F) fp32 in channels-last memory format."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, pool):
+        B, Cc, T, F = x.shape
+        L = _lib.lib()
+        Fo = F // 2 if pool else F
+        y = torch.empty((B, Cc, T, Fo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        stats = torch.empty((4, Cc), dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(L.amtx_bn_train_workspace_bytes(Cc)), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.amtx_bn_relu_pool_train_fwd(_lib.ptr(x), B * T, F, Cc, int(pool), _lib.ptr(weight), _lib.ptr(bias), float(eps),
+                                                     float(momentum), _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(y),
+                                                     _lib.ptr(stats), _lib.ptr(ws), ws.numel(), _lib.current_stream(x.device)),
+                       'amtx_bn_relu_pool_train_fwd')
+        ctx.save_for_backward(x, stats)
+        ctx.pool = int(pool)
+        ctx.ws = ws
+        ctx.affine = weight is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        B, Cc, T, F = x.shape
+        L = _lib.lib()
+        dy = dy.contiguous(memory_format=torch.channels_last).float()
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if ctx.affine else None
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device) if ctx.affine else None
+        with torch.cuda.device(x.device):
+            _lib.check(L.amtx_bn_relu_pool_train_bwd(_lib.ptr(x), B * T, F, Cc, ctx.pool, _lib.ptr(stats), _lib.ptr(dy), _lib.ptr(dx),
+                                                     _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(ctx.ws), ctx.ws.numel(),
+                                                     _lib.current_stream(x.device)), 'amtx_bn_relu_pool_train_bwd')
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_pool_supported(x, bn):
+    """The HIP path takes fp32 channels-last CUDA maps in training mode with a fixed momentum and tracked running statistics."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and bn.training and bn.track_running_stats and bn.momentum is not None
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def bn_relu_pool(x, bn, pool):
+    """nn.Sequential(bn, ReLU(), [MaxPool2d((1, 2))]) on x through the HIP kernels, differentiably, with bn's running statistics
+    and num_batches_tracked updated as nn.BatchNorm2d does in training mode."""
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BNReLUPoolFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, bool(pool))

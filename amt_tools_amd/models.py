@@ -151,8 +151,28 @@ class AcousticModel(nn.Module):
                                     nn.MaxPool2d((1, 2)), nn.Dropout(0.25))
         self.fc1 = nn.Sequential(nn.Linear(nf3 * (dim_in // 4), dim_out), nn.Dropout(0.50))
 
+    use_hip_bn = True        # False: stock nn.BatchNorm2d / ReLU / MaxPool2d (ATen + MIOpen) also on the GPU in training mode
+
+    def _stage(self, layer, x):
+        """One conv stage.  Training on a GPU: the convolution stays ATen / MIOpen, BatchNorm (batch statistics) + ReLU (+ MaxPool)
+        run as the HIP passes of amt_tools_amd/autograd.py (bn_relu_pool); the Dropout behind them is the module's own."""
+        mods = list(layer)
+        if self.training and self.use_hip_bn and x.is_cuda:
+            from .autograd import bn_relu_pool, bn_relu_pool_supported
+            y = mods[0](x)
+            if bn_relu_pool_supported(y, mods[1]):
+                pool = len(mods) > 3 and isinstance(mods[3], nn.MaxPool2d)
+                y = bn_relu_pool(y, mods[1], pool)
+                for m in mods[(4 if pool else 3):]:
+                    y = m(y)
+                return y
+            for m in mods[1:]:
+                y = m(y)
+            return y
+        return layer(x)
+
     def forward(self, in_feats):
-        x = self.layer3(self.layer2(self.layer1(in_feats)))
+        x = self._stage(self.layer3, self._stage(self.layer2, self._stage(self.layer1, in_feats)))
         x = x.transpose(-3, -2).flatten(-2)
         return self.fc1(x)
 
@@ -352,10 +372,13 @@ class OnsetsFrames(TranscriptionModel):
         self.__dict__.pop('_engine_out', None)
         self.__dict__.pop('_engine_offsets', None)
         output = dict()
-        if feats.is_cuda and self.training and self.__dict__.get('overlap_heads', True):
-            # The two heads only meet at the adjoin layer.  The onset head (acoustic model + a 625-step BiLSTM that occupies 4 of
-            # the 256 CUs at 8 clips) runs on a side stream next to the pitch head; autograd replays each op's backward on the
-            # stream of its forward, so the backward passes overlap the same way.
+        if feats.is_cuda and self.training and self.__dict__.get('overlap_heads', False):
+            # OPT-IN (model.__dict__['overlap_heads'] = True), off by default: the two heads only meet at the adjoin layer, so the
+            # onset head (acoustic model + a 625-step BiLSTM that occupies 4 of the 256 CUs at 8 clips) can run on a side stream
+            # next to the pitch head; autograd replays each op's backward on the stream of its forward, so the backward passes
+            # overlap the same way (15.6 -> 14.0 ms per step).  It is off because with two streams the training loop hung
+            # intermittently on MI355X / ROCm 7.2 (torch.cuda.synchronize() never returning after 7-13 steps, with the stock ATen
+            # BatchNorm path as well as with the HIP one; not root-caused: two hardware queues + kernels with scratch memory).
             main = torch.cuda.current_stream(feats.device)
             side = self.__dict__.get('_side_stream')
             if side is None or side.device != feats.device:

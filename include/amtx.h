@@ -159,6 +159,17 @@ int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int pl
                           void* stream);
 int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
                           int num_frames, void* stream);
+/* Training-mode BatchNorm2d (batch statistics, running statistics updated as nn.BatchNorm2d does) + ReLU (+ MaxPool2d((1,2)) when
+ * pool = 1) of the acoustic model's conv stages (amt_tools/models/onsetsframes.py:375-416 under amt_tools/train.py:126-141), and its
+ * backward.  Channels-last fp32: x (rows = B*T, num_bins, channels), y / dy (rows, num_bins / 2 or num_bins, channels).
+ * stats [4][channels] (mean, invstd, gamma * invstd, beta - mean * gamma * invstd) is written by the forward and read by the backward.
+ * gamma / beta / running_* may be null; dgamma / dbeta may be null. */
+size_t amtx_bn_train_workspace_bytes(int channels);
+int amtx_bn_relu_pool_train_fwd(const float* x, int64_t rows, int num_bins, int channels, int pool, const float* gamma, const float* beta,
+                                float eps, float momentum, float* running_mean, float* running_var, float* y, float* stats,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int amtx_bn_relu_pool_train_bwd(const float* x, int64_t rows, int num_bins, int channels, int pool, const float* stats, const float* dy,
+                                float* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 /* LogisticBank.get_loss (amt_tools/models/common.py:541-584) forward and backward in one pass: logits (B, T, keys) fp32 with row
  * stride ld, labels (B, keys, T) fp32, weight = optional per-key weights (`OutputLayer.weights`);
  * *loss = mean_b sum_k mean_t w_k BCEWithLogits, grad (optional, (B, T, keys) contiguous) = d loss / d logits.

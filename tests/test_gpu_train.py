@@ -65,6 +65,8 @@ def test_training_step_on_gpu_matches_reference_golden():
     for mod in model.modules():
         if hasattr(mod, 'use_hip_autograd'):
             mod.use_hip_autograd = False
+        if hasattr(mod, 'use_hip_bn'):
+            mod.use_hip_bn = False
     model.zero_grad()
     out2 = model.run_on_batch(batch)
     assert abs(out2[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].item() - loss[tools.KEY_LOSS_TOTAL].item()) < 1e-3
@@ -90,3 +92,47 @@ def test_bce_logits_loss_matches_torch(B, T, K, weighted):
     assert (x.grad.double() - x64.grad).abs().max().item() <= 1e-6 * x64.grad.abs().max().item() + 1e-9
     again = bce_logits_loss(x.detach(), y, w)
     assert again.item() == loss.item()                                             # deterministic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,C,T,F,pool', [(2, 32, 9, 229, False), (2, 32, 9, 229, True), (3, 64, 5, 114, True), (1, 48, 7, 18, True),
+                                          (1, 96, 3, 2, True), (2, 4, 3, 5, False), (8, 32, 64, 229, True)])
+def test_bn_relu_pool_training_matches_torch(B, C, T, F, pool):
+    """amtx_bn_relu_pool_train_fwd / _bwd = nn.BatchNorm2d (training) -> ReLU -> [MaxPool2d((1,2))] against torch in float64:
+    output, input gradient, gamma / beta gradients, running statistics, num_batches_tracked."""
+    from amt_tools_amd.autograd import bn_relu_pool, bn_relu_pool_supported
+    gen = torch.Generator().manual_seed(B * 100 + C + T + F)
+    x = (torch.randn(B, C, T, F, generator=gen) * 1.5 + 0.3)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=gen) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=gen) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, generator=gen) * 0.1)
+        bn.running_var.copy_(torch.rand(C, generator=gen) + 0.5)
+    import copy
+    ref_bn = copy.deepcopy(bn).double()
+    x64 = x.double().requires_grad_(True)
+    y_ref = torch.relu(ref_bn(x64))
+    if pool:
+        y_ref = torch.nn.functional.max_pool2d(y_ref, (1, 2))
+    gy = torch.randn(y_ref.shape, generator=gen)
+    y_ref.backward(gy.double())
+
+    bn = bn.cuda()
+    xc = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    assert bn_relu_pool_supported(xc, bn)
+    y = bn_relu_pool(xc, bn, pool)
+    assert y.shape == y_ref.shape
+    y.backward(gy.cuda())
+    assert _rel(y.detach().cpu().double(), y_ref.detach()) < 2e-6
+    assert _rel(xc.grad.cpu().double(), x64.grad) < 2e-5
+    assert _rel(bn.weight.grad.cpu().double(), ref_bn.weight.grad) < 2e-5
+    assert _rel(bn.bias.grad.cpu().double(), ref_bn.bias.grad) < 2e-5
+    assert _rel(bn.running_mean.cpu().double(), ref_bn.running_mean) < 1e-6
+    assert _rel(bn.running_var.cpu().double(), ref_bn.running_var) < 1e-6
+    assert int(bn.num_batches_tracked) == 1
+    # deterministic (no atomics)
+    xc2 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y2 = bn_relu_pool(xc2, bn, pool)
+    y2.backward(gy.cuda())
+    assert torch.equal(xc2.grad, xc.grad)

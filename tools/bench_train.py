@@ -2,8 +2,8 @@
 """Training-step timing (BASELINE config 4): OnsetsFrames(mc=2) fwd + bwd + Adam on 8 clips x 625 frames per GPU,
 clip-level data parallelism through amt_tools_amd.dp.DataParallelOptimizer (one flat gradient all-reduce per step;
 backend nccl = RCCL).  Features come from the HIP mel front-end in `model.frontend`; the model's forward/backward in
-training mode is ATen autograd for the convolutions / BatchNorm / Linear layers and the HIP BiLSTM autograd function
-(amt_tools_amd/autograd.py: one persistent kernel forward, one backward) for the three recurrences.
+training mode is ATen autograd for the convolutions / Linear layers, the HIP BiLSTM autograd function (amt_tools_amd/autograd.py:
+one persistent kernel forward, one backward) for the three recurrences and the HIP BatchNorm(batch statistics)+ReLU+MaxPool passes.
 
     python tools/bench_train.py [--steps K] [--warmup W] [--clips 8]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py
@@ -70,6 +70,6 @@ if rank == 0:
     print(json.dumps({'metric': 'train step time (OnsetsFrames fwd+bwd+Adam, 8 clips x 625 frames per GPU)', 'value': dt / args.steps * 1e3,
                       'unit': 'ms/step', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': False,
                       'scaling': 'weak', 'frames_per_s': world * B * 625 * args.steps / dt, 'loss': float(loss),
-                      'backward': 'ATen autograd (conv / BN / linear) + HIP BiLSTM forward/backward kernels'}))
+                      'backward': 'ATen autograd (conv / linear) + HIP BiLSTM and BatchNorm+ReLU+MaxPool forward/backward kernels'}))
 if world > 1:
     dist.destroy_process_group()
