@@ -209,8 +209,13 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     for (int k = 0; k < NF1; ++k) {
         const int it = tid + k * NTH;
         const int itc = it < nfeat ? it : 0;
-        const int j = itc % (FT + 4), rest = itc / (FT + 4);
-        fdesc[k] = (it < nfeat ? 0x80000000u : 0u) | ((unsigned)(rest / FROWS1) << 16) | ((unsigned)(rest % FROWS1) << 8) | (unsigned)j;
+        int ci, i, j;
+        if (a.f_stride_t < a.f_stride_f) {        // frames contiguous (a (B,C,F,T) tensor): consecutive lanes = consecutive frames of one column
+            i = itc % FROWS1; j = (itc / FROWS1) % (FT + 4); ci = itc / (FROWS1 * (FT + 4));
+        } else {                                  // columns contiguous (the model layout the log-mel kernels write)
+            j = itc % (FT + 4); i = (itc / (FT + 4)) % FROWS1; ci = itc / (FROWS1 * (FT + 4));
+        }
+        fdesc[k] = (it < nfeat ? 0x80000000u : 0u) | ((unsigned)ci << 16) | ((unsigned)i << 8) | (unsigned)j;
     }
     const int nfk = (nfeat + NTH - 1) / NTH;                   // items per thread that exist for this c_in (uniform)
     auto load_f = [&](int tile, float (&fr)[NF1], unsigned& okmask) {
@@ -566,6 +571,7 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
 // C_out chunk (in 16-channel tiles) the general kernel keeps in LDS at a time
 int amtx_conv3x3_gen_ntc(int c_in, int c_out) {
     if (c_in == 48 && c_out % 48 == 0) return 3;
+    if (c_in == 32 && c_out == 32) return 2;          // model_complexity 2 with a multi-channel first conv (HCQT), see ofmodel.hip
     return 0;
 }
 
@@ -641,6 +647,7 @@ int amtx_launch_conv3x3_gen(const ConvArgs& a, int c_in, hipStream_t stream) {
     AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F >= 2 && a.groups > 0, "conv3x3 (general): bad sizes");
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3 (general): planes must be 1 or 2");
     if (c_in == 48 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 3) return dispatch_gen<3, 3>(a, stream);
+    if (c_in == 32 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 2) return dispatch_gen<2, 2>(a, stream);
     amtx_set_error("conv3x3 (general): unsupported channel counts %d -> %d", c_in, a.c_out);
     return AMTX_ERR_UNSUPPORTED;
 }

@@ -52,6 +52,7 @@ struct amtx_of_model {
     int kfc_pad;                               // fc1's K rounded up to the DMA GEMM's 64-deep k-tile (rows of a3 are this long)
     int hid, xw;                               // LSTM hidden size per direction, width of an x-projection row (2 dirs x 4 gates x hid)
     bool gen_conv = false;                     // channel counts other than 32/32/64: convg.hip (weights in LDS) instead of conv.hip
+    bool gen_conv2 = false;                    // conv2 (+ fused first conv) through convg.hip: gen_conv, or 32 -> 32 with a multi-channel input
     int n_heads;                               // acoustic heads: onset, (offset), pitch
     int n_rec;                                 // recurrent heads feeding the joint: onset, (offset)
     std::vector<std::string> head_names;       // state_dict prefixes of the acoustic models, group order
@@ -208,13 +209,17 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->kfc_pad = (m->kfc + 63) / 64 * 64;
     m->hid = m->dim_lm / 2; m->xw = 8 * m->hid;
     m->gen_conv = m->nf1 != 32;
+    // 32/32/64 channels with more than one input channel (HCQT): conv.hip's fused first conv runs its 9 c_in taps as four legacy
+    // 16-deep MFMA steps and stages c_in x 20 x (columns + 4) feature values per tile through a register-starved loop (3.6 ms per
+    // 512 HCQT clips); convg.hip's fused first conv (two 32-deep steps, weights in LDS) is the faster one there
+    m->gen_conv2 = m->gen_conv || (in_channels > 1 && getenv("AMTX_NO_CONVG_MC2") == nullptr && amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes));
     m->head_names = {"onset_head"};
     if (has_offsets) m->head_names.push_back("offset_head");
     m->n_rec = (int)m->head_names.size();
     m->head_names.push_back("pitch_head");
     m->n_heads = (int)m->head_names.size();
     m->dim_aj = (m->n_rec + 1) * n_out;
-    m->fuse_conv1 = m->gen_conv ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
+    m->fuse_conv1 = m->gen_conv2 ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
     *out = m;
     return AMTX_OK;
 }
@@ -242,10 +247,10 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     const int nh = m->n_heads;
     // ---- acoustic heads
     std::vector<float> c1w((size_t)nh * m->nf1 * m->in_channels * 9), c1s((size_t)nh * m->nf1);
-    m->fuse_conv1 = m->gen_conv ? amtx_conv3x3_gen_can_fuse1(m->in_channels, m->nf1, m->nf2, m->planes) : (9 * m->in_channels <= 64);
-    const size_t c1f_per = m->gen_conv ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, m->planes) : amtx_conv1_wfrag_elems(m->in_channels, m->planes);
+    m->fuse_conv1 = m->gen_conv2 ? amtx_conv3x3_gen_can_fuse1(m->in_channels, m->nf1, m->nf2, m->planes) : (9 * m->in_channels <= 64);
+    const size_t c1f_per = m->gen_conv2 ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, m->planes) : amtx_conv1_wfrag_elems(m->in_channels, m->planes);
     std::vector<bf16_t> c1f(m->fuse_conv1 ? c1f_per * nh : 0);
-    const size_t c2w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, m->planes) : amtx_conv3x3_wfrag_elems(m->nf2, m->planes);
+    const size_t c2w_per = m->gen_conv2 ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, m->planes) : amtx_conv3x3_wfrag_elems(m->nf2, m->planes);
     const size_t c3w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, m->planes) : amtx_conv3x3_wfrag_elems(m->nf3, m->planes);
     if (m->gen_conv && (!amtx_conv3x3_gen_ntc(m->nf1, m->nf2) || !amtx_conv3x3_gen_ntc(m->nf2, m->nf3))) {
         amtx_set_error("of_model: no convolution kernel for %d -> %d -> %d channels", m->nf1, m->nf2, m->nf3);
@@ -265,13 +270,13 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
             for (int i = 0; i < m->in_channels * 9; ++i)
                 c1w[((size_t)h * m->nf1 + co) * m->in_channels * 9 + i] = w[(size_t)co * m->in_channels * 9 + i] * scale[co];
         memcpy(c1s.data() + (size_t)h * m->nf1, shift.data(), sizeof(float) * m->nf1);
-        if (m->fuse_conv1 && m->gen_conv) amtx_conv1g_pack_host(w, scale.data(), m->in_channels, m->nf1, m->planes, c1f.data() + c1f_per * h);
+        if (m->fuse_conv1 && m->gen_conv2) amtx_conv1g_pack_host(w, scale.data(), m->in_channels, m->nf1, m->planes, c1f.data() + c1f_per * h);
         else if (m->fuse_conv1) amtx_conv1_pack_host(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
 
         rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
-        if (m->gen_conv) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
+        if (m->gen_conv2) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
         else amtx_conv3x3_pack_host(w, scale.data(), m->nf2, m->planes, c2w.data() + c2w_per * h);
         memcpy(c2s.data() + (size_t)h * m->nf2, shift.data(), sizeof(float) * m->nf2);
 
@@ -403,15 +408,15 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     c2.in = w.a1; c2.in_type = at; c2.wfrag = (const bf16_t*)m->conv2_w.p; c2.planes = pl; c2.shift = (const float*)m->conv2_s.p;
     c2.out = w.a2; c2.out_type = at; c2.B = B; c2.T = T; c2.F = F; c2.c_out = m->nf2;
     c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.shift_gs = m->nf2;
-    c2.w_gs = (int64_t)(m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, pl) : amtx_conv3x3_wfrag_elems(m->nf2, pl));
+    c2.w_gs = (int64_t)(m->gen_conv2 ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, pl) : amtx_conv3x3_wfrag_elems(m->nf2, pl));
     c2.out_gs = BT * F2 * m->nf2;
     if (m->fuse_conv1) {   // Conv(c_in->32)+BN+ReLU computed inside the conv2 kernel; a1 is never materialised
         c2.in = nullptr;
         c2.feats = feats; c2.f_stride_b = stride_b; c2.f_stride_c = stride_c; c2.f_stride_t = stride_t; c2.f_stride_f = stride_f;
         c2.c_in = m->in_channels; c2.w1frag = (const bf16_t*)m->conv1_frag.p; c2.shift1 = (const float*)m->conv1_s.p;
-        c2.w1_gs = (int64_t)(m->gen_conv ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, pl) : amtx_conv1_wfrag_elems(m->in_channels, pl));
+        c2.w1_gs = (int64_t)(m->gen_conv2 ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, pl) : amtx_conv1_wfrag_elems(m->in_channels, pl));
     }
-    if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
+    if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c3 = c2;
