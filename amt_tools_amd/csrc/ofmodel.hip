@@ -211,7 +211,8 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->gen_conv = m->nf1 != 32;
     // 32/32/64 channels with more than one input channel (HCQT): conv.hip's fused first conv runs its 9 c_in taps as four legacy
     // 16-deep MFMA steps and stages c_in x 20 x (columns + 4) feature values per tile through a register-starved loop (3.6 ms per
-    // 512 HCQT clips); convg.hip's fused first conv (two 32-deep steps, weights in LDS) is the faster one there
+    // 512 HCQT clips); convg.hip's fused first conv (two 32-deep steps, weights in LDS) is the faster one there (2.7 ms).  With one
+    // input channel conv.hip stays far ahead: 5.6 vs 9.7 ms per 1024 mel clips (weights stationary in registers, 18 x 46 tiles).
     m->gen_conv2 = m->gen_conv || (in_channels > 1 && getenv("AMTX_NO_CONVG_MC2") == nullptr && amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes));
     m->head_names = {"onset_head"};
     if (has_offsets) m->head_names.push_back("offset_head");
