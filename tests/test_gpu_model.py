@@ -223,6 +223,47 @@ def test_fused_frontend_audio_to_pianoroll(precision):
         assert out[key].shape == (2, 88, 24)
 
 
+def test_of2_experiment_shape_audio_to_notes():
+    """The reference's OnsetsFrames2 experiment end to end (scripts of_2.py:87-110,157-175): audio -> HTK log-mel front-end fused
+    into the model -> OnsetsFrames2 as shipped (model_complexity 3, offset head) -> piano rolls + offset probabilities -> notes.
+    Against oracle front-end + oracle model (fp32-class mode), and the batched driver against one-clip-at-a-time run_offline."""
+    from oracle import frontend_np as fe, model_ref
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.inference import run_offline, run_offline_batched
+    from amt_tools_amd.models import OnsetsFrames2
+    from amt_tools_amd.transcribe import NoteTranscriber
+    sd = synth_state_dict(21, dim_in=229, in_channels=1, model_complexity=3, offsets=True)
+    model = OnsetsFrames2(229, tools.PianoProfile(), 1, device='cuda:0', precision='x3')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    mod = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048, htk=True)
+    model.frontend = torch.nn.Sequential(mod.frontend())
+    T = 40
+    clips = np.stack([synth_clip(i, num_samples=512 * T - 1) for i in range(5)])
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_AUDIO: torch.from_numpy(clips[:2])})
+    assert set(out.keys()) == {tools.KEY_ONSETS, tools.KEY_OFFSETS, tools.KEY_MULTIPITCH}
+    feats = np.stack([fe.melspec_process_audio(a, 22050, htk=True) for a in clips[:2]]).astype(np.float32)
+    sdt = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith('frontend')}
+    with torch.no_grad():
+        ref = model_ref.run_on_batch(torch.from_numpy(feats), sdt)
+    for key in ('onsets', 'multi_pitch'):
+        near = np.abs(ref['logits'][key].transpose(-1, -2).numpy()) < 2e-4
+        assert out[key].shape == (2, 88, T)
+        assert np.all((out[key].cpu().numpy() == ref[key].numpy()) | near)
+    off = out[tools.KEY_OFFSETS].cpu().numpy()
+    assert off.shape == (2, 88, T) and off.min() >= 0.0 and off.max() <= 1.0            # probabilities (onsetsframes.py:323-325)
+    assert np.abs(off - torch.sigmoid(ref['logits']['offsets']).transpose(-1, -2).numpy()).max() < 1e-4
+    times = (np.arange(T) * 512 / 22050.0).astype(np.float32)
+    res = run_offline_batched(clips, model, times=times, batch_size=2, decode_notes=True)
+    est = NoteTranscriber(tools.PianoProfile())
+    for i in (0, 4):
+        single = run_offline({tools.KEY_AUDIO: clips[i], tools.KEY_TIMES: times}, model, est)
+        for key in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH, tools.KEY_OFFSETS, tools.KEY_NOTES):
+            np.testing.assert_array_equal(res[i][key], single[key])
+
+
 def test_full_size_batch_properties():
     """BASELINE-size clips (625 frames): clip independence (a clip's result does not depend on its batch
     neighbours) and time-reversal consistency are size-independent properties of the path."""
