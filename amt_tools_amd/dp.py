@@ -102,24 +102,26 @@ class DataParallelOptimizer(torch.optim.Optimizer):
         if flat is None or flat.numel() != numel or flat.device != params[0].device:
             flat = torch.zeros(numel, dtype=torch.float32, device=params[0].device)
             self.__dict__['_flat'] = flat
-        off = 0
+        # one multi-tensor copy into the flat buffer and one back (a Python loop of ~60 small copies each way kept the host busy
+        # for longer than the all-reduce itself takes over xGMI)
+        views, off = [], 0
         for p in params:
             n = p.numel()
-            if p.grad is None:
-                flat[off:off + n].zero_()
-            else:
-                flat[off:off + n].copy_(p.grad.reshape(-1))
+            views.append(flat[off:off + n].view(p.shape))
             off += n
+        have = [i for i, p in enumerate(params) if p.grad is not None]
+        for i, p in enumerate(params):
+            if p.grad is None:
+                views[i].zero_()
+        if have:
+            torch._foreach_copy_([views[i] for i in have], [params[i].grad for i in have])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._group)
         flat.div_(world)
-        off = 0
-        for p in params:
-            n = p.numel()
+        if have:
+            torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])
+        for i, p in enumerate(params):
             if p.grad is None:
-                p.grad = flat[off:off + n].view_as(p).clone()
-            else:
-                p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
+                p.grad = views[i].clone()
 
     def step(self, closure=None):
         loss = None

@@ -173,6 +173,18 @@ class AcousticModel(nn.Module):
 
     def forward(self, in_feats):
         x = self._stage(self.layer3, self._stage(self.layer2, self._stage(self.layer1, in_feats)))
+        if (self.training and x.is_cuda and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+                and not x.is_contiguous()):
+            # channels-last map: (B,T,F,C) is a free view, so the reference's (channel, freq) flatten order is applied to fc1's
+            # weight columns (7.5 MB, differentiable permute) instead of transposing the activations (73 MB per head and step,
+            # forward and backward)
+            lin = self.fc1[0]
+            B, C, T, F = x.shape
+            w = lin.weight.view(lin.out_features, C, F).transpose(1, 2).reshape(lin.out_features, F * C)
+            y = torch.nn.functional.linear(x.permute(0, 2, 3, 1).reshape(B, T, F * C), w, lin.bias)
+            for m in list(self.fc1)[1:]:
+                y = m(y)
+            return y
         x = x.transpose(-3, -2).flatten(-2)
         return self.fc1(x)
 
