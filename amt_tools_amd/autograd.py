@@ -62,7 +62,8 @@ class BiLSTMFunction(torch.autograd.Function):
                                                _lib.current_stream(dout.device)), 'amtx_bilstm_train_bwd')
         dx = (dxproj @ w_ih).reshape(B, T, I) if ctx.needs_input_grad[0] else None
         dw_ih = dxproj.t() @ x2                                                       # (1024, I)
-        db = dxproj.sum(dim=0)
+        # column sums as a (1, B*T) x (B*T, 1024) product: ATen's reduce kernel over the strided dimension took 0.4 ms per LSTM
+        db = torch.ones((1, B * T), dtype=torch.float32, device=dxproj.device).mm(dxproj).squeeze(0)
         # h_{t-1} of the forward direction / h_{t+1} of the backward direction (zero initial state)
         hp_f = torch.zeros((B, T, H), dtype=torch.float32, device=out.device)
         hp_f[:, 1:] = out[:, :-1, :H]
