@@ -14,52 +14,54 @@ from . import _lib
 
 __all__ = ['bilstm', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction']
 
-H = 128
+HIDDEN_SIZES = (128, 256)       # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3)
 
 
 def _pack(w_hh_f, w_hh_b):
     L = _lib.lib()
-    n = int(L.amtx_bilstm_packed_elems(2))
+    H = w_hh_f.shape[1]
+    n = int(L.amtx_bilstm_h_packed_elems(H, 2))
     fwd = torch.empty(n, dtype=torch.int16, device=w_hh_f.device)
     bwd = torch.empty(n, dtype=torch.int16, device=w_hh_f.device)
     wf, wb = w_hh_f.detach().contiguous().float(), w_hh_b.detach().contiguous().float()
-    _lib.check(L.amtx_bilstm_pack_device(_lib.ptr(wf), _lib.ptr(wb), 2, _lib.ptr(fwd), _lib.ptr(bwd), _lib.current_stream(wf.device)),
-               'amtx_bilstm_pack_device')
+    _lib.check(L.amtx_bilstm_h_pack_device(_lib.ptr(wf), _lib.ptr(wb), H, 2, _lib.ptr(fwd), _lib.ptr(bwd), _lib.current_stream(wf.device)),
+               'amtx_bilstm_h_pack_device')
     return fwd, bwd
 
 
 class BiLSTMFunction(torch.autograd.Function):
-    """y = BiLSTM(x) with PyTorch's parameter layout (gate order i, f, g, o; weight_ih (512, I), weight_hh (512, 128), two biases
-    per direction), zero initial state, batch_first.  x (B, T, I) fp32 CUDA -> y (B, T, 256)."""
+    """y = BiLSTM(x) with PyTorch's parameter layout (gate order i, f, g, o; weight_ih (4H, I), weight_hh (4H, H), two biases
+    per direction), zero initial state, batch_first, H in HIDDEN_SIZES.  x (B, T, I) fp32 CUDA -> y (B, T, 2H)."""
 
     @staticmethod
     def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b):
         B, T, I = x.shape
+        H = w_hh_f.shape[1]
         L = _lib.lib()
         x2 = x.reshape(B * T, I)
-        w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                      # (1024, I)
+        w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                      # (8 H, I)
         bias = torch.cat([b_ih_f + b_hh_f, b_ih_b + b_hh_b], dim=0)
-        xproj = torch.addmm(bias, x2, w_ih.t()).contiguous()                           # (B*T, 2*512) = [B][T][2][512]
+        xproj = torch.addmm(bias, x2, w_ih.t()).contiguous()                           # (B*T, 2*4H) = [B][T][2][4H]
         frag_fwd, frag_bwd = _pack(w_hh_f, w_hh_b)
         out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
         save = torch.empty((B, T, 2, 5, H), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
-            _lib.check(L.amtx_bilstm_train_fwd(_lib.ptr(xproj), _lib.ptr(frag_fwd), 2, _lib.ptr(out), _lib.ptr(save), B, T,
-                                               _lib.current_stream(x.device)), 'amtx_bilstm_train_fwd')
+            _lib.check(L.amtx_bilstm_h_train_fwd(_lib.ptr(xproj), _lib.ptr(frag_fwd), H, 2, _lib.ptr(out), _lib.ptr(save), B, T,
+                                                 _lib.current_stream(x.device)), 'amtx_bilstm_h_train_fwd')
         ctx.save_for_backward(x2, w_ih, w_hh_f, w_hh_b, out, save, frag_bwd)
-        ctx.dims = (B, T, I)
+        ctx.dims = (B, T, I, H)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x2, w_ih, w_hh_f, w_hh_b, out, save, frag_bwd = ctx.saved_tensors
-        B, T, I = ctx.dims
+        B, T, I, H = ctx.dims
         L = _lib.lib()
         dout = dout.contiguous().float()
         dxproj = torch.empty((B * T, 4 * 2 * H), dtype=torch.float32, device=dout.device)
         with torch.cuda.device(dout.device):
-            _lib.check(L.amtx_bilstm_train_bwd(_lib.ptr(dout), _lib.ptr(save), _lib.ptr(frag_bwd), 2, _lib.ptr(dxproj), B, T,
-                                               _lib.current_stream(dout.device)), 'amtx_bilstm_train_bwd')
+            _lib.check(L.amtx_bilstm_h_train_bwd(_lib.ptr(dout), _lib.ptr(save), _lib.ptr(frag_bwd), H, 2, _lib.ptr(dxproj), B, T,
+                                                 _lib.current_stream(dout.device)), 'amtx_bilstm_h_train_bwd')
         dx = (dxproj @ w_ih).reshape(B, T, I) if ctx.needs_input_grad[0] else None
         dw_ih = dxproj.t() @ x2                                                       # (1024, I)
         # column sums as a (1, B*T) x (B*T, 1024) product: ATen's reduce kernel over the strided dimension took 0.4 ms per LSTM
@@ -77,7 +79,7 @@ class BiLSTMFunction(torch.autograd.Function):
 
 
 def bilstm(x, lstm):
-    """Run `lstm` (an nn.LSTM(batch_first, bidirectional, hidden 128, one layer)) on x through the HIP kernels, differentiably."""
+    """Run `lstm` (an nn.LSTM(batch_first, bidirectional, hidden in HIDDEN_SIZES, one layer)) on x through the HIP kernels, differentiably."""
     return BiLSTMFunction.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
                                 lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
 

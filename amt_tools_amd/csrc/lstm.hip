@@ -654,7 +654,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
         const int64_t t = tidx(s);
 #pragma unroll
         for (int ub = 0; ub < UPW; ++ub) {
-            float h[4];
+            float h[4], sv[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ig = sigmoid_f<FAST>(acc[ub][0][r]);
@@ -663,6 +663,13 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
                 const float og = sigmoid_f<FAST>(acc[ub][3][r]);
                 c[ub][r] = fg * c[ub][r] + ig * gg;
                 h[r] = og * tanh_f<FAST>(c[ub][r]);
+                sv[0][r] = ig; sv[1][r] = fg; sv[2][r] = gg; sv[3][r] = og;
+            }
+            if (a.save && clip_ok) {                          // training: post-activation gates and the cell state, [B][T][2][5][HH]
+                float* sp = a.save + ((((int64_t)grp * a.B + b) * T + t) * 2 + dir) * (5 * HH) + 16 * UPW * wave + 16 * ub + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(sp + q * HH) = make_float4(sv[q][0], sv[q][1], sv[q][2], sv[q][3]);
+                *reinterpret_cast<float4*>(sp + 4 * HH) = make_float4(c[ub][0], c[ub][1], c[ub][2], c[ub][3]);
             }
             uint2 hiw, low = make_uint2(0, 0);
             if (NS == 2) {
@@ -682,6 +689,186 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
         }
         cur ^= 1;
         lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward recurrence for any hidden size HH = 128 k (training at model_complexity 3): dout [B][T][2 HH], the forward's saved
+// gates / cell states -> dxproj [B][T][2][4 HH].  Lane mapping of bilstm4_bwd_kernel (four clips per block in rows 0/4/8/12 of the
+// dgates tile, lane = (unit, clip), product not swapped), but the 4 HH x HH recurrent weights (1 MiB in two planes at HH = 256)
+// are streamed from L2 every step through the same four-slot register ring as the forward stream kernel; every wave owns
+// HH / 8 hidden units = UT unit tiles.
+struct LstmBwdHArgs {
+    const float* dout; const float* save; const bf16_t* whh_t; float* dxproj; int B, T;
+};
+
+template <int HH, int NS>
+__global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) {
+    constexpr int UT = HH / 128;                   // unit tiles per wave
+    constexpr int KSN = 4 * HH / 32;               // k-steps over the gate rows
+    constexpr int SGK = NS == 2 ? 2 : 4;
+    constexpr int NG = UT * KSN / SGK;             // streamed groups per step and wave
+    constexpr int RS = 4;
+    constexpr int GPH = 4 * HH + 8;                // bf16 elements per row of the dgates tile
+    constexpr int GBH = 16 * GPH * 2;              // one plane of one buffer
+    static_assert(NG % RS == 0, "hidden size must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][GPH] bf16, rows 0/4/8/12 used
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = lane >> 4;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * 4 + cg;
+    const bool clip_ok = b < a.B;
+    const int T = a.T;
+    const int unit0 = 16 * UT * wave + (lane & 15);               // + 16 ut
+
+    for (int i = tid; i < 2 * NS * GBH / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+
+    // transposed fragments: uint4 index ((((dir * 8 + wave) * UT + ut) * KSN + ks) * NS + p) * 64 + lane
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* wbase = reinterpret_cast<const char*>(a.whh_t) + ((int64_t)(dir * 8 + wave_u) * UT * KSN * NS) * 1024;
+    const unsigned wlane = lane * 16;
+    typedef const __attribute__((address_space(1))) char* gchar_p;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+    typedef __attribute__((address_space(1))) u32x4_t gu4_t;
+    gchar_p wb = (gchar_p)wbase;
+    uint4 w[RS][SGK][NS];
+    auto load_frag = [&](int gi, int k, int p) {
+        return __builtin_bit_cast(uint4, *reinterpret_cast<const gu4_t*>(wb + ((gi * SGK + k) * NS + p) * 1024 + wlane));
+    };
+
+    const int64_t bb = clip_ok ? b : 0;
+    const float* sv0 = a.save + ((bb * T) * 2 + dir) * (5 * HH) + unit0;          // + t * (2*5*HH) + 16 ut + q * HH
+    const float* do0 = a.dout + (bb * T) * (2 * HH) + dir * HH + unit0;            // + t * 2 HH + 16 ut
+    float* dx0 = a.dxproj + (bb * T) * (8 * HH) + dir * 4 * HH + unit0;            // + t * 8 HH + q * HH + 16 ut
+    const int gwoff = (4 * cg * GPH + unit0) * 2;                                   // byte offset of (slot, gate 0, ut 0) in a tile plane
+
+    float dh_rec[UT], dc_rec[UT];
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut) { dh_rec[ut] = 0.f; dc_rec[ut] = 0.f; }
+    auto frame = [&](int s_) { s_ = s_ < T ? s_ : T - 1; return dir == 0 ? T - 1 - s_ : s_; };
+    float nv[UT][6];                                                              // i, f, g, o, c, dout of the next step
+    auto load_next = [&](int tn) {
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            const float* sv = sv0 + (int64_t)tn * (2 * 5 * HH) + 16 * ut;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) nv[ut][q] = sv[q * HH];
+            nv[ut][5] = do0[(int64_t)tn * (2 * HH) + 16 * ut];
+        }
+    };
+    load_next(frame(0));
+    static_for<0, RS - 1>([&](auto sc) {
+        constexpr int gi = decltype(sc)::value;
+        static_for<0, SGK>([&](auto kc) {
+            static_for<0, NS>([&](auto pc) { w[gi % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
+        });
+    });
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        wb = (gchar_p)wbase;
+        asm volatile("" : "+s"(wb));                          // see bilstm_stream_kernel: keeps the fragment addresses scalar
+        const int t = frame(s);
+        float cur[UT][6];
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) cur[ut][q] = nv[ut][q];
+        load_next(frame(s + 1));
+        char* gt = smem + (s & 1) * NS * GBH;
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) {
+            asm volatile("" : "+v"(nv[ut][4]));
+            const float cp = s + 1 < T ? nv[ut][4] : 0.f;     // cell state before step t in forward order (zero initial state)
+            const float ig = cur[ut][0], fg = cur[ut][1], gg = cur[ut][2], og = cur[ut][3], ct = cur[ut][4];
+            const float dh = cur[ut][5] + dh_rec[ut];
+            const float tc = tanh_f<true>(ct);
+            const float d_o = dh * tc * og * (1.f - og);
+            const float dc = dc_rec[ut] + dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg * ig * (1.f - ig);
+            const float d_g = dc * ig * (1.f - gg * gg);
+            const float d_f = dc * cp * fg * (1.f - fg);
+            dc_rec[ut] = dc * fg;
+            const float dgv[4] = {d_i, d_f, d_g, d_o};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (clip_ok) dx0[(int64_t)t * (8 * HH) + q * HH + 16 * ut] = dgv[q];
+                uint32_t hiw, low = 0;
+                if (NS == 2) split_bf16x2(dgv[q], 0.f, hiw, low);
+                else hiw = pack_bf16x2(dgv[q], 0.f);
+                *reinterpret_cast<unsigned short*>(gt + gwoff + (q * HH + 16 * ut) * 2) = (unsigned short)hiw;
+                if (NS == 2) *reinterpret_cast<unsigned short*>(gt + GBH + gwoff + (q * HH + 16 * ut) * 2) = (unsigned short)low;
+            }
+        }
+        lds_barrier();
+        // dh_prev[unit] = sum over the 4 HH gate rows of dgates[clip][row] * W_hh[row][unit]
+        f32x4_t acc[UT];
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) acc[ut] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        static_for<0, NG>([&](auto ic) {
+            constexpr int gi = decltype(ic)::value;
+            constexpr int ut = gi / (KSN / SGK), sub = gi % (KSN / SGK);
+            constexpr int gn = (gi + RS - 1) % NG;
+            static_for<0, SGK>([&](auto kc) {
+                static_for<0, NS>([&](auto pc) { w[gn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
+            });
+            static_for<0, SGK>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                constexpr int ks = sub * SGK + k;
+                uint4 gf[NS];
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    gf[p] = *reinterpret_cast<const uint4*>(gt + p * GBH + ((lane & 15) * GPH + 32 * ks + 8 * (lane >> 4)) * 2);
+                acc[ut] = mfma16(gf[0], w[gi % RS][k][0], acc[ut]);
+                if constexpr (NS == 2) {
+                    acc[ut] = mfma16(gf[NS - 1], w[gi % RS][k][0], acc[ut]);
+                    acc[ut] = mfma16(gf[0], w[gi % RS][k][NS - 1], acc[ut]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int ut = 0; ut < UT; ++ut) dh_rec[ut] = acc[ut][0];
+    }
+}
+
+// fp32 W_hh (4 hidden x hidden, both directions) on the DEVICE -> forward fragments of bilstm_stream_kernel and transposed
+// fragments of bilstm_stream_bwd_kernel, hi/lo planes
+__global__ void bilstm_pack_dev_h_kernel(const float* __restrict__ whh_fwd, const float* __restrict__ whh_bwd, int hidden, int planes,
+                                         bf16_t* __restrict__ frag_fwd, bf16_t* __restrict__ frag_bwd) {
+    const int HHr = hidden, nu = HHr / 16, ksn = HHr / 32, ut_n = HHr / 128, ksn_b = 4 * HHr / 32;
+    const int n = 2 * 4 * HHr * HHr;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        {   // forward: [dir][u][q][ks][p][l][j]
+            int r = idx;
+            const int j = r & 7; r >>= 3;
+            const int l = r & 63; r >>= 6;
+            const int ks = r % ksn; r /= ksn;
+            const int q = r & 3; r >>= 2;
+            const int u = r % nu; r /= nu;
+            const int dir = r;
+            const float* W = dir == 0 ? whh_fwd : whh_bwd;
+            const float v = W[(size_t)(q * HHr + 16 * u + (l & 15)) * HHr + 32 * ks + 8 * (l >> 4) + j];
+            const bf16_t hi = f32_to_bf16_rn(v);
+            const size_t base = ((((size_t)(dir * nu + u) * 4 + q) * ksn + ks) * planes) * 512 + (size_t)l * 8 + j;
+            frag_fwd[base] = hi;
+            if (planes == 2) frag_fwd[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+        }
+        {   // transposed: [dir][wave][ut][ks][p][l][j] = W[row 32 ks + 8 (l >> 4) + j][unit 16 ut_n wave + 16 ut + (l & 15)]
+            int r = idx;
+            const int j = r & 7; r >>= 3;
+            const int l = r & 63; r >>= 6;
+            const int ks = r % ksn_b; r /= ksn_b;
+            const int ut = r % ut_n; r /= ut_n;
+            const int wv = r & 7; r >>= 3;
+            const int dir = r;
+            const float* W = dir == 0 ? whh_fwd : whh_bwd;
+            const float v = W[(size_t)(32 * ks + 8 * (l >> 4) + j) * HHr + 16 * ut_n * wv + 16 * ut + (l & 15)];
+            const bf16_t hi = f32_to_bf16_rn(v);
+            const size_t base = ((((size_t)(dir * 8 + wv) * ut_n + ut) * ksn_b + ks) * planes) * 512 + (size_t)l * 8 + j;
+            frag_bwd[base] = hi;
+            if (planes == 2) frag_bwd[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+        }
     }
 }
 
@@ -779,7 +966,7 @@ int amtx_launch_bilstm(const LstmArgs& a, hipStream_t stream) {
     AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.groups > 0, "bilstm: bad sizes");
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "bilstm: planes must be 1 or 2");
     if (a.hidden != H) {
-        AMTX_REQUIRE(!a.save, "bilstm: the training forward exists for hidden = 128 only");
+        AMTX_REQUIRE(!a.save || a.planes == 2, "bilstm: the training forward (save) is built for the two-plane precision");
         if (a.hidden == 256) return dispatch_stream<256>(a, stream);
         amtx_set_error("bilstm: unsupported hidden size %d (128 and 256 are built)", a.hidden);
         return AMTX_ERR_UNSUPPORTED;
@@ -815,6 +1002,32 @@ int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* w
     } else {
         hipLaunchKernelGGL(bilstm4_bwd_kernel<1>, grid, dim3(LTHREADS), lds, stream, a);
     }
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_launch_bilstm_pack_dev_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream) {
+    AMTX_REQUIRE(whh_fwd && whh_bwd && frag_fwd && frag_bwd && (planes == 1 || planes == 2), "bilstm pack: bad argument");
+    if (hidden == H) return amtx_launch_bilstm_pack_dev(whh_fwd, whh_bwd, planes, frag_fwd, frag_bwd, stream);
+    AMTX_REQUIRE(hidden == 256, "bilstm pack: hidden size %d is not built (128, 256)", hidden);
+    hipLaunchKernelGGL(bilstm_pack_dev_h_kernel, dim3(256), dim3(256), 0, stream, whh_fwd, whh_bwd, hidden, planes, frag_fwd, frag_bwd);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t* whh_t, int hidden, int planes, float* dxproj, int B, int T, hipStream_t stream) {
+    if (hidden == H) return amtx_launch_bilstm_bwd(dout, save, whh_t, planes, dxproj, B, T, stream);
+    AMTX_REQUIRE(dout && save && whh_t && dxproj, "bilstm backward: null pointer");
+    AMTX_REQUIRE(B > 0 && T > 0 && planes == 2 && hidden == 256, "bilstm backward: hidden 256 is built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
+    LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T};
+    dim3 grid((unsigned)((B + 3) / 4), 2);
+    const size_t lds = 2 * (size_t)planes * 16 * (4 * 256 + 8) * 2;
+    static bool done = false;
+    if (!done) {
+        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_stream_bwd_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    hipLaunchKernelGGL((bilstm_stream_bwd_kernel<256, 2>), grid, dim3(512), lds, stream, a);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

@@ -144,3 +144,23 @@ extern "C" int amtx_bilstm_train_bwd(const float* dout, const float* save, const
                                      int num_frames, void* stream) {
     return amtx_launch_bilstm_bwd(dout, save, (const bf16_t*)whh_t_packed, planes, dxproj, batch, num_frames, (hipStream_t)stream);
 }
+
+// ---- training recurrences for any built hidden size (128: the register-stationary kernels, 256: the streaming ones)
+extern "C" int amtx_bilstm_h_pack_device(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd,
+                                         void* stream) {
+    return amtx_launch_bilstm_pack_dev_h(whh_fwd, whh_bwd, hidden, planes, frag_fwd, frag_bwd, (hipStream_t)stream);
+}
+
+extern "C" int amtx_bilstm_h_train_fwd(const float* xproj, const uint16_t* whh_packed, int hidden, int planes, float* out, float* save, int batch,
+                                       int num_frames, void* stream) {
+    AMTX_REQUIRE(save, "amtx_bilstm_h_train_fwd: null save buffer");
+    LstmArgs l;
+    l.xproj = xproj; l.x_type = AMTX_T_F32; l.whh = whh_packed; l.planes = planes; l.out = out; l.out_type = AMTX_T_F32;
+    l.B = batch; l.T = num_frames; l.groups = 1; l.x_gs = l.w_gs = l.out_gs = 0; l.hidden = hidden; l.save = save;
+    return amtx_launch_bilstm(l, (hipStream_t)stream);
+}
+
+extern "C" int amtx_bilstm_h_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int hidden, int planes, float* dxproj,
+                                       int batch, int num_frames, void* stream) {
+    return amtx_launch_bilstm_bwd_h(dout, save, whh_t_packed, hidden, planes, dxproj, batch, num_frames, (hipStream_t)stream);
+}

@@ -207,7 +207,8 @@ class LanguageModel(nn.Module):
     def forward(self, in_feats):
         # differentiable path on a GPU (training, or eval outside the engine): both directions' recurrence is one persistent HIP
         # kernel forward and one backward (amt_tools_amd/autograd.py) instead of MIOpen's per-time-step LSTM
-        if (in_feats.is_cuda and in_feats.dtype == torch.float32 and self.num_directions == 2 and self.hidden_size == 128
+        from .autograd import HIDDEN_SIZES
+        if (in_feats.is_cuda and in_feats.dtype == torch.float32 and self.num_directions == 2 and self.hidden_size in HIDDEN_SIZES
                 and self.mlm.num_layers == 1 and self.use_hip_autograd):
             from .autograd import bilstm
             return bilstm(in_feats, self.mlm)

@@ -159,6 +159,14 @@ int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int pl
                           void* stream);
 int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
                           int num_frames, void* stream);
+/* The same three calls for any built hidden size (128, 256): save is [B][T][2][5][hidden], dxproj [B][T][2][4 hidden], fragments
+ * amtx_bilstm_h_packed_elems(hidden, planes) elements each.  Two-plane precision only. */
+int amtx_bilstm_h_pack_device(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd,
+                              void* stream);
+int amtx_bilstm_h_train_fwd(const float* xproj, const uint16_t* whh_packed, int hidden, int planes, float* out, float* save, int batch,
+                            int num_frames, void* stream);
+int amtx_bilstm_h_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int hidden, int planes, float* dxproj,
+                            int batch, int num_frames, void* stream);
 /* Training-mode BatchNorm2d (batch statistics, running statistics updated as nn.BatchNorm2d does) + ReLU (+ MaxPool2d((1,2)) when
  * pool = 1) of the acoustic model's conv stages (amt_tools/models/onsetsframes.py:375-416 under amt_tools/train.py:126-141), and its
  * backward.  Channels-last fp32: x (rows = B*T, num_bins, channels), y / dy (rows, num_bins / 2 or num_bins, channels).

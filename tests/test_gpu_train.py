@@ -15,16 +15,18 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
 
 
+@pytest.mark.parametrize('H', [128, 256])
 @pytest.mark.parametrize('B,T,I', [(1, 1, 16), (3, 20, 64), (8, 37, 176), (5, 64, 512)])
-def test_bilstm_autograd_matches_torch_lstm(B, T, I):
+def test_bilstm_autograd_matches_torch_lstm(B, T, I, H):
+    """hidden 128: register-stationary kernels; hidden 256 (model_complexity 3): the streaming forward / backward kernels."""
     from amt_tools_amd.autograd import bilstm
     torch.manual_seed(B * 1000 + T)
-    ref = torch.nn.LSTM(I, 128, batch_first=True, bidirectional=True).double()
+    ref = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).double()
     x = torch.randn(B, T, I, dtype=torch.float64, requires_grad=True)
-    gy = torch.randn(B, T, 256, dtype=torch.float64)
+    gy = torch.randn(B, T, 2 * H, dtype=torch.float64)
     y_ref = ref(x)[0]
     y_ref.backward(gy)
-    mine = torch.nn.LSTM(I, 128, batch_first=True, bidirectional=True).cuda()
+    mine = torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).cuda()
     mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
     xc = x.detach().float().cuda().requires_grad_(True)
     y = bilstm(xc, mine)

@@ -24,11 +24,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--warmup', type=int, default=3)
 ap.add_argument('--clips', type=int, default=8)
+ap.add_argument('--of2', action='store_true', help='OnsetsFrames2 as shipped (model_complexity 3, offset head, detach_heads) instead of OnsetsFrames(mc=2)')
 args = ap.parse_args()
 
 rank, world, device = init_distributed()
 torch.manual_seed(0)
-model = OnsetsFrames(229, tools.PianoProfile(), 1, 2, device=str(device))
+if args.of2:
+    from amt_tools_amd.models import OnsetsFrames2
+    model = OnsetsFrames2(229, tools.PianoProfile(), 1, device=str(device))
+else:
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 2, device=str(device))
 model.frontend = torch.nn.Sequential(MelSpec(sample_rate=22050, device=str(device)).frontend())
 model.change_device()
 broadcast_parameters(model)
@@ -40,6 +45,8 @@ lab = [synth_labels(rank * B + i) for i in range(B)]
 batch = {tools.KEY_AUDIO: audio,
          tools.KEY_MULTIPITCH: torch.from_numpy(np.stack([l[0] for l in lab])).to(device),
          tools.KEY_ONSETS: torch.from_numpy(np.stack([l[1] for l in lab])).to(device)}
+if args.of2:
+    batch[tools.KEY_OFFSETS] = torch.from_numpy(np.stack([l[1][:, ::-1].copy() for l in lab])).to(device)   # any sparse binary map
 
 
 def step():
@@ -67,7 +74,7 @@ if world > 1:
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 if rank == 0:
-    print(json.dumps({'metric': 'train step time (OnsetsFrames fwd+bwd+Adam, 8 clips x 625 frames per GPU)', 'value': dt / args.steps * 1e3,
+    print(json.dumps({'metric': 'train step time (%s fwd+bwd+Adam, 8 clips x 625 frames per GPU)' % ('OnsetsFrames2 mc=3' if args.of2 else 'OnsetsFrames'), 'value': dt / args.steps * 1e3,
                       'unit': 'ms/step', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'higher_is_better': False,
                       'scaling': 'weak', 'frames_per_s': world * B * 625 * args.steps / dt, 'loss': float(loss),
                       'backward': 'ATen autograd (conv / linear) + HIP BiLSTM and BatchNorm+ReLU+MaxPool forward/backward kernels'}))
