@@ -707,11 +707,14 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
     constexpr int UT = HH / 128;                   // unit tiles per wave
     constexpr int KSN = 4 * HH / 32;               // k-steps over the gate rows
     constexpr int SGK = NS == 2 ? 2 : 4;
-    constexpr int NG = UT * KSN / SGK;             // streamed groups per step and wave
+    constexpr int NG = UT * KSN / SGK;             // fragment groups (16 VGPRs each) per step and wave
     constexpr int RS = 4;
+    // every fourth group is pinned in registers for the whole launch (the kernel needs ~106 VGPRs of the 256 it may use), the
+    // other three are streamed: a quarter fewer bytes per step
+    constexpr int NPINB = NG / 4, NSGB = NG - NPINB;
     constexpr int GPH = 4 * HH + 8;                // bf16 elements per row of the dgates tile
     constexpr int GBH = 16 * GPH * 2;              // one plane of one buffer
-    static_assert(NG % RS == 0, "hidden size must be a multiple of 128");
+    static_assert(NG % 4 == 0 && NSGB % RS == 0, "hidden size must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][GPH] bf16, rows 0/4/8/12 used
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = lane >> 4;
@@ -757,10 +760,17 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
         }
     };
     load_next(frame(0));
-    static_for<0, RS - 1>([&](auto sc) {
-        constexpr int gi = decltype(sc)::value;
+    uint4 wpin[NPINB][SGK][NS];
+    static_for<0, NPINB>([&](auto gc) {
         static_for<0, SGK>([&](auto kc) {
-            static_for<0, NS>([&](auto pc) { w[gi % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
+            static_for<0, NS>([&](auto pc) { wpin[decltype(gc)::value][decltype(kc)::value][decltype(pc)::value] = load_frag(4 * decltype(gc)::value, decltype(kc)::value, decltype(pc)::value); });
+        });
+    });
+    static_for<0, RS - 1>([&](auto sc) {
+        constexpr int si = decltype(sc)::value;
+        constexpr int gi = (si / 3) * 4 + 1 + si % 3;        // streamed group si -> group index
+        static_for<0, SGK>([&](auto kc) {
+            static_for<0, NS>([&](auto pc) { w[si % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
         });
     });
     __syncthreads();
@@ -808,10 +818,15 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
         static_for<0, NG>([&](auto ic) {
             constexpr int gi = decltype(ic)::value;
             constexpr int ut = gi / (KSN / SGK), sub = gi % (KSN / SGK);
-            constexpr int gn = (gi + RS - 1) % NG;
-            static_for<0, SGK>([&](auto kc) {
-                static_for<0, NS>([&](auto pc) { w[gn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
-            });
+            constexpr bool pinned = (gi & 3) == 0;
+            constexpr int si = (gi >> 2) * 3 + (gi & 3) - 1;                     // index among the streamed groups
+            if constexpr (!pinned) {
+                constexpr int sn = (si + RS - 1) % NSGB;                         // behind the last RS - 1 streamed groups
+                constexpr int gn = (sn / 3) * 4 + 1 + sn % 3;
+                static_for<0, SGK>([&](auto kc) {
+                    static_for<0, NS>([&](auto pc) { w[sn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
+                });
+            }
             static_for<0, SGK>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
                 constexpr int ks = sub * SGK + k;
@@ -819,10 +834,13 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
                     gf[p] = *reinterpret_cast<const uint4*>(gt + p * GBH + ((lane & 15) * GPH + 32 * ks + 8 * (lane >> 4)) * 2);
-                acc[ut] = mfma16(gf[0], w[gi % RS][k][0], acc[ut]);
+                uint4 w0, w1;
+                if constexpr (pinned) { w0 = wpin[gi >> 2][k][0]; w1 = wpin[gi >> 2][k][NS - 1]; }
+                else { w0 = w[si % RS][k][0]; w1 = w[si % RS][k][NS - 1]; }
+                acc[ut] = mfma16(gf[0], w0, acc[ut]);
                 if constexpr (NS == 2) {
-                    acc[ut] = mfma16(gf[NS - 1], w[gi % RS][k][0], acc[ut]);
-                    acc[ut] = mfma16(gf[0], w[gi % RS][k][NS - 1], acc[ut]);
+                    acc[ut] = mfma16(gf[NS - 1], w0, acc[ut]);
+                    acc[ut] = mfma16(gf[0], w1, acc[ut]);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
