@@ -80,8 +80,8 @@ _SIGNATURES = {
     'amtx_cqt_workspace_bytes': (C.c_size_t, [_P, _I, _L]),
     'amtx_cqt_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _P]),
     'amtx_bilstm_h_pack_device': (_I, [_P, _P, _I, _I, _P, _P, _P]),
-    'amtx_bilstm_h_train_fwd': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _P]),
-    'amtx_bilstm_h_train_bwd': (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _P]),
+    'amtx_bilstm_h_train_fwd': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
+    'amtx_bilstm_h_train_bwd': (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P]),
     'amtx_bn_train_workspace_bytes': (C.c_size_t, [_I]),
     'amtx_bn_relu_pool_train_fwd': (_I, [_P, _L, _I, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     'amtx_bn_relu_pool_train_bwd': (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-__all__ = ['bilstm', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction']
+__all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction']
 
 HIDDEN_SIZES = (128, 256)       # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3)
 
@@ -30,58 +30,95 @@ def _pack(w_hh_f, w_hh_b):
 
 
 class BiLSTMFunction(torch.autograd.Function):
-    """y = BiLSTM(x) with PyTorch's parameter layout (gate order i, f, g, o; weight_ih (4H, I), weight_hh (4H, H), two biases
-    per direction), zero initial state, batch_first, H in HIDDEN_SIZES.  x (B, T, I) fp32 CUDA -> y (B, T, 2H)."""
+    """y_g = BiLSTM_g(x_g) for G independent LSTMs of the same (B, T, hidden) in ONE launch per direction of time (forward kernel,
+    backward kernel), PyTorch's parameter layout (gate order i, f, g, o; weight_ih (4H, I_g), weight_hh (4H, H), two biases per
+    direction), zero initial state, batch_first, H in HIDDEN_SIZES.  Arguments: G, then per LSTM x (B, T, I_g) fp32 CUDA and its
+    eight parameters; returns G tensors (B, T, 2H)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b):
-        B, T, I = x.shape
-        H = w_hh_f.shape[1]
+    def forward(ctx, G, *args):
+        assert len(args) == 9 * G
+        groups = [args[9 * g:9 * g + 9] for g in range(G)]
+        x0 = groups[0][0]
+        B, T = x0.shape[:2]
+        H = groups[0][2].shape[1]
         L = _lib.lib()
-        x2 = x.reshape(B * T, I)
-        w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                      # (8 H, I)
-        bias = torch.cat([b_ih_f + b_hh_f, b_ih_b + b_hh_b], dim=0)
-        xproj = torch.addmm(bias, x2, w_ih.t()).contiguous()                           # (B*T, 2*4H) = [B][T][2][4H]
-        frag_fwd, frag_bwd = _pack(w_hh_f, w_hh_b)
-        out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
-        save = torch.empty((B, T, 2, 5, H), dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
-            _lib.check(L.amtx_bilstm_h_train_fwd(_lib.ptr(xproj), _lib.ptr(frag_fwd), H, 2, _lib.ptr(out), _lib.ptr(save), B, T,
-                                                 _lib.current_stream(x.device)), 'amtx_bilstm_h_train_fwd')
-        ctx.save_for_backward(x2, w_ih, w_hh_f, w_hh_b, out, save, frag_bwd)
-        ctx.dims = (B, T, I, H)
-        return out
+        dev = x0.device
+        n = int(L.amtx_bilstm_h_packed_elems(H, 2))
+        xproj = torch.empty((G, B * T, 8 * H), dtype=torch.float32, device=dev)
+        frag_fwd = torch.empty((G, n), dtype=torch.int16, device=dev)
+        frag_bwd = torch.empty((G, n), dtype=torch.int16, device=dev)
+        saved = []
+        for g, (x, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_b, w_hh_b, b_ih_b, b_hh_b) in enumerate(groups):
+            assert x.shape[:2] == (B, T) and w_hh_f.shape[1] == H
+            x2 = x.reshape(B * T, x.shape[2])
+            w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                  # (8 H, I)
+            bias = torch.cat([b_ih_f + b_hh_f, b_ih_b + b_hh_b], dim=0)
+            torch.addmm(bias, x2, w_ih.t(), out=xproj[g])                              # [B][T][2][4H]
+            wf, wb = w_hh_f.detach().contiguous().float(), w_hh_b.detach().contiguous().float()
+            _lib.check(L.amtx_bilstm_h_pack_device(_lib.ptr(wf), _lib.ptr(wb), H, 2, _lib.ptr(frag_fwd[g]), _lib.ptr(frag_bwd[g]),
+                                                   _lib.current_stream(dev)), 'amtx_bilstm_h_pack_device')
+            saved += [x2, w_ih]
+        out = torch.empty((G, B, T, 2 * H), dtype=torch.float32, device=dev)
+        save = torch.empty((G, B, T, 2, 5, H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.amtx_bilstm_h_train_fwd(_lib.ptr(xproj), _lib.ptr(frag_fwd), H, 2, _lib.ptr(out), _lib.ptr(save), B, T, G,
+                                                 _lib.current_stream(dev)), 'amtx_bilstm_h_train_fwd')
+        ctx.save_for_backward(out, save, frag_bwd, *saved)
+        ctx.dims = (G, B, T, H)
+        ctx.need_dx = [bool(ctx.needs_input_grad[1 + 9 * g]) for g in range(G)]
+        return tuple(out[g] for g in range(G))
 
     @staticmethod
-    def backward(ctx, dout):
-        x2, w_ih, w_hh_f, w_hh_b, out, save, frag_bwd = ctx.saved_tensors
-        B, T, I, H = ctx.dims
+    def backward(ctx, *douts):
+        out, save, frag_bwd, *saved = ctx.saved_tensors
+        G, B, T, H = ctx.dims
         L = _lib.lib()
-        dout = dout.contiguous().float()
-        dxproj = torch.empty((B * T, 4 * 2 * H), dtype=torch.float32, device=dout.device)
-        with torch.cuda.device(dout.device):
-            _lib.check(L.amtx_bilstm_h_train_bwd(_lib.ptr(dout), _lib.ptr(save), _lib.ptr(frag_bwd), H, 2, _lib.ptr(dxproj), B, T,
-                                                 _lib.current_stream(dout.device)), 'amtx_bilstm_h_train_bwd')
-        dx = (dxproj @ w_ih).reshape(B, T, I) if ctx.needs_input_grad[0] else None
-        dw_ih = dxproj.t() @ x2                                                       # (1024, I)
-        # column sums as a (1, B*T) x (B*T, 1024) product: ATen's reduce kernel over the strided dimension took 0.4 ms per LSTM
-        db = torch.ones((1, B * T), dtype=torch.float32, device=dxproj.device).mm(dxproj).squeeze(0)
-        # h_{t-1} of the forward direction / h_{t+1} of the backward direction (zero initial state)
-        hp_f = torch.zeros((B, T, H), dtype=torch.float32, device=out.device)
-        hp_f[:, 1:] = out[:, :-1, :H]
-        hp_b = torch.zeros((B, T, H), dtype=torch.float32, device=out.device)
-        hp_b[:, :-1] = out[:, 1:, H:]
-        dg = dxproj.reshape(B * T, 2, 4 * H)
-        dw_hh_f = dg[:, 0].t() @ hp_f.reshape(B * T, H)
-        dw_hh_b = dg[:, 1].t() @ hp_b.reshape(B * T, H)
+        dev = out.device
+        dout = torch.stack([d.contiguous().float() for d in douts], dim=0)
+        dxproj = torch.empty((G, B * T, 8 * H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.amtx_bilstm_h_train_bwd(_lib.ptr(dout), _lib.ptr(save), _lib.ptr(frag_bwd), H, 2, _lib.ptr(dxproj), B, T, G,
+                                                 _lib.current_stream(dev)), 'amtx_bilstm_h_train_bwd')
+        ones = torch.ones((1, B * T), dtype=torch.float32, device=dev)
+        grads = [None]
         n = 4 * H
-        return (dx, dw_ih[:n], dw_hh_f, db[:n], db[:n], dw_ih[n:], dw_hh_b, db[n:], db[n:])
+        for g in range(G):
+            x2, w_ih = saved[2 * g], saved[2 * g + 1]
+            dxp = dxproj[g]
+            dx = (dxp @ w_ih).reshape(B, T, x2.shape[1]) if ctx.need_dx[g] else None
+            dw_ih = dxp.t() @ x2                                                      # (8 H, I)
+            # column sums as a (1, B*T) x (B*T, 8 H) product: ATen's reduce kernel over the strided dimension is slower
+            db = ones.mm(dxp).squeeze(0)
+            # h_{t-1} of the forward direction / h_{t+1} of the backward direction (zero initial state)
+            hp_f = torch.zeros((B, T, H), dtype=torch.float32, device=dev)
+            hp_f[:, 1:] = out[g, :, :-1, :H]
+            hp_b = torch.zeros((B, T, H), dtype=torch.float32, device=dev)
+            hp_b[:, :-1] = out[g, :, 1:, H:]
+            dg = dxp.reshape(B * T, 2, 4 * H)
+            dw_hh_f = dg[:, 0].t() @ hp_f.reshape(B * T, H)
+            dw_hh_b = dg[:, 1].t() @ hp_b.reshape(B * T, H)
+            grads += [dx, dw_ih[:n], dw_hh_f, db[:n], db[:n], dw_ih[n:], dw_hh_b, db[n:], db[n:]]
+        return tuple(grads)
+
+
+def _lstm_args(x, lstm):
+    return (x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
+            lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
 
 
 def bilstm(x, lstm):
     """Run `lstm` (an nn.LSTM(batch_first, bidirectional, hidden in HIDDEN_SIZES, one layer)) on x through the HIP kernels, differentiably."""
-    return BiLSTMFunction.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0,
-                                lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse, lstm.bias_hh_l0_reverse)
+    return BiLSTMFunction.apply(1, *_lstm_args(x, lstm))[0]
+
+
+def bilstm_multi(xs, lstms):
+    """Independent LSTMs of the same hidden size on inputs of the same (B, T) in one launch each way (the onset and offset
+    recurrences of OnsetsFrames2, which otherwise run one after the other with two blocks busy each)."""
+    args = []
+    for x, lstm in zip(xs, lstms):
+        args += list(_lstm_args(x, lstm))
+    return BiLSTMFunction.apply(len(xs), *args)
 
 
 class BCELogitsLossFunction(torch.autograd.Function):

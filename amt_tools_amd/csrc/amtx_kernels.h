@@ -84,7 +84,8 @@ int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* w
 size_t amtx_bilstm_wfrag_elems(int planes);              // per LSTM (both directions)
 void amtx_bilstm_pack_host(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* out);   // each (512,128)
 int amtx_launch_bilstm_pack_dev_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream);
-int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t* whh_t, int hidden, int planes, float* dxproj, int B, int T, hipStream_t stream);
+int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t* whh_t, int hidden, int planes, float* dxproj, int B, int T, int groups,
+                             hipStream_t stream);
 size_t amtx_bilstm_wfrag_elems_h(int hidden, int planes);
 void amtx_bilstm_pack_host_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* out);   // each (4 hidden, hidden)
 

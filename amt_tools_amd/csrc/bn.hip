@@ -61,7 +61,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
 // ---- forward pass 1b: mean / invstd, fused affine (scale, shift), running statistics (momentum < 0: cumulative average is the caller's job)
 __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int C, double n, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
-                                      float* __restrict__ running_var, float* __restrict__ stats /*[4][C]: mean, invstd, scale, shift*/) {
+                                      float* __restrict__ running_var, float* __restrict__ stats /*[4][C]: mean, invstd, gamma, beta*/) {
     // one wave per channel: lanes stride over the partials, fixed-order butterfly in fp64 (a single thread walking 1024 partials
     // was 0.3 ms of pure load latency per layer)
     const int c = blockIdx.x;
@@ -76,14 +76,19 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nbl
     const double g = gamma ? (double)gamma[c] : 1.0, bt = beta ? (double)beta[c] : 0.0;
     stats[c] = (float)mean;
     stats[C + c] = (float)invstd;
-    stats[2 * C + c] = (float)(g * invstd);
-    stats[3 * C + c] = (float)(bt - mean * g * invstd);
+    stats[2 * C + c] = (float)g;
+    stats[3 * C + c] = (float)bt;
     if (running_mean && running_var) {
         const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
 }
+
+// The normalised pre-activation in nn.BatchNorm2d's own operation order ((x - mean) * invstd) * gamma + beta, not as one fused
+// multiply-add with a folded scale / shift: ReLU's gradient is decided by the sign of this value, and an ulp of difference flips it
+// for the rare element that sits at zero (seen as a 2 % change of one channel's beta gradient against the stock path).
+__device__ __forceinline__ float bnz(float x, float mean, float inv, float gamma, float beta) { return ((x - mean) * inv) * gamma + beta; }
 
 // ---- forward pass 2
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(BnArgs a, const float* __restrict__ stats, float* __restrict__ y) {
@@ -94,14 +99,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(BnArgs a, const fl
         const int64_t po = i / c4n;
         const int fo = (int)(po % Fo);
         const int64_t row = po / Fo;
+        const float4 mu = *reinterpret_cast<const float4*>(stats + 4 * cg), iv = *reinterpret_cast<const float4*>(stats + a.C + 4 * cg);
         const float4 sc = *reinterpret_cast<const float4*>(stats + 2 * a.C + 4 * cg), sh = *reinterpret_cast<const float4*>(stats + 3 * a.C + 4 * cg);
         const float* xp = a.x + ((row * a.F + (a.pool ? 2 * fo : fo)) * a.C + 4 * cg);
         float4 v = *reinterpret_cast<const float4*>(xp);
-        float4 z = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+        float4 z = make_float4(bnz(v.x, mu.x, iv.x, sc.x, sh.x), bnz(v.y, mu.y, iv.y, sc.y, sh.y), bnz(v.z, mu.z, iv.z, sc.z, sh.z), bnz(v.w, mu.w, iv.w, sc.w, sh.w));
         if (a.pool) {
             v = *reinterpret_cast<const float4*>(xp + a.C);
-            z.x = fmaxf(z.x, fmaf(v.x, sc.x, sh.x)); z.y = fmaxf(z.y, fmaf(v.y, sc.y, sh.y));
-            z.z = fmaxf(z.z, fmaf(v.z, sc.z, sh.z)); z.w = fmaxf(z.w, fmaf(v.w, sc.w, sh.w));
+            z.x = fmaxf(z.x, bnz(v.x, mu.x, iv.x, sc.x, sh.x)); z.y = fmaxf(z.y, bnz(v.y, mu.y, iv.y, sc.y, sh.y));
+            z.z = fmaxf(z.z, bnz(v.z, mu.z, iv.z, sc.z, sh.z)); z.w = fmaxf(z.w, bnz(v.w, mu.w, iv.w, sc.w, sh.w));
         }
         *reinterpret_cast<float4*>(y + po * a.C + 4 * cg) = make_float4(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f));
     }
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(BnArgs a, co
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float d0, d1;
-                route(fmaf(x0_[k], sc_[k], sh_[k]), fmaf(x1_[k], sc_[k], sh_[k]), g_[k], a.pool != 0, d0, d1);
+                route(bnz(x0_[k], m_[k], i_[k], sc_[k], sh_[k]), bnz(x1_[k], m_[k], i_[k], sc_[k], sh_[k]), g_[k], a.pool != 0, d0, d1);
                 s[k] += d0 + d1;
                 q[k] = fmaf(d0, (x0_[k] - m_[k]) * i_[k], q[k]);
                 q[k] = fmaf(d1, (x1_[k] - m_[k]) * i_[k], q[k]);
@@ -209,9 +215,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_dx_kernel(BnArgs a, const f
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float d0 = 0.f, d1 = 0.f;
-            if (!a.pool || fp < Fo) route(fmaf(x0_[k], sc_[k], sh_[k]), fmaf(x1_[k], sc_[k], sh_[k]), g_[k], paired, d0, d1);
-            o0[k] = sc_[k] * (d0 - c0_[k] - (x0_[k] - m_[k]) * i_[k] * c1_[k]);
-            o1[k] = sc_[k] * (d1 - c0_[k] - (x1_[k] - m_[k]) * i_[k] * c1_[k]);
+            if (!a.pool || fp < Fo) route(bnz(x0_[k], m_[k], i_[k], sc_[k], sh_[k]), bnz(x1_[k], m_[k], i_[k], sc_[k], sh_[k]), g_[k], paired, d0, d1);
+            const float gs = sc_[k] * i_[k];                                     // gamma * invstd
+            o0[k] = gs * (d0 - c0_[k] - (x0_[k] - m_[k]) * i_[k] * c1_[k]);
+            o1[k] = gs * (d1 - c0_[k] - (x1_[k] - m_[k]) * i_[k] * c1_[k]);
         }
         *reinterpret_cast<float4*>(dx + xo) = make_float4(o0[0], o0[1], o0[2], o0[3]);
         if (paired) *reinterpret_cast<float4*>(dx + xo + C) = make_float4(o1[0], o1[1], o1[2], o1[3]);

@@ -700,6 +700,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
 // HH / 8 hidden units = UT unit tiles.
 struct LstmBwdHArgs {
     const float* dout; const float* save; const bf16_t* whh_t; float* dxproj; int B, T;
+    int64_t w_gs;      // fragment elements per LSTM: blockIdx.z walks independent LSTMs of the same (B, T) (dout / save / dxproj are [groups][B]...)
 };
 
 template <int HH, int NS>
@@ -728,7 +729,8 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
 
     // transposed fragments: uint4 index ((((dir * 8 + wave) * UT + ut) * KSN + ks) * NS + p) * 64 + lane
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const char* wbase = reinterpret_cast<const char*>(a.whh_t) + ((int64_t)(dir * 8 + wave_u) * UT * KSN * NS) * 1024;
+    const int grp = blockIdx.z;
+    const char* wbase = reinterpret_cast<const char*>(a.whh_t + (int64_t)grp * a.w_gs) + ((int64_t)(dir * 8 + wave_u) * UT * KSN * NS) * 1024;
     const unsigned wlane = lane * 16;
     typedef const __attribute__((address_space(1))) char* gchar_p;
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
         return __builtin_bit_cast(uint4, *reinterpret_cast<const gu4_t*>(wb + ((gi * SGK + k) * NS + p) * 1024 + wlane));
     };
 
-    const int64_t bb = clip_ok ? b : 0;
+    const int64_t bb = (int64_t)grp * a.B + (clip_ok ? b : 0);
     const float* sv0 = a.save + ((bb * T) * 2 + dir) * (5 * HH) + unit0;          // + t * (2*5*HH) + 16 ut + q * HH
     const float* do0 = a.dout + (bb * T) * (2 * HH) + dir * HH + unit0;            // + t * 2 HH + 16 ut
     float* dx0 = a.dxproj + (bb * T) * (8 * HH) + dir * 4 * HH + unit0;            // + t * 8 HH + q * HH + 16 ut
@@ -1033,12 +1035,22 @@ int amtx_launch_bilstm_pack_dev_h(const float* whh_fwd, const float* whh_bwd, in
     return AMTX_OK;
 }
 
-int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t* whh_t, int hidden, int planes, float* dxproj, int B, int T, hipStream_t stream) {
-    if (hidden == H) return amtx_launch_bilstm_bwd(dout, save, whh_t, planes, dxproj, B, T, stream);
+int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t* whh_t, int hidden, int planes, float* dxproj, int B, int T, int groups,
+                             hipStream_t stream) {
+    AMTX_REQUIRE(groups >= 1, "bilstm backward: bad group count");
+    if (hidden == H) {
+        for (int g = 0; g < groups; ++g) {        // the register-stationary kernel takes one LSTM per launch
+            const int64_t bt = (int64_t)B * T;
+            int rc = amtx_launch_bilstm_bwd(dout + g * bt * 2 * H, save + g * bt * 2 * 5 * H, whh_t + (size_t)g * amtx_bilstm_wfrag_elems(planes), planes,
+                                            dxproj + g * bt * 8 * H, B, T, stream);
+            if (rc != AMTX_OK) return rc;
+        }
+        return AMTX_OK;
+    }
     AMTX_REQUIRE(dout && save && whh_t && dxproj, "bilstm backward: null pointer");
     AMTX_REQUIRE(B > 0 && T > 0 && planes == 2 && hidden == 256, "bilstm backward: hidden 256 is built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
-    LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T};
-    dim3 grid((unsigned)((B + 3) / 4), 2);
+    LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T, (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes)};
+    dim3 grid((unsigned)((B + 3) / 4), 2, (unsigned)groups);
     const size_t lds = 2 * (size_t)planes * 16 * (4 * 256 + 8) * 2;
     static bool done = false;
     if (!done) {

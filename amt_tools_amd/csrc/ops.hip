@@ -152,15 +152,17 @@ extern "C" int amtx_bilstm_h_pack_device(const float* whh_fwd, const float* whh_
 }
 
 extern "C" int amtx_bilstm_h_train_fwd(const float* xproj, const uint16_t* whh_packed, int hidden, int planes, float* out, float* save, int batch,
-                                       int num_frames, void* stream) {
-    AMTX_REQUIRE(save, "amtx_bilstm_h_train_fwd: null save buffer");
+                                       int num_frames, int groups, void* stream) {
+    AMTX_REQUIRE(save && groups >= 1, "amtx_bilstm_h_train_fwd: null save buffer / bad group count");
+    const int64_t bt = (int64_t)batch * num_frames;
     LstmArgs l;
     l.xproj = xproj; l.x_type = AMTX_T_F32; l.whh = whh_packed; l.planes = planes; l.out = out; l.out_type = AMTX_T_F32;
-    l.B = batch; l.T = num_frames; l.groups = 1; l.x_gs = l.w_gs = l.out_gs = 0; l.hidden = hidden; l.save = save;
+    l.B = batch; l.T = num_frames; l.hidden = hidden; l.save = save;
+    l.groups = groups; l.x_gs = bt * 8 * hidden; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes); l.out_gs = bt * 2 * hidden;
     return amtx_launch_bilstm(l, (hipStream_t)stream);
 }
 
 extern "C" int amtx_bilstm_h_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int hidden, int planes, float* dxproj,
-                                       int batch, int num_frames, void* stream) {
-    return amtx_launch_bilstm_bwd_h(dout, save, whh_t_packed, hidden, planes, dxproj, batch, num_frames, (hipStream_t)stream);
+                                       int batch, int num_frames, int groups, void* stream) {
+    return amtx_launch_bilstm_bwd_h(dout, save, whh_t_packed, hidden, planes, dxproj, batch, num_frames, groups, (hipStream_t)stream);
 }

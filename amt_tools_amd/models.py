@@ -406,11 +406,19 @@ class OnsetsFrames(TranscriptionModel):
             onsets.record_stream(main)
         else:
             multi_pitch = self.pitch_head(feats)
-            onsets = self.onset_head(feats)
+            onsets = None if self._grouped_recurrences(feats) else self.onset_head(feats)
+        offsets = None
+        if self.has_offsets and feats.is_cuda and self.training and onsets is None:
+            # the onset and offset heads are independent: their two recurrences run as ONE grouped launch each way
+            from .autograd import bilstm_multi
+            (am_on, lm_on, lb_on), (am_off, lm_off, lb_off) = self.onset_head, self.offset_head
+            l_on, l_off = bilstm_multi([am_on(feats), am_off(feats)], [lm_on.mlm, lm_off.mlm])
+            onsets, offsets = lb_on(l_on), lb_off(l_off)
         output[tools.KEY_ONSETS] = onsets
         heads = [onsets]
         if self.has_offsets:
-            offsets = self.offset_head(feats)
+            if offsets is None:
+                offsets = self.offset_head(feats)
             output[tools.KEY_OFFSETS] = offsets
             heads.append(offsets)
         if self.detach_heads:
@@ -418,6 +426,15 @@ class OnsetsFrames(TranscriptionModel):
         joint = torch.cat(heads + [multi_pitch], -1)
         output[tools.KEY_MULTIPITCH] = self.adjoin(joint)
         return output
+
+    def _grouped_recurrences(self, feats):
+        """Training on a GPU with an offset head whose LSTM and the onset head's are both on the HIP autograd path."""
+        if not (self.has_offsets and feats.is_cuda and self.training and feats.dtype == torch.float32):
+            return False
+        from .autograd import HIDDEN_SIZES
+        lms = (self.onset_head[1], self.offset_head[1])
+        return all(isinstance(lm, LanguageModel) and lm.use_hip_autograd and lm.num_directions == 2 and lm.mlm.num_layers == 1
+                   and lm.hidden_size in HIDDEN_SIZES for lm in lms) and lms[0].hidden_size == lms[1].hidden_size
 
     def post_proc(self, batch):
         """Losses (when ground truth is present) + final piano rolls (onsetsframes.py:138-196)."""

@@ -160,17 +160,19 @@ int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int pl
 int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
                           int num_frames, void* stream);
 /* The same three calls for any built hidden size (128, 256): save is [B][T][2][5][hidden], dxproj [B][T][2][4 hidden], fragments
- * amtx_bilstm_h_packed_elems(hidden, planes) elements each.  Two-plane precision only. */
+ * amtx_bilstm_h_packed_elems(hidden, planes) elements each.  Two-plane precision only.  `groups` independent LSTMs of the same
+ * (batch, num_frames, hidden) run in one launch (the onset and offset recurrences of OnsetsFrames2): every array gets a leading
+ * [groups] axis. */
 int amtx_bilstm_h_pack_device(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd,
                               void* stream);
 int amtx_bilstm_h_train_fwd(const float* xproj, const uint16_t* whh_packed, int hidden, int planes, float* out, float* save, int batch,
-                            int num_frames, void* stream);
+                            int num_frames, int groups, void* stream);
 int amtx_bilstm_h_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int hidden, int planes, float* dxproj,
-                            int batch, int num_frames, void* stream);
+                            int batch, int num_frames, int groups, void* stream);
 /* Training-mode BatchNorm2d (batch statistics, running statistics updated as nn.BatchNorm2d does) + ReLU (+ MaxPool2d((1,2)) when
  * pool = 1) of the acoustic model's conv stages (amt_tools/models/onsetsframes.py:375-416 under amt_tools/train.py:126-141), and its
  * backward.  Channels-last fp32: x (rows = B*T, num_bins, channels), y / dy (rows, num_bins / 2 or num_bins, channels).
- * stats [4][channels] (mean, invstd, gamma * invstd, beta - mean * gamma * invstd) is written by the forward and read by the backward.
+ * stats [4][channels] (mean, invstd, gamma, beta) is written by the forward and read by the backward.
  * gamma / beta / running_* may be null; dgamma / dbeta may be null. */
 size_t amtx_bn_train_workspace_bytes(int channels);
 int amtx_bn_relu_pool_train_fwd(const float* x, int64_t rows, int num_bins, int channels, int pool, const float* gamma, const float* beta,

@@ -138,3 +138,78 @@ def test_bn_relu_pool_training_matches_torch(B, C, T, F, pool):
     y2 = bn_relu_pool(xc2, bn, pool)
     y2.backward(gy.cuda())
     assert torch.equal(xc2.grad, xc.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mc', [2, 3])
+def test_onsetsframes2_training_step_hip_vs_stock_path(mc):
+    """OnsetsFrames2 (offset head; mc 3 = as shipped) in training mode: the HIP path (BatchNorm passes, onset + offset recurrences
+    as one grouped launch each way, adjoin recurrence) against the stock ATen / MIOpen path on the same parameters and batch
+    (dropout off): losses and gradients."""
+    from amt_tools_amd.models import OnsetsFrames2, AcousticModel
+    from amt_tools_amd.synth import synth_state_dict
+    sd = synth_state_dict(31, dim_in=229, in_channels=1, model_complexity=mc, offsets=True)
+    rng = np.random.default_rng(mc)
+    B, T = 3, 24
+    batch = {tools.KEY_FEATS: torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32)),
+             tools.KEY_MULTIPITCH: torch.from_numpy((rng.random((B, 88, T)) < 0.05).astype(np.float32)),
+             tools.KEY_ONSETS: torch.from_numpy((rng.random((B, 88, T)) < 0.02).astype(np.float32)),
+             tools.KEY_OFFSETS: torch.from_numpy((rng.random((B, 88, T)) < 0.02).astype(np.float32))}
+    results = []
+    for hip in (True, False):
+        model = OnsetsFrames2(229, tools.PianoProfile(), 1, mc, device='cuda:0')
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        model.change_device()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if hasattr(mod, 'use_hip_autograd'):
+                mod.use_hip_autograd = hip
+            if isinstance(mod, AcousticModel):
+                mod.use_hip_bn = hip
+        model.train()
+        out = model.run_on_batch(batch)
+        loss = out[tools.KEY_LOSS]
+        loss[tools.KEY_LOSS_TOTAL].backward()
+        results.append(({k: float(v) for k, v in loss.items()}, {n: p.grad.detach().cpu() for n, p in model.named_parameters() if p.grad is not None}))
+    (l_hip, g_hip), (l_ref, g_ref) = results
+    assert set(l_hip) == set(l_ref) and 'loss_offsets' in l_hip
+    for k in l_ref:
+        assert abs(l_hip[k] - l_ref[k]) < 2e-3 * max(1.0, abs(l_ref[k])), k
+    assert set(g_hip) == set(g_ref)
+    rels = []
+    for n in g_ref:
+        if n.endswith('.0.bias') and '.layer' in n:
+            # a convolution bias in front of a BatchNorm: the batch mean removes it, its gradient is rounding noise on both paths
+            assert g_hip[n].abs().max().item() < 1e-4 and g_ref[n].abs().max().item() < 1e-4, n
+            continue
+        # ReLU / max-pool gradients are discontinuous: an element whose pre-activation sits within an ulp of zero moves one channel's
+        # gradients by a per cent or two between two correct fp32 evaluations (seen on either path against a float64 CPU run,
+        # depending on the input: tools notes in DESIGN.md).  Every tensor within 3e-2 in relative L2, the typical one within 1e-3.
+        rels.append((g_hip[n] - g_ref[n]).norm().item() / max(1e-9, g_ref[n].norm().item()))
+        assert rels[-1] < 3e-2, n
+    assert float(np.median(rels)) < 1e-3
+
+
+@pytest.mark.gpu
+def test_bilstm_multi_equals_separate_launches():
+    from amt_tools_amd.autograd import bilstm, bilstm_multi
+    torch.manual_seed(7)
+    B, T, H = 5, 19, 256
+    lstms = [torch.nn.LSTM(I, H, batch_first=True, bidirectional=True).cuda() for I in (96, 64)]
+    xs = [torch.randn(B, T, I, device='cuda', requires_grad=True) for I in (96, 64)]
+    gys = [torch.randn(B, T, 2 * H, device='cuda') for _ in range(2)]
+    ys = bilstm_multi(xs, [l for l in lstms])
+    (ys[0] * gys[0]).sum().add((ys[1] * gys[1]).sum()).backward()
+    got = [x.grad.clone() for x in xs] + [p.grad.clone() for l in lstms for p in l.parameters()]
+    for x in xs:
+        x.grad = None
+    for l in lstms:
+        l.zero_grad()
+    ys2 = [bilstm(x, l) for x, l in zip(xs, lstms)]
+    (ys2[0] * gys[0]).sum().add((ys2[1] * gys[1]).sum()).backward()
+    ref = [x.grad for x in xs] + [p.grad for l in lstms for p in l.parameters()]
+    for a, b in zip(ys, ys2):
+        assert torch.equal(a, b)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
