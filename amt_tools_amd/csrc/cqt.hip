@@ -16,6 +16,8 @@
 
 #include "amtx_kernels.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -119,6 +121,80 @@ __global__ __launch_bounds__(256) void cqt_decimate_kernel(const float* __restri
     for (int i = 0; i < DEC_OPT; ++i) {
         const int64_t m = m0 + (int64_t)DEC_OPT * j + i;
         if (m < n_out) dst[m] = 1.41421356237309505f * acc[i];
+    }
+}
+
+// The same decimation on the matrix cores.  For a block of 16 consecutive outputs y[16 q + i] = sum_k h[k] in[32 q + 2 i + k - HALF]
+// is a 16 x KW Toeplitz matrix T[i][j] = h[j - 2 i] (constant: fragments built once per plan) times the window
+// in[32 q - HALF .. + KW); 16 such blocks q are the 16 columns of one MFMA, so 256 outputs cost NKS x 6 MFMAs and 3 NKS 16-byte
+// LDS reads per lane instead of ~1200 vector FMAs per lane.  Operands are split into THREE bf16 planes (hi + mid + lo = all 24
+// mantissa bits) and the six products down to 2^-24 are kept: the decimator feeds up to seven further stages and the -80 dB floor
+// of the log-magnitude map, and with the two-plane split of the other kernels (2^-17 per operand) the 8-octave CQT of config 1
+// missed its 1e-3 tolerance (1.07e-3).  The input tile is split once at staging; windows of neighbouring columns overlap in LDS,
+// lanes read 16 contiguous bytes at 64 q + 16 g: conflict-free.
+constexpr int DEC_KW = 352;                       // >= 30 + DEC_TAPS, a multiple of 32
+constexpr int DEC_NKS = DEC_KW / 32;
+constexpr int DEC_MCH = 4096;                     // outputs per block: 4 waves x 4 iterations x 256
+constexpr int DEC_MXS = 2 * DEC_MCH + DEC_KW;     // input samples per block
+
+typedef __attribute__((ext_vector_type(8))) __bf16 cq_bf16x8;
+__device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cq_bf16x8, a), __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
+                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag) {
+    __shared__ __attribute__((aligned(16))) unsigned short xh[DEC_MXS + 8], xm[DEC_MXS + 8], xl[DEC_MXS + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int64_t m0 = (int64_t)blockIdx.x * DEC_MCH;
+    const float* src = in + (int64_t)b * in_stride + pad;
+    const int64_t base = 2 * m0 - DEC_HALF;
+    for (int i = 2 * tid; i < DEC_MXS; i += 512) {
+        const int64_t g0 = base + i, g1 = g0 + 1;
+        const float v0 = (g0 >= 0 && g0 < n_in) ? src[g0] : 0.f, v1 = (g1 >= 0 && g1 < n_in) ? src[g1] : 0.f;
+        const uint32_t hi = pack_bf16x2(v0, v1);
+        const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
+        uint32_t mid, lo;
+        split_bf16x2(r0, r1, mid, lo);
+        *reinterpret_cast<uint32_t*>(xh + i) = hi;
+        *reinterpret_cast<uint32_t*>(xm + i) = mid;
+        *reinterpret_cast<uint32_t*>(xl + i) = lo;
+    }
+    uint4 th[DEC_NKS], tm[DEC_NKS], tl[DEC_NKS];   // Toeplitz fragments: [ks][plane][lane]
+#pragma unroll
+    for (int ks = 0; ks < DEC_NKS; ++ks) {
+        th[ks] = tfrag[(ks * 3 + 0) * 64 + lane]; tm[ks] = tfrag[(ks * 3 + 1) * 64 + lane]; tl[ks] = tfrag[(ks * 3 + 2) * 64 + lane];
+    }
+    __syncthreads();
+    const int q = lane & 15, g = lane >> 4;
+    float* dst = out + (int64_t)b * out_stride + pad;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+#pragma unroll 1
+    for (int it = 0; it < DEC_MCH / 1024; ++it) {
+        const int o0 = (it * 4 + wave) * 256;                       // first output of this wave's 256, relative to the block
+        const int s0 = 2 * o0 + 32 * q + 8 * g;                      // first sample of this lane's fragments
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < DEC_NKS; ++ks) {
+            const uint4 bh = *reinterpret_cast<const uint4*>(xh + s0 + 32 * ks), bm = *reinterpret_cast<const uint4*>(xm + s0 + 32 * ks),
+                        bl = *reinterpret_cast<const uint4*>(xl + s0 + 32 * ks);
+            acc = cq_mfma(tl[ks], bh, acc);                            // smallest terms first
+            acc = cq_mfma(th[ks], bl, acc);
+            acc = cq_mfma(tm[ks], bm, acc);
+            acc = cq_mfma(tm[ks], bh, acc);
+            acc = cq_mfma(th[ks], bm, acc);
+            acc = cq_mfma(th[ks], bh, acc);
+        }
+        const int64_t m = m0 + o0 + 16 * q + 4 * g;
+        const float r2 = 1.41421356237309505f;
+        if (vec_ok && m + 3 < n_out) {
+            *reinterpret_cast<float4*>(dst + m) = make_float4(r2 * acc[0], r2 * acc[1], r2 * acc[2], r2 * acc[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m + r < n_out) dst[m + r] = r2 * acc[r];
+        }
     }
 }
 
@@ -240,6 +316,7 @@ struct amtx_cqt_plan {
     std::vector<Level> levels;
     int pad = 0;                      // centre padding of every pyramid level (max n_fft / 2)
     float* d_taps = nullptr;
+    void* d_tfrag = nullptr;                       // Toeplitz fragments of the decimator for cqt_decimate_mfma_kernel
 };
 
 namespace {
@@ -319,6 +396,7 @@ extern "C" int amtx_cqt_plan_destroy(amtx_cqt_plan* p) {
     for (auto& l : p->levels)
         if (l.d_w) (void)hipFree(l.d_w);
     if (p->d_taps) (void)hipFree(p->d_taps);
+    if (p->d_tfrag) (void)hipFree(p->d_tfrag);
     delete p;
     return AMTX_OK;
 }
@@ -427,8 +505,23 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
         }
         for (int i = 0; i < DEC_TAPS; ++i) taps[i] = (float)(h[i] / sum);
     }
+    std::vector<bf16_t> tfrag((size_t)DEC_NKS * 3 * 64 * 8);
+    for (int ks = 0; ks < DEC_NKS; ++ks)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int i = l & 15, k = 32 * ks + 8 * (l >> 4) + j, tap = k - 2 * i;
+                const float v = (tap >= 0 && tap < DEC_TAPS) ? taps[tap] : 0.0f;
+                const bf16_t hi = f32_to_bf16_rn(v);
+                const float r1 = v - bf16_to_f32(hi);
+                const bf16_t mid = f32_to_bf16_rn(r1);
+                tfrag[((size_t)(ks * 3 + 0) * 64 + l) * 8 + j] = hi;
+                tfrag[((size_t)(ks * 3 + 1) * 64 + l) * 8 + j] = mid;
+                tfrag[((size_t)(ks * 3 + 2) * 64 + l) * 8 + j] = f32_to_bf16_rn(r1 - bf16_to_f32(mid));
+            }
     hipError_t e = hipMalloc(&p->d_taps, taps.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&p->d_tfrag, tfrag.size() * sizeof(bf16_t));
+    if (e == hipSuccess) e = hipMemcpy(p->d_tfrag, tfrag.data(), tfrag.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         amtx_set_error("amtx_cqt_plan_create: device allocation failed: %s", hipGetErrorString(e));
         amtx_cqt_plan_destroy(p);
@@ -544,9 +637,17 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
             const unsigned nb = (unsigned)std::min<int64_t>((num_samples + 255) / 256, 4096);
             hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad);
         } else {
-            const unsigned nb = (unsigned)((d.len[l] + DEC_CH - 1) / DEC_CH);
-            hipLaunchKernelGGL(cqt_decimate_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
-                               d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps);
+            // AMTX_CQT_VALU_DECIMATE=1: the vector-ALU FIR (kept as the A/B reference: 1.62 vs 0.x ms per HCQT call, see DESIGN)
+            static const bool valu = getenv("AMTX_CQT_VALU_DECIMATE") != nullptr;
+            if (valu) {
+                const unsigned nb = (unsigned)((d.len[l] + DEC_CH - 1) / DEC_CH);
+                hipLaunchKernelGGL(cqt_decimate_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
+                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps);
+            } else {
+                const unsigned nb = (unsigned)((d.len[l] + DEC_MCH - 1) / DEC_MCH);
+                hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
+                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag);
+            }
         }
         AMTX_CHECK_LAUNCH();
         hipLaunchKernelGGL(cqt_pad_kernel, dim3(8, B), dim3(256), 0, s, pyr, d.len[l], d.stride[l], p->pad, p->lib09);
