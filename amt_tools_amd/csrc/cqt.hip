@@ -150,9 +150,22 @@ __global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __r
     const int64_t m0 = (int64_t)blockIdx.x * DEC_MCH;
     const float* src = in + (int64_t)b * in_stride + pad;
     const int64_t base = 2 * m0 - DEC_HALF;
-    for (int i = 2 * tid; i < DEC_MXS; i += 512) {
+    // all loads of a thread first (clamped addresses, the zeroing applied afterwards): a load -> test -> store loop pays one memory
+    // round trip per iteration
+    constexpr int NPAIR = (DEC_MXS / 2 + 255) / 256;
+    float ld0[NPAIR], ld1[NPAIR];
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+        const int64_t g0 = base + 2 * (tid + 256 * k), g1 = g0 + 1;
+        ld0[k] = src[min(max(g0, (int64_t)0), n_in - 1)];
+        ld1[k] = src[min(max(g1, (int64_t)0), n_in - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+        const int i = 2 * (tid + 256 * k);
+        if (i >= DEC_MXS) break;
         const int64_t g0 = base + i, g1 = g0 + 1;
-        const float v0 = (g0 >= 0 && g0 < n_in) ? src[g0] : 0.f, v1 = (g1 >= 0 && g1 < n_in) ? src[g1] : 0.f;
+        const float v0 = (g0 >= 0 && g0 < n_in) ? ld0[k] : 0.f, v1 = (g1 >= 0 && g1 < n_in) ? ld1[k] : 0.f;
         const uint32_t hi = pack_bf16x2(v0, v1);
         const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
         uint32_t mid, lo;
