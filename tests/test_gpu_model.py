@@ -279,6 +279,29 @@ def test_full_size_batch_properties():
         assert torch.isfinite(full[key]).all()
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'x3'])
+def test_full_size_batch_properties_complexity_3(precision):
+    """The same size-independent property for the general-channel conv kernels / streaming recurrences of model_complexity 3 at
+    the BASELINE clip length: a clip's logits do not depend on its batch neighbours (persistent blocks walk tiles of several
+    clips; the recurrence packs 16 clips per block), and reversing the batch order permutes the results."""
+    from amt_tools_amd.models import OnsetsFrames2
+    sd = synth_state_dict(41, dim_in=229, in_channels=1, model_complexity=3, offsets=True)
+    model = OnsetsFrames2(229, tools.PianoProfile(), 1, device='cuda:0', precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    rng = np.random.default_rng(10)
+    feats = torch.from_numpy(rng.random((19, 1, 229, 625)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        full = {k: v.clone() for k, v in model.engine_logits(feats).items()}
+        solo = {k: v.clone() for k, v in model.engine_logits(feats[17:18]).items()}
+        flipped = model.engine_logits(feats.flip(0))
+    for key in ('onsets', 'offsets', 'multi_pitch'):
+        assert torch.equal(full[key][17], solo[key][0]), key
+        assert torch.equal(full[key], flipped[key].flip(0)), key
+        assert torch.isfinite(full[key]).all()
+
+
 def test_config3_hcqt_frontend_fused_into_the_model():
     """BASELINE config 3: audio -> HIP HCQT (6 x 72) as model.frontend -> OnsetsFrames(dim_in=72, in_channels=6)."""
     from oracle import cqt_np as cq, model_ref
