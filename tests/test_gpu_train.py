@@ -213,3 +213,35 @@ def test_bilstm_multi_equals_separate_launches():
         assert torch.equal(a, b)
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_onsetsframes2_training_step_on_gpu_matches_reference_golden():
+    """The reference's own OnsetsFrames2 (model_complexity 3) training-mode losses and gradients (tests/golden/of2_train.npz) with the
+    model on the GPU: ATen convolutions + HIP BatchNorm passes + the streaming hidden-256 recurrences (onset + offset grouped)."""
+    from amt_tools_amd.models import OnsetsFrames2
+    from amt_tools_amd.synth import synth_state_dict
+    g = load_golden('of2_train.npz')
+    mc = int(g['model_complexity'])
+    model = OnsetsFrames2(int(g['dim_in']), tools.PianoProfile(), 1, mc, device='cuda:0')
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=1, model_complexity=mc, offsets=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    batch = {tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_MULTIPITCH: torch.from_numpy(g['multi_pitch']),
+             tools.KEY_ONSETS: torch.from_numpy(g['onsets']), tools.KEY_OFFSETS: torch.from_numpy(g['offsets'])}
+    loss = model.run_on_batch(batch)[tools.KEY_LOSS]
+    for k, v in zip(g['loss_keys'], g['loss_values']):
+        assert abs(loss[str(k)].item() - float(v)) < 2e-3 * max(1.0, abs(float(v))), k
+    loss[tools.KEY_LOSS_TOTAL].backward()
+    named = dict(model.named_parameters())
+    rels = []
+    for i, k in enumerate(g['grad_keys']):
+        ref = torch.from_numpy(g[f'grad_{i}'])
+        got = named[str(k)].grad.cpu()
+        rels.append((got - ref).norm().item() / max(1e-9, ref.norm().item()))
+        assert rels[-1] < 3e-2, (k, rels[-1])        # see test_onsetsframes2_training_step_hip_vs_stock_path for the metric
+    assert float(np.median(rels)) < 2e-3

@@ -180,3 +180,32 @@ def test_config1_tabcnn_matches_reference_on_cpu():
     np.testing.assert_array_equal(fr[0], [[0, 0, 1], [0, 1, 2], [1, 2, 3], [2, 3, 4], [3, 4, 0]])
     assert tools.framify_activations(x, 9, pad=False).shape == (1, 1, 9)
     assert tools.note_to_midi(['E2', 'A2', 'D3', 'G3', 'B3', 'E4']) == [40, 45, 50, 55, 59, 64] and tools.note_to_midi('Bb3') == 58
+
+
+def test_onsetsframes2_training_step_matches_reference_losses_and_grads():
+    """OnsetsFrames2 as shipped (model_complexity 3, offset head, detach_heads) in training mode on the CPU: the four losses and
+    a few gradients recorded from the REAL reference classes (tests/golden/of2_train.npz, tools/gen_golden.py)."""
+    from amt_tools_amd.models import OnsetsFrames2
+    from amt_tools_amd.synth import synth_state_dict
+    g = load_golden('of2_train.npz')
+    mc = int(g['model_complexity'])
+    model = OnsetsFrames2(int(g['dim_in']), tools.PianoProfile(), 1, mc)
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=1, model_complexity=mc, offsets=True)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    batch = {tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_MULTIPITCH: torch.from_numpy(g['multi_pitch']),
+             tools.KEY_ONSETS: torch.from_numpy(g['onsets']), tools.KEY_OFFSETS: torch.from_numpy(g['offsets'])}
+    loss = model.run_on_batch(batch)[tools.KEY_LOSS]
+    assert sorted(loss.keys()) == [str(k) for k in g['loss_keys']]
+    for k, v in zip(g['loss_keys'], g['loss_values']):
+        assert abs(loss[str(k)].item() - float(v)) < 1e-3 * max(1.0, abs(float(v))), k
+    loss[tools.KEY_LOSS_TOTAL].backward()
+    named = dict(model.named_parameters())
+    for i, k in enumerate(g['grad_keys']):
+        ref = g[f'grad_{i}']
+        if str(k).endswith('.0.bias') and '.layer' in str(k):
+            continue
+        assert np.abs(named[str(k)].grad.numpy() - ref).max() / max(1e-6, np.abs(ref).max()) < 2e-3, k

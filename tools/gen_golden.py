@@ -168,6 +168,37 @@ def gen_of_train(name, seed, dim_in, mc, B, T):
     print(name, 'losses', rec['loss_pitch'], rec['loss_onsets'], rec['loss_total'])
 
 
+def gen_of2_train(name, seed, dim_in, mc, B, T):
+    """Training-mode golden of OnsetsFrames2 as shipped (offset head, detach_heads=True default, model_complexity 3): the
+    reference's four losses and a few small gradients (Dropout p = 0)."""
+    profile = rtools.PianoProfile()
+    model = OnsetsFrames2(dim_in, profile, 1, mc)
+    sd_np = load_weights(model, seed, dim_in=dim_in, in_channels=1, model_complexity=mc, offsets=True)
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    feats = features(seed + 100, B, 1, dim_in, T)
+    mp, on, off = labels(seed + 200, B, T, 0.05), labels(seed + 300, B, T, 0.01), labels(seed + 400, B, T, 0.01)
+    batch = {rtools.KEY_FEATS: torch.from_numpy(feats), rtools.KEY_MULTIPITCH: torch.from_numpy(mp),
+             rtools.KEY_ONSETS: torch.from_numpy(on), rtools.KEY_OFFSETS: torch.from_numpy(off)}
+    out = model.run_on_batch(batch)
+    loss = out[rtools.KEY_LOSS]
+    loss[rtools.KEY_LOSS_TOTAL].backward()
+    named = dict(model.named_parameters())
+    gkeys = ['offset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'offset_head.1.mlm.bias_hh_l0',
+             'onset_head.1.mlm.bias_ih_l0_reverse', 'pitch_head.0.fc1.0.bias', 'pitch_head.0.layer2.1.bias',
+             'adjoin.0.mlm.bias_hh_l0', 'adjoin.1.output_layer.bias', 'offset_head.2.output_layer.bias']
+    rec = dict(seed=seed, dim_in=dim_in, model_complexity=mc, feats=feats, multi_pitch=mp, onsets=on, offsets=off,
+               wsum=weight_checksum(sd_np), loss_keys=np.array(sorted(loss.keys())),
+               loss_values=np.array([loss[k].item() for k in sorted(loss.keys())]))
+    for i, k in enumerate(gkeys):
+        rec[f'grad_{i}'] = named[k].grad.detach().numpy().copy()
+    rec['grad_keys'] = np.array(gkeys)
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, dict(zip(rec['loss_keys'], rec['loss_values'])))
+
+
 def gen_tabcnn(name, seed, dim_in, B, T):
     """BASELINE config 1 (TabCNN + CQT features, CPU): eval output and training loss of the reference's TabCNN with a
     GuitarProfile(num_frets=19) on seed features of a GuitarSet-shape CQT (192 bins)."""
@@ -290,6 +321,7 @@ if __name__ == '__main__':
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
     gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
     gen_of_train('of1_train.npz', seed=21, dim_in=229, mc=2, B=2, T=24)
+    gen_of2_train('of2_train.npz', seed=22, dim_in=229, mc=3, B=2, T=24)
     gen_tabcnn('tabcnn_eval.npz', seed=41, dim_in=192, B=2, T=30)
     gen_labels_and_cache('labels.npz', 'feature_cache_ref.npz', seed=51, T=200, n_notes=60)
     gen_feature_bookkeeping('feature_bookkeeping.npz')
