@@ -483,13 +483,15 @@ __global__ void bilstm_pack_dev_kernel(const float* __restrict__ whh_fwd, const 
 // ---------------------------------------------------------------------------------------------------------------
 // Any hidden size HH = 128 k (OnsetsFrames at model_complexity 3: 256, onsetsframes.py:57-58 dim_lm = 256 (mc - 1)).
 // 4 HH x HH bf16 recurrent weights of one direction (512 KiB at HH = 256) are as large as a CU's whole register file, so
-// they are NOT stationary here: every step each wave streams the fragments of its unit tiles from L2 (all blocks of a launch
-// read the same <= 2 MiB, which stays cache-resident), double-buffered one (unit tile, gate) group ahead of the MFMAs, the
-// first group of the next step already in flight across the step barrier.  One block = one direction x 16 clips x all T
-// steps, eight waves; product swapped (D' = W_hh . h^T) so the four gates of a (clip, unit) meet in one lane; h_{t-1}
-// exchanged through a double-buffered LDS tile; c in registers.  Per step and block: 8 HH^2 bytes from L2 against
-// 128 HH^2 flops -> the step time is the L2 stream (about 3.4 us at HH = 256), T steps per launch: latency-bound like the
-// register-stationary kernels, only with a longer step.
+// they cannot all be stationary: the fragments of a wave's unit tiles form 4-KiB groups (16 VGPRs); in the bf16 mode every
+// fourth group is pinned in registers, every fourth in LDS, the other half is streamed from L2 every step (all blocks of a
+// launch read the same <= 2 MiB, which stays cache-resident) through a four-slot register ring, three groups ahead of the MFMAs,
+// the first groups of the next step already in flight across the step barrier (two-plane mode: everything streamed).  One
+// block = one direction x 16 clips x all T steps, eight waves; product swapped (D' = W_hh . h^T) so the four gates of a
+// (clip, unit) meet in one lane; h_{t-1} exchanged through a double-buffered LDS tile; c in registers.  With `save` set it is
+// also the training forward (post-activation gates and cell states written per step).  Step time at HH = 256: 5.3 us bf16
+// (7.3 us all-streamed), 10 us two-plane: T dependent steps per launch, latency-bound like the register-stationary kernels,
+// only with a longer step.
 // compile-time loop: the body sees its index as a constant expression (register arrays indexed through it stay in registers;
 // with a plain unrolled loop and computed indices hipcc left the weight arrays in scratch memory)
 template <int I, int N, class F>
