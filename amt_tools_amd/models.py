@@ -390,8 +390,10 @@ class OnsetsFrames(TranscriptionModel):
             # onset head (acoustic model + a 625-step BiLSTM that occupies 4 of the 256 CUs at 8 clips) can run on a side stream
             # next to the pitch head; autograd replays each op's backward on the stream of its forward, so the backward passes
             # overlap the same way (15.6 -> 14.0 ms per step).  It is off because with two streams the training loop hung
-            # intermittently on MI355X / ROCm 7.2 (torch.cuda.synchronize() never returning after 7-13 steps, with the stock ATen
-            # BatchNorm path as well as with the HIP one; not root-caused: two hardware queues + kernels with scratch memory).
+            # intermittently on MI355X / ROCm 7.2 (torch.cuda.synchronize() never returning after 7-13 steps).  Narrowed down so
+            # far: it needs the HIP BiLSTM autograd kernels (amt_tools_amd/autograd.py: BiLSTMFunction) together with the second
+            # stream -- stock nn.LSTM with the HIP BatchNorm / loss kernels on two streams ran 2 x 42 steps clean, all-HIP with
+            # precomputed features (no spectrogram kernel in the loop) hung twice; on one stream everything ran 100+ steps.
             main = torch.cuda.current_stream(feats.device)
             side = self.__dict__.get('_side_stream')
             if side is None or side.device != feats.device:
