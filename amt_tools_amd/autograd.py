@@ -17,6 +17,12 @@ __all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELo
 HIDDEN_SIZES = (128, 256)       # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3)
 
 
+def training_backend():
+    """One line for benchmark records: which kernels a GPU training step runs on."""
+    return ('HIP: BiLSTM fwd/bwd, BatchNorm+ReLU+MaxPool fwd/bwd, BCE loss+grad; ATen (MIOpen / hipBLASLt): conv fwd/dgrad/wgrad, '
+            'Linear fwd/bwd, Adam')
+
+
 def _pack(w_hh_f, w_hh_b):
     L = _lib.lib()
     H = w_hh_f.shape[1]

@@ -60,54 +60,65 @@ def cached_process_audio(data_proc, audio, path, sample_rate=None, hop_length=No
 
 
 def filter_notes(pitches, intervals, profile=None, min_time=-np.inf, max_time=np.inf, suppress_warnings=True):
-    pitches_r = np.round(pitches)
+    """Drop notes that cannot be drawn: nominal (rounded) pitch outside the instrument's range, onset after `max_time`, or offset
+    before `min_time`.  Returns (pitches, intervals) of the survivors, order kept.  Behaviour contract:
+    amt_tools/tools/utils.py:620-700."""
+    pitches, intervals = np.asarray(pitches), np.asarray(intervals)
+    reasons = []
     if profile is not None:
-        in_pitch = np.logical_and(pitches_r >= profile.low, pitches_r <= profile.high)
-        if np.sum(np.logical_not(in_pitch)) and not suppress_warnings:
-            warnings.warn('Ignoring notes with nominal pitch exceeding supported boundaries.', category=RuntimeWarning)
-    on_ok = intervals[:, 0] <= max_time
-    off_ok = intervals[:, 1] >= min_time
-    if not suppress_warnings:
-        if np.sum(np.logical_not(on_ok)):
-            warnings.warn('Ignoring notes with onsets occurring after specified time maximum.', category=RuntimeWarning)
-        if np.sum(np.logical_not(off_ok)):
-            warnings.warn('Ignoring notes with offsets occurring before specified time minimum.', category=RuntimeWarning)
-    valid = np.logical_and(on_ok, off_ok)
-    if profile is not None:
-        valid = np.logical_and(valid, in_pitch)
-    return pitches[valid], intervals[valid]
+        nominal = np.round(pitches)
+        reasons.append(('pitch outside the supported range', (nominal < profile.low) | (nominal > profile.high)))
+    reasons.append(('onset after the time maximum', intervals[:, 0] > max_time))
+    reasons.append(('offset before the time minimum', intervals[:, 1] < min_time))
+    drop = np.zeros(len(pitches), dtype=bool)
+    for why, mask in reasons:
+        if not suppress_warnings and mask.any():
+            warnings.warn(f'Ignoring {int(mask.sum())} note(s): {why}.', category=RuntimeWarning)
+        drop |= mask
+    return pitches[~drop], intervals[~drop]
+
+
+def _frame_of(grid_ext, t, overflow):
+    """Index of the last grid point <= t on the extended (T+1)-point grid; times before the first point and times at or beyond
+    the extension point map to `overflow` (the reference's `argmin(...) - 1 == -1` case covers both, utils.py:1716-1722)."""
+    idx = np.searchsorted(grid_ext, t, side='right') - 1
+    last = len(grid_ext) - 1
+    return np.where((idx < 0) | (idx >= last), overflow, idx)
 
 
 def notes_to_multi_pitch(pitches, intervals, times, profile, include_offsets=True):
-    """(N,) MIDI pitches + (N,2) onset/offset seconds -> (F,T) float64 activation map on the frame grid `times`."""
-    num_frames = len(times)
-    multi_pitch = np.zeros((profile.get_range_len(), num_frames))
-    _times = np.append(times, times[-1] + estimate_hop_length(times))
-    pitches, intervals = filter_notes(pitches, intervals, profile, min_time=np.min(_times), max_time=np.max(_times))
-    num_notes = len(pitches)
-    pitches = np.round(pitches - profile.low).astype('int64')
-    times_broadcast = np.concatenate([[_times]] * max(1, num_notes), axis=0)
-    onsets = np.argmin(times_broadcast <= intervals[..., :1], axis=1) - 1
-    offsets = np.argmin(times_broadcast <= intervals[..., 1:], axis=1) - 1
-    onsets[onsets == -1], offsets[offsets == -1] = 0, num_frames - 1
-    for i in range(num_notes):
-        multi_pitch[pitches[i], onsets[i]: offsets[i] + int(include_offsets)] = 1
-    return multi_pitch
+    """(N,) MIDI pitches + (N,2) onset/offset seconds -> (keys, T) float64 activation map on the ascending frame grid `times`.
+    Behaviour contract: amt_tools/tools/utils.py:1665-1737.  Every note becomes +1 / -1 in a per-key difference array at its
+    first frame / one past its last frame; a running sum along time then marks the covered frames -- O(N + keys*T) with no
+    per-note slice assignment and no (N, T) broadcast."""
+    times = np.asarray(times, dtype=np.float64)
+    T = len(times)
+    keys = profile.get_range_len()
+    grid_ext = np.append(times, times[-1] + estimate_hop_length(times))
+    pitches, intervals = filter_notes(pitches, intervals, profile, min_time=grid_ext.min(), max_time=grid_ext.max())
+    if len(pitches) == 0:
+        return np.zeros((keys, T))
+    key = np.round(pitches - profile.low).astype(np.int64)
+    first = _frame_of(grid_ext, intervals[:, 0], 0)
+    stop = np.minimum(_frame_of(grid_ext, intervals[:, 1], T - 1) + int(include_offsets), T)      # exclusive
+    drawn = stop > first
+    delta = np.zeros((keys, T + 1), dtype=np.int64)
+    np.add.at(delta, (key[drawn], first[drawn]), 1)
+    np.add.at(delta, (key[drawn], stop[drawn]), -1)
+    return (np.cumsum(delta[:, :T], axis=1) > 0).astype(np.float64)
 
 
 def notes_to_onsets(pitches, intervals, times, profile, ambiguity=None):
-    onset_times = np.copy(intervals[..., :1])
-    offset_times = np.copy(intervals[..., 1:])
-    if ambiguity is not None:
-        offset_times = onset_times + np.minimum(offset_times - onset_times, ambiguity)
-    else:
-        offset_times = np.copy(onset_times)
-    return notes_to_multi_pitch(pitches, np.concatenate((onset_times, offset_times), axis=-1), times, profile)
+    """Onset map: every note shrunk to its onset frame, or to min(duration, `ambiguity`) seconds from its onset
+    (behaviour contract: amt_tools/tools/utils.py:2329-2378)."""
+    start = np.asarray(intervals, dtype=np.float64)[:, 0]
+    length = np.zeros_like(start) if ambiguity is None else np.minimum(np.asarray(intervals, dtype=np.float64)[:, 1] - start, ambiguity)
+    return notes_to_multi_pitch(pitches, np.stack([start, start + length], axis=1), times, profile)
 
 
 def notes_to_offsets(pitches, intervals, times, profile, ambiguity=None):
-    offset_times = np.copy(intervals[..., 1:])
-    onset_times = np.copy(offset_times)
-    if ambiguity is not None:
-        offset_times += ambiguity
-    return notes_to_multi_pitch(pitches, np.concatenate((onset_times, offset_times), axis=-1), times, profile)
+    """Offset map: every note shrunk to its offset frame, optionally extended by `ambiguity` seconds
+    (behaviour contract: amt_tools/tools/utils.py:2508-2552)."""
+    end = np.asarray(intervals, dtype=np.float64)[:, 1]
+    tail = 0.0 if ambiguity is None else ambiguity
+    return notes_to_multi_pitch(pitches, np.stack([end, end + tail], axis=1), times, profile)

@@ -10,6 +10,13 @@
 
 // ------------------------------------------------------------------ error plumbing
 void amtx_set_error(const char* fmt, ...);
+// raise a kernel's dynamic-LDS limit to `bytes` on the CURRENT device if it is not there yet (thread-safe, per device)
+int amtx_grant_lds(const void* kernel, size_t bytes);
+#define AMTX_GRANT_LDS(kern, bytes)                                                      \
+    do {                                                                                 \
+        int _rc = amtx_grant_lds(reinterpret_cast<const void*>(kern), (size_t)(bytes));  \
+        if (_rc != AMTX_OK) return _rc;                                                  \
+    } while (0)
 
 #define AMTX_CHECK_HIP(expr)                                                             \
     do {                                                                                 \

@@ -756,11 +756,7 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
             return AMTX_ERR_ARG;
         }
     auto kern = conv3x3_dma_kernel<NT>;
-    static bool done = false;   // per instantiation
-    if (!done) {
-        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        done = true;
-    }
+    AMTX_GRANT_LDS(kern, 80 * 1024);
     int64_t gx = ntiles;
     const int64_t per_group = std::max<int64_t>(1, 512 / std::max(1, a.groups));
     if (gx > per_group) gx = per_group;
@@ -779,13 +775,7 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
     const size_t lds = (size_t)NS * (FUSE1 ? CM_BYTES : PLANE_BYTES) + (FUSE1 ? ((size_t)a.c_in * FROWS * fw_pitch(KS) + FSLACK) * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
     auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1, KS>;
-    if (lds > 64 * 1024) {
-        static size_t granted = 0;   // per instantiation; the size grows with c_in
-        if (lds > granted) {
-            AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            granted = lds;
-        }
-    }
+    AMTX_GRANT_LDS(kern, lds);   // the size grows with c_in
     const int cols = ft + 2;
     const int inv_cols = 65536 / cols + 1;
     for (int pos = 0; pos < 1024; ++pos)

@@ -528,11 +528,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
     auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1>;
-    static size_t granted = 0;
-    if (lds > granted && lds > 64 * 1024) {
-        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        granted = lds;
-    }
+    AMTX_GRANT_LDS(kern, lds);
     // persistent grid: as many blocks as fit the chip at once (LDS allows 160 KiB / lds per CU), a multiple of 8 per group so a
     // block's tiles stay on its XCD
     const int per_cu = std::max(1, (int)(160 * 1024 / lds));

@@ -622,11 +622,7 @@ int launch_pp(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(ntiles < (1ll << 31), "gemm: too many output tiles");
     const size_t lds = (size_t)RST * RSTAGE + (size_t)g.n_pad * sizeof(float);
     auto kern = gemm_pp_kernel<C_TYPE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RST * RSTAGE + RING_MAX_NPAD * sizeof(float))));
-        attr_done = true;
-    }
+    AMTX_GRANT_LDS(kern, RST * RSTAGE + RING_MAX_NPAD * sizeof(float));
     int64_t gx = 256 / std::max(1, g.groups);
     gx = std::max<int64_t>(8, gx / 8 * 8);
     if (gx > ntiles) gx = ntiles;
@@ -646,11 +642,7 @@ int launch_glds(const GemmArgs& g, hipStream_t stream) {
     gx = std::max<int64_t>(8, gx / 8 * 8);
     if (gx > ntiles) gx = ntiles;
     auto kern = gemm_glds_kernel<C_TYPE, TB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    AMTX_GRANT_LDS(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(TB * 2), lds, stream, g, (int)ntiles);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;

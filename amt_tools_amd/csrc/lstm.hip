@@ -899,11 +899,7 @@ int launch_stream(const LstmArgs& a, hipStream_t stream) {
     // h tiles + (bf16 mode) the LDS-resident quarter of W_hh: 8 waves x (groups / 4) x 4 KiB
     const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 ? (size_t)8 * ((HH / 128) * 4 * (HH / 32 / 4) / 4) * 4096 : 0);
     auto kern = bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>;
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    AMTX_GRANT_LDS(kern, lds);
     dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
     AMTX_CHECK_LAUNCH();
@@ -1015,11 +1011,7 @@ int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* w
     dim3 grid((unsigned)((B + 3) / 4), 2);
     const size_t lds = 2 * (size_t)planes * GBUF_BYTES;
     if (planes == 2) {
-        static bool done = false;
-        if (!done) {
-            AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm4_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            done = true;
-        }
+        AMTX_GRANT_LDS(bilstm4_bwd_kernel<2>, lds);
         hipLaunchKernelGGL(bilstm4_bwd_kernel<2>, grid, dim3(LTHREADS), lds, stream, a);
     } else {
         hipLaunchKernelGGL(bilstm4_bwd_kernel<1>, grid, dim3(LTHREADS), lds, stream, a);
@@ -1054,11 +1046,7 @@ int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t*
     LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T, (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes)};
     dim3 grid((unsigned)((B + 3) / 4), 2, (unsigned)groups);
     const size_t lds = 2 * (size_t)planes * 16 * (4 * 256 + 8) * 2;
-    static bool done = false;
-    if (!done) {
-        AMTX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bilstm_stream_bwd_kernel<256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        done = true;
-    }
+    AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<256, 2>), lds);
     hipLaunchKernelGGL((bilstm_stream_bwd_kernel<256, 2>), grid, dim3(512), lds, stream, a);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;

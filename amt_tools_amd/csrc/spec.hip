@@ -573,12 +573,7 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M / 2 + 64) * sizeof(float2) +
                        64 * MAX_MEL_ROUNDS * sizeof(int) + (mel_lds ? (size_t)mel_slots * 64 * sizeof(float) : 0);
     auto launch = [&](auto kern) -> int {
-        static size_t granted = 64 * 1024;   // per kernel instantiation
-        if (lds > granted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { amtx_set_error("amtx_spec_power: %s", hipGetErrorString(e)); return AMTX_ERR_HIP; }
-            granted = lds;
-        }
+        AMTX_GRANT_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio, num_samples, audio_stride, T, power,
                            (unsigned*)clip_max);
         return AMTX_OK;

@@ -161,38 +161,56 @@ class WaveformWrapper(FeatureModule):
         return self.win_length
 
 
+def _index_of(device):
+    """Device index of an int / str / torch.device ('cuda' without an index = the current device)."""
+    import torch
+    if isinstance(device, int):
+        return device
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        raise _lib.AmtxError(f'the HIP front-end runs on a GPU, not on {dev}')
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
 class _SpecPlanOwner(object):
     """Lazily created amtx_spec_plan (device tables) shared by STFT / MelSpec instances."""
 
     def _plan_args(self):
         raise NotImplementedError
 
-    def _get_plan(self):
-        plan = self.__dict__.get('_plan')
+    def _get_plan(self, device=None):
+        """The plan (device tables) for `device` (a torch.device / index; default: the module's own device).  Plans are cached per
+        device index and created under that device, so a module built with the default device='cuda:0' can be handed tensors that
+        live on another GPU (one process per GPU under torchrun: rank k's tensors are on cuda:k) without its kernels
+        dereferencing cuda:0 allocations."""
+        import torch
+        index = self._device_index() if device is None else _index_of(device)
+        plans = self.__dict__.setdefault('_plans', {})
+        plan = plans.get(index)
         if plan is None:
-            import torch
             if not torch.cuda.is_available():
                 raise _lib.AmtxError('no GPU visible: the spectral front-end has no CPU fallback')
             handle = C.c_void_p()
-            with torch.cuda.device(self._device_index()):
+            with torch.cuda.device(index):
                 _lib.check(_lib.lib().amtx_spec_plan_create(C.byref(handle), *self._plan_args()), 'amtx_spec_plan_create')
-            plan = self.__dict__['_plan'] = handle
+            plan = plans[index] = handle
         return plan
 
     def _device_index(self):
-        import torch
-        dev = torch.device(self.device if not isinstance(self.device, int) else f'cuda:{self.device}')
-        return dev.index if dev.index is not None else 0
+        return _index_of(self.device)
+
+    def change_device(self, device):
+        """Follow the model to its device (TranscriptionModel.change_device propagates here through SpectralFrontend)."""
+        self.device = device
 
     def __getstate__(self):   # plans hold device pointers: never pickle them (DataLoader workers, torch.save)
         state = dict(self.__dict__)
-        state.pop('_plan', None)
+        state.pop('_plans', None)
         state.pop('_prof_events', None)
         return state
 
     def __del__(self):
-        plan = self.__dict__.get('_plan')
-        if plan is not None:
+        for plan in self.__dict__.get('_plans', {}).values():
             try:
                 _lib.lib().amtx_spec_plan_destroy(plan)
             except Exception:
@@ -205,7 +223,7 @@ class _SpecPlanOwner(object):
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
         audio = audio.contiguous()
         B, N = audio.shape
-        plan = self._get_plan()
+        plan = self._get_plan(audio.device)
         L = _lib.lib()
         T = _lib.check(L.amtx_spec_num_frames(plan, N), 'amtx_spec_num_frames')
         F = L.amtx_spec_num_bins(plan)
@@ -248,7 +266,7 @@ class _SpecPlanOwner(object):
         out = torch.empty((B, 1, T, F) if model_layout else (B, 1, F, T), dtype=torch.float32, device=power.device)
         with torch.cuda.device(power.device):
             ev = self._prof_begin()
-            _lib.check(L.amtx_spec_scale(self._get_plan(), _lib.ptr(power), _lib.ptr(clip_max), _lib.ptr(ref), B, T, transform,
+            _lib.check(L.amtx_spec_scale(self._get_plan(power.device), _lib.ptr(power), _lib.ptr(clip_max), _lib.ptr(ref), B, T, transform,
                                          1 if model_layout else 0, _lib.ptr(out), _lib.current_stream(power.device)),
                        'amtx_spec_scale')
             self._prof_end('spec_scale', ev)
@@ -361,36 +379,41 @@ class _CqtPlanOwner(object):
         raise NotImplementedError
 
     def _device_index(self):
-        import torch
-        dev = torch.device(self.device if not isinstance(self.device, int) else f'cuda:{self.device}')
-        return dev.index if dev.index is not None else 0
+        return _index_of(self.device)
 
-    def _get_plan(self):
-        plan = self.__dict__.get('_plan')
+    def change_device(self, device):
+        self.device = device
+        for m in getattr(self, 'modules', []):
+            m.device = device
+
+    def _get_plan(self, device=None):
+        """Per-device plan cache, see _SpecPlanOwner._get_plan."""
+        import torch
+        index = self._device_index() if device is None else _index_of(device)
+        plans = self.__dict__.setdefault('_plans', {})
+        plan = plans.get(index)
         if plan is None:
-            import torch
             if not torch.cuda.is_available():
                 raise _lib.AmtxError('no GPU visible: the CQT front-end has no CPU fallback')
             fmin, harmonics, truncate = self._cqt_args()
             arr = (C.c_double * len(harmonics))(*[float(h) for h in harmonics])
             handle = C.c_void_p()
-            with torch.cuda.device(self._device_index()):
+            with torch.cuda.device(index):
                 _lib.check(_lib.lib().amtx_cqt_plan_create(C.byref(handle), int(self.sample_rate), int(self.hop_length), float(fmin),
                                                            int(self.n_bins), int(self.bins_per_octave), float(self.gamma), arr,
                                                            len(harmonics), int(truncate),
                                                            int(str(self.librosa_version).startswith('0.9'))), 'amtx_cqt_plan_create')
-            plan = self.__dict__['_plan'] = handle
+            plan = plans[index] = handle
         return plan
 
     def __getstate__(self):
         state = dict(self.__dict__)
-        state.pop('_plan', None)
+        state.pop('_plans', None)
         state.pop('_workspace', None)
         return state
 
     def __del__(self):
-        plan = self.__dict__.get('_plan')
-        if plan is not None:
+        for plan in self.__dict__.get('_plans', {}).values():
             try:
                 _lib.lib().amtx_cqt_plan_destroy(plan)
             except Exception:
@@ -403,7 +426,7 @@ class _CqtPlanOwner(object):
         audio = audio.contiguous()
         B, N = audio.shape
         L = _lib.lib()
-        plan = self._get_plan()
+        plan = self._get_plan(audio.device)
         T = _lib.check(L.amtx_cqt_num_frames(plan, N), 'amtx_cqt_num_frames')
         H = L.amtx_cqt_num_harmonics(plan)
         need = L.amtx_cqt_workspace_bytes(plan, B, N)

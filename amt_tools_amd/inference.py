@@ -27,6 +27,16 @@ def run_offline(track_data, model, estimator=None):
     return predictions
 
 
+def _frame_times(model, num_frames):
+    """Frame grid of the model's on-device front-end: frames * hop_length / sample_rate in float64 (FeatureModule.get_times,
+    amt_tools/features/common.py:232-258).  Without a front-end module there is nothing to derive the grid from."""
+    for m in getattr(model, 'frontend', []):
+        mod = getattr(m, 'module', None)
+        if mod is not None and hasattr(mod, 'get_hop_length') and hasattr(mod, 'get_sample_rate'):
+            return (np.arange(num_frames) * mod.get_hop_length()).astype(np.float64) / float(mod.get_sample_rate())
+    raise ValueError('decode_notes=True needs `times` when the model has no front-end module to take hop_length / sample_rate from')
+
+
 @torch.no_grad()
 def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=1, decode_notes=False, keep=None):
     """clips: (num_clips, N) float32 array / CPU tensor of equally long clips (the model needs a front-end in
@@ -91,14 +101,18 @@ def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=
         idx = mine[s:s + batch_size]
         data, sync = nxt
         if sync is not None:
-            torch.cuda.current_stream(device).wait_event(sync[0])
+            main = torch.cuda.current_stream(device)
+            main.wait_event(sync[0])
+            # `data` was allocated from the copy stream's pool: tell the allocator that the main stream reads it, or the block
+            # could be handed to the upload of batch n+2 (and overwritten by DMA) while this batch's first kernel still reads it
+            data.record_stream(main)
         if n + 1 < len(starts):
             nxt = stage(mine[starts[n + 1]:starts[n + 1] + batch_size])
         preds = model.run_on_batch({key: data})
         handle = None
         if decode_notes:
             T = preds[tools.KEY_MULTIPITCH].shape[-1]
-            t = times if times is not None else np.arange(T) * 512 / 22050.0
+            t = times if times is not None else _frame_times(model, T)
             if preds[tools.KEY_MULTIPITCH].is_cuda:
                 from .transcribe import decode_notes_batch_async
                 handle = decode_notes_batch_async(preds[tools.KEY_ONSETS], preds[tools.KEY_MULTIPITCH], t, model.profile.low)

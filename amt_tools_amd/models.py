@@ -13,8 +13,10 @@ Execution paths
 * eval mode on a CUDA (ROCm) device  -> the HIP inference engine behind include/amtx.h
   (`amtx_of_forward`): conv1 -> conv3x3+BN+ReLU+pool (MFMA) -> fc1 (MFMA GEMM) -> persistent BiLSTM ->
   LogisticBank heads -> piano roll.  No fallback: a missing extension raises.
-* training mode (autograd) and CPU devices -> stock torch ops on the same parameters (ATen; the
-  reference's own arithmetic).  Hand-written backward kernels are future work.
+* training mode on a GPU (autograd) -> hand-written HIP forward + backward kernels behind autograd.Functions
+  (amt_tools_amd/autograd.py): the three BiLSTM recurrences, BatchNorm(batch statistics)+ReLU+MaxPool, the
+  LogisticBank loss; `autograd.training_backend()` names what still runs on ATen.
+* CPU devices -> stock torch ops on the same parameters (ATen; the reference's own arithmetic).
 
 `precision='bf16'` (default; bf16 MFMA operands, fp32 accumulate) or `'x3'` (split-bf16, fp32-class
 accuracy) selects the engine's dense arithmetic.
@@ -59,6 +61,11 @@ class TranscriptionModel(nn.Module):
             # the autograd (training) path runs its convolutions / BatchNorms through MIOpen: channels-last weights and
             # activations pick its faster kernels (train step 18.9 -> 15.5 ms); values, shapes and state_dict are unchanged
             self.to(memory_format=torch.channels_last)
+        # an on-device front-end follows the model (its plans / tables are created per device on first use)
+        for m in self.frontend:
+            mod = getattr(m, 'module', None)
+            if mod is not None and hasattr(mod, 'change_device'):
+                mod.change_device(self.device)
 
     def pre_proc(self, batch):
         """To-device copy (the caller's dict is not modified) + optional front-end on the raw audio
@@ -474,8 +481,9 @@ class OnsetsFrames(TranscriptionModel):
 
 class OnsetsFrames2(OnsetsFrames):
     """Onsets & Frames V2 (amt_tools/models/onsetsframes.py:199-327): adds an offset detector head whose logits join the
-    refinement stage; `offsets` are returned as probabilities.  The HIP engine runs it for model_complexity=2; other
-    complexities raise from `amtx_of_model_create` in eval mode on a GPU (training / CPU use ATen for any complexity)."""
+    refinement stage; `offsets` are returned as probabilities.  The HIP engine runs it at the model complexities
+    `amtx_of_model_create` is built for (2, and 3 = the reference's default for this class); anything else raises there in eval
+    mode on a GPU -- it never falls back."""
 
     has_offsets = True
 
@@ -516,7 +524,8 @@ class OnsetsFrames2(OnsetsFrames):
 
 
 class SoftmaxGroups(OutputLayer):
-    """One softmax per degree of freedom (amt_tools/models/common.py:305-483)."""
+    """One categorical distribution per degree of freedom: `num_groups` x `num_classes` logits per frame, the LAST class meaning
+    "inactive" (labelled -1 in ground truth and in the final output).  Behaviour contract: amt_tools/models/common.py:305-483."""
 
     def __init__(self, dim_in, num_groups, num_classes, weights=None):
         self.num_groups = num_groups
@@ -527,51 +536,53 @@ class SoftmaxGroups(OutputLayer):
     def forward(self, feats):
         return self.output_layer(feats)
 
+    def _grouped(self, logits):
+        """(B, T, G*C) -> (B, T, G, C)"""
+        return logits.reshape(logits.shape[0], -1, self.num_groups, self.num_classes)
+
     def get_loss(self, estimated, reference):
-        estimated = estimated.clone()
-        reference = reference.clone()
-        batch_size = estimated.size(0)
-        if self.weights is None:
-            estimated = estimated.view(-1, self.num_classes)
-            reference = reference.transpose(-2, -1)
-            reference[reference == -1] = self.num_classes - 1
-            reference = reference.flatten().long()
-            loss = F.cross_entropy(estimated.float(), reference, reduction='none')
-            loss = torch.sum(loss.view(batch_size, -1, self.num_groups), dim=-1)
-        else:
-            loss = 0
-            estimated = estimated.view(-1, self.num_groups, self.num_classes).float()
-            reference[reference == -1] = self.num_classes - 1
-            weight = self.weights.view(self.num_groups, -1)
-            for smax in range(self.num_groups):
-                loss += F.cross_entropy(estimated[:, smax], reference[:, smax].flatten().long(), weight=weight[smax], reduction='none')
-            loss = loss.view(batch_size, -1)
-        return torch.mean(torch.mean(loss, dim=-1))
+        """Negative log-likelihood of the labelled class of every group: summed over groups, averaged over frames, then over the
+        batch; optional per-(group, class) weights multiply each term (what F.cross_entropy(weight=..., reduction='none') does).
+        estimated (B, T, G*C) logits, reference (B, G, T) class indices with -1 for the inactive class."""
+        log_prob = torch.log_softmax(self._grouped(estimated).float(), dim=-1)                 # (B, T, G, C)
+        target = reference.transpose(-2, -1).long()                                             # (B, T, G)
+        target = torch.where(target < 0, torch.full_like(target, self.num_classes - 1), target)
+        nll = -log_prob.gather(-1, target.unsqueeze(-1)).squeeze(-1)                            # (B, T, G)
+        if self.weights is not None:
+            per_class = self.weights.to(nll.device).reshape(self.num_groups, self.num_classes)
+            group_idx = torch.arange(self.num_groups, device=nll.device).expand_as(target)
+            nll = nll * per_class[group_idx, target]
+        return nll.sum(dim=-1).mean(dim=-1).mean()
 
     def finalize_output(self, raw_output, last_negative=True):
-        final = raw_output.clone().detach()
-        batch_size = final.size(0)
-        final = final.view(batch_size, -1, self.num_groups, self.num_classes)
-        final = torch.argmax(torch.softmax(final, dim=-1), dim=-1)
+        """Most likely class per group and frame as (B, G, T) indices; the inactive class becomes -1 when `last_negative`."""
+        winners = torch.softmax(self._grouped(raw_output.detach()), dim=-1).argmax(dim=-1)      # (B, T, G)
         if last_negative:
-            final[final == self.num_classes - 1] = -1
-        return final.transpose(-2, -1)
+            winners = torch.where(winners == self.num_classes - 1, torch.full_like(winners, -1), winners)
+        return winners.transpose(-2, -1)
 
 
 class TabCNN(TranscriptionModel):
-    """TabCNN (amt_tools/models/tabcnn.py:17-221), BASELINE config 1: CPU plumbing on stock torch ops -- there is no HIP kernel
-    work for this model; it exists so that the reference's CQT + TabCNN experiment runs against this
-    package's FeatureModule / TranscriptionModel objects unchanged."""
+    """TabCNN, BASELINE config 1 (behaviour contract: amt_tools/models/tabcnn.py:17-221).  CPU plumbing on stock torch ops -- there
+    is no HIP kernel work for this model; it exists so that the reference's CQT + TabCNN experiment runs
+    against this package's FeatureModule / TranscriptionModel objects unchanged.  Module names and indices (`conv.{0,2,4}`,
+    `dense.{0,3}`) are the reference's, so its checkpoints load; the 9-frame context windows are built on the model's device with a
+    strided `unfold` view instead of the reference's device -> NumPy -> device round trip (tabcnn.py:122-127)."""
+
+    CONTEXT = 9      # frames seen by one prediction (tabcnn.py:40)
 
     def __init__(self, dim_in, profile, in_channels=1, model_complexity=1, device='cpu'):
-        super().__init__(dim_in, profile, in_channels, model_complexity, 9, device)
+        super().__init__(dim_in, profile, in_channels, model_complexity, self.CONTEXT, device)
         self.online = False
-        nf1 = 32 * self.model_complexity
-        nf2 = nf3 = 64 * self.model_complexity
-        self.conv = nn.Sequential(nn.Conv2d(self.in_channels, nf1, (3, 3)), nn.ReLU(), nn.Conv2d(nf1, nf2, (3, 3)), nn.ReLU(),
-                                  nn.Conv2d(nf2, nf3, (3, 3)), nn.ReLU(), nn.MaxPool2d((2, 2)), nn.Dropout(0.25))
-        self.conv_embedding_size = nf3 * ((self.dim_in - 6) // 2) * ((self.frame_width - 6) // 2)
-        self.fc_embedding_size = 128 * self.model_complexity
+        widths = (32 * model_complexity, 64 * model_complexity, 64 * model_complexity)
+        layers, c_prev = [], self.in_channels
+        for c in widths:
+            layers += [nn.Conv2d(c_prev, c, (3, 3)), nn.ReLU()]
+            c_prev = c
+        self.conv = nn.Sequential(*layers, nn.MaxPool2d((2, 2)), nn.Dropout(0.25))
+        # three unpadded 3x3 convolutions shave 6 off both axes, the pooling halves them
+        self.conv_embedding_size = widths[-1] * ((self.dim_in - 6) // 2) * ((self.frame_width - 6) // 2)
+        self.fc_embedding_size = 128 * model_complexity
         self.dense = nn.Sequential(nn.Linear(self.conv_embedding_size, self.fc_embedding_size), nn.ReLU(), nn.Dropout(0.50),
                                    SoftmaxGroups(self.fc_embedding_size, self.profile.get_num_dofs(), self.profile.num_pitches + 1))
 
@@ -579,25 +590,29 @@ class TabCNN(TranscriptionModel):
         self.online = not self.online
 
     def pre_proc(self, batch):
+        """Features (B, C, F, T) -> one context window per frame, (B, T', C, F, W).  Offline: T' = T, the sequence is zero-padded
+        by W // 2 frames on both sides; online: no padding (the caller supplies exactly the frames of a window)."""
         batch = super().pre_proc(batch)
-        feats = tools.tensor_to_array(batch[tools.KEY_FEATS])
-        feats = tools.framify_activations(feats, self.frame_width, pad=(not self.online))      # (B,C,F,T,W)
-        feats = tools.array_to_tensor(feats, self.device)
-        batch[tools.KEY_FEATS] = feats.transpose(-2, -3).transpose(-3, -4)                      # (B,T,C,F,W)
+        feats = batch[tools.KEY_FEATS]
+        W = self.frame_width
+        if not self.online:
+            feats = F.pad(feats, (W // 2, W // 2))
+        elif feats.shape[-1] < W:
+            feats = F.pad(feats, ((W - feats.shape[-1]) // 2, W - feats.shape[-1] - (W - feats.shape[-1]) // 2))
+        windows = feats.unfold(-1, W, 1)                                  # (B, C, F, T', W) view
+        batch[tools.KEY_FEATS] = windows.permute(0, 3, 1, 2, 4)           # (B, T', C, F, W)
         return batch
 
     def forward(self, feats):
-        batch_size = feats.size(0)
-        feats = feats.reshape(-1, self.in_channels, self.dim_in, self.frame_width)
-        embeddings = self.conv(feats).flatten(1)
-        embeddings = embeddings.view(batch_size, -1, embeddings.size(-1))
-        return {tools.KEY_TABLATURE: self.dense(embeddings)}
+        B, T = feats.shape[:2]
+        embeddings = self.conv(feats.reshape(B * T, self.in_channels, self.dim_in, self.frame_width))
+        return {tools.KEY_TABLATURE: self.dense(embeddings.reshape(B, T, -1))}
 
     def post_proc(self, batch):
         output = batch[tools.KEY_OUTPUT]
-        layer = self.dense[-1]
-        tablature_est = output[tools.KEY_TABLATURE]
-        if tools.KEY_TABLATURE in batch.keys():
-            output[tools.KEY_LOSS] = {tools.KEY_LOSS_TOTAL: layer.get_loss(tablature_est, batch[tools.KEY_TABLATURE])}
-        output[tools.KEY_TABLATURE] = layer.finalize_output(tablature_est)
+        head = self.dense[-1]
+        logits = output[tools.KEY_TABLATURE]
+        if tools.KEY_TABLATURE in batch:
+            output[tools.KEY_LOSS] = {tools.KEY_LOSS_TOTAL: head.get_loss(logits, batch[tools.KEY_TABLATURE])}
+        output[tools.KEY_TABLATURE] = head.finalize_output(logits)
         return output

@@ -22,14 +22,18 @@ __all__ = ['NoteTranscriber', 'PitchListWrapper', 'multi_pitch_to_notes', 'decod
 
 
 def estimate_hop_length(times):
-    """Median regular spacing of a time grid (amt_tools/tools/utils.py:3197-3229)."""
-    if not len(times):
-        raise ValueError('Cannot estimate hop length from an empty time array.')
-    times = np.sort(times)
-    non_gaps = np.append([False], np.isclose(np.diff(times, n=2), 0))
-    if not np.sum(non_gaps):
-        raise ValueError('Time observations are too irregular.')
-    return np.median(np.diff(times)[non_gaps])
+    """Spacing of a (possibly gappy) frame grid: the median of those steps that equal their predecessor, i.e. steps inside a
+    regular run (behaviour contract: amt_tools/tools/utils.py:3197-3229, including the 1e-8 absolute tolerance of np.isclose
+    against zero and ValueError for grids that are empty or have no two equal consecutive steps)."""
+    grid = np.sort(np.asarray(times, dtype=np.float64).ravel())
+    if grid.size == 0:
+        raise ValueError('hop length of an empty time grid is undefined')
+    steps = grid[1:] - grid[:-1]
+    change = steps[1:] - steps[:-1]                      # == np.diff(grid, n=2)
+    regular = steps[1:][np.abs(change) <= 1e-8]          # a step counts when it repeats the step before it
+    if regular.size == 0:
+        raise ValueError('time grid has no regularly spaced stretch to take a hop length from')
+    return np.median(regular)
 
 
 def _impulses(x):

@@ -7,11 +7,18 @@ One "step" = one pass of the hot path over one batch of clips already resident i
     audio (B,N) -> HIP mel front-end -> HIP Onsets&Frames engine -> piano rolls (B,88,T) x2
 through the product API (`model.run_on_batch({'audio': ...})` with the front-end in `model.frontend`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--clips B] [--mode infer|train]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, clips sharded across ranks, no data-path collective (inference shares nothing);
-the only collectives are the timing barrier and the MAX over ranks of the elapsed time.  Weak scaling.
+N > 1: one process per GPU.  `python bench.py --gpus N` on its own starts the N ranks itself (fresh child processes with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, before this process has touched the GPU) and relays rank 0's JSON line; under
+torchrun the ranks already exist.  WORLD_SIZE != --gpus is an error, never a silent 1-GPU run.
+
+  --mode infer (default): clips sharded across ranks, no data-path collective (inference shares nothing); the only collectives
+                          are the timing barrier and the MAX over ranks of the elapsed time.  Weak scaling.
+  --mode train          : BASELINE metric (ii), train step time: OnsetsFrames fwd + bwd + Adam on `--clips` (default 8) clips x
+                          625 frames per GPU, clip-level data parallelism (amt_tools_amd.dp.DataParallelOptimizer: ONE flat RCCL
+                          gradient all-reduce inside optimizer.step(), amt_tools/train.py:126-141 unchanged).  Weak scaling.
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline     -- dominant kernel of the timed region, timed live with HIP events on the launch stream
@@ -22,6 +29,8 @@ import ctypes as C
 import gc
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,12 +39,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np   # noqa: E402
-import torch         # noqa: E402
+import torch         # noqa: E402   (importing torch does not initialise the GPU; nothing below does before launch())
 
 SR, HOP, N_MELS, N_FFT = 22050, 512, 229, 2048
 CLIP_SAMPLES, CLIP_FRAMES = 319999, 625
 PEAK_MFMA_BF16_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+MODEL_FLOPS_PER_FRAME = 26.70e6
+TRAIN_FLOPS_PER_FRAME = 80.0e6      # ~3x forward
 
 # algorithmic work per clip-frame; flops for MFMA stages, bytes for streaming stages
 STAGE_FLOPS = {
@@ -64,18 +75,109 @@ STAGE_BYTES = {
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--clips', type=int, default=1024, help='clips per GPU per step (sweep on MI355X: 256: 26.7, 512: 29.1, 1024: 31.1, 2048: 31.1 M frames/s)')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
+    ap.add_argument('--clips', type=int, default=None, help='clips per GPU per step (default 1024 for infer -- sweep on MI355X: 256: 26.7, '
+                                                            '512: 29.1, 1024: 31.1, 2048: 31.1 M frames/s -- and 8 for train, the reference batch)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3'])
+    ap.add_argument('--of2', action='store_true', help='train mode: OnsetsFrames2 as shipped (model_complexity 3, offset head)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time budget of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the bf16-vs-x3 / oracle cell-mismatch count and the x3 throughput leg')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only for the "
                                                       "single-GPU smoke test of the multi-process path)")
     ap.add_argument('--share-device', action='store_true', help='test only: every rank uses cuda:0')
-    return ap.parse_args()
+    ap.add_argument('--dry-run', action='store_true', help='test only (CPU): ranks rendezvous over gloo and rank 0 prints a line '
+                                                           'without touching a GPU -- exercises the launcher and the relay')
+    args = ap.parse_args(argv)
+    if args.clips is None:
+        args.clips = 1024 if args.mode == 'infer' else 8
+    return args
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torchrun
+# ------------------------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """Start `args.gpus` fresh rank processes of this script and relay rank 0's JSON line.  Runs before anything in this process
+    has touched the GPU (children are started with Popen, nothing is exec'ed from a GPU-initialised process)."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    line = None
+    for out in procs[0].stdout:
+        out = out.rstrip('\n')
+        if out.startswith('{') and '"metric"' in out:
+            line = out
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rcs = [p.wait() for p in procs]
+    if any(rcs) or line is None:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f'bench.py launcher: rank exit codes {rcs}, result line {"present" if line else "missing"}', file=sys.stderr, flush=True)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+def init_ranks(args):
+    """(rank, world, device) from the torchrun-style environment; WORLD_SIZE must equal --gpus."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs')
+    import torch.distributed as dist
+    if args.dry_run:
+        if world > 1:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        return rank, world, 'cpu'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
+    if args.share_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus
+    return rank, world, device
+
+
+def max_over_ranks(elapsed, world, device, backend):
+    if world == 1:
+        return elapsed
+    import torch.distributed as dist
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(world):
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
 
 
 def build_model(device, precision):
@@ -93,53 +195,134 @@ def build_model(device, precision):
     return model, mel, sd
 
 
-def cpu_baseline(budget_s, sd):
-    """Oracle on the host cores: numpy front-end restatement + torch-CPU fp32 model restatement, one clip
-    per call (the reference's run_offline pattern, amt_tools/inference.py:38-41).  Bounded by wall time:
-    clips are processed until `budget_s` is used up (at least one, at most 64).  The thread count is capped
-    at 16: the per-step LSTM matmuls are tiny and more threads only add synchronisation cost."""
+# ------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle = checker; here it is the thing timed, on the host cores, rank 0 at N = 1 only)
+# ------------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(budget_s, sd, keep=8):
+    """Oracle on the host cores: numpy front-end restatement + torch-CPU fp32 model restatement (its recurrences through ATen's
+    nn.LSTM, what the reference itself runs on a CPU), one clip per call (the reference's run_offline pattern,
+    amt_tools/inference.py:38-41).  Bounded by wall time: clips are processed until `budget_s` is used up (at least one, at most
+    64); the clips are synthesised BEFORE the clock starts.  The thread count is capped at 16: the per-step LSTM matmuls are tiny
+    and more threads only add synchronisation cost.  Returns (record, piano rolls of the first `keep` clips) -- the latter feed
+    the bf16 cell-mismatch count."""
     from amt_tools_amd.synth import synth_clip
     from oracle import frontend_np as fe, model_ref
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
+    model_ref.LSTM_IMPL = 'aten'
     sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
-    t0 = time.perf_counter()
-    t_fe, n = 0.0, 0
+    # one clip takes ~0.15-0.3 s: synthesise as many as the budget can use, outside the timed loop
+    clips = [synth_clip(i) for i in range(8)]
+    rolls = []
+    t_fe, t_total, n = 0.0, 0.0, 0
     while n < 64:
-        y = synth_clip(n)
+        if n >= len(clips):
+            clips.append(synth_clip(n))
+        y = clips[n]
         a = time.perf_counter()
         feats = fe.melspec_process_audio(y, SR, HOP, N_MELS, N_FFT, dtype=np.float32).astype(np.float32)
-        t_fe += time.perf_counter() - a
+        b = time.perf_counter()
         with torch.no_grad():
-            model_ref.run_on_batch(torch.from_numpy(feats[None]), sdt)
+            o = model_ref.run_on_batch(torch.from_numpy(feats[None]), sdt)
+        c = time.perf_counter()
+        t_fe += b - a
+        t_total += c - a
+        if n < keep:
+            rolls.append((o['onsets'][0].numpy().copy(), o['multi_pitch'][0].numpy().copy(),
+                          o['logits']['onsets'][0].numpy().copy(), o['logits']['multi_pitch'][0].numpy().copy()))
         n += 1
-        if time.perf_counter() - t0 > budget_s:
+        if t_total > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {'value': n * CLIP_FRAMES / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} synthetic clips x {CLIP_FRAMES} frames in {dt:.1f} s, one clip per call, fp32 '
-                      f'(front-end share {t_fe / dt:.2f}; includes clip synthesis)'}
+    rec = {'value': n * CLIP_FRAMES / t_total, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{n} synthetic clips x {CLIP_FRAMES} frames in {t_total:.1f} s of oracle time (clip synthesis excluded), one clip per '
+                     f'call, fp32, numpy front-end (share {t_fe / t_total:.2f}) + torch-CPU model restatement with ATen nn.LSTM recurrences'}
+    return rec, rolls
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device(device))
-        else:
-            dist.init_process_group(args.backend)
+def cpu_train_baseline(budget_s):
+    """Train-mode CPU reference point: the package's CPU path (stock torch ops on the reference's module layout = the reference's
+    own arithmetic) for one fwd + bwd + Adam step on 2 clips x 625 frames of precomputed oracle features."""
+    from amt_tools_amd import tools
+    from amt_tools_amd.models import OnsetsFrames
+    from amt_tools_amd.synth import synth_clip, synth_labels
+    from oracle import frontend_np as fe
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = OnsetsFrames(N_MELS, tools.PianoProfile(), 1, 2, device='cpu')
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=6e-4)
+    Bc = 2
+    feats = np.stack([fe.melspec_process_audio(synth_clip(i), SR, HOP, N_MELS, N_FFT, dtype=np.float32) for i in range(Bc)]).astype(np.float32)
+    lab = [synth_labels(i) for i in range(Bc)]
+    batch = {tools.KEY_FEATS: torch.from_numpy(feats), tools.KEY_MULTIPITCH: torch.from_numpy(np.stack([l[0] for l in lab])),
+             tools.KEY_ONSETS: torch.from_numpy(np.stack([l[1] for l in lab]))}
+    times = []
+    t0 = time.perf_counter()
+    while len(times) < 4 and (time.perf_counter() - t0 < budget_s or len(times) < 2):
+        a = time.perf_counter()
+        opt.zero_grad()
+        model.run_on_batch(batch)[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+        opt.step()
+        times.append(time.perf_counter() - a)
+    step_s = min(times[1:]) if len(times) > 1 else times[0]
+    return {'value': step_s * 1e3 * 8 / Bc, 'unit': 'ms/step', 'cores': cores, 'kind': 'port',
+            'sample': f'torch-CPU fp32 fwd+bwd+Adam on {Bc} clips x {CLIP_FRAMES} frames of oracle features: {step_s:.2f} s per step '
+                      f'(best of {max(1, len(times) - 1)} after one warm-up step), scaled x{8 // Bc} to the 8-clip batch'}
 
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# inference mode
+# ------------------------------------------------------------------------------------------------------------------------------
+def parity_leg(model, audio, out_bf16, device, oracle_rolls):
+    """After the timed region: (1) the fp32-class `x3` mode on the same clips -- its throughput, and the fraction of piano-roll
+    cells in which the headline bf16 mode differs from it; (2) both modes against the CPU oracle's piano rolls of the same clips
+    (computed by the cpu_baseline leg).  SURVEY F8: on thresholded outputs the mismatch count IS the parity metric."""
+    from amt_tools_amd import tools
+    res = {}
+    Bx = min(128, audio.shape[0])
+    mx, _, _ = build_model(device, 'x3')
+    bx = {tools.KEY_AUDIO: audio[:Bx]}
+    with torch.no_grad():
+        ox = mx.run_on_batch(bx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ox = mx.run_on_batch(bx)
+        torch.cuda.synchronize()
+        res['x3_frames_per_s'] = 3 * Bx * CLIP_FRAMES / (time.perf_counter() - t0)
+        res['x3_clips_per_step'] = Bx
+    nd = min(8, Bx)       # distinct clips (the batch tiles 8)
+    cells, diff = 0, 0
+    for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
+        a, b = out_bf16[k][:nd], ox[k][:nd]
+        cells += a.numel()
+        diff += int((a != b).sum().item())
+    res['bf16_cell_mismatch_rate_vs_x3'] = diff / cells
+    res['bf16_cells_compared'] = cells
+    if oracle_rolls:
+        n = min(nd, len(oracle_rolls))
+        for tag, o in (('bf16', out_bf16), ('x3', ox)):
+            d = c = 0
+            for i in range(n):
+                for j, k in enumerate((tools.KEY_ONSETS, tools.KEY_MULTIPITCH)):
+                    got = o[k][i].cpu().numpy()
+                    d += int((got != oracle_rolls[i][j]).sum())
+                    c += got.size
+            res[f'{tag}_cell_mismatch_rate_vs_cpu_oracle'] = d / c
+        res['oracle_clips_compared'] = n
+        # x3 logits against the oracle's: the 1e-4 gate of north_star, on the bench workload itself
+        lx = mx.engine_logits(mx.frontend(audio[:n].unsqueeze(-2)))
+        err = 0.0
+        for i in range(n):
+            err = max(err, float(np.abs(lx['onsets'][i].cpu().numpy() - oracle_rolls[i][2]).max()),
+                      float(np.abs(lx['multi_pitch'][i].cpu().numpy() - oracle_rolls[i][3]).max()))
+        res['x3_max_abs_logit_err_vs_cpu_oracle'] = err
+    del mx
+    return res
+
+
+def run_infer(args, rank, world, device):
     from amt_tools_amd import _lib, tools
     from amt_tools_amd.synth import synth_clip
 
@@ -152,11 +335,6 @@ def main():
     def step():
         with torch.no_grad():
             return model.run_on_batch(batch)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
 
     for _ in range(args.warmup):
         out = step()
@@ -173,17 +351,14 @@ def main():
     # 11.4 ms/step with identical per-kernel times.  Collect now, keep the collector off while timing.
     gc.collect()
     gc.disable()
-    barrier()
+    barrier(world)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    barrier()
+    barrier(world)
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, device, args.backend)
 
     stage_ms = (C.c_double * L.amtx_of_num_stages())()
     nfw = C.c_int(0)
@@ -197,52 +372,162 @@ def main():
     for name, v in fe_ms.items():
         per_launch[name] = float(np.mean(v))
 
+    if rank != 0:
+        return None
+    frames_per_launch = B * CLIP_FRAMES
+    total_frames = world * B * CLIP_FRAMES * args.steps
+    dom = max(per_launch, key=per_launch.get)
+    dur_s = per_launch[dom] * 1e-3
+    if dom in STAGE_FLOPS:
+        ach = STAGE_FLOPS[dom] * frames_per_launch / dur_s / 1e12
+        roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None}
+    else:
+        ach = STAGE_BYTES[dom] * frames_per_launch / dur_s / 1e9
+        roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': ach / PEAK_HBM_GBS, 'traffic': None}
+    # HBM traffic from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes, FETCH_SIZE doubled per MI355X_MICROARCH.md -- counters and timing cannot share a run), scaled to this launch's clips
+    hbm_measured = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            pmc = json.load(f)
+        src = pmc.get('_source', 'profiles/pmc_traffic.json')
+        if dom in pmc:
+            roof['traffic'] = pmc[dom]['hbm_bytes_corrected'] * B / pmc[dom]['clips']
+            roof['traffic_unit'] = 'bytes per launch'
+            roof['traffic_source'] = src
+            roof['algorithmic_bytes'] = ALGO_BYTES.get(dom, 0) * frames_per_launch or None
+        tot = sum(v['hbm_bytes_corrected'] / v['clips'] for k, v in pmc.items() if isinstance(v, dict) and 'hbm_bytes_corrected' in v)
+        hbm_measured = (tot * B, src)
+    except (OSError, ValueError, KeyError):
+        pass
+    roof['avg_launch_ms'] = per_launch[dom]
+    roof['kernel_ms_per_step'] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
+    fps = total_frames / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    config = {'workload': 'OnsetsFrames(mc=2)+MelSpec(229 bins, n_fft 2048, hop 512) inference, synthetic 22.05 kHz clips of 319999 '
+                          'samples (625 frames; 8 distinct clips per rank tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
+              'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
+              'rccl_ranks': world,
+              'whole_path_frac_of_mfma_roof': fps / world * MODEL_FLOPS_PER_FRAME / 2.5e15,
+              'whole_path_frac_of_compulsory_hbm_roof': fps / world * 2752 / 8.0e12}
+    if hbm_measured is not None:
+        # bytes this build really moves per step (sum of the PMC-counted kernels) over the step time, against 8 TB/s
+        config['whole_path_hbm_frac_measured'] = hbm_measured[0] / (ms_per_step * 1e-3) / 8.0e12
+        config['whole_path_hbm_bytes_per_frame_measured'] = hbm_measured[0] / frames_per_launch
+        config['whole_path_hbm_source'] = hbm_measured[1]
+    res = {
+        'metric': 'audio frames/sec (OnsetsFrames+Mel-229 inference)', 'value': fps, 'unit': 'frames/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if args.precision == 'bf16' else 'bf16x3', 'data': 'synthetic',
+        'config': config, 'roofline': roof,
+    }
+    oracle_rolls = None
+    if world == 1 and args.cpu_seconds > 0:
+        res['cpu_baseline'], oracle_rolls = cpu_baseline(args.cpu_seconds, sd)
+    if world == 1 and not args.no_parity and args.precision == 'bf16':
+        config.update(parity_leg(model, audio, out, device, oracle_rolls))
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# training mode (BASELINE metric ii)
+# ------------------------------------------------------------------------------------------------------------------------------
+def run_train(args, rank, world, device):
+    from amt_tools_amd import tools
+    from amt_tools_amd.dp import DataParallelOptimizer, broadcast_parameters
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
+    from amt_tools_amd.synth import synth_clip, synth_labels
+
+    torch.manual_seed(0)
+    if args.of2:
+        model = OnsetsFrames2(N_MELS, tools.PianoProfile(), 1, device=device)
+    else:
+        model = OnsetsFrames(N_MELS, tools.PianoProfile(), 1, 2, device=device)
+    model.frontend = torch.nn.Sequential(MelSpec(sample_rate=SR, hop_length=HOP, n_mels=N_MELS, n_fft=N_FFT, device=device).frontend())
+    model.change_device()
+    broadcast_parameters(model)
+    model.train()
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4)
+    B = args.clips
+    audio = torch.from_numpy(np.stack([synth_clip(rank * B + i) for i in range(B)])).to(device)
+    lab = [synth_labels(rank * B + i) for i in range(B)]
+    batch = {tools.KEY_AUDIO: audio,
+             tools.KEY_MULTIPITCH: torch.from_numpy(np.stack([l[0] for l in lab])).to(device),
+             tools.KEY_ONSETS: torch.from_numpy(np.stack([l[1] for l in lab])).to(device)}
+    if args.of2:
+        batch[tools.KEY_OFFSETS] = torch.from_numpy(np.stack([l[1][:, ::-1].copy() for l in lab])).to(device)   # any sparse binary map
+
+    def step():       # amt_tools/train.py:122-141
+        opt.zero_grad()
+        loss = model.run_on_batch(batch)[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    gc.collect()
+    gc.disable()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    elapsed = max_over_ranks(elapsed, world, device, args.backend)
+    if rank != 0:
+        return None
+    ms = elapsed / args.steps * 1e3
+    fps = world * B * CLIP_FRAMES * args.steps / elapsed
+    name = 'OnsetsFrames2(mc=3)' if args.of2 else 'OnsetsFrames(mc=2)'
+    flops = (3 * 93.6e6 if args.of2 else TRAIN_FLOPS_PER_FRAME)
+    ach = flops * fps / world / 1e12
+    from amt_tools_amd.autograd import training_backend
+    res = {
+        'metric': f'train step time ({name} fwd+bwd+Adam, DP over clips)', 'value': ms, 'unit': 'ms/step', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (split-bf16 MFMA products in the HIP kernels, fp32 accumulate / parameters / optimizer)', 'data': 'synthetic',
+        'config': {'workload': f'{name}+MelSpec(229) training step, {B} clips x {CLIP_FRAMES} frames per GPU, Adam lr 6e-4, labels Bernoulli '
+                               f'(synth_labels), audio resident in HBM', 'clips_per_gpu_per_step': B, 'global_batch': world * B,
+                   'frames_per_s': fps, 'parallelism': f'dp{world}: one flat fp32 gradient all-reduce per step', 'rccl_ranks': world,
+                   'loss': float(loss), 'backward': training_backend()},
+        'roofline': {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None,
+                     'note': f'{flops / 1e6:.1f} MFLOP per clip-frame (SURVEY 8d: ~3x forward) x frames / step time; at 8 clips per GPU the step is '
+                             f'latency-bound (three 625-step recurrences each way), see DESIGN.md'},
+    }
+    if world == 1 and args.cpu_seconds > 0 and not args.of2:
+        res['cpu_baseline'] = cpu_train_baseline(args.cpu_seconds)
+    return res
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch(args, argv))            # nothing above has touched the GPU
+    rank, world, device = init_ranks(args)
+    if args.dry_run:
+        import torch.distributed as dist
+        elapsed = max_over_ranks(1e-3 * (rank + 1), world, 'cpu', 'gloo')
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'dry run (launcher / rendezvous / relay only)', 'value': 0.0, 'unit': 'none', 'n_gpus': world,
+                              'steps': 0, 'warmup': 0, 'ms_per_step': elapsed * 1e3, 'dry_run': True}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    res = run_infer(args, rank, world, device) if args.mode == 'infer' else run_train(args, rank, world, device)
     if rank == 0:
-        frames_per_launch = B * CLIP_FRAMES
-        total_frames = world * B * CLIP_FRAMES * args.steps
-        dom = max(per_launch, key=per_launch.get)
-        dur_s = per_launch[dom] * 1e-3
-        if dom in STAGE_FLOPS:
-            ach = STAGE_FLOPS[dom] * frames_per_launch / dur_s / 1e12
-            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None}
-        else:
-            ach = STAGE_BYTES[dom] * frames_per_launch / dur_s / 1e9
-            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                    'frac': ach / PEAK_HBM_GBS, 'traffic': None}
-        # HBM traffic of the same kernel from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate passes, FETCH_SIZE doubled per MI355X_MICROARCH.md), scaled to this launch's clips
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')) as f:
-                pmc = json.load(f)
-            if dom in pmc:
-                roof['traffic'] = pmc[dom]['hbm_bytes_corrected'] * B / pmc[dom]['clips']
-                roof['traffic_unit'] = 'bytes per launch'
-                roof['algorithmic_bytes'] = ALGO_BYTES.get(dom, 0) * frames_per_launch or None
-        except (OSError, ValueError, KeyError):
-            pass
-        roof['avg_launch_ms'] = per_launch[dom]
-        roof['kernel_ms_per_step'] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
-        fps = total_frames / elapsed
-        res = {
-            'metric': 'audio frames/sec (OnsetsFrames+Mel-229 inference)', 'value': fps, 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if args.precision == 'bf16' else 'bf16x3', 'data': 'synthetic',
-            'config': {'workload': 'OnsetsFrames(mc=2)+MelSpec(229 bins, n_fft 2048, hop 512) inference, synthetic 22.05 kHz '
-                                   'clips of 319999 samples (625 frames), audio resident in HBM -> piano rolls',
-                       'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
-                       'whole_path_frac_of_mfma_roof': fps / world * 26.70e6 / 2.5e15,
-                       'whole_path_frac_of_compulsory_hbm_roof': fps / world * 2752 / 8.0e12,
-                       # a layer-by-layer implementation moves ~125 kB of bf16 activations per frame -> 6.4e7 frames/s
-                       # at 8 TB/s (this build moves ~81 kB: PMC, profiles/pmc_traffic.json + the small kernels)
-                       'whole_path_frac_of_layerwise_hbm_roof': fps / world * 125.0e3 / 8.0e12},
-            'roofline': roof,
-        }
-        if world == 1 and args.cpu_seconds > 0:
-            res['cpu_baseline'] = cpu_baseline(args.cpu_seconds, sd)
         print(json.dumps(res), flush=True)
     if world > 1:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
 

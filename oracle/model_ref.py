@@ -66,9 +66,26 @@ def _lstm_direction(x, w_ih, w_hh, b_ih, b_hh, reverse):
     return out
 
 
+LSTM_IMPL = 'loop'      # 'loop': the explicit time loop above (the restatement proper); 'aten': the same weights through
+                        # torch.nn.LSTM, i.e. the ATen kernel the reference itself runs on a CPU -- used by bench.py's
+                        # cpu_baseline so that the baseline is not slowed down by 2 x T Python iterations per recurrence
+                        # (tests/test_oracle_model.py checks that both give the same values)
+
+
+def _lstm_aten(x, sd, p):
+    H = sd[p + 'weight_hh_l0'].shape[1]
+    mod = torch.nn.LSTM(input_size=x.shape[-1], hidden_size=H, batch_first=True, bidirectional=True)
+    with torch.no_grad():
+        for name, _ in list(mod.named_parameters()):
+            getattr(mod, name).copy_(sd[p + name])
+    return mod(x)[0]
+
+
 def language_model(x, sd, prefix):
     """LanguageModel.forward (onsetsframes.py:504-575): full-sequence BiLSTM, fwd | bwd concatenated."""
     p = prefix + '.mlm.'
+    if LSTM_IMPL == 'aten':
+        return _lstm_aten(x, sd, p)
     fwd = _lstm_direction(x, sd[p + 'weight_ih_l0'], sd[p + 'weight_hh_l0'],
                           sd[p + 'bias_ih_l0'], sd[p + 'bias_hh_l0'], False)
     bwd = _lstm_direction(x, sd[p + 'weight_ih_l0_reverse'], sd[p + 'weight_hh_l0_reverse'],

@@ -37,6 +37,17 @@ def test_eval_logits_and_outputs_match_reference(name):
         np.testing.assert_allclose(out['offsets'].numpy(), g['out_offsets'], atol=tol, rtol=0)
 
 
+def test_aten_lstm_option_of_the_oracle_matches_the_golden_too(monkeypatch):
+    """bench.py's cpu_baseline runs the oracle with LSTM_IMPL='aten' (nn.LSTM on the same weights): same values."""
+    g = load_golden('of1_eval.npz')
+    sd = _sd(g)
+    monkeypatch.setattr(model_ref, 'LSTM_IMPL', 'aten')
+    with torch.no_grad():
+        out = model_ref.run_on_batch(torch.from_numpy(g['feats']), sd)
+    for key in ('onsets', 'multi_pitch', 'pitch_head'):
+        np.testing.assert_allclose(out['logits'][key].numpy(), g['logits_' + key], atol=2e-5, rtol=0)
+
+
 def test_train_losses_and_grads_match_reference():
     g = load_golden('of1_train.npz')
     sd = _sd(g)

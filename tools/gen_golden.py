@@ -250,6 +250,33 @@ def gen_labels_and_cache(name, cache_name, seed, T, n_notes, hop=512, sr=22050):
     print(name, {k: v.shape for k, v in rec.items()}, 'active cells', int(rec['multi_pitch'].sum()))
 
 
+def gen_labels_edges(name, hop=512, sr=22050, T=50):
+    """Rasterisation edge cases: onsets / offsets exactly on grid points, on the extension point one hop past the last frame,
+    before the first frame, beyond the end, zero-length notes, notes on the pitch-range borders and half-way pitches."""
+    profile = rtools.PianoProfile()
+    times = np.arange(T) * hop / float(sr)
+    h = hop / float(sr)
+    end = times[-1] + h                      # the extension point
+    iv = [[times[3], times[7]], [times[3], times[3]], [0.0, 0.0], [-1.0, 0.0], [-1.0, -0.5], [-0.2, times[2] + 0.3 * h],
+          [times[-1], end], [end, end], [end, end + 1.0], [times[-2], end + 1.0], [end + 0.1, end + 0.2], [times[10] + 0.5 * h, times[10] + 0.6 * h],
+          [times[20], times[20] + h], [times[20] - 1e-12, times[25] + 1e-12], [times[30], times[29]], [0.0, end], [times[40], times[44]],
+          [times[41], times[42]]]
+    pitches = np.array([60, 61, 21, 108, 50, 20.5, 108.49, 70, 71, 72, 73, 20.4, 107.5, 64.5, 65, 30, 90, 90], dtype=np.float64)[:len(iv)]
+    intervals = np.array(iv, dtype=np.float64)
+    rec = dict(pitches=pitches, intervals=intervals, times=times)
+    for key, fn, kw in (('multi_pitch', rtools.notes_to_multi_pitch, {}), ('multi_pitch_no_off', rtools.notes_to_multi_pitch, {'include_offsets': False}),
+                        ('onsets', rtools.notes_to_onsets, {}), ('onsets_amb', rtools.notes_to_onsets, {'ambiguity': 0.05}),
+                        ('offsets', rtools.notes_to_offsets, {}), ('offsets_amb', rtools.notes_to_offsets, {'ambiguity': 0.05})):
+        rec[key] = fn(pitches.copy(), intervals.copy(), times, profile, **kw)
+    fp, fi = rtools.filter_notes(pitches.copy(), intervals.copy(), profile, min_time=0.0, max_time=end)
+    rec['filtered_pitches'], rec['filtered_intervals'] = fp, fi
+    irregular = np.concatenate([times[:10], times[10:20] + 3.0, [times[19] + 3.0 + 0.7 * h]])
+    rec['irregular_times'] = irregular
+    rec['irregular_hop'] = np.array(rtools.estimate_hop_length(irregular))
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, {k: v.shape for k, v in rec.items()}, 'active cells', int(rec['multi_pitch'].sum()))
+
+
 def gen_feature_bookkeeping(name):
     """Frame / sample bookkeeping of the reference's STFT and MelSpec FeatureModules (features/common.py:41-150,232-321,
     stft.py, mel.py; waveform.py for the non-centred framing) -- pure arithmetic, runs under the librosa stub -- and their
@@ -316,6 +343,9 @@ def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'labels_edges':
+        gen_labels_edges('labels_edges.npz')
+        sys.exit(0)
     gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
     gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
@@ -324,6 +354,7 @@ if __name__ == '__main__':
     gen_of2_train('of2_train.npz', seed=22, dim_in=229, mc=3, B=2, T=24)
     gen_tabcnn('tabcnn_eval.npz', seed=41, dim_in=192, B=2, T=30)
     gen_labels_and_cache('labels.npz', 'feature_cache_ref.npz', seed=51, T=200, n_notes=60)
+    gen_labels_edges('labels_edges.npz')
     gen_feature_bookkeeping('feature_bookkeeping.npz')
     gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
