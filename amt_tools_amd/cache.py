@@ -91,7 +91,7 @@ def notes_to_multi_pitch(pitches, intervals, times, profile, include_offsets=Tru
     Behaviour contract: amt_tools/tools/utils.py:1665-1737.  Every note becomes +1 / -1 in a per-key difference array at its
     first frame / one past its last frame; a running sum along time then marks the covered frames -- O(N + keys*T) with no
     per-note slice assignment and no (N, T) broadcast."""
-    times = np.asarray(times, dtype=np.float64)
+    times = np.asarray(times)
     T = len(times)
     keys = profile.get_range_len()
     grid_ext = np.append(times, times[-1] + estimate_hop_length(times))

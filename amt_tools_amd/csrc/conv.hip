@@ -85,12 +85,19 @@ __device__ unsigned long long g_conv_prof[32];   // [16..22]: sections of the fi
 #else
 #define CONV_TICK(SLOT) do {} while (0)
 #endif
+// ticks inside the first-conv loops: every s_memtime costs a scalar-memory round trip (hundreds of cycles with lgkmcnt(0) behind
+// it), so the per-section numbers are only meaningful relative to each other; off unless asked for
+#ifdef AMTX_CONV_TIMING_FINE
+#define CONV_TICK_FINE(SLOT) CONV_TICK(SLOT)
+#else
+#define CONV_TICK_FINE(SLOT) do {} while (0)
+#endif
 
 constexpr int FROWS = ROWS + 2;      // feature tile rows of the fused first conv
-// Feature tile row pitch (floats).  c_in = 1 (KS = 1): the im2col gather of lane (g, column) reads row min(g, 2), so lanes
-// 0-31 of a ds_read_b32 take 16 consecutive floats of two rows: a pitch of 16 (mod 32) puts them on disjoint banks (lanes
-// 32-63 share one row and broadcast).  c_in > 1 (KS = 4): the tightest pitch, so that two blocks still fit one CU's LDS.
-constexpr int fw_pitch(int ks) { return ks == 1 ? 80 : FT_MAX + 4; }
+// Feature tile row pitch (floats).  c_in = 1 (KS = 1, the Toeplitz first conv below): lane (row n, k-group g) reads 8 consecutive
+// floats of row n + g with two ds_read_b128; a pitch of 4 floats (mod 64) puts the 16 rows of a lane group on 16 distinct 16-byte
+// slots of the 256-byte bank row.  c_in > 1 (KS = 4): the tightest pitch, so that two blocks still fit one CU's LDS.
+constexpr int fw_pitch(int ks) { return ks == 1 ? 68 : FT_MAX + 4; }
 
 constexpr int ITEMS = (ROWS * (FT_MAX + 2) * 4 + 255) / 256;   // 16-byte staging items per thread (14)
 constexpr int FSLACK = 16;          // floats after the feature tile: gathers of columns past the tile stay in LDS we own
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 
     // ---- constants of the fused first conv
     float* ftile = reinterpret_cast<float*>(smem + NS * PB);
-    const int fcols = ft + 4 + (KS == 1 ? 1 : 0);       // KS == 1: one more column for the zero-weight fourth slot of a lane's row segment
+    const int fcols = ft + 4;
     const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
     const bool fprefetch = FUSE1 && fitems <= FPRE * NTH;
     constexpr int KSA = KS > 0 ? KS : 1;
@@ -180,7 +187,26 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     int ksteps = 0;
     int kaddr[KSA][4];                                  // koff + the lane's column inside a 16-column block
     const int wlane = g * CM_PLANE + (lane & 15) * 16;   // lane part of the chunk-major store address
-    if constexpr (FUSE1) {
+    // c_in = 1: Toeplitz form of the first conv (see the phase below): 4 output columns x 2 channel halves of stationary A fragments
+    uint4 w1t[KS == 1 ? 4 : 1][2][NS];
+    if constexpr (FUSE1 && KS == 1) {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) w1t[q][nt][p] = wp[((q * 2 + nt) * NS + p) * 64];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh1[nt][r] = a.shift1[(int64_t)grp * 32 + g * 8 + 4 * nt + r];
+        // feature columns past the staged ones (fcols .. FW) are only ever multiplied by zero weights, but must hold finite
+        // values (NaN x 0 is NaN): zero them once (disjoint from the cells staging writes, so no barrier is needed in between)
+        for (int i = tid; i < FROWS * FW + FSLACK; i += NTH)
+            if (i >= FROWS * FW || i % FW >= fcols) ftile[i] = 0.f;
+    }
+    if constexpr (FUSE1 && KS != 1) {
         const int kvalid = 9 * a.c_in;
         ksteps = (kvalid + 15) >> 4;                    // K = 16 per MFMA step, <= 4 steps
 #pragma unroll
@@ -216,9 +242,17 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int p = 0; p < NS; ++p) settle(wf[tap][nt][p]);
+    if constexpr (FUSE1 && KS == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int p = 0; p < NS; ++p) settle(w1t[q][nt][p]);
+    }
     if constexpr (FUSE1) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+        for (int ks = 0; ks < (KS == 1 ? 0 : KS); ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -300,6 +334,128 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             __syncthreads();
             CONV_TICK(1);
             if (fprefetch && has_next) CONV_ISSUE_FEAT_LOADS(tn);
+            if constexpr (KS == 1) {
+            // ---- c_in = 1: the first conv as a TOEPLITZ product on the matrix cores.  One "unit" = 16 tile rows x 4 tile columns:
+            //        D[(column q, channel), row n] = sum_{(dy, e)} Tw[(q, channel), (dy, e)] . f[n + dy, 4 xb + e],   e = 0..7, dy = 0..2
+            // with Tw[(q, co), (dy, e)] = w[co, dy, e - q] for 0 <= e - q <= 2 and 0 elsewhere (host-packed, stationary in 32
+            // registers).  The MFMA's B operand of lane (row n, k-group g = dy) is then 8 CONSECUTIVE floats of feature row n + g:
+            // two ds_read_b128 + four conversions feed the 8 MFMAs of 64 positions x 32 channels -- the im2col form gathered four
+            // scalars per lane and 16 positions (24 ds_read_b32 + 12 conversions for the same 64 positions), and that gather, not
+            // the matrix work, was half of a tile's issue time.  The two halo rows (16, 17) of all column blocks form their own
+            // units with lane n -> (row 16 + (n & 1), column block n >> 1).  A lane ends up with 8 consecutive channels of one
+            // position per (q): one ds_write_b128 into the chunk-major input tile of conv2, as before.
+            const int n16 = lane & 15;
+            const int nmain = (cols + 3) >> 2;
+            const int nunits = nmain + ((nmain + 7) >> 3);
+            const int gg = min(g, 2);                                   // k-group 3 has zero weights: re-read group 2's row
+            const int fa_main = (n16 + gg) * FW * 4;
+            const int fa_halo = ((TT + (n16 & 1) + gg) * FW + 4 * (n16 >> 1)) * 4;
+            const int oa_main = g * CM_PLANE + n16 * PITCH * 16;
+            const int oa_halo = g * CM_PLANE + ((TT + (n16 & 1)) * PITCH + 4 * (n16 >> 1)) * 16;
+            const char* fbytes = reinterpret_cast<const char*>(ftile);
+            const bool interior = t0 >= 1 && t0 + TT < a.T && f0 >= 1 && f0 + ft < a.F;   // no position of the tile is padding
+            // scratch lines for masked stores (one 16-byte slot per lane and plane) behind the shift table
+            const int scratch_off = NS * PB + (a.c_in * FROWS * FW + FSLACK) * 4 + COUT * 4 + lane * 16;
+            f32x4_t c1[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) c1[nt] = (f32x4_t){sh1[nt][0], sh1[nt][1], sh1[nt][2], sh1[nt][3]};
+            __builtin_amdgcn_s_setprio(2);
+            float4 fv0 = make_float4(0.f, 0.f, 0.f, 0.f), fv1 = fv0;
+#define CONV1T_LOAD(U)                                                                                     \
+            do {                                                                                           \
+                const int uu = min((U), nunits - 1);                                                       \
+                const int fa = uu < nmain ? fa_main + uu * 16 : fa_halo + (uu - nmain) * 128;              \
+                fv0 = *reinterpret_cast<const float4*>(fbytes + fa);                                       \
+                fv1 = *reinterpret_cast<const float4*>(fbytes + fa + 16);                                  \
+            } while (0)
+            CONV1T_LOAD(wave_u);
+            for (int u = wave_u; u < nunits; u += NW) {
+                uint4 bh, bl = make_uint4(0, 0, 0, 0);
+                if (NS == 2) {
+                    split_bf16x2(fv0.x, fv0.y, bh.x, bl.x);
+                    split_bf16x2(fv0.z, fv0.w, bh.y, bl.y);
+                    split_bf16x2(fv1.x, fv1.y, bh.z, bl.z);
+                    split_bf16x2(fv1.z, fv1.w, bh.w, bl.w);
+                } else {
+                    bh = make_uint4(pack_bf16x2(fv0.x, fv0.y), pack_bf16x2(fv0.z, fv0.w), pack_bf16x2(fv1.x, fv1.y), pack_bf16x2(fv1.z, fv1.w));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                CONV_TICK_FINE(8);
+                CONV1T_LOAD(u + NW);
+                __builtin_amdgcn_sched_barrier(0);
+                CONV_TICK_FINE(9);
+                f32x4_t acc1[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc1[q][nt] = mfma16(w1t[q][nt][0], bh, c1[nt]);
+                        if (NS == 2) {
+                            acc1[q][nt] = mfma16(w1t[q][nt][0], bl, acc1[q][nt]);
+                            acc1[q][nt] = mfma16(w1t[q][nt][1], bh, acc1[q][nt]);
+                        }
+                    }
+                CONV_TICK_FINE(10);
+                const bool mainu = u < nmain;                                                    // scalar
+                const int oa = mainu ? oa_main + u * 64 : oa_halo + (u - nmain) * 512;
+                // wave-uniform: no position of this unit is padding or past the tile's last column -> unconditional epilogue
+                const bool fast = __builtin_amdgcn_readfirstlane((int)(interior && mainu && 4 * u + 3 < cols)) != 0;
+                if (fast) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (NS == 1) {
+                            // round first, then ReLU on the packed pairs as a signed 16-bit max with 0 (a negative bf16 is a
+                            // negative int16, -0 included)
+                            typedef short s16x2 __attribute__((ext_vector_type(2)));
+                            uint32_t pk[4];
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                const uint32_t v = pack_bf16x2(acc1[q][h >> 1][2 * (h & 1)], acc1[q][h >> 1][2 * (h & 1) + 1]);
+                                pk[h] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, v), (s16x2){0, 0}));
+                            }
+                            *reinterpret_cast<uint4*>(smem + oa + q * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                        } else {
+                            float y[8];
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) y[nt * 4 + r] = fmaxf(acc1[q][nt][r], 0.f);
+                            uint4 hi, lo;
+                            cvt8(y, true, hi, lo);
+                            *reinterpret_cast<uint4*>(smem + oa + q * 16) = hi;
+                            *reinterpret_cast<uint4*>(smem + PB + oa + q * 16) = lo;
+                        }
+                    }
+                } else {
+                    // border tiles, the halo-row units and a ragged last column block: branch-free per-lane padding (ReLU and the
+                    // zero padding of the map in one v_med3 against inf / 0) and a per-lane store address (positions past the
+                    // tile's last column go to a scratch line) -- a version with per-position branches cost 2000 cycles per tile
+                    const int jl = mainu ? 4 * u : 4 * (8 * (u - nmain) + (n16 >> 1));           // first tile column of this lane's positions
+                    const int tl = t0 - 1 + (mainu ? n16 : TT + (n16 & 1));
+                    const bool row_ok = (unsigned)tl < (unsigned)a.T;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = row_ok && (unsigned)(f0 - 1 + jl + q) < (unsigned)a.F;
+                        const float lim = ok ? __builtin_inff() : 0.f;
+                        float y[8];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) y[nt * 4 + r] = __builtin_amdgcn_fmed3f(acc1[q][nt][r], 0.f, lim);
+                        uint4 hi, lo;
+                        cvt8(y, NS == 2, hi, lo);
+                        const bool in_tile = jl + q < cols;
+                        *reinterpret_cast<uint4*>(smem + (in_tile ? oa + q * 16 : scratch_off)) = hi;
+                        if (NS == 2) *reinterpret_cast<uint4*>(smem + (in_tile ? PB + oa + q * 16 : scratch_off + 1024)) = lo;
+                    }
+                }
+                CONV_TICK_FINE(12);
+#ifdef AMTX_CONV_TIMING
+                prof_acc[14] += 1;
+#endif
+            }
+#undef CONV1T_LOAD
+            } else {
             // Position groups are (tile row i, 16-column block jb): row and block are wave-uniform (scalar registers), only
             // the column inside the block is per lane, so the position arithmetic costs no vector instructions.
             // Two groups per iteration; the im2col gathers of the NEXT iteration are issued (unconditionally: padded k slots
@@ -423,6 +579,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 #endif
             }
 #undef CONV1_GATHER
+            }
             __builtin_amdgcn_s_setprio(0);
             CONV_TICK(2);
         } else if constexpr (PREFETCH) {
@@ -773,7 +930,8 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int ntt = (a.T + TT - 1) / TT;
     const int64_t nblocks = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(nblocks < (1ll << 31), "conv3x3: grid too large");
-    const size_t lds = (size_t)NS * (FUSE1 ? CM_BYTES : PLANE_BYTES) + (FUSE1 ? ((size_t)a.c_in * FROWS * fw_pitch(KS) + FSLACK) * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float);
+    const size_t lds = (size_t)NS * (FUSE1 ? CM_BYTES : PLANE_BYTES) + (FUSE1 ? ((size_t)a.c_in * FROWS * fw_pitch(KS) + FSLACK) * sizeof(float) : 0) + (size_t)NT * 16 * sizeof(float) +
+                       (FUSE1 && KS == 1 ? (size_t)NS * 1024 : 0);   // + the Toeplitz first conv's scratch lines
     auto kern = conv3x3_kernel<NT, NS, IN_TYPE, OUT_TYPE, FUSE1, KS>;
     AMTX_GRANT_LDS(kern, lds);   // the size grows with c_in
     const int cols = ft + 2;
@@ -903,9 +1061,32 @@ void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int p
             }
 }
 
-size_t amtx_conv1_wfrag_elems(int c_in, int planes) { return (size_t)((9 * c_in + 15) / 16) * 2 * planes * 64 * 4; }
+size_t amtx_conv1_wfrag_elems(int c_in, int planes) {
+    if (c_in == 1) return (size_t)4 * 2 * planes * 64 * 8;    // Toeplitz fragments: 4 output columns x 2 channel halves, 32-deep
+    return (size_t)((9 * c_in + 15) / 16) * 2 * planes * 64 * 4;
+}
 
 void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int planes, bf16_t* out) {
+    if (c_in == 1) {
+        // Toeplitz A fragments of the fused first conv (conv3x3_kernel, KS == 1): fragment (q, nt), lane l = (row, k-group g):
+        // row -> channel co = 8 (row >> 2) + 4 nt + (row & 3) (a lane of the D tile then holds 8 consecutive channels over nt = 0, 1),
+        // k = 8 g + e -> tap (dy = g, kw = e - q) of output column q within a 4-column unit; everything else is zero
+        for (int q = 0; q < 4; ++q)
+            for (int nt = 0; nt < 2; ++nt)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = l & 15, g = l >> 4;
+                    const int co = (row >> 2) * 8 + 4 * nt + (row & 3);
+                    for (int e = 0; e < 8; ++e) {
+                        const int kw = e - q;
+                        const float v = (g < 3 && kw >= 0 && kw <= 2) ? w[(size_t)co * 9 + g * 3 + kw] * (scale ? scale[co] : 1.0f) : 0.0f;
+                        const bf16_t hi = f32_to_bf16_rn(v);
+                        const size_t base = ((size_t)(q * 2 + nt) * planes) * 64 * 8 + (size_t)l * 8 + e;
+                        out[base] = hi;
+                        if (planes == 2) out[base + 64 * 8] = f32_to_bf16_rn(v - bf16_to_f32(hi));
+                    }
+                }
+        return;
+    }
     const int kvalid = 9 * c_in, ksteps = (kvalid + 15) / 16;
     for (int ks = 0; ks < ksteps; ++ks)
         for (int nt = 0; nt < 2; ++nt)

@@ -267,3 +267,19 @@ def seed_everything(seed):
     np.random.seed(seed)
     if torch is not None:
         torch.manual_seed(seed)
+
+
+def register_safe_globals():
+    """amt_tools/train.py:106 resumes with `torch.load(model_path)` of a whole pickled module; torch >= 2.6 defaults to
+    weights_only=True there, which rejects any class that is not allow-listed (the reference's own classes fail the same way).
+    Call this once before `train(..., resume=True)`: it registers every class a pickled model of this package can contain
+    (the package's modules, feature modules and profiles, and the stock torch.nn layers they are built from)."""
+    from torch import nn
+    from . import features, models
+    classes = [getattr(models, n) for n in ('TranscriptionModel', 'OutputLayer', 'LogisticBank', 'SoftmaxGroups', 'AcousticModel',
+                                            'LanguageModel', 'OnsetsFrames', 'OnsetsFrames2', 'TabCNN', 'SpectralFrontend')]
+    classes += [getattr(features, n) for n in features.__all__]
+    classes += [InstrumentProfile, PianoProfile, TablatureProfile, GuitarProfile]
+    classes += [nn.Sequential, nn.Conv2d, nn.BatchNorm2d, nn.ReLU, nn.MaxPool2d, nn.Dropout, nn.Linear, nn.LSTM, nn.SyncBatchNorm]
+    torch.serialization.add_safe_globals(classes)
+    return classes

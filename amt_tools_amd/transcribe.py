@@ -25,7 +25,7 @@ def estimate_hop_length(times):
     """Spacing of a (possibly gappy) frame grid: the median of those steps that equal their predecessor, i.e. steps inside a
     regular run (behaviour contract: amt_tools/tools/utils.py:3197-3229, including the 1e-8 absolute tolerance of np.isclose
     against zero and ValueError for grids that are empty or have no two equal consecutive steps)."""
-    grid = np.sort(np.asarray(times, dtype=np.float64).ravel())
+    grid = np.sort(np.asarray(times).ravel())            # dtype kept: run_offline hands float32 grids over (inference.py:36)
     if grid.size == 0:
         raise ValueError('hop length of an empty time grid is undefined')
     steps = grid[1:] - grid[:-1]

@@ -131,6 +131,36 @@ def test_complexity_3_engine_vs_oracle_on_ragged_batches(dim_in, in_channels):
             assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
 
 
+@pytest.mark.parametrize('dim_in', [229, 40, 88, 54, 192, 8])
+def test_complexity_2_engine_vs_oracle_feature_sizes_and_ragged_batches(dim_in):
+    """OnsetsFrames at model_complexity 2 (the headline engine: Toeplitz first conv fused into conv2) against the oracle on fresh
+    inputs: feature sizes whose tile width is / is not a multiple of the first conv's 4-column units and that need 1 .. 5
+    frequency tiles, frame counts that do not fill the 16-frame tiles (halo-row units, padded rows), batches that do not fill
+    the persistent grid.  x3 (the parity gate): logits within 3e-4 / activations within 1e-4; bf16: a loose 1e-1 screen for gross errors."""
+    from oracle import model_ref
+    from amt_tools_amd.models import OnsetsFrames
+    sd = synth_state_dict(17, dim_in=dim_in, in_channels=1, model_complexity=2)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    rng = np.random.default_rng(dim_in)
+    cases = ((1, 1), (3, 17), (17, 9), (2, 40), (1, 33))
+    feats = [torch.from_numpy(rng.random((B, 1, dim_in, T)).astype(np.float32)) for B, T in cases]
+    with torch.no_grad():
+        refs = [model_ref.run_on_batch(f, sdt) for f in feats]
+    for precision, tol in (('x3', 3e-4), ('bf16', 1e-1)):
+        model = OnsetsFrames(dim_in, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+        model.load_state_dict(sdt)
+        model.change_device()
+        model.eval()
+        for f, ref in zip(feats, refs):
+            with torch.no_grad():
+                got = model.engine_logits(f.cuda())
+            for key in ('onsets', 'multi_pitch', 'pitch_head'):
+                err = (got[key].cpu() - ref['logits'][key]).abs().max().item()
+                assert err < tol, (precision, tuple(f.shape), key, err)
+                if precision == 'x3':
+                    assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize('mc', [2, 3])
 @pytest.mark.parametrize('precision', ['bf16', 'x3'])
 def test_engine_is_deterministic_run_to_run(mc, precision):

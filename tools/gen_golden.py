@@ -318,7 +318,7 @@ def gen_feature_bookkeeping(name):
     print(name, {k: (v.tolist() if v.size < 20 else v.shape) for k, v in rec.items() if 'mel_c' in k})
 
 
-def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
+def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050, times_dtype=np.float64):
     rng = np.random.default_rng(seed)
     profile = rtools.PianoProfile()
     est = NoteTranscriber(profile=profile)
@@ -330,7 +330,7 @@ def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050):
         state = np.where(state, flip > 0.15, flip < p_mp * 0.3)
         mp[:, t] = state
     on = (rng.random((88, T)) < p_on).astype(np.float32)
-    times = np.arange(T) * hop / float(sr)
+    times = (np.arange(T) * hop / float(sr)).astype(times_dtype)     # run_offline casts the grid to float32 (inference.py:36)
     raw = {rtools.KEY_MULTIPITCH: mp.copy(), rtools.KEY_TIMES: times.copy()}
     if with_onsets:
         raw[rtools.KEY_ONSETS] = on.copy()
@@ -346,6 +346,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'labels_edges':
         gen_labels_edges('labels_edges.npz')
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'notes_f32':
+        gen_notes('notes_f32times.npz', 35, 625, 0.01, 0.05, True, sr=16000, times_dtype=np.float32)
+        sys.exit(0)
     gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
     gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
@@ -360,3 +363,4 @@ if __name__ == '__main__':
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
     gen_notes('notes_noonsets.npz', 33, 200, 0.0, 0.06, False)
     gen_notes('notes_empty.npz', 34, 64, 0.0, 0.0, True)
+    gen_notes('notes_f32times.npz', 35, 625, 0.01, 0.05, True, sr=16000, times_dtype=np.float32)
