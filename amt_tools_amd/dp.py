@@ -13,9 +13,18 @@ stay unchanged, so the exchange step lives in an object `train()` already calls:
                                                  unflatten -> inner optimizer step
 
 The loss is already a batch mean (amt_tools/models/common.py:582), so averaging gradients over ranks is
-the gradient of the mean over the global batch.  BatchNorm uses per-rank batch statistics (the reference
-has neither DP nor SyncBN); `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` keeps the state_dict
-keys if global statistics are wanted.
+the gradient of the mean over the global batch.
+
+BatchNorm policy under DP (the reference has neither DP nor SyncBN, so there is nothing to mirror):
+  * training-mode normalisation uses PER-RANK batch statistics (each rank's own clips x frames x bins --
+    625 x 229 x clips values per channel, so the statistics of 8 clips per rank are already tight);
+  * the running statistics (and any other floating-point buffer handed over as `buffers=`) are AVERAGED over
+    ranks inside the same flat all-reduce as the gradients, so every rank holds the same eval-mode model and
+    the checkpoint rank 0 writes describes all shards, not only its own;
+  * `torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)` keeps the state_dict keys if global batch
+    statistics are wanted; the model then runs those layers as stock modules (their collective), not through
+    the HIP BatchNorm passes.
+tests/test_dp.py measures what the per-rank statistics cost against a single-process step on the whole batch.
 
 `train()` re-initialises the optimizer in place on resume with
 `super(type(optimizer), optimizer).__init__(model.parameters(), optimizer.defaults)` (train.py:111); the
@@ -70,12 +79,15 @@ def broadcast_parameters(model, src=0):
 class DataParallelOptimizer(torch.optim.Optimizer):
     """Wraps an optimizer class; `step()` averages gradients over all ranks with one flat all-reduce first."""
 
-    def __init__(self, params, optimizer_cls=torch.optim.Adam, process_group=None, **optimizer_kwargs):
+    def __init__(self, params, optimizer_cls=torch.optim.Adam, process_group=None, buffers=None, **optimizer_kwargs):
+        """`buffers`: optional iterable of tensors (e.g. `model.buffers()`) whose floating-point members -- BatchNorm running
+        statistics -- are averaged over ranks in the same all-reduce as the gradients."""
         params = list(params)
         inner = optimizer_cls(params, **optimizer_kwargs)
         self.__dict__['_inner'] = inner
         self.__dict__['_group'] = process_group
         self.__dict__['_flat'] = None
+        self.__dict__['_buffers'] = [b for b in (buffers or []) if torch.is_tensor(b) and b.dtype.is_floating_point]
         super().__init__(params, dict(inner.defaults))
 
     def _bind(self):
@@ -97,7 +109,8 @@ class DataParallelOptimizer(torch.optim.Optimizer):
         params = [p for g in self.param_groups for p in g['params'] if p.requires_grad]
         if not params:
             return
-        numel = sum(p.numel() for p in params)
+        bufs = self.__dict__.get('_buffers', [])
+        numel = sum(p.numel() for p in params) + sum(b.numel() for b in bufs)
         flat = self._flat
         if flat is None or flat.numel() != numel or flat.device != params[0].device:
             flat = torch.zeros(numel, dtype=torch.float32, device=params[0].device)
@@ -115,10 +128,19 @@ class DataParallelOptimizer(torch.optim.Optimizer):
                 views[i].zero_()
         if have:
             torch._foreach_copy_([views[i] for i in have], [params[i].grad for i in have])
+        bviews = []
+        for b in bufs:
+            n = b.numel()
+            bviews.append(flat[off:off + n].view(b.shape))
+            off += n
+        if bufs:
+            torch._foreach_copy_(bviews, [b.detach() for b in bufs])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._group)
         flat.div_(world)
         if have:
             torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])
+        if bufs:
+            torch._foreach_copy_([b.detach() for b in bufs], bviews)
         for i, p in enumerate(params):
             if p.grad is None:
                 p.grad = views[i].clone()

@@ -164,7 +164,7 @@ class AcousticModel(nn.Module):
         """One conv stage.  Training on a GPU: the convolution stays ATen / MIOpen, BatchNorm (batch statistics) + ReLU (+ MaxPool)
         run as the HIP passes of amt_tools_amd/autograd.py (bn_relu_pool); the Dropout behind them is the module's own."""
         mods = list(layer)
-        if self.training and self.use_hip_bn and x.is_cuda:
+        if self.training and self.use_hip_bn and x.is_cuda and not isinstance(mods[1], nn.SyncBatchNorm):
             from .autograd import bn_relu_pool, bn_relu_pool_supported
             y = mods[0](x)
             if bn_relu_pool_supported(y, mods[1]):
@@ -341,7 +341,6 @@ class OnsetsFrames(TranscriptionModel):
         state.pop('_engine', None)
         state.pop('_engine_out', None)
         state.pop('_engine_offsets', None)
-        state.pop('_side_stream', None)
         return state
 
     def _get_engine(self, device):
@@ -392,30 +391,11 @@ class OnsetsFrames(TranscriptionModel):
         self.__dict__.pop('_engine_out', None)
         self.__dict__.pop('_engine_offsets', None)
         output = dict()
-        if feats.is_cuda and self.training and self.__dict__.get('overlap_heads', False):
-            # OPT-IN (model.__dict__['overlap_heads'] = True), off by default: the two heads only meet at the adjoin layer, so the
-            # onset head (acoustic model + a 625-step BiLSTM that occupies 4 of the 256 CUs at 8 clips) can run on a side stream
-            # next to the pitch head; autograd replays each op's backward on the stream of its forward, so the backward passes
-            # overlap the same way (15.6 -> 14.0 ms per step).  It is off because with two streams the training loop hung
-            # intermittently on MI355X / ROCm 7.2 (torch.cuda.synchronize() never returning after 7-13 steps).  Narrowed down so
-            # far: it needs the HIP BiLSTM autograd kernels (amt_tools_amd/autograd.py: BiLSTMFunction) together with the second
-            # stream -- stock nn.LSTM with the HIP BatchNorm / loss kernels on two streams ran 2 x 42 steps clean, all-HIP with
-            # precomputed features (no spectrogram kernel in the loop) hung twice; on one stream everything ran 100+ steps.
-            main = torch.cuda.current_stream(feats.device)
-            side = self.__dict__.get('_side_stream')
-            if side is None or side.device != feats.device:
-                side = torch.cuda.Stream(device=feats.device)
-                self.__dict__['_side_stream'] = side
-            side.wait_stream(main)
-            feats.record_stream(side)
-            with torch.cuda.stream(side):
-                onsets = self.onset_head(feats)
-            multi_pitch = self.pitch_head(feats)
-            main.wait_stream(side)
-            onsets.record_stream(main)
-        else:
-            multi_pitch = self.pitch_head(feats)
-            onsets = None if self._grouped_recurrences(feats) else self.onset_head(feats)
+        # (A side-stream overlap of the two detector heads lived here in round 1: with two streams the training loop hung
+        # intermittently on MI355X / ROCm 7.2 -- HIP BiLSTM autograd kernels + a second stream, never root-caused, DESIGN.md section 5.
+        # One stream + the HIP BatchNorm passes is faster than the overlap was, so the switch is gone rather than shipped.)
+        multi_pitch = self.pitch_head(feats)
+        onsets = None if self._grouped_recurrences(feats) else self.onset_head(feats)
         offsets = None
         if self.has_offsets and feats.is_cuda and self.training and onsets is None:
             # the onset and offset heads are independent: their two recurrences run as ONE grouped launch each way

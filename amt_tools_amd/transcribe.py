@@ -18,7 +18,7 @@ import numpy as np
 
 from . import _lib, tools
 
-__all__ = ['NoteTranscriber', 'PitchListWrapper', 'multi_pitch_to_notes', 'decode_notes_batch', 'estimate_hop_length']
+__all__ = ['NoteTranscriber', 'PitchListWrapper', 'multi_pitch_to_notes', 'decode_notes_batch', 'estimate_hop_length', 'inhibit_activations']
 
 
 def estimate_hop_length(times):
@@ -52,9 +52,11 @@ def _extend_times(times):
     return np.append(times, times[-1] + estimate_hop_length(times))
 
 
-def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low, times_ext=None):
+def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low, times_ext=None, min_duration=None):
     """(key, onset frame, offset frame) events in np.nonzero order -> (K,3) rows ordered like the reference.
-    `times_ext` = _extend_times(times) when the caller already has it (one grid shared by a whole batch)."""
+    `times_ext` = _extend_times(times) when the caller already has it (one grid shared by a whole batch).
+    `min_duration`: the reference's duration filter (transcribe.py:36-80), which sits between its first and second sort:
+    notes shorter than the threshold go (threshold 0: zero-length notes go)."""
     if times_ext is None:
         times_ext = _extend_times(times)
     if len(pitch_idcs) == 0:
@@ -65,6 +67,11 @@ def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low, times_ext=No
     # array three times, 40 % less host time per clip -- the host assembly bounds the batched transcription driver).
     onset_t = times_ext[on_frames]
     perm = np.argsort(onset_t)
+    if min_duration is not None:
+        dur = times_ext[np.asarray(off_frames)[perm]] - onset_t[perm]
+        perm = perm[dur >= min_duration] if min_duration else perm[dur > min_duration]
+        if len(perm) == 0:
+            return np.empty([0, 3])
     for _ in range(2):
         perm = perm[np.argsort(onset_t[perm])]
     batched = np.empty((len(perm), 3))
@@ -74,7 +81,27 @@ def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low, times_ext=No
     return batched
 
 
-def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH, onsets=None):
+def inhibit_activations(activations, times, window_length):
+    """Keep an activation only if no KEPT activation of the same row started less than `window_length` seconds before it
+    (behaviour contract: amt_tools/tools/utils.py:2987-3038, which rescans the whole map once per kept activation).  Per row the
+    non-zero frames are walked once: keep the first, jump with one binary search to the first frame at or past its time +
+    window, keep the next non-zero from there on.  Returns a new {0,1} map of the input's dtype."""
+    activations = np.asarray(activations)
+    times = np.asarray(times)
+    out = np.zeros_like(activations)
+    rows, frames = np.nonzero(activations)
+    bounds = np.searchsorted(rows, np.arange(activations.shape[0] + 1))
+    for r in range(activations.shape[0]):
+        fr = frames[bounds[r]:bounds[r + 1]]
+        i = 0
+        while i < len(fr):
+            out[r, fr[i]] = 1
+            release = np.searchsorted(times, times[fr[i]] + window_length, side='left')      # first frame outside the window
+            i = np.searchsorted(fr, max(release, fr[i] + 1), side='left')
+    return out
+
+
+def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH, onsets=None, min_duration=None):
     """Vectorised tools.multi_pitch_to_notes for host arrays: returns (K,3) batched notes."""
     multi_pitch = np.asarray(multi_pitch)
     if onsets is None:
@@ -90,7 +117,7 @@ def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITC
     nearest = np.minimum.accumulate(idx[..., ::-1], axis=-1)[..., ::-1]          # nearest stop at >= t
     after = np.concatenate([nearest[..., 1:], np.full(nearest.shape[:-1] + (1,), T)], axis=-1)   # strictly after t
     pitch_idcs, frame_idcs = imp.nonzero()
-    return _events_to_notes(pitch_idcs, frame_idcs, after[pitch_idcs, frame_idcs], np.asarray(times), low)
+    return _events_to_notes(pitch_idcs, frame_idcs, after[pitch_idcs, frame_idcs], np.asarray(times), low, min_duration=min_duration)
 
 
 class _PendingNotes(object):
@@ -154,13 +181,15 @@ def decode_notes_batch(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWES
 
 
 class NoteTranscriber(object):
-    """amt_tools.transcribe.NoteTranscriber with inhibition_window=None, minimum_duration=None (the paper scripts'
-    settings); other settings are not part of the hot path and raise."""
+    """amt_tools.transcribe.NoteTranscriber (transcribe.py:717-785 over StackedNoteTranscriber :373-481), all constructor options:
+    `inhibition_window` (seconds after a kept onset in which the same pitch cannot start again) acts -- exactly as in the
+    reference, transcribe.py:463-468 -- only when the model supplies no onset map (the onsets are then the inhibited positive
+    first difference of the multi-pitch map); `minimum_duration` drops shorter notes (0: zero-length notes)."""
 
     def __init__(self, profile, inhibition_window=None, minimum_duration=None, multi_pitch_key=None, onsets_key=None,
                  offsets_key=None, estimates_key=None, save_dir=None):
-        if inhibition_window is not None or minimum_duration is not None:
-            raise NotImplementedError('inhibition_window / minimum_duration are outside the accelerated path')
+        self.inhibition_window = inhibition_window
+        self.minimum_duration = minimum_duration
         self.profile = profile
         self.multi_pitch_key = tools.KEY_MULTIPITCH if multi_pitch_key is None else multi_pitch_key
         self.onsets_key = tools.KEY_ONSETS if onsets_key is None else onsets_key
@@ -178,7 +207,10 @@ class NoteTranscriber(object):
         multi_pitch = tools.tensor_to_array(tools.unpack_dict(raw_output, self.multi_pitch_key))
         onsets = tools.tensor_to_array(tools.unpack_dict(raw_output, self.onsets_key))
         times = tools.tensor_to_array(tools.unpack_dict(raw_output, tools.KEY_TIMES))
-        return multi_pitch_to_notes(multi_pitch, times, self.profile.low, onsets)
+        if self.inhibition_window is not None and onsets is None:
+            derived = _impulses(multi_pitch).astype(np.asarray(multi_pitch).dtype)
+            onsets = inhibit_activations(derived, times, self.inhibition_window)
+        return multi_pitch_to_notes(multi_pitch, times, self.profile.low, onsets, self.minimum_duration)
 
     def process_track(self, raw_output, track=None):
         return {self.get_key(): self.estimate(raw_output)}

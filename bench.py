@@ -451,7 +451,7 @@ def run_train(args, rank, world, device):
     model.change_device()
     broadcast_parameters(model)
     model.train()
-    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4)
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4, buffers=model.buffers())   # BatchNorm policy: amt_tools_amd/dp.py
     B = args.clips
     audio = torch.from_numpy(np.stack([synth_clip(rank * B + i) for i in range(B)])).to(device)
     lab = [synth_labels(rank * B + i) for i in range(B)]

@@ -16,13 +16,13 @@ from amt_tools_amd.models import OnsetsFrames
 DIM_IN, T = 16, 10
 
 
-def _make_model(seed):
+def _make_model(seed, freeze_bn=True):
     torch.manual_seed(seed)
     model = OnsetsFrames(DIM_IN, tools.PianoProfile(), 1, 2)
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-        if isinstance(m, torch.nn.BatchNorm2d):      # per-rank batch statistics are a documented difference; freeze them here
+        if freeze_bn and isinstance(m, torch.nn.BatchNorm2d):   # the exact-equivalence test freezes the statistics; the policy test does not
             m.eval()
     return model
 
@@ -87,6 +87,62 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
     for k, v in model.state_dict().items():
         if v.dtype.is_floating_point:
             assert torch.allclose(got[k], v, atol=2e-5, rtol=1e-4), k
+
+
+def _bn_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    model = _make_model(seed=rank, freeze_bn=False)
+    broadcast_parameters(model, src=0)
+    model.train()                                   # BatchNorm in training mode: per-rank batch statistics
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=1e-2, buffers=model.buffers())
+    losses = []
+    for it in range(2):
+        mine = [_batch(4 * it + i) for i in shard_indices(4, rank, world)]
+        opt.zero_grad()
+        loss = model.run_on_batch(_cat(mine))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.save({'sd': {k: v.clone() for k, v in model.state_dict().items()}, 'losses': losses}, out + f'.{rank}')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_batchnorm_policy_under_dp_per_rank_statistics_and_averaged_running_stats(tmp_path, capsys):
+    """The stated BatchNorm policy of amt_tools_amd/dp.py with BatchNorm really in training mode: (1) after every step all ranks
+    hold identical parameters AND identical running statistics (averaged in the gradient all-reduce); (2) what per-rank batch
+    statistics cost against the single-process step on the whole batch (global statistics) is measured: the parameters after two
+    Adam steps stay within a few percent of the single-process ones -- not bit-equal, which is why it is a documented policy."""
+    out = str(tmp_path / 'bn')
+    mp.spawn(_bn_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+    for k, v in r0['sd'].items():
+        if v.dtype.is_floating_point:
+            assert torch.equal(v, r1['sd'][k]), k                          # parameters and running statistics agree bit for bit
+    torch.set_num_threads(2)
+    model = _make_model(seed=0, freeze_bn=False)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    ref_losses = []
+    for it in range(2):
+        opt.zero_grad()
+        loss = model.run_on_batch(_cat([_batch(4 * it + i) for i in range(4)]))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss.detach()))
+    dp_loss = [(a + b) / 2 for a, b in zip(r0['losses'], r1['losses'])]
+    rel = []
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point and v.numel() > 1:
+            rel.append(float((r0['sd'][k] - v).norm() / (v.norm() + 1e-12)))
+    with capsys.disabled():
+        print(f'\n[BatchNorm under DP] mean loss per step: 2 ranks x 2 clips (per-rank statistics) {dp_loss} vs one process x 4 clips '
+              f'{ref_losses}; relative L2 distance of the tensors after 2 Adam steps: median {np.median(rel):.2e}, max {max(rel):.2e}')
+    assert abs(dp_loss[0] - ref_losses[0]) / ref_losses[0] < 0.05          # first step: same weights, only the statistics differ
+    assert np.median(rel) < 0.15                                          # Adam at lr 1e-2 on 320-value statistics amplifies it; see the printed numbers
 
 
 def test_wrapper_survives_the_in_place_reinit_of_train_py():

@@ -394,3 +394,55 @@ def test_engine_long_single_clip():
     for key in ('onsets', 'multi_pitch'):
         assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
         assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+
+
+def test_bench_workload_parity_of_both_precisions_against_the_cpu_oracle(capsys):
+    """The headline workload itself (BASELINE config 2: audio -> HIP mel front-end -> engine -> piano rolls, 64 distinct synthetic
+    clips x 625 frames, synthetic weights) in both engine precisions against the CPU oracle (numpy fp64 front-end + torch fp32
+    model restatement).  SURVEY F8: on thresholded outputs the parity metric is the count of differing cells.
+      x3  : logits within 2e-4 and activations (sigmoid) within 1e-4 of the oracle -- the mode that meets north_star's 1e-4 --
+            and fewer than 1e-4 of the piano-roll cells differ (cells whose logit is ~0);
+      bf16: the headline throughput mode; the fraction of differing cells is measured, printed and bounded (< 5e-3)."""
+    from oracle import frontend_np as fe, model_ref
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.models import OnsetsFrames
+    n_clips = 64
+    sd = synth_state_dict(0, dim_in=229, in_channels=1, model_complexity=2)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    clips = np.stack([synth_clip(i) for i in range(n_clips)])
+    old_impl, model_ref.LSTM_IMPL = model_ref.LSTM_IMPL, 'aten'
+    try:
+        feats = np.stack([fe.melspec_process_audio(y, 22050, 512, 229, 2048, dtype=np.float32) for y in clips]).astype(np.float32)
+        with torch.no_grad():
+            ref = [model_ref.run_on_batch(torch.from_numpy(feats[i:i + 8]), sdt) for i in range(0, n_clips, 8)]
+    finally:
+        model_ref.LSTM_IMPL = old_impl
+    ref_roll = {k: torch.cat([r[k] for r in ref]).numpy() for k in ('onsets', 'multi_pitch')}
+    ref_logit = {k: torch.cat([r['logits'][k] for r in ref]) for k in ('onsets', 'multi_pitch')}
+    audio = torch.from_numpy(clips).cuda()
+    report = {}
+    for precision in ('x3', 'bf16'):
+        model = OnsetsFrames(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+        model.load_state_dict(sdt)
+        model.frontend = torch.nn.Sequential(MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048).frontend())
+        model.change_device()
+        model.eval()
+        with torch.no_grad():
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})
+            logits = model.engine_logits(model.frontend(audio.unsqueeze(-2)))
+        assert out[tools.KEY_ONSETS].shape == (n_clips, 88, 625)
+        cells = diff = 0
+        for k in ('onsets', 'multi_pitch'):
+            got = out[k].cpu().numpy()
+            cells += got.size
+            diff += int((got != ref_roll[k]).sum())
+        err_logit = max((logits[k].cpu() - ref_logit[k]).abs().max().item() for k in ref_logit)
+        err_act = max((torch.sigmoid(logits[k].cpu()) - torch.sigmoid(ref_logit[k])).abs().max().item() for k in ref_logit)
+        report[precision] = (diff / cells, err_logit, err_act)
+    with capsys.disabled():
+        for p, (rate, el, ea) in report.items():
+            print(f'\n[parity, {n_clips} clips x 625 frames vs CPU oracle] {p}: cell mismatch rate {rate:.3e}, max |dlogit| {el:.3e}, max |dsigmoid| {ea:.3e}')
+    rate, el, ea = report['x3']
+    assert el < 2e-4 and ea < 1e-4 and rate < 1e-4, report['x3']
+    rate, el, ea = report['bf16']
+    assert rate < 5e-3 and el < 0.12, report['bf16']

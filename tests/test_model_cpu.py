@@ -209,3 +209,22 @@ def test_onsetsframes2_training_step_matches_reference_losses_and_grads():
         if str(k).endswith('.0.bias') and '.layer' in str(k):
             continue
         assert np.abs(named[str(k)].grad.numpy() - ref).max() / max(1e-6, np.abs(ref).max()) < 2e-3, k
+
+
+def test_frame_times_come_from_the_front_end_module_and_safe_globals_cover_a_pickled_model(tmp_path):
+    """run_offline_batched(decode_notes=True) without `times` derives the grid from the model's front-end (hop / sample rate of
+    THAT module, not a hard-coded 512 / 22050) and refuses to guess without one; register_safe_globals() lets torch >= 2.6 load a
+    whole pickled model the way amt_tools/train.py:106 does on resume."""
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.inference import _frame_times
+    from amt_tools_amd.models import OnsetsFrames
+    model = OnsetsFrames(40, tools.PianoProfile(), 1, 2)
+    with pytest.raises(ValueError):
+        _frame_times(model, 5)
+    model.frontend = torch.nn.Sequential(MelSpec(sample_rate=16000, hop_length=256, n_mels=40).frontend())
+    np.testing.assert_array_equal(_frame_times(model, 4), np.arange(4) * 256 / 16000.0)
+    path = str(tmp_path / 'model.pt')
+    torch.save(model, path)
+    tools.register_safe_globals()
+    loaded = torch.load(path)                       # weights_only default of the installed torch
+    assert isinstance(loaded, OnsetsFrames) and loaded.frontend[0].module.hop_length == 256

@@ -7,7 +7,7 @@ from conftest import load_golden
 from oracle import notes_np
 
 
-@pytest.mark.parametrize('name', ['notes_dense.npz', 'notes_sparse.npz', 'notes_noonsets.npz', 'notes_empty.npz'])
+@pytest.mark.parametrize('name', ['notes_dense.npz', 'notes_sparse.npz', 'notes_noonsets.npz', 'notes_empty.npz', 'notes_f32times.npz'])
 def test_notes_bit_exact(name):
     g = load_golden(name)
     onsets = g['onsets'] if int(g['with_onsets']) else None

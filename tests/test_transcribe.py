@@ -8,7 +8,7 @@ from amt_tools_amd import tools
 from amt_tools_amd.transcribe import NoteTranscriber, PitchListWrapper, multi_pitch_to_notes
 from oracle import notes_np
 
-CASES = ['notes_dense.npz', 'notes_sparse.npz', 'notes_noonsets.npz', 'notes_empty.npz']
+CASES = ['notes_dense.npz', 'notes_sparse.npz', 'notes_noonsets.npz', 'notes_empty.npz', 'notes_f32times.npz']
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -20,6 +20,30 @@ def test_host_decoder_bit_exact_with_reference(name):
     notes = NoteTranscriber(tools.PianoProfile()).estimate(raw)
     assert notes.shape == g['notes'].shape and np.array_equal(notes, g['notes'])
     np.testing.assert_array_equal(raw[tools.KEY_MULTIPITCH], g['multi_pitch'])      # inputs not modified
+
+
+@pytest.mark.parametrize('name', ['notes_inhibit.npz', 'notes_inhibit_onsets.npz', 'notes_mindur.npz', 'notes_mindur0.npz', 'notes_inhibit_mindur.npz'])
+def test_note_transcriber_options_bit_exact_with_reference(name):
+    """inhibition_window / minimum_duration (transcribe.py:373-481): goldens recorded from the reference's NoteTranscriber with the
+    same options, including its quirk that the inhibition window is ignored when an onset map is supplied."""
+    g = load_golden(name)
+    iw, md = float(g['inhibition_window']), float(g['minimum_duration'])
+    est = NoteTranscriber(tools.PianoProfile(), inhibition_window=None if iw < 0 else iw, minimum_duration=None if md < 0 else md)
+    raw = {tools.KEY_MULTIPITCH: g['multi_pitch'].copy(), tools.KEY_TIMES: g['times'].copy()}
+    if int(g['with_onsets']):
+        raw[tools.KEY_ONSETS] = g['onsets'].copy()
+    notes = est.estimate(raw)
+    assert notes.shape == g['notes'].shape and np.array_equal(notes, g['notes'])
+    np.testing.assert_array_equal(raw[tools.KEY_MULTIPITCH], g['multi_pitch'])
+
+
+def test_inhibit_activations_is_a_greedy_per_row_scan():
+    from amt_tools_amd.transcribe import inhibit_activations
+    times = np.arange(10) * 0.1
+    act = np.array([[1, 1, 0, 1, 0, 0, 1, 1, 1, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 1]], dtype=np.float32)
+    out = inhibit_activations(act, times, 0.25)          # window covers the kept frame and the next two
+    np.testing.assert_array_equal(out, [[1, 0, 0, 1, 0, 0, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0, 0, 0, 1]])
+    np.testing.assert_array_equal(inhibit_activations(act, times, 0.0), act)     # an empty window still keeps everything
 
 
 def test_host_decoder_random_maps_vs_oracle():

@@ -318,10 +318,11 @@ def gen_feature_bookkeeping(name):
     print(name, {k: (v.tolist() if v.size < 20 else v.shape) for k, v in rec.items() if 'mel_c' in k})
 
 
-def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050, times_dtype=np.float64):
+def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050, times_dtype=np.float64, inhibition_window=None,
+              minimum_duration=None):
     rng = np.random.default_rng(seed)
     profile = rtools.PianoProfile()
-    est = NoteTranscriber(profile=profile)
+    est = NoteTranscriber(profile=profile, inhibition_window=inhibition_window, minimum_duration=minimum_duration)
     # sticky activations so notes have duration
     mp = np.zeros((88, T), dtype=np.float32)
     state = rng.random(88) < p_mp
@@ -335,7 +336,9 @@ def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050, ti
     if with_onsets:
         raw[rtools.KEY_ONSETS] = on.copy()
     notes = est.estimate(raw)
-    rec = dict(multi_pitch=mp, times=times, notes=np.asarray(notes, dtype=np.float64), with_onsets=int(with_onsets))
+    rec = dict(multi_pitch=mp, times=times, notes=np.asarray(notes, dtype=np.float64), with_onsets=int(with_onsets),
+               inhibition_window=np.array(-1.0 if inhibition_window is None else inhibition_window),
+               minimum_duration=np.array(-1.0 if minimum_duration is None else minimum_duration))
     if with_onsets:
         rec['onsets'] = on
     np.savez_compressed(os.path.join(OUT, name), **rec)
@@ -345,6 +348,13 @@ def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050, ti
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'labels_edges':
         gen_labels_edges('labels_edges.npz')
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'notes_opts':
+        gen_notes('notes_inhibit.npz', 36, 300, 0.0, 0.08, False, inhibition_window=0.08)
+        gen_notes('notes_inhibit_onsets.npz', 37, 300, 0.02, 0.08, True, inhibition_window=0.08)      # no effect with onsets given (transcribe.py:463-468)
+        gen_notes('notes_mindur.npz', 38, 300, 0.02, 0.08, True, minimum_duration=0.06)
+        gen_notes('notes_mindur0.npz', 39, 300, 0.0, 0.08, False, minimum_duration=0.0)
+        gen_notes('notes_inhibit_mindur.npz', 40, 400, 0.0, 0.1, False, inhibition_window=0.05, minimum_duration=0.05)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'notes_f32':
         gen_notes('notes_f32times.npz', 35, 625, 0.01, 0.05, True, sr=16000, times_dtype=np.float32)
@@ -364,3 +374,8 @@ if __name__ == '__main__':
     gen_notes('notes_noonsets.npz', 33, 200, 0.0, 0.06, False)
     gen_notes('notes_empty.npz', 34, 64, 0.0, 0.0, True)
     gen_notes('notes_f32times.npz', 35, 625, 0.01, 0.05, True, sr=16000, times_dtype=np.float32)
+    gen_notes('notes_inhibit.npz', 36, 300, 0.0, 0.08, False, inhibition_window=0.08)
+    gen_notes('notes_inhibit_onsets.npz', 37, 300, 0.02, 0.08, True, inhibition_window=0.08)
+    gen_notes('notes_mindur.npz', 38, 300, 0.02, 0.08, True, minimum_duration=0.06)
+    gen_notes('notes_mindur0.npz', 39, 300, 0.0, 0.08, False, minimum_duration=0.0)
+    gen_notes('notes_inhibit_mindur.npz', 40, 400, 0.0, 0.1, False, inhibition_window=0.05, minimum_duration=0.05)
