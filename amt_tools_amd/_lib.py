@@ -91,6 +91,14 @@ _SIGNATURES = {
     'amtx_rms_norm': (_I, [_P, _L, _L, _I, _P, _L, _P, C.c_size_t, _P]),
     'amtx_notes_decode': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'amtx_pianoroll_fwd': (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
+    'amtx_matmul_workspace_bytes': (C.c_size_t, [_L, _L, _L]),
+    'amtx_matmul_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _L, _L, _L, _L, _P, C.c_size_t, _P]),
+    'amtx_linear_train_fwd': (_I, [_P, _L, _P, _L, _P, _P, _L, _L, _I, _I, _P]),
+    'amtx_linear_bwd_workspace_bytes': (C.c_size_t, [_L, _I, _I]),
+    'amtx_linear_bwd': (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _P, C.c_size_t, _P]),
+    'amtx_conv3x3_train_workspace_bytes': (C.c_size_t, [_L, _I, _I, _I]),
+    'amtx_conv3x3_train_fwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, C.c_size_t, _P]),
+    'amtx_conv3x3_bwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, C.c_size_t, _P]),
 }
 
 

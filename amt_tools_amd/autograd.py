@@ -12,15 +12,176 @@ import torch
 
 from . import _lib
 
-__all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction']
+__all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction',
+           'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend']
 
 HIDDEN_SIZES = (128, 256)       # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3)
 
 
+USE_HIP_DENSE = True            # False: nn.Conv2d / nn.Linear / the LSTM's matmuls through ATen (MIOpen / hipBLASLt) -- the A/B switch of the tests
+
+
 def training_backend():
     """One line for benchmark records: which kernels a GPU training step runs on."""
+    if USE_HIP_DENSE:
+        return ('HIP: Conv2d fwd/dgrad/wgrad and every Linear / LSTM projection fwd/bwd (split-bf16 implicit GEMMs), BiLSTM fwd/bwd, '
+                'BatchNorm+ReLU+MaxPool fwd/bwd, BCE loss+grad; ATen: elementwise glue, Dropout, Adam')
     return ('HIP: BiLSTM fwd/bwd, BatchNorm+ReLU+MaxPool fwd/bwd, BCE loss+grad; ATen (MIOpen / hipBLASLt): conv fwd/dgrad/wgrad, '
             'Linear fwd/bwd, Adam')
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# dense layers of the training step on the amtx_matmul_f32 / amtx_linear_* / amtx_conv3x3_* kernels (csrc/train.hip)
+# ---------------------------------------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch buffer per device (split-contraction partials, permuted conv weights).  Stream-ordered reuse: every
+    consumer is enqueued on the current stream right behind its producer."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
+def _ok2d(t):
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def matmul_f32(a, b, a_trans=False, b_trans=False, bias=None, out=None):
+    """C[m, n] = sum_k A(m, k) B(n, k) (+ bias[n]) on the HIP kernel, no autograd.  `a` is the (m, k) matrix (a_trans False) or is
+    stored as (k, m) (a_trans True); `b` likewise with n.  Rows may be strided views (e.g. half of a concatenated buffer)."""
+    assert a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and _ok2d(a) and _ok2d(b), 'matmul_f32: unsupported operand layout'
+    m, k = (a.shape[1], a.shape[0]) if a_trans else a.shape
+    n, k2 = (b.shape[1], b.shape[0]) if b_trans else b.shape
+    assert k == k2
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    L = _lib.lib()
+    need = int(L.amtx_matmul_workspace_bytes(m, n, k))
+    ws = _workspace(need, a.device) if need else None
+    with torch.cuda.device(a.device):
+        _lib.check(L.amtx_matmul_f32(_lib.ptr(a), a.stride(0), int(a_trans), _lib.ptr(b), b.stride(0), int(b_trans), _lib.ptr(bias), _lib.ptr(out),
+                                     out.stride(0), m, n, k, _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.current_stream(a.device)),
+                   'amtx_matmul_f32')
+    return out
+
+
+def _colsum(x2):
+    """Column sums of a (rows, n) matrix (bias gradients) through amtx_linear_bwd's db output."""
+    m, n = x2.shape
+    L = _lib.lib()
+    db = torch.empty(n, dtype=torch.float32, device=x2.device)
+    ws = _workspace(int(L.amtx_linear_bwd_workspace_bytes(m, n, 4)), x2.device)
+    with torch.cuda.device(x2.device):
+        _lib.check(L.amtx_linear_bwd(_lib.ptr(x2), x2.stride(0), None, 0, None, 0, None, 0, None, _lib.ptr(db), m, n, 4, _lib.ptr(ws), ws.numel(),
+                                     _lib.current_stream(x2.device)), 'amtx_linear_bwd')
+    return db
+
+
+def linear_supported(x, weight):
+    return (USE_HIP_DENSE and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2
+            and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and x.shape[-1] == weight.shape[1])
+
+
+class LinearFunction(torch.autograd.Function):
+    """nn.Linear (fc1, LogisticBank.output_layer): y = x w^T + b on amtx_linear_train_fwd, gradients on amtx_linear_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not _ok2d(x2):
+            x2 = x2.contiguous()
+        w = weight if _ok2d(weight) else weight.contiguous()
+        y = matmul_f32(x2, w, bias=bias)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.shape = x.shape
+        return y.reshape(x.shape[:-1] + (w.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        n, k = w.shape
+        dy2 = dy.reshape(-1, n)
+        if not _ok2d(dy2):
+            dy2 = dy2.contiguous()
+        m = dy2.shape[0]
+        L = _lib.lib()
+        dev = dy2.device
+        dx = torch.empty((m, k), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty((n, k), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        db = torch.empty(n, dtype=torch.float32, device=dev) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        ws = _workspace(int(L.amtx_linear_bwd_workspace_bytes(m, n, k)), dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.amtx_linear_bwd(_lib.ptr(dy2), dy2.stride(0), _lib.ptr(x2), x2.stride(0), _lib.ptr(w), w.stride(0), _lib.ptr(dx),
+                                         k, _lib.ptr(dw), _lib.ptr(db), m, n, k, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                       'amtx_linear_bwd')
+        return (dx.reshape(ctx.shape) if dx is not None else None), dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear on the HIP kernels, differentiably (fp32 CUDA tensors; in/out features multiples of 4)."""
+    return LinearFunction.apply(x, weight, bias)
+
+
+def conv3x3_supported(x, conv):
+    """nn.Conv2d(3x3, padding 1, stride 1) on an fp32 CUDA map whose input gradient, if wanted, the kernels can produce."""
+    if not (USE_HIP_DENSE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d)):
+        return False
+    if not (conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.bias is not None and conv.padding_mode == 'zeros'):
+        return False
+    c_in, c_out = conv.in_channels, conv.out_channels
+    if c_in % 4 == 0:
+        return c_out % 4 == 0
+    return c_in == 1 and c_out % 8 == 0 and not x.requires_grad
+
+
+class Conv3x3Function(torch.autograd.Function):
+    """nn.Conv2d(c_in, c_out, 3, padding 1) on channels-last fp32 maps: implicit GEMMs forward (amtx_conv3x3_train_fwd), input and weight
+    gradients (amtx_conv3x3_bwd).  x (B, c_in, T, F) -> y (B, c_out, T, F), both in channels-last memory format."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, Ci, T, F = x.shape
+        Co = weight.shape[0]
+        L = _lib.lib()
+        xc = x.contiguous(memory_format=torch.channels_last) if Ci > 1 else x.contiguous()
+        w = weight.contiguous()
+        y = torch.empty((B, Co, T, F), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        ws = _workspace(int(L.amtx_conv3x3_train_workspace_bytes(B * T, F, Ci, Co)), x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(L.amtx_conv3x3_train_fwd(_lib.ptr(xc), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(y), B * T, T, F, Ci, Co, _lib.ptr(ws), ws.numel(),
+                                                _lib.current_stream(x.device)), 'amtx_conv3x3_train_fwd')
+        ctx.save_for_backward(xc, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, w = ctx.saved_tensors
+        B, Ci, T, F = xc.shape
+        Co = w.shape[0]
+        L = _lib.lib()
+        dev = dy.device
+        dyc = dy.contiguous(memory_format=torch.channels_last)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, Ci, T, F), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(Co, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        ws = _workspace(int(L.amtx_conv3x3_train_workspace_bytes(B * T, F, Ci, Co)), dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.amtx_conv3x3_bwd(_lib.ptr(dyc), _lib.ptr(xc), _lib.ptr(w), _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B * T, T, F, Ci, Co,
+                                          _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), 'amtx_conv3x3_bwd')
+        return dx, dw, db
+
+
+def conv3x3(x, conv):
+    """`conv(x)` for an nn.Conv2d(3x3, padding 1) on the HIP kernels, differentiably."""
+    return Conv3x3Function.apply(x, conv.weight, conv.bias)
 
 
 def _pack(w_hh_f, w_hh_b):
@@ -60,7 +221,13 @@ class BiLSTMFunction(torch.autograd.Function):
             x2 = x.reshape(B * T, x.shape[2])
             w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                  # (8 H, I)
             bias = torch.cat([b_ih_f + b_hh_f, b_ih_b + b_hh_b], dim=0)
-            torch.addmm(bias, x2, w_ih.t(), out=xproj[g])                              # [B][T][2][4H]
+            hip_mm = USE_HIP_DENSE and x2.shape[1] % 4 == 0
+            if hip_mm:
+                if not _ok2d(x2):
+                    x2 = x2.contiguous()
+                matmul_f32(x2, w_ih, bias=bias, out=xproj[g])                          # [B][T][2][4H]
+            else:
+                torch.addmm(bias, x2, w_ih.t(), out=xproj[g])
             wf, wb = w_hh_f.detach().contiguous().float(), w_hh_b.detach().contiguous().float()
             _lib.check(L.amtx_bilstm_h_pack_device(_lib.ptr(wf), _lib.ptr(wb), H, 2, _lib.ptr(frag_fwd[g]), _lib.ptr(frag_bwd[g]),
                                                    _lib.current_stream(dev)), 'amtx_bilstm_h_pack_device')
@@ -71,6 +238,7 @@ class BiLSTMFunction(torch.autograd.Function):
             _lib.check(L.amtx_bilstm_h_train_fwd(_lib.ptr(xproj), _lib.ptr(frag_fwd), H, 2, _lib.ptr(out), _lib.ptr(save), B, T, G,
                                                  _lib.current_stream(dev)), 'amtx_bilstm_h_train_fwd')
         ctx.save_for_backward(out, save, frag_bwd, *saved)
+        ctx.hip_mm = [USE_HIP_DENSE and saved[2 * g].shape[1] % 4 == 0 for g in range(G)]
         ctx.dims = (G, B, T, H)
         ctx.need_dx = [bool(ctx.needs_input_grad[1 + 9 * g]) for g in range(G)]
         return tuple(out[g] for g in range(G))
@@ -92,18 +260,25 @@ class BiLSTMFunction(torch.autograd.Function):
         for g in range(G):
             x2, w_ih = saved[2 * g], saved[2 * g + 1]
             dxp = dxproj[g]
-            dx = (dxp @ w_ih).reshape(B, T, x2.shape[1]) if ctx.need_dx[g] else None
-            dw_ih = dxp.t() @ x2                                                      # (8 H, I)
-            # column sums as a (1, B*T) x (B*T, 8 H) product: ATen's reduce kernel over the strided dimension is slower
-            db = ones.mm(dxp).squeeze(0)
             # h_{t-1} of the forward direction / h_{t+1} of the backward direction (zero initial state)
             hp_f = torch.zeros((B, T, H), dtype=torch.float32, device=dev)
             hp_f[:, 1:] = out[g, :, :-1, :H]
             hp_b = torch.zeros((B, T, H), dtype=torch.float32, device=dev)
             hp_b[:, :-1] = out[g, :, 1:, H:]
-            dg = dxp.reshape(B * T, 2, 4 * H)
-            dw_hh_f = dg[:, 0].t() @ hp_f.reshape(B * T, H)
-            dw_hh_b = dg[:, 1].t() @ hp_b.reshape(B * T, H)
+            if ctx.hip_mm[g]:
+                dx = matmul_f32(dxp, w_ih, b_trans=True).reshape(B, T, x2.shape[1]) if ctx.need_dx[g] else None     # dxp @ w_ih
+                dw_ih = matmul_f32(dxp, x2, a_trans=True, b_trans=True)                                            # dxp^T @ x2, (8 H, I)
+                db = _colsum(dxp)
+                dw_hh_f = matmul_f32(dxp[:, :n], hp_f.reshape(B * T, H), a_trans=True, b_trans=True)               # (4 H, H)
+                dw_hh_b = matmul_f32(dxp[:, n:], hp_b.reshape(B * T, H), a_trans=True, b_trans=True)
+            else:
+                dx = (dxp @ w_ih).reshape(B, T, x2.shape[1]) if ctx.need_dx[g] else None
+                dw_ih = dxp.t() @ x2                                                  # (8 H, I)
+                # column sums as a (1, B*T) x (B*T, 8 H) product: ATen's reduce kernel over the strided dimension is slower
+                db = ones.mm(dxp).squeeze(0)
+                dg = dxp.reshape(B * T, 2, 4 * H)
+                dw_hh_f = dg[:, 0].t() @ hp_f.reshape(B * T, H)
+                dw_hh_b = dg[:, 1].t() @ hp_b.reshape(B * T, H)
             grads += [dx, dw_ih[:n], dw_hh_f, db[:n], db[:n], dw_ih[n:], dw_hh_b, db[n:], db[n:]]
         return tuple(grads)
 

@@ -64,6 +64,7 @@ struct Conv1Args {
     void* out; int out_type;                             // [B][T][F][c_out] channels-last
     int B, T, F, c_in, c_out;
     int groups; int64_t w_gs, shift_gs, out_gs;
+    int relu = 1;                                        // 0: plain convolution + shift (the training path applies BatchNorm first)
 };
 int amtx_launch_conv1(const Conv1Args& c, hipStream_t stream);
 

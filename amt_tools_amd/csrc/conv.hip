@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void conv1_kernel(Conv1Args a) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] = fmaxf(acc[k] + sl[cg * 8 + k], 0.f);
+        for (int k = 0; k < 8; ++k) acc[k] = a.relu ? fmaxf(acc[k] + sl[cg * 8 + k], 0.f) : acc[k] + sl[cg * 8 + k];
         const int64_t o = (((int64_t)b * a.T + t) * a.F + f) * a.c_out + cg * 8;
         if (OUT_TYPE == AMTX_T_BF16) {
             bf16_t* dst = reinterpret_cast<bf16_t*>(a.out) + (int64_t)grp * a.out_gs + o;

@@ -121,6 +121,10 @@ class LogisticBank(OutputLayer):
         self.output_layer = nn.Linear(self.dim_in, self.dim_out)
 
     def forward(self, feats):
+        if feats.is_cuda and torch.is_grad_enabled():
+            from .autograd import linear, linear_supported      # training on a GPU: the HIP GEMMs, forward and backward
+            if linear_supported(feats, self.output_layer.weight):
+                return linear(feats, self.output_layer.weight, self.output_layer.bias)
         return self.output_layer(feats)
 
     def get_loss(self, estimated, reference):
@@ -161,12 +165,13 @@ class AcousticModel(nn.Module):
     use_hip_bn = True        # False: stock nn.BatchNorm2d / ReLU / MaxPool2d (ATen + MIOpen) also on the GPU in training mode
 
     def _stage(self, layer, x):
-        """One conv stage.  Training on a GPU: the convolution stays ATen / MIOpen, BatchNorm (batch statistics) + ReLU (+ MaxPool)
-        run as the HIP passes of amt_tools_amd/autograd.py (bn_relu_pool); the Dropout behind them is the module's own."""
+        """One conv stage.  Training on a GPU: the convolution is an implicit GEMM on the HIP kernels (autograd.conv3x3: forward,
+        input and weight gradients), BatchNorm (batch statistics) + ReLU (+ MaxPool) run as the HIP passes of
+        amt_tools_amd/autograd.py (bn_relu_pool); the Dropout behind them is the module's own."""
         mods = list(layer)
         if self.training and self.use_hip_bn and x.is_cuda and not isinstance(mods[1], nn.SyncBatchNorm):
-            from .autograd import bn_relu_pool, bn_relu_pool_supported
-            y = mods[0](x)
+            from .autograd import bn_relu_pool, bn_relu_pool_supported, conv3x3, conv3x3_supported
+            y = conv3x3(x, mods[0]) if conv3x3_supported(x, mods[0]) else mods[0](x)
             if bn_relu_pool_supported(y, mods[1]):
                 pool = len(mods) > 3 and isinstance(mods[3], nn.MaxPool2d)
                 y = bn_relu_pool(y, mods[1], pool)
@@ -188,7 +193,9 @@ class AcousticModel(nn.Module):
             lin = self.fc1[0]
             B, C, T, F = x.shape
             w = lin.weight.view(lin.out_features, C, F).transpose(1, 2).reshape(lin.out_features, F * C)
-            y = torch.nn.functional.linear(x.permute(0, 2, 3, 1).reshape(B, T, F * C), w, lin.bias)
+            from .autograd import linear, linear_supported
+            xin = x.permute(0, 2, 3, 1).reshape(B, T, F * C)
+            y = linear(xin, w, lin.bias) if linear_supported(xin, w) else torch.nn.functional.linear(xin, w, lin.bias)
             for m in list(self.fc1)[1:]:
                 y = m(y)
             return y

@@ -187,6 +187,34 @@ int amtx_bn_relu_pool_train_bwd(const float* x, int64_t rows, int num_bins, int 
 size_t amtx_bce_logits_loss_workspace_bytes(int batch, int num_frames, int keys);
 int amtx_bce_logits_loss(const float* logits, int64_t ld, const float* labels, const float* weight, int batch, int num_frames, int keys,
                          float* loss, float* grad, void* workspace, size_t workspace_bytes, void* stream);
+/* ------------------------------------------------------------------------------------------------
+ * Dense layers of the TRAINING step (amt_tools/train.py:126-141 drives them through autograd): fp32 in / fp32 out, every product as
+ * split-bf16 ("x3", fp32-class accuracy) on the matrix cores.  No vendor BLAS / MIOpen behind any of them.
+ * ------------------------------------------------------------------------------------------------ */
+/* C[m][n] = sum_k A(m,k) B(n,k) (+ bias[n]);  A(m,k) = a[m*lda + k] (a_trans = 0) or a[k*lda + m] (a_trans = 1), B likewise.
+ * Operands 16-byte aligned, leading dimensions and the contiguous extents multiples of 4.  workspace (optional): split-contraction
+ * partials, amtx_matmul_workspace_bytes(m, n, k); used only when ldc == n. */
+size_t amtx_matmul_workspace_bytes(int64_t m, int64_t n, int64_t k);
+int amtx_matmul_f32(const float* a, int64_t lda, int a_trans, const float* b, int64_t ldb, int b_trans, const float* bias, float* c, int64_t ldc,
+                    int64_t m, int64_t n, int64_t k, void* workspace, size_t workspace_bytes, void* stream);
+/* nn.Linear in training mode: fc1 (models/onsetsframes.py:422-427), LogisticBank.output_layer (models/common.py:539), the nn.LSTM
+ * input projections (onsetsframes.py:498-501).  y[m][n] = x[m][:] . w[n][:] + bias[n]. */
+int amtx_linear_train_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy, int64_t m, int n,
+                          int k, void* stream);
+/* its backward: dx[m][k] = dy w, dw[n][k] = dy^T x (contiguous), db[n] = column sums of dy; any of dx / dw / db may be null. */
+size_t amtx_linear_bwd_workspace_bytes(int64_t m, int n, int k);
+int amtx_linear_bwd(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* w, int64_t ldw, float* dx, int64_t lddx, float* dw,
+                    float* db, int64_t m, int n, int k, void* workspace, size_t workspace_bytes, void* stream);
+/* nn.Conv2d(c_in, c_out, 3, padding 1) of the acoustic model's three stages in training mode (models/onsetsframes.py:375-416; the
+ * BatchNorm behind it is amtx_bn_relu_pool_train_*).  Channels-last fp32: x (rows = clips x frames_per_clip, num_bins, c_in),
+ * y / dy (rows, num_bins, c_out); w / dw in the reference's (c_out, c_in, 3, 3) layout; zero padding at every clip's first / last frame
+ * and bin.  Implicit GEMMs (im2col on the operand fetch).  c_in not a multiple of 4 (the first layer): direct fp32 forward, weight
+ * gradient through the same GEMM, no dx.  workspace: amtx_conv3x3_train_workspace_bytes(rows, num_bins, c_in, c_out). */
+size_t amtx_conv3x3_train_workspace_bytes(int64_t rows, int num_bins, int c_in, int c_out);
+int amtx_conv3x3_train_fwd(const float* x, const float* w, const float* bias, float* y, int64_t rows, int frames_per_clip, int num_bins, int c_in,
+                           int c_out, void* workspace, size_t workspace_bytes, void* stream);
+int amtx_conv3x3_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int64_t rows, int frames_per_clip,
+                     int num_bins, int c_in, int c_out, void* workspace, size_t workspace_bytes, void* stream);
 /* LogisticBank.finalize_output: sigmoid -> (B,keys,T) -> threshold (< 0: keep probabilities)  (models/common.py:586-620) */
 int amtx_pianoroll_fwd(const float* logits, int64_t ld, int col0, int batch, int num_frames, int keys, float threshold, float* out,
                        void* stream);

@@ -245,3 +245,85 @@ def test_onsetsframes2_training_step_on_gpu_matches_reference_golden():
         rels.append((got - ref).norm().item() / max(1e-9, ref.norm().item()))
         assert rels[-1] < 3e-2, (k, rels[-1])        # see test_onsetsframes2_training_step_hip_vs_stock_path for the metric
     assert float(np.median(rels)) < 2e-3
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 4, 4), (37, 88, 256), (625, 512, 3648), (5000, 88, 512), (130, 1024, 176), (4999, 132, 36)])
+def test_linear_fwd_bwd_matches_float64(M, N, K):
+    """autograd.linear (amtx_linear_train_fwd / amtx_linear_bwd: split-bf16 GEMMs, split contraction for the weight gradient) against
+    torch's float64 linear: output, input gradient, weight gradient, bias gradient."""
+    from amt_tools_amd.autograd import linear
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(N, K, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(N, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(M, N, dtype=torch.float64)
+    y = torch.nn.functional.linear(x, w, b)
+    y.backward(gy)
+    xc, wc, bc = (t.detach().float().cuda().requires_grad_(True) for t in (x, w, b))
+    yc = linear(xc, wc, bc)
+    yc.backward(gy.float().cuda())
+    assert _rel(yc.detach().cpu().double(), y.detach()) < 2e-5
+    assert _rel(xc.grad.cpu().double(), x.grad) < 2e-5
+    assert _rel(wc.grad.cpu().double(), w.grad) < 2e-5
+    assert _rel(bc.grad.cpu().double(), b.grad) < 2e-5
+    # 3-D input with a strided row view as nn.Linear sees them inside the model
+    x3 = torch.randn(2, 5, 2 * K, device='cuda')[..., :K].requires_grad_(True)
+    y3 = linear(x3, wc.detach(), bc.detach())
+    ref3 = torch.nn.functional.linear(x3.detach().double().cpu(), w.detach(), b.detach())
+    assert y3.shape == (2, 5, N) and _rel(y3.detach().cpu().double(), ref3) < 2e-5
+
+
+@pytest.mark.parametrize('ci,co', [(1, 32), (32, 32), (32, 64), (48, 96), (16, 16)])
+@pytest.mark.parametrize('B,T,F', [(1, 1, 2), (2, 7, 13), (3, 20, 57), (1, 33, 229)])
+def test_conv3x3_fwd_bwd_matches_float64(ci, co, B, T, F):
+    """autograd.conv3x3 (implicit GEMMs of csrc/train.hip) against torch's float64 Conv2d: output, input gradient (where the layer
+    has one: not the one-channel first layer), weight and bias gradients; zero padding at clip boundaries in time and at the band
+    edges, clips of a batch independent."""
+    from amt_tools_amd.autograd import conv3x3
+    torch.manual_seed(ci * 1000 + co + B + T + F)
+    ref = torch.nn.Conv2d(ci, co, 3, padding=1).double()
+    x = torch.randn(B, ci, T, F, dtype=torch.float64, requires_grad=ci > 1)
+    gy = torch.randn(B, co, T, F, dtype=torch.float64)
+    y = ref(x)
+    y.backward(gy)
+    mine = torch.nn.Conv2d(ci, co, 3, padding=1).cuda()
+    mine.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    xc = x.detach().float().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(ci > 1)
+    yc = conv3x3(xc, mine)
+    assert yc.is_contiguous(memory_format=torch.channels_last) or ci == 1 or F * T == 1
+    yc.backward(gy.float().cuda())
+    assert _rel(yc.detach().cpu().double(), y.detach()) < 2e-5
+    if ci > 1:
+        assert _rel(xc.grad.cpu().double(), x.grad) < 2e-5
+    assert _rel(mine.weight.grad.cpu().double(), ref.weight.grad) < 2e-5
+    assert _rel(mine.bias.grad.cpu().double(), ref.bias.grad) < 2e-5
+
+
+def test_training_step_runs_without_vendor_gemm_or_conv_kernels():
+    """With the HIP dense layers on (the default) a whole training step of OnsetsFrames must not launch a MIOpen / hipBLASLt /
+    rocBLAS kernel: checked with torch's profiler on the kernel names of one step."""
+    from amt_tools_amd.models import OnsetsFrames
+    from amt_tools_amd.synth import synth_labels
+    torch.manual_seed(0)
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 2, device='cuda:0')
+    model.change_device()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=6e-4)
+    B, T = 2, 64
+    lab = [synth_labels(i, num_frames=T) for i in range(B)]
+    batch = {tools.KEY_FEATS: torch.rand(B, 1, 229, T), tools.KEY_MULTIPITCH: torch.from_numpy(np.stack([l[0] for l in lab])),
+             tools.KEY_ONSETS: torch.from_numpy(np.stack([l[1] for l in lab]))}
+
+    def step():
+        opt.zero_grad()
+        model.run_on_batch(batch)[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+        opt.step()
+
+    step()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages() if e.device_type == torch.autograd.DeviceType.CUDA or 'kernel' in e.key.lower()]
+    vendor = [n for n in names if any(t in n.lower() for t in ('miopen', 'cijk_', 'rocblas', 'hipblas', 'igemm', 'gemv'))]
+    assert not vendor, vendor
+    assert any('xgemm_kernel' in n for n in names), names[:20]
