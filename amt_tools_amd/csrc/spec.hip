@@ -1,4 +1,4 @@
-// Spectral front-end for gfx950: framed real FFT (n_fft = 2048) with LDS butterfly staging ->
+// Spectral front-end for gfx950: framed real FFT (n_fft = 2048 tuned; any other power of two 128 .. 4096 through a generic kernel) with LDS butterfly staging ->
 // power spectrum -> sparse triangular mel filterbank (wave-parallel rows) -> per-clip max [K1],
 // then dB / scale / layout [K2].
 //
@@ -43,6 +43,7 @@ struct SpecDev {
     int round_max[MAX_MEL_ROUNDS];   // taps of round r = max tap count of rows [64r, 64r+64), rounded up to a multiple of MEL_UNROLL
     int round_off[MAX_MEL_ROUNDS];   // first tap slot of round r in mel_wt
     int hop, n_out, n_mels, center, pad_mode;
+    int n_fft;               // frame length; the tuned kernel below is n_fft = 2048 only, spec_power_pow2_kernel takes 128 .. 4096
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -330,6 +331,84 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));   // values >= 0: uint order == float order
 }
 
+// Any other power-of-two frame length (128 .. 4096; amt_tools/features/stft.py:15-40 and mel.py:15-38 take any n_fft): one wave per
+// frame, the n_fft real samples as m = n_fft / 2 complex points in a wave-private LDS buffer, in-place radix-2 decimation-in-time
+// (bit-reversed on the way in, log2(m) butterfly passes separated by wave-level LDS ordering only), the same real-FFT untangling and
+// the same lane-per-row mel gather as the tuned 2048 kernel.  Not tuned: ~log2(m) LDS round trips per frame instead of two.
+__global__ __launch_bounds__(256) void spec_power_pow2_kernel(SpecDev p, int log2m, int fpw, const float* __restrict__ audio, int64_t num_samples,
+                                                           int64_t audio_stride, int64_t num_frames, float* __restrict__ power,
+                                                           unsigned* __restrict__ clip_max, int mel) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = 1 << log2m, nfft = 2 * m;
+    const int pb_elems = m + 1 + 128 + 3;                       // bins a zero-padded mel tap batch may touch
+    float2* z = reinterpret_cast<float2*>(smem) + (size_t)wave * m;
+    float* pb = reinterpret_cast<float*>(smem + (size_t)WAVES * m * sizeof(float2)) + (size_t)wave * pb_elems;
+    const int fpb = fpw * WAVES;
+    const unsigned chunks = (unsigned)((num_frames + fpb - 1) / fpb);
+    const unsigned clip_idx = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const float* clip = audio + (int64_t)clip_idx * audio_stride;
+    const int rounds = mel ? (p.n_mels + 63) / 64 : 0;
+    for (int i = m + 1 + lane; i < pb_elems; i += 64) pb[i] = 0.0f;
+    float run_max = 0.0f;
+    const int64_t half = p.center ? nfft / 2 : 0;
+    for (int i = 0; i < fpw; ++i) {
+        const int64_t t = (int64_t)chunk * fpb + i * WAVES + wave;
+        if (t >= num_frames) break;
+        const int64_t s0 = t * p.hop - half;
+        // windowed samples -> bit-reversed complex points
+        for (int j = lane; j < m; j += 64) {
+            const float xr = fetch_padded(clip, s0 + 2 * j, num_samples, p.pad_mode) * p.window[2 * j];
+            const float xi = fetch_padded(clip, s0 + 2 * j + 1, num_samples, p.pad_mode) * p.window[2 * j + 1];
+            z[__brev((unsigned)j) >> (32 - log2m)] = make_float2(xr, xi);
+        }
+        wave_lds_sync();
+        for (int s = 0; s < log2m; ++s) {
+            const int h = 1 << s;
+            for (int b = lane; b < m / 2; b += 64) {
+                const int j = b & (h - 1), i0 = ((b >> s) << (s + 1)) + j;
+                const float2 w = p.tw_fft[j << (log2m - 1 - s)];          // exp(-2 pi i j / (2 h))
+                const float2 a = z[i0], c = cmul(z[i0 + h], w);
+                z[i0] = make_float2(a.x + c.x, a.y + c.y);
+                z[i0 + h] = make_float2(a.x - c.x, a.y - c.y);
+            }
+            wave_lds_sync();
+        }
+        // real-FFT untangling: bins k and m - k from Z[k], Z[m - k]; k = 0 gives DC and Nyquist, k = m / 2 is its own partner
+        for (int k = lane; k <= m / 2; k += 64) {
+            const float2 zk = z[k], zp = z[(m - k) & (m - 1)];
+            float pk, pmk;
+            untangle_pair(zk, zp, p.tw_post[k], pk, pmk);
+            pb[k] = pk;
+            pb[m - k] = pmk;
+        }
+        wave_lds_sync();
+        float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
+        if (mel) {
+            for (int r = 0; r < rounds; ++r) {
+                const int row = r * 64 + lane;
+                const int start = p.mel_start[row];
+                const float* wt = p.mel_wt + p.round_off[r] * 64 + lane;
+                float acc = 0.0f;
+                for (int j = 0; j < p.round_max[r]; ++j) acc = fmaf(wt[j * 64], pb[min(start + j, pb_elems - 1)], acc);
+                if (row < p.n_mels) {
+                    out_row[row] = acc;
+                    run_max = fmaxf(run_max, acc);
+                }
+            }
+        } else {
+            for (int k = lane; k < p.n_out; k += 64) {
+                const float val = pb[k];
+                out_row[k] = val;
+                run_max = fmaxf(run_max, val);
+            }
+        }
+        wave_lds_sync();
+    }
+    run_max = wave_max_f32(run_max);
+    if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));
+}
+
 // K2: dB conversion / scaling / layout.  One block = 32 frames x 32 bins tile.
 __global__ __launch_bounds__(256) void spec_scale_kernel(const float* __restrict__ power, const float* __restrict__ clip_max,
                                                          const float* __restrict__ ref, int64_t num_frames, int n_bins,
@@ -415,10 +494,11 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
                                      int n_mels, int htk, int center, int pad_mode) {
     AMTX_REQUIRE(out != nullptr, "amtx_spec_plan_create: null plan pointer");
     *out = nullptr;
-    if (n_fft != NFFT) {
-        amtx_set_error("amtx_spec_plan_create: only n_fft = 2048 is implemented (got %d)", n_fft);
+    if (n_fft < 128 || n_fft > 4096 || (n_fft & (n_fft - 1)) != 0) {
+        amtx_set_error("amtx_spec_plan_create: n_fft must be a power of two in 128 .. 4096 (got %d)", n_fft);
         return AMTX_ERR_UNSUPPORTED;
     }
+    const int M = n_fft / 2;   // (shadows the tuned kernel's compile-time constant: tables are sized by THIS plan's frame length)
     if (win_length <= 0) win_length = n_fft;
     AMTX_REQUIRE(win_length <= n_fft && hop_length > 0 && sample_rate > 0, "amtx_spec_plan_create: bad win/hop/sr");
     AMTX_REQUIRE(n_mels >= 0 && n_mels <= 64 * MAX_MEL_ROUNDS, "amtx_spec_plan_create: n_mels out of range (0..%d)", 64 * MAX_MEL_ROUNDS);
@@ -483,7 +563,7 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
         m_w.assign((size_t)slots * 64, 0.0f);
         for (int i = 0; i < n_mels; ++i) {
             const int r = i / 64, l = i % 64;
-            if (m_start[i] + pl->dev.round_max[r] > PB_BINS) {
+            if (m_start[i] + pl->dev.round_max[r] > pl->n_bins_fft + 128) {
                 amtx_set_error("amtx_spec_plan_create: mel row %d (%d taps from bin %d) does not fit the padded power row", i, m_count[i], m_start[i]);
                 delete pl;
                 return AMTX_ERR_UNSUPPORTED;
@@ -519,7 +599,7 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
     pl->dev.mel_start = (const int*)(d + o_ms);
     pl->dev.mel_wt = (const float*)(d + o_mw);
     pl->dev.hop = hop_length; pl->dev.n_out = pl->n_out; pl->dev.n_mels = n_mels;
-    pl->dev.center = center; pl->dev.pad_mode = pad_mode;
+    pl->dev.center = center; pl->dev.pad_mode = pad_mode; pl->dev.n_fft = n_fft;
     *out = pl;
     return AMTX_OK;
 }
@@ -562,6 +642,20 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const int64_t T = amtx_spec_num_frames(plan, num_samples);
     AMTX_REQUIRE(T > 0, "amtx_spec_power: clip too short for one frame");
     AMTX_CHECK_HIP(hipMemsetAsync(clip_max, 0, sizeof(float) * batch, stream));
+    if (plan->n_fft != NFFT) {
+        int log2m = 0;
+        while ((2 << log2m) < plan->n_fft) ++log2m;
+        const int m = plan->n_fft / 2, fpw = 8;
+        const int64_t chunks_g = (T + fpw * WAVES - 1) / (fpw * WAVES);
+        const int64_t nblocks_g = chunks_g * batch;
+        AMTX_REQUIRE(nblocks_g < (1ll << 31), "amtx_spec_power: grid too large");
+        const size_t lds_g = (size_t)WAVES * m * sizeof(float2) + (size_t)WAVES * (m + 1 + 128 + 3) * sizeof(float);
+        AMTX_GRANT_LDS(spec_power_pow2_kernel, lds_g);
+        hipLaunchKernelGGL(spec_power_pow2_kernel, dim3((unsigned)nblocks_g), dim3(256), lds_g, stream, plan->dev, log2m, fpw, audio, num_samples,
+                           audio_stride, T, power, (unsigned*)clip_max, plan->n_mels > 0 ? 1 : 0);
+        AMTX_CHECK_LAUNCH();
+        return AMTX_OK;
+    }
     constexpr int FPW = 8;
     constexpr int FPB = FPW * WAVES;
     const int64_t chunks = (T + FPB - 1) / FPB;

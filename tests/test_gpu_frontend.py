@@ -153,3 +153,47 @@ def test_rms_norm_batch_matches_reference_formula():
         assert np.abs(got[b] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
     assert np.all(got[3] == 0)
     assert abs(np.sqrt(np.mean(got[1].astype(np.float64) ** 2)) - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize('n_fft', [128, 512, 1024, 4096])
+@pytest.mark.parametrize('kind', ['mel', 'stft'])
+def test_other_frame_lengths_match_oracle(n_fft, kind):
+    """STFT / MelSpec take any n_fft (amt_tools/features/stft.py:15-40, mel.py:15-38): powers of two 128 .. 4096 besides the tuned 2048
+    run on the generic radix-2 kernel; same tolerances as the 2048 path, both librosa padding conventions, linear and dB output."""
+    MelSpec, STFT = _mods()
+    y = synth_clip(20 + n_fft % 7, num_samples=30000)
+    hop = max(32, n_fft // 4)
+    for lv in ('0.10', '0.9'):
+        if kind == 'mel':
+            n_mels = min(229, n_fft // 8)
+            mod = MelSpec(sample_rate=22050, hop_length=hop, n_mels=n_mels, n_fft=n_fft, librosa_version=lv)
+            ref = fe.melspec_process_audio(y, 22050, hop, n_mels, n_fft, lv=lv)
+        else:
+            mod = STFT(sample_rate=22050, hop_length=hop, n_fft=n_fft, librosa_version=lv)
+            ref = fe.stft_process_audio(y, hop, n_fft, lv=lv)
+        got = mod.process_audio(y)
+        assert got.shape == ref.shape and got.dtype == np.float32
+        assert np.abs(got - ref).max() < TOL_SCALED, (n_fft, kind, lv)
+    lin = STFT(sample_rate=22050, hop_length=hop, n_fft=n_fft, decibels=False)
+    ref = fe.stft_process_audio(y, hop, n_fft, decibels=False)
+    assert np.abs(lin.process_audio(y) - ref).max() <= 4e-6 * ref.max()
+
+
+def test_short_window_not_centered_stft_is_the_bookkeeping_goldens_module():
+    """The `stft_nc` module of tests/golden/feature_bookkeeping.npz (n_fft 1024, win_length 800, hop 256, center=False, 16 kHz) now
+    also runs on the GPU: values and frame counts against the oracle (= what librosa.stft returns for the reference's padded
+    audio: frames are n_fft long).  Reference quirk, recorded not fixed: its own get_expected_frames counts win_length-long frames
+    (features/waveform.py:43-67), so for win_length < n_fft it predicts one frame more than its process_audio returns -- the mirror
+    reproduces the prediction (tests/test_feature_bookkeeping.py, golden) and the kernels reproduce the output."""
+    _, STFT = _mods()
+    mod = STFT(sample_rate=16000, hop_length=256, n_fft=1024, win_length=800, center=False)
+    for n in (1024, 1025, 2047, 2048, 2049, 4095, 4096, 22050):
+        y = synth_clip(n % 5, num_samples=n)
+        got = mod.process_audio(y)
+        ref = fe.stft_process_audio(y, 256, 1024, win_length=800, center=False)
+        assert got.shape == ref.shape and got.shape[-1] >= 1, (n, got.shape, ref.shape)
+        assert np.abs(got - ref).max() < TOL_SCALED, n
+    # the same window shape on the tuned 2048 kernel (win_length < n_fft there too), centred
+    y = synth_clip(2, num_samples=20000)
+    wide = STFT(sample_rate=22050, hop_length=512, n_fft=2048, win_length=1500)
+    assert np.abs(wide.process_audio(y) - fe.stft_process_audio(y, 512, 2048, win_length=1500)).max() < TOL_SCALED
