@@ -65,7 +65,7 @@ struct amtx_of_model {
     LinearPack rec_ih;                         // groups = n_rec, N = 1024
     DevBuf rec_hh;                             // groups = n_rec
     LinearPack rec_out;                        // groups = n_rec, N = n_out, K = dim_lm
-    LinearPack pitch_out;                      // K = dim_am
+    LinearPack pitch_out;                      // the pitch head's fc1 and LogisticBank folded into one layer: K = kfc_pad, N = n_out
     LinearPack adj_ih;                         // K = dim_aj, N = 1024
     DevBuf adj_hh;
     LinearPack adj_out;
@@ -307,7 +307,15 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     if ((rc = m->conv2_s.upload(c2s.data(), c2s.size() * 4)) != AMTX_OK) return rc;
     if ((rc = m->conv3_w.upload(c3w.data(), c3w.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv3_s.upload(c3s.data(), c3s.size() * 4)) != AMTX_OK) return rc;
-    if ((rc = pack_linear_groups(m, m->fc1, fcw, fcb, m->dim_am, m->kfc_pad)) != AMTX_OK) return rc;
+    {
+        // fc1 of the RECURRENT heads only.  The pitch head's fc1 feeds its LogisticBank directly (AcousticModel.fc1 is Linear +
+        // Dropout, no activation: onsetsframes.py:422-427, then models/common.py:539), so in eval mode the two Linear layers are one:
+        //     logits = W_out (W_fc1 a + b_fc1) + b_out = (W_out W_fc1) a + (W_out b_fc1 + b_out)
+        // folded here in double precision (the same kind of weight folding as the BatchNorms above): a K = kfc, N = n_out GEMM
+        // replaces a K = kfc, N = dim_am one plus a K = dim_am, N = n_out one, and the dim_am-wide activation never exists.
+        std::vector<std::vector<float>> fcw_rec(fcw.begin(), fcw.begin() + m->n_rec), fcb_rec(fcb.begin(), fcb.begin() + m->n_rec);
+        if (m->n_rec > 0 && (rc = pack_linear_groups(m, m->fc1, fcw_rec, fcb_rec, m->dim_am, m->kfc_pad)) != AMTX_OK) return rc;
+    }
 
     // ---- recurrent heads (onset, offset): LSTM + LogisticBank
     {
@@ -332,8 +340,25 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
         const float *w, *b;
         NEED("pitch_head.1.output_layer.weight", (size_t)m->n_out * m->dim_am, w);
         NEED("pitch_head.1.output_layer.bias", (size_t)m->n_out, b);
-        std::vector<std::vector<float>> W{std::vector<float>(w, w + (size_t)m->n_out * m->dim_am)}, Bv{std::vector<float>(b, b + m->n_out)};
-        if ((rc = pack_linear_groups(m, m->pitch_out, W, Bv, m->n_out, m->dim_am)) != AMTX_OK) return rc;
+        const std::vector<float>& fw = fcw[nh - 1];   // (dim_am, kfc_pad), columns already in the engine's (freq, channel) order
+        const std::vector<float>& fb1 = fcb[nh - 1];
+        std::vector<std::vector<float>> W(1), Bv(1);
+        W[0].assign((size_t)m->n_out * m->kfc_pad, 0.0f);
+        Bv[0].assign(m->n_out, 0.0f);
+        std::vector<double> rowacc(m->kfc_pad);
+        for (int o = 0; o < m->n_out; ++o) {
+            std::fill(rowacc.begin(), rowacc.end(), 0.0);
+            double bacc = b[o];
+            for (int j = 0; j < m->dim_am; ++j) {
+                const double wo = w[(size_t)o * m->dim_am + j];
+                const float* frow = fw.data() + (size_t)j * m->kfc_pad;
+                for (int k = 0; k < m->kfc_pad; ++k) rowacc[k] += wo * frow[k];
+                bacc += wo * fb1[j];
+            }
+            for (int k = 0; k < m->kfc_pad; ++k) W[0][(size_t)o * m->kfc_pad + k] = (float)rowacc[k];
+            Bv[0][o] = (float)bacc;
+        }
+        if ((rc = pack_linear_groups(m, m->pitch_out, W, Bv, m->n_out, m->kfc_pad)) != AMTX_OK) return rc;
     }
     // ---- adjoin: LSTM over the joint logits + LogisticBank
     {
@@ -437,8 +462,8 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
     mark();
 
-    // fc1 for every acoustic head
-    GemmArgs g = gemm_args(w.a3, m->kfc_pad, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_heads, BT * m->kfc_pad, BT * m->dim_am);
+    // fc1 of the recurrent heads (heads 0..n_rec-1 of a3); the pitch head's fc1 is folded into its output layer below
+    GemmArgs g = gemm_args(w.a3, m->kfc_pad, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_rec, BT * m->kfc_pad, BT * m->dim_am);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
@@ -456,8 +481,8 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
     g = gemm_args(w.l1, m->dim_lm, at, m->rec_out, pl, w.joint, m->dim_aj, AMTX_T_F32, BT, m->n_rec, BT * m->dim_lm, m->n_out);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
-    // pitch head LogisticBank -> last n_out columns of joint
-    g = gemm_args(w.e + (size_t)(m->n_heads - 1) * BT * m->dim_am * amtx_tsize(at), m->dim_am, at, m->pitch_out, pl,
+    // pitch head: (fc1 . LogisticBank) folded, straight from its conv3 map -> last n_out columns of joint
+    g = gemm_args(w.a3 + (size_t)(m->n_heads - 1) * BT * m->kfc_pad * amtx_tsize(at), m->kfc_pad, at, m->pitch_out, pl,
                   w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();

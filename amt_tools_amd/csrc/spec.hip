@@ -123,6 +123,20 @@ __device__ __forceinline__ void untangle_pair(float2 zk, float2 zp, float2 w, fl
 // to cover them) become conflict-free LDS reads.  Plans whose table does not leave room for two blocks per CU keep it in memory.
 constexpr int MEL_LDS_MAX_SLOTS = 80;
 
+#ifdef AMTX_SPEC_TIMING
+// debug build only: cycles wave 0 of every block spends per section of a frame, summed: [0] window + next-frame load issue, [1] pass A +
+// exchange 1, [2] pass B + exchange 2, [3] radix-4 tail + untangling, [4] mel gather + stores, [5] frames
+__device__ unsigned long long g_spec_prof[8];
+#define SPEC_TICK(SLOT)                                                    \
+    do {                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();      \
+        prof_acc[SLOT] += now_ - prof_t;                                   \
+        prof_t = now_;                                                     \
+    } while (0)
+#else
+#define SPEC_TICK(SLOT) do {} while (0)
+#endif
+
 template <int FPW, bool MEL, bool MELLDS>
 __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const float* __restrict__ audio, int64_t num_samples,
                                                          int64_t audio_stride, int64_t num_frames,
@@ -194,10 +208,18 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         if (tfirst < num_frames) SPEC_LOAD_FRAME(tfirst);
     }
 
+#ifdef AMTX_SPEC_TIMING
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof_t = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
     for (int i = 0; i < FPW; ++i) {
         const int64_t t = (int64_t)chunk * FPB + i * WAVES + wave;
         if (t >= num_frames) break;
+#ifdef AMTX_SPEC_TIMING
+        prof_t = __builtin_readcyclecounter();
+        prof_acc[5] += 1;
+#endif
 
         // ---- window: v[n1] = z[64 n1 + lane]
         float2 v[16];
@@ -208,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
             if (i + 1 < FPW && tnext < num_frames) SPEC_LOAD_FRAME(tnext);
         }
 
+        SPEC_TICK(0);
         // ---- pass A: DFT-16 over n1, twiddle W_1024^(lane*k1), exchange 1
         dft16(v);
 #pragma unroll
@@ -223,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
             for (int a = 0; a < 16; ++a) v[a] = row[4 * a];
         }
         wave_lds_sync();
+        SPEC_TICK(1);
         // ---- pass B: DFT-16 over a, twiddle W_64^(b*c), exchange 2 into [k1][c][b]
         dft16(v);
         {
@@ -233,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         }
         wave_lds_sync();
 
+        SPEC_TICK(2);
         // ---- radix-4 tail merged with the real-FFT untangling: 128 tasks = exactly two full-wave iterations.
         // A task takes a 4-point group (k1, c) and its partner group ((16 - k1) & 15, 15 - c), runs the two DFT-4s and
         // untangles the four bin pairs (k, M - k), k = k1 + 16 c + 256 d.  The two self-paired groups (0,0) and (0,8) would be
@@ -275,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         }
         wave_lds_sync();
 
+        SPEC_TICK(3);
         float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
         if (MEL) {
             // ---- sparse mel: lane-per-row gather over contiguous bin ranges.  Weights are tap-major and zero padded to
@@ -324,8 +350,13 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
             }
         }
         wave_lds_sync();   // pb / xb are rewritten by the next frame
+        SPEC_TICK(4);
     }
 #undef SPEC_LOAD_FRAME
+#ifdef AMTX_SPEC_TIMING
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&g_spec_prof[i], prof_acc[i]);
+#endif
 
     run_max = wave_max_f32(run_max);
     if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));   // values >= 0: uint order == float order
@@ -694,3 +725,14 @@ extern "C" int amtx_spec_scale(const amtx_spec_plan* plan, const float* power, c
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
+
+#ifdef AMTX_SPEC_TIMING
+extern "C" int amtxdbg_spec_prof(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_spec_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_spec_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -45,7 +45,10 @@ SR, HOP, N_MELS, N_FFT = 22050, 512, 229, 2048
 CLIP_SAMPLES, CLIP_FRAMES = 319999, 625
 PEAK_MFMA_BF16_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-MODEL_FLOPS_PER_FRAME = 26.70e6
+MODEL_FLOPS_PER_FRAME = 26.70e6     # the reference's layer-by-layer arithmetic
+# what the engine executes: the pitch head's fc1 (3648 -> 512) and LogisticBank (512 -> 88) are two Linear layers with nothing in
+# between in eval mode and are folded into one 3648 -> 88 layer when the weights are loaded (same results, 3.18 MFLOP less per frame)
+EXECUTED_FLOPS_PER_FRAME = MODEL_FLOPS_PER_FRAME - 2 * (3648 * 512 + 512 * 88 - 3648 * 88)
 TRAIN_FLOPS_PER_FRAME = 80.0e6      # ~3x forward
 
 # algorithmic work per clip-frame; flops for MFMA stages, bytes for streaming stages
@@ -53,11 +56,11 @@ STAGE_FLOPS = {
     'conv1': 2 * 2 * 229 * 32 * 9,
     'conv2_pool': 2 * 2 * 229 * 32 * 32 * 9,
     'conv3_pool': 2 * 2 * 114 * 32 * 64 * 9,
-    'fc1_gemm': 2 * 2 * 3648 * 512,
+    'fc1_gemm': 2 * 3648 * 512,                 # the onset head's fc1; the pitch head's is folded into its output layer, see below
     'rec_xproj_gemm': 2 * 512 * 1024,
     'rec_bilstm': 2 * 2 * 512 * 128,
     'rec_head_gemm': 2 * 256 * 88,
-    'pitch_head_gemm': 2 * 512 * 88,
+    'pitch_head_gemm': 2 * 3648 * 88,           # (fc1 . LogisticBank) of the pitch head as ONE K = 3648, N = 88 layer (weights folded at load time)
     'adj_xproj_gemm': 2 * 176 * 1024,
     'adj_bilstm': 2 * 2 * 512 * 128,
     'adj_head_gemm': 2 * 256 * 88,
@@ -66,7 +69,8 @@ STAGE_FLOPS = {
 ALGO_BYTES = {
     'conv2_pool': 2 * (229 * 4 + 114 * 32 * 2),         # both heads: read the log-mel row, write the pooled 114 x 32 map
     'conv3_pool': 2 * (114 * 32 * 2 + 57 * 64 * 2),
-    'fc1_gemm': 2 * (3648 * 2 + 512 * 2),
+    'fc1_gemm': 3648 * 2 + 512 * 2,
+    'pitch_head_gemm': 3648 * 2 + 88 * 4,
 }
 STAGE_BYTES = {
     'spec_power': HOP * 4 + N_MELS * 4,            # read hop samples, write the mel-power row
@@ -411,6 +415,9 @@ def run_infer(args, rank, world, device):
               'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
               'rccl_ranks': world,
               'whole_path_frac_of_mfma_roof': fps / world * MODEL_FLOPS_PER_FRAME / 2.5e15,
+              'whole_path_frac_of_mfma_roof_executed_flops': fps / world * EXECUTED_FLOPS_PER_FRAME / 2.5e15,
+              'flops_per_frame': {'reference_algorithmic': MODEL_FLOPS_PER_FRAME, 'executed': EXECUTED_FLOPS_PER_FRAME,
+                                  'note': 'pitch head fc1 + LogisticBank folded into one linear layer at weight load (eval mode has nothing between them)'},
               'whole_path_frac_of_compulsory_hbm_roof': fps / world * 2752 / 8.0e12}
     if hbm_measured is not None:
         # bytes this build really moves per step (sum of the PMC-counted kernels) over the step time, against 8 TB/s
