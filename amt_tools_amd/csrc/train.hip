@@ -388,16 +388,21 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // unconditional loads (rows off the clip re-read the base row) + a validity bit per load, applied when the strip is stored:
+    // a branch around a load makes hipcc wait for that load at the join (one memory round trip per load instead of one per strip)
     float4 v[PRE ? 3 : 1][NS];
+    unsigned vmask[PRE ? 3 : 1];
 #define XCONV_LOAD(SLOT, DY)                                                                                  \
+    vmask[SLOT] = 0;                                                                                          \
     _Pragma("unroll") for (int j = 0; j < NS; ++j) {                                                          \
-        v[SLOT][j] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
-        if (spos[j] >= 0 && (unsigned)(st[j] + (DY)) < (unsigned)g.T)                                          \
-            v[SLOT][j] = *reinterpret_cast<const float4*>(g.x + spos[j] + (int64_t)(DY) * g.F * C);            \
+        const bool ok_ = spos[j] >= 0 && (unsigned)(st[j] + (DY)) < (unsigned)g.T;                              \
+        vmask[SLOT] |= (unsigned)ok_ << j;                                                                    \
+        v[SLOT][j] = *reinterpret_cast<const float4*>(g.x + (spos[j] >= 0 ? spos[j] : 0) + (ok_ ? (int64_t)(DY) * g.F * C : 0)); \
     }
 #define XCONV_STORE(SLOT, BUF)                                                                                \
     _Pragma("unroll") for (int j = 0; j < NS; ++j) {                                                          \
         if (j < ns && tid + 256 * j < SROWS * cq4) {                                                          \
+            if (!(vmask[SLOT] >> j & 1)) v[SLOT][j] = make_float4(0.f, 0.f, 0.f, 0.f);                        \
             uint2 h, l;                                                                                       \
             split_bf16x2(v[SLOT][j].x, v[SLOT][j].y, h.x, l.x);                                               \
             split_bf16x2(v[SLOT][j].z, v[SLOT][j].w, h.y, l.y);                                               \
@@ -499,6 +504,226 @@ __global__ __launch_bounds__(256) void xconv_kernel(XConvArgs g) {
     }
 #undef XCONV_LOAD
 #undef XCONV_STORE
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Conv2d(3x3) WEIGHT gradient for C_in = 32, C_out = 32 / 64:  G[(tap, ci)][co] = sum_p x[p + off(tap)][ci] * dy[p][co].
+// In the generic kernel the contraction runs over a million positions and every tap re-fetches and re-converts its own shifted copy
+// of x (9 x) and every 128-row tile its own copy of dy (3 x).  Here ONE block keeps the whole 288 x C_out gradient in registers
+// (36 / 72 per thread) and streams over its share of the positions, 32 at a time:
+//   * per kernel row dy one strip of 48 positions x 32 channels of x is fetched, split into hi / lo bf16 ONCE and stored TRANSPOSED
+//     ([channel][position]: the contraction index must be contiguous in an MFMA operand); the three taps dx = -1, 0, +1 read it at a
+//     2-byte offset: the dx = 0 fragment is one aligned 16-byte read, the other two are cut out of a 32-byte window with
+//     v_alignbyte (LDS b128 reads want 16-byte alignment);
+//   * the dy tile (32 positions x C_out) is converted once and stored three times, once per dx, with the positions whose column
+//     f + dx falls off the band zeroed (the product must vanish there; masking the shared x strip per tap would cost a select per
+//     element); rows off the clip (t + dy) are zeroed in the x strip at load time.
+// 18 (tap, 16-channel) row fragments are dealt to the four waves (5, 5, 4, 4).  Partial gradients go to [block][288][C_out] and are
+// summed by xreduce_kernel in a fixed order.
+struct XWgradArgs {
+    const float* x;        // [positions][32]
+    const float* dy;       // [positions][CO]
+    float* partial;        // [gridDim.x][288][CO]
+    int64_t M;             // positions
+    int T, F;
+    int64_t steps_per_block;   // 32-position steps per block
+};
+
+constexpr int WG_C = 32;
+constexpr int WG_XP = 112;             // bytes per channel row of a strip: 48 positions x 2 B + 16 B pad
+constexpr int WG_DP = 80;              // bytes per output-channel row of a dy tile: 32 positions x 2 B + 16 B pad
+
+template <int NT>
+__global__ __launch_bounds__(256) void xwgrad_kernel(XWgradArgs g) {
+    constexpr int CO = 16 * NT;
+    __shared__ __attribute__((aligned(16))) char wsm[3 * 2 * WG_C * WG_XP + 3 * 2 * CO * WG_DP];
+    char* xs = wsm;                                  // [dy 3][plane 2][ci 32][WG_XP]
+    char* ds = wsm + 3 * 2 * WG_C * WG_XP;           // [dx 3][plane 2][co CO][WG_DP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t step0 = (int64_t)blockIdx.x * g.steps_per_block;
+    const int64_t nsteps_all = (g.M + 31) / 32;
+    const int64_t step1 = step0 + g.steps_per_block < nsteps_all ? step0 + g.steps_per_block : nsteps_all;
+
+    // this wave's row fragments: j = wave, wave + 4, ... < 18; fragment j = (tap = j / 2, channel half = j % 2)
+    constexpr int MAXF = 5;
+    f32x4_t acc[MAXF][NT];
+#pragma unroll
+    for (int a = 0; a < MAXF; ++a)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[a][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // x strip work items: 3 strips x (12 position quads x 8 channel quads) = 288 4x4 blocks, two rounds of 256 threads
+    // dy work items: 8 position quads x CO / 4 channel quads
+    constexpr int DYB = 8 * (CO / 4);                // 64 or 128 4x4 blocks of the dy tile
+    constexpr int DYR = (3 * DYB + 255) / 256;       // rounds of (block, dx variant) work items: 1 (C_out 32) or 2 (64)
+    float4 xv[2][4], dv[DYR][4];
+    unsigned xmask = 0, dmask = 0;                   // validity bits of the loads in flight (unconditional loads, mask at store)
+    // work distribution: x items 0..255 -> all threads, 256..287 -> threads 0..31; dy items (block, dx variant) are dealt from the
+    // LAST thread downwards (item = 255 - tid) so that the first wave, which has the second x round, gets none of them
+    auto dy_item = [&](int r) __attribute__((always_inline)) { return r == 0 ? 255 - tid : 256 + tid; };
+    // (column, frame) of this thread's first strip position of each round and column of its first dy position, advanced by 32
+    // positions per step (no division in the loop)
+    int xf[2], xt[2], df[DYR];
+    {
+        const int64_t tf = (int64_t)g.T * g.F;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = tid + 256 * r, rem = idx % 96, pq = rem >> 3;
+            const int64_t bb = step0 * 32 - 8 + 4 * pq + 8 * tf;               // + a multiple of a clip: non-negative, same (t, f)
+            xf[r] = (int)(bb % g.F);
+            xt[r] = (int)((bb / g.F) % g.T);
+        }
+#pragma unroll
+        for (int r = 0; r < DYR; ++r) {
+            const int blk = min(dy_item(r), 3 * DYB - 1) % DYB;
+            df[r] = (int)((step0 * 32 + 4 * (blk / (CO / 4))) % g.F);
+        }
+    }
+    auto load_step = [&](int64_t step) __attribute__((always_inline)) {
+        const int64_t p0 = step * 32;
+        xmask = dmask = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = min(tid + 256 * r, 287);                               // threads past the 288 work items repeat the last one (never stored)
+            const int dyi = idx / 96, rem = idx - dyi * 96, pq = rem >> 3, cq = rem & 7;
+            int f = xf[r], t = xt[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t b = p0 - 8 + 4 * pq + j;                             // base position (same row as the outputs that use it)
+                const bool inside = b >= 0 && b < g.M;
+                const bool ok = inside && (unsigned)(t + dyi - 1) < (unsigned)g.T;
+                xmask |= (unsigned)ok << (4 * r + j);
+                const int64_t bc = inside ? b : (b < 0 ? 0 : g.M - 1);
+                xv[r][j] = *reinterpret_cast<const float4*>(g.x + (bc + (ok ? (int64_t)(dyi - 1) * g.F : 0)) * WG_C + 4 * cq);
+                if (++f == g.F) { f = 0; if (++t == g.T) t = 0; }
+            }
+            xf[r] += 32;
+            while (xf[r] >= g.F) { xf[r] -= g.F; if (++xt[r] == g.T) xt[r] = 0; }
+        }
+#pragma unroll
+        for (int r = 0; r < DYR; ++r) {
+            const int blk = min(dy_item(r), 3 * DYB - 1) % DYB;
+            const int pq = blk / (CO / 4), cq = blk - pq * (CO / 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t p = p0 + 4 * pq + j;
+                dmask |= (unsigned)(p < g.M) << (4 * r + j);
+                dv[r][j] = *reinterpret_cast<const float4*>(g.dy + (p < g.M ? p : g.M - 1) * CO + 4 * cq);
+            }
+        }
+    };
+    auto comp = [](const float4& v, int e) __attribute__((always_inline)) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
+    auto store_step = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(xmask >> (4 * r + j) & 1)) xv[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < DYR; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (!(dmask >> (4 * r + j) & 1)) dv[r][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int idx = tid + 256 * r;
+            if (idx < 288) {
+                const int dyi = idx / 96, rem = idx - dyi * 96, pq = rem >> 3, cq = rem & 7;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                                       // channel 4 cq + e: four consecutive positions
+                    uint2 h, l;
+                    split_bf16x2(comp(xv[r][0], e), comp(xv[r][1], e), h.x, l.x);
+                    split_bf16x2(comp(xv[r][2], e), comp(xv[r][3], e), h.y, l.y);
+                    const int off = ((dyi * 2) * WG_C + 4 * cq + e) * WG_XP + pq * 8;
+                    *reinterpret_cast<uint2*>(xs + off) = h;
+                    *reinterpret_cast<uint2*>(xs + off + WG_C * WG_XP) = l;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DYR; ++r) {
+            const int item = dy_item(r);
+            bool zero[4];                                                            // dx = -1: column 0, dx = +1: column F - 1 of the band
+            {
+                const int dxi = min(item, 3 * DYB - 1) / DYB;
+                int f = df[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    zero[j] = (dxi == 0 && f == 0) || (dxi == 2 && f == g.F - 1);
+                    if (++f == g.F) f = 0;
+                }
+                df[r] += 32;
+                while (df[r] >= g.F) df[r] -= g.F;
+            }
+            if (item >= 0 && item < 3 * DYB) {
+                const int dxi = item / DYB, blk = item - dxi * DYB;
+                const int pq = blk / (CO / 4), cq = blk - pq * (CO / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) u[j] = zero[j] ? 0.f : comp(dv[r][j], e);
+                    uint2 h, l;
+                    split_bf16x2(u[0], u[1], h.x, l.x);
+                    split_bf16x2(u[2], u[3], h.y, l.y);
+                    const int off = ((dxi * 2) * CO + 4 * cq + e) * WG_DP + pq * 8;
+                    *reinterpret_cast<uint2*>(ds + off) = h;
+                    *reinterpret_cast<uint2*>(ds + off + CO * WG_DP) = l;
+                }
+            }
+        }
+    };
+    // 16-byte fragment of 8 consecutive positions starting `shift` bf16 into an aligned 32-byte window
+    auto frag = [](const char* base, int dxi) __attribute__((always_inline)) -> uint4 {
+        // base = address of strip position 8 c + 8 (16-byte aligned); dx = dxi - 1 moves the start by 2 dx bytes
+        if (dxi == 1) return *reinterpret_cast<const uint4*>(base);
+        if (dxi == 0) {   // bytes [base - 2, base + 14): window [base - 16, base + 16), byte offset 14 = dword 3 + 2 bytes
+            const uint4 w0 = *reinterpret_cast<const uint4*>(base - 16), w1 = *reinterpret_cast<const uint4*>(base);
+            return make_uint4(__builtin_amdgcn_alignbyte(w1.x, w0.w, 2), __builtin_amdgcn_alignbyte(w1.y, w1.x, 2),
+                              __builtin_amdgcn_alignbyte(w1.z, w1.y, 2), __builtin_amdgcn_alignbyte(w1.w, w1.z, 2));
+        }
+        const uint4 w0 = *reinterpret_cast<const uint4*>(base), w1 = *reinterpret_cast<const uint4*>(base + 16);   // bytes [base + 2, base + 18)
+        return make_uint4(__builtin_amdgcn_alignbyte(w0.y, w0.x, 2), __builtin_amdgcn_alignbyte(w0.z, w0.y, 2),
+                          __builtin_amdgcn_alignbyte(w0.w, w0.z, 2), __builtin_amdgcn_alignbyte(w1.x, w0.w, 2));
+    };
+
+    if (step0 < step1) load_step(step0);
+    for (int64_t step = step0; step < step1; ++step) {
+        store_step();
+        __syncthreads();
+        if (step + 1 < step1) load_step(step + 1);
+        const int arow = (lane & 15) * WG_XP + (lane >> 4) * 16 + 16;      // strip position 8 (lane >> 4) + 8 of channel row lane & 15
+        const int brow = (lane & 15) * WG_DP + (lane >> 4) * 16;
+#pragma unroll
+        for (int a = 0; a < MAXF; ++a) {
+            const int j = wave + 4 * a;
+            if (j < 18) {
+                const int tap = j >> 1, half = j & 1, dyi = tap / 3, dxi = tap - 3 * dyi;
+                const char* xb = xs + ((dyi * 2) * WG_C + 16 * half) * WG_XP + arow;
+                const uint4 ah = frag(xb, dxi), al = frag(xb + WG_C * WG_XP, dxi);
+                const char* db = ds + (dxi * 2) * CO * WG_DP + brow;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const uint4 bh = *reinterpret_cast<const uint4*>(db + 16 * n * WG_DP);
+                    const uint4 bl = *reinterpret_cast<const uint4*>(db + CO * WG_DP + 16 * n * WG_DP);
+                    acc[a][n] = xmfma(ah, bh, acc[a][n]);
+                    acc[a][n] = xmfma(ah, bl, acc[a][n]);
+                    acc[a][n] = xmfma(al, bh, acc[a][n]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = g.partial + (int64_t)blockIdx.x * 288 * CO;
+#pragma unroll
+    for (int a = 0; a < MAXF; ++a) {
+        const int j = wave + 4 * a;
+        if (j >= 18) continue;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) out[(16 * j + 4 * (lane >> 4) + rr) * CO + 16 * n + (lane & 15)] = acc[a][n][rr];
+    }
 }
 
 // out[i] = sum_s partial[s * stride + i] (+ bias[i % ncols]) in a fixed order: 64 outputs per block, four lanes per output walk the
@@ -728,7 +953,8 @@ size_t conv_ws_w(int c_in, int c_out) { return ((size_t)9 * c_in * c_out * sizeo
 extern "C" size_t amtx_conv3x3_train_workspace_bytes(int64_t rows, int num_bins, int c_in, int c_out) {
     const int64_t positions = rows * num_bins;
     const size_t split = amtx_matmul_workspace_bytes((int64_t)9 * c_in, c_out, positions);
-    const size_t image = (size_t)2 * 64 * (18 * std::max(c_in, c_out) + 16);                     // weight image of the strip kernel
+    const size_t image = std::max<size_t>((size_t)2 * 64 * (18 * std::max(c_in, c_out) + 16),    // weight image of the strip kernel
+                                          (size_t)768 * 288 * c_out * sizeof(float));           // partial gradients of xwgrad_kernel
     return 2 * conv_ws_w(c_in, c_out) + std::max(std::max<size_t>(split, (size_t)256 * c_out * sizeof(float)), image) + 256;
 }
 
@@ -780,8 +1006,23 @@ extern "C" int amtx_conv3x3_bwd(const float* dy, const float* x, const float* w,
     }
     if (dw) {   // G[(tap, ci)][co] = sum_pos x[pos + off(tap)][ci] dy[pos][co], then back to (c_out, c_in, 3, 3)
         AMTX_REQUIRE(x && (c_in == 1 || c_in % 4 == 0), "amtx_conv3x3_bwd: dw needs x and c_in = 1 or a multiple of 4");
-        XOp A{x, 0, XK_CONV_COLS, frames_per_clip, num_bins, c_in};
-        if ((rc = matmul(A, cols_op(dy, c_out), nullptr, gt, c_out, (int64_t)9 * c_in, c_out, positions, rest, rest_bytes, stream)) != AMTX_OK) return rc;
+        const int wg_blocks = (int)std::min<int64_t>(768, (positions + 31) / 32);
+        if (c_in == WG_C && (c_out == 32 || c_out == 64) && rest_bytes >= (size_t)wg_blocks * 288 * c_out * sizeof(float)) {
+            XWgradArgs wa{x, dy, static_cast<float*>(rest), positions, frames_per_clip, num_bins, 0};
+            const int64_t nsteps = (positions + 31) / 32;
+            wa.steps_per_block = (nsteps + wg_blocks - 1) / wg_blocks;
+            const int used = (int)((nsteps + wa.steps_per_block - 1) / wa.steps_per_block);
+            if (c_out == 32) hipLaunchKernelGGL(xwgrad_kernel<2>, dim3(used), dim3(256), 0, stream, wa);
+            else hipLaunchKernelGGL(xwgrad_kernel<4>, dim3(used), dim3(256), 0, stream, wa);
+            AMTX_CHECK_LAUNCH();
+            const int64_t count = (int64_t)288 * c_out;
+            hipLaunchKernelGGL(xreduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, stream, (const float*)rest, used, count, count,
+                               (const float*)nullptr, c_out, gt);
+            AMTX_CHECK_LAUNCH();
+        } else {
+            XOp A{x, 0, XK_CONV_COLS, frames_per_clip, num_bins, c_in};
+            if ((rc = matmul(A, cols_op(dy, c_out), nullptr, gt, c_out, (int64_t)9 * c_in, c_out, positions, rest, rest_bytes, stream)) != AMTX_OK) return rc;
+        }
         hipLaunchKernelGGL(conv_w_permute_kernel, dim3((unsigned)((9 * c_in * c_out + 255) / 256)), dim3(256), 0, stream, (const float*)gt, dw, c_out, c_in, 2);
         AMTX_CHECK_LAUNCH();
     }
