@@ -16,6 +16,11 @@ struct GemmArgs {
     void* C; int64_t ldc; int c_type;
     int64_t M; int N, K;
     int groups; int64_t a_gs, w_gs, bias_gs, c_gs;       // per-group strides in elements (grid.z = groups)
+    // optional magnitude epilogue (fp32-A / fp32-C kernel only; the CQT basis products): columns (2p, 2p+1) are (re, im) of output
+    // pair p and what is stored is sqrt(re^2 + im^2), TRANSPOSED: pair_out[grp * pair_gs + pair_map[p].x * pair_pitch + m] for rows
+    // m < pair_rows[pair_map[p].y]; C is not written.
+    const int2* pair_map = nullptr; float* pair_out = nullptr; int64_t pair_gs = 0, pair_pitch = 0;
+    int pair_rows[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);
 void amtx_gemm_pack_dims(int N, int K, int* n_pad, int* k_pad);

@@ -230,45 +230,6 @@ __global__ __launch_bounds__(256) void cqt_pad_kernel(float* __restrict__ pyr, i
     }
 }
 
-// |R| of every bank of one level -> mag[b][h][bin][t] for t < frames(bank): a (time x filter) -> (filter x time) transpose,
-// staged through a 32 x 33 LDS tile so that both the reads (filters contiguous in R) and the writes (frames contiguous in
-// mag) are coalesced.  grid = (time tiles, banks, clips); a block walks the bank's filter tiles.
-__global__ __launch_bounds__(256) void cqt_mag_kernel(const float* __restrict__ R, LevelDev lv, int64_t t_level, int n_harm, int n_bins,
-                                                      int64_t t_buf, float* __restrict__ mag) {
-    __shared__ float tile[32][33];
-    const int b = blockIdx.z;
-    const int bank = blockIdx.y;
-    if (bank >= lv.nbanks) return;
-    const BankDev bk = lv.b[bank];
-    const float* Rb = R + (int64_t)b * t_level * lv.ncols;
-    float* mb = mag + (((int64_t)b * n_harm + bk.harm) * n_bins + bk.bin0) * t_buf;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8
-    for (int64_t t0 = (int64_t)blockIdx.x * 32; t0 < bk.frames; t0 += (int64_t)gridDim.x * 32) {
-        for (int k0 = 0; k0 < bk.nf; k0 += 32) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t t = t0 + ty + 8 * r;
-                const int k = k0 + tx;
-                float v = 0.f;
-                if (t < bk.frames && k < bk.nf) {
-                    const float re = Rb[t * lv.ncols + bk.col0 + k];
-                    const float im = Rb[t * lv.ncols + bk.col0 + bk.nf + k];
-                    v = sqrtf(re * re + im * im);
-                }
-                tile[ty + 8 * r][tx] = v;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = k0 + ty + 8 * r;
-                const int64_t t = t0 + tx;
-                if (t < bk.frames && k < bk.nf) mb[(int64_t)k * t_buf + t] = tile[tx][ty + 8 * r];
-            }
-            __syncthreads();
-        }
-    }
-}
-
 // max over one (clip, harmonic) map [n_bins][frames_h] (row pitch t_buf)
 __global__ __launch_bounds__(256) void cqt_max_kernel(const float* __restrict__ mag, HarmFrames frames_h, int n_harm, int n_bins,
                                                       int64_t t_buf, float* __restrict__ maxbuf) {
@@ -316,6 +277,7 @@ struct Level {
     std::vector<float> W;          // [ncols][nfft] fp32 row-major (built incrementally per bank at bank nfft, re-centred later)
     std::vector<std::pair<int, std::vector<std::complex<double>>>> raw;   // (bank nfft, kernels nf x nfft)
     bf16_t* d_w = nullptr;
+    int2* d_map = nullptr;          // per output pair (filter): {row of the (harmonic, bin) in the magnitude map, harmonic}
     int n_pad = 0, k_pad = 0;
 };
 
@@ -406,8 +368,10 @@ void build_bank(const std::vector<double>& freqs, double sr_i, double sr_base, d
 
 extern "C" int amtx_cqt_plan_destroy(amtx_cqt_plan* p) {
     if (!p) return AMTX_OK;
-    for (auto& l : p->levels)
+    for (auto& l : p->levels) {
         if (l.d_w) (void)hipFree(l.d_w);
+        if (l.d_map) (void)hipFree(l.d_map);
+    }
     if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_tfrag) (void)hipFree(p->d_tfrag);
     delete p;
@@ -487,8 +451,9 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
             for (int k = 0; k < bd.nf; ++k)
                 for (int n = 0; n < nfft; ++n) {
                     const std::complex<double> v = L.raw[bi].second[(size_t)k * nfft + n];
-                    W[(size_t)(bd.col0 + k) * L.nfft + off + n] = (float)v.real();
-                    W[(size_t)(bd.col0 + bd.nf + k) * L.nfft + off + n] = (float)v.imag();
+                    // (re, im) of a filter in neighbouring columns: the GEMM's magnitude epilogue combines them in registers
+                    W[(size_t)(bd.col0 + 2 * k) * L.nfft + off + n] = (float)v.real();
+                    W[(size_t)(bd.col0 + 2 * k + 1) * L.nfft + off + n] = (float)v.imag();
                 }
         }
         L.raw.clear();
@@ -497,6 +462,13 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
         amtx_gemm_pack_host(W.data(), L.nfft, L.ncols, L.nfft, 2, packed.data());
         hipError_t e = hipMalloc(&L.d_w, packed.size() * 2);
         if (e == hipSuccess) e = hipMemcpy(L.d_w, packed.data(), packed.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            std::vector<int2> map((size_t)L.ncols / 2);
+            for (const BankDev& bd : L.banks)
+                for (int k = 0; k < bd.nf; ++k) map[(size_t)bd.col0 / 2 + k] = make_int2(bd.harm * n_bins + bd.bin0 + k, bd.harm);
+            e = hipMalloc(&L.d_map, map.size() * sizeof(int2));
+            if (e == hipSuccess) e = hipMemcpy(L.d_map, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice);
+        }
         if (e != hipSuccess) {
             amtx_set_error("amtx_cqt_plan_create: weight upload failed: %s", hipGetErrorString(e));
             amtx_cqt_plan_destroy(p);
@@ -586,11 +558,8 @@ CqtDims dims(const amtx_cqt_plan* p, int B, int64_t n) {
         d.pyr_off[l] = off;
         off += ((size_t)B * d.stride[l] * 4 + 255) & ~(size_t)255;
     }
-    d.off_r = off;
-    for (int l = 0; l < nl; ++l) {
-        d.r_off[l] = off;
-        off += ((size_t)B * d.frames[l] * p->levels[l].ncols * 4 + 255) & ~(size_t)255;
-    }
+    d.off_r = off;          // (the complex responses used to live here; the GEMM's magnitude epilogue writes the map directly)
+    for (int l = 0; l < nl; ++l) d.r_off[l] = off;
     const int n_oct = (p->n_bins + p->bpo - 1) / p->bpo;
     d.frames_h.resize(p->n_harm);
     int64_t tmin = -1, tref = -1;
@@ -671,21 +640,19 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
     for (int l = 0; l < nl; ++l) {
         const Level& L = p->levels[l];
         if (L.banks.empty()) continue;
-        float* R = (float*)(ws + d.r_off[l]);
+        // the basis product with the magnitude epilogue: |re + i im| of every filter goes straight into mag[b][harmonic][bin][t]
+        // (transposed, truncated to the harmonic's frame count); the complex response never touches HBM (it was written by the GEMM
+        // and read back by a magnitude / transpose kernel: 0.4 GB per level and 512 clips, a third of the front-end's traffic)
         GemmArgs g;
         g.A = (const float*)(ws + d.pyr_off[l]) + (p->pad - L.nfft / 2); g.lda = L.hop; g.a_type = AMTX_T_F32;
         g.W = L.d_w; g.n_pad = L.n_pad; g.k_pad = L.k_pad; g.planes = 2; g.bias = nullptr;
-        g.C = R; g.ldc = L.ncols; g.c_type = AMTX_T_F32;
+        g.C = nullptr; g.ldc = L.ncols; g.c_type = AMTX_T_F32;
         g.M = d.frames[l]; g.N = L.ncols; g.K = L.nfft;
-        g.groups = B; g.a_gs = d.stride[l]; g.w_gs = 0; g.bias_gs = 0; g.c_gs = d.frames[l] * L.ncols;
+        g.groups = B; g.a_gs = d.stride[l]; g.w_gs = 0; g.bias_gs = 0; g.c_gs = 0;
+        g.pair_map = L.d_map; g.pair_out = mag; g.pair_gs = (int64_t)p->n_harm * p->n_bins * d.t_buf; g.pair_pitch = d.t_buf;
+        for (int h = 0; h < p->n_harm && h < 16; ++h) g.pair_rows[h] = d.frames_h[h];
         int rc = amtx_launch_gemm(g, s);
         if (rc != AMTX_OK) return rc;
-        LevelDev lv;
-        lv.nbanks = (int)L.banks.size(); lv.ncols = L.ncols;
-        for (int i = 0; i < lv.nbanks; ++i) { lv.b[i] = L.banks[i]; lv.b[i].frames = d.frames_h[L.banks[i].harm]; }
-        hipLaunchKernelGGL(cqt_mag_kernel, dim3((unsigned)std::min<int64_t>(64, (d.frames[l] + 31) / 32), lv.nbanks, B), dim3(256), 0, s, (const float*)R, lv, d.frames[l], p->n_harm, p->n_bins,
-                           d.t_buf, mag);
-        AMTX_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(cqt_max_kernel, dim3(B * p->n_harm), dim3(256), 0, s, (const float*)mag, hf, p->n_harm, p->n_bins,
                        d.t_buf, maxbuf);

@@ -170,6 +170,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[r] = bias[n + r];
         }
+        if (C_TYPE == AMTX_T_F32 && g.pair_map) {
+            // magnitude epilogue: this lane's four columns are two (re, im) pairs; 16 lanes = 16 consecutive rows m -> 64 contiguous
+            // bytes of the transposed (pair-major) output
+            const int2 pa = g.pair_map[n >> 1], pb = g.pair_map[(n >> 1) + (n + 2 < g.N ? 1 : 0)];
+            float* po = g.pair_out + (int64_t)grp * g.pair_gs;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
+                const f32x4_t v = acc[nt][mt];
+                if (m < g.pair_rows[pa.y & 15]) po[(int64_t)pa.x * g.pair_pitch + m] = sqrtf(v[0] * v[0] + v[1] * v[1]);
+                if (n + 2 < g.N && m < g.pair_rows[pb.y & 15]) po[(int64_t)pb.x * g.pair_pitch + m] = sqrtf(v[2] * v[2] + v[3] * v[3]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
@@ -688,7 +702,8 @@ void amtx_gemm_pack_host(const float* W, int64_t ldw, int N, int K, int planes, 
 }
 
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
-    AMTX_REQUIRE(g.A && g.W && g.C, "gemm: null pointer");
+    AMTX_REQUIRE(g.A && g.W && (g.C || g.pair_map), "gemm: null pointer");
+    AMTX_REQUIRE(!g.pair_map || (g.a_type == AMTX_T_F32 && g.c_type == AMTX_T_F32 && g.pair_out && g.N % 2 == 0), "gemm: the magnitude epilogue needs fp32 A / C, an output and an even N");
     AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
     AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
     AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
