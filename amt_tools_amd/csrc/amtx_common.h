@@ -98,6 +98,28 @@ static __device__ __forceinline__ float wave_max_f32(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
     return v;
 }
+// dB scaling of one power value (librosa.power_to_db with top_db = 80 relative to the clip's own maximum, then / 80 + 1; reference:
+// amt_tools/features/common.py:199,218-228).  ONE definition, contraction pinned, for spec_scale_kernel and for the conv kernel that
+// applies it to raw power values while staging them: both paths produce the same bits.  10 log10(x) is 10 log10(2) * v_log_f32(x)
+// (the argument is clamped to >= 1e-10, so the hardware log2 sees no denormals; its ~1 ulp error is ~1e-7 on the scaled feature,
+// three orders below the 1e-4 the features are held to) and / 80 is a multiplication: the conv kernel runs this per staged value.
+struct DbScale { float offs, floor_db; };
+static __device__ __forceinline__ float db_of_power(float s) {
+#pragma clang fp contract(off)
+    return 3.01029995663981195f * __log2f(fmaxf(1e-10f, s));
+}
+static __device__ __forceinline__ DbScale db_scale_make(float own_max, float ref) {
+#pragma clang fp contract(off)
+    DbScale d;
+    d.offs = db_of_power(ref);
+    d.floor_db = (db_of_power(own_max) - d.offs) - 80.0f;   // log_spec.max() - top_db
+    return d;
+}
+static __device__ __forceinline__ float db_scale_apply(float s, DbScale d) {
+#pragma clang fp contract(off)
+    const float db = fmaxf(db_of_power(s) - d.offs, d.floor_db);
+    return db * 0.0125f + 1.0f;
+}
 static __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -41,6 +41,9 @@ struct ConvArgs {
     int c_in = 0;
     const bf16_t* w1frag = nullptr; const float* shift1 = nullptr;   // per-group strides: w1_gs, 32
     int64_t w1_gs = 0;
+    // c_in = 1 only: `feats` holds raw POWER values and the kernel applies the dB scaling (db_scale_apply, amtx_common.h) while it stages
+    // them: f_clip_max[b] = the clip's own maximum, f_ref[b] = the reference power (null: the own maximum).  Null f_clip_max: features as is.
+    const float* f_clip_max = nullptr; const float* f_ref = nullptr;
     int64_t out_ts = 0;                                  // convg.hip only: elements between consecutive (b, t) rows of `out`; 0 = (F/2) * c_out
 };
 int amtx_launch_conv3x3(const ConvArgs& c, hipStream_t stream);

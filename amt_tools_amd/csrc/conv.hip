@@ -126,10 +126,6 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int 
 constexpr int conv_threads(bool fuse1, int ks, int ns) { return 256; }
 __device__ uint4 g_conv_zero16;              // zero-initialised: source of padded positions (DMA staging)
 __device__ uint4 g_conv_trash[4];            // sink of masked stores (kernels that count their store instructions)
-#ifndef AMTX_CONV_EXP
-#define AMTX_CONV_EXP 0
-#endif
-constexpr bool EXP_NOLOAD = (AMTX_CONV_EXP & 1) != 0, EXP_NOSTORE = (AMTX_CONV_EXP & 2) != 0;
 
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS>
 __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_threads(FUSE1, KS, NS) / 128 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
@@ -261,6 +257,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     unsigned premask = 0;        // PREFETCH: bit n = item n of the tile in flight is inside the image
     int stores_since = 0;        // PREFETCH: store instructions this wave issued after the loads in flight (uniform)
     float fpre[FPRE];
+    float fown = 0.f, fref = 0.f;   // dB staging (a.f_clip_max): the prefetched tile's clip maximum and reference power
     int tile = blockIdx.x;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -316,8 +313,12 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             const int it = tid + NTH * n;                                                                  \
             const int fi = it / fcols, fj = it - fi * fcols;                                               \
             const int t = (TC).t0 - 2 + fi, f = (TC).f0 - 2 + fj;                                          \
-            fpre[n] = 0.f;                                                                                 \
+            fpre[n] = a.f_clip_max ? -1.f : 0.f; /* power is never negative: -1 marks the zero padding */  \
             if (it < fitems && t >= 0 && t < a.T && f >= 0 && f < a.F) fpre[n] = fb[t * a.f_stride_t + f * a.f_stride_f]; \
+        }                                                                                                  \
+        if (a.f_clip_max) {                                                                                \
+            fown = a.f_clip_max[(TC).b];                                                                   \
+            fref = a.f_ref ? a.f_ref[(TC).b] : fown;                                                       \
         }                                                                                                  \
     } while (0)
 
@@ -345,12 +346,30 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             // ---- fused first conv: features (c_in, 20 x (ft+4)) -> LDS, then Conv(c_in->32)+BN+ReLU on the matrix cores
             // (K = 9*c_in in steps of 16, im2col patches gathered from LDS as the MFMA B operand), written straight
             // into this kernel's input tile in fragment order.  a1 never touches HBM.
+            DbScale dbs = {0.f, 0.f};
+            if (a.f_clip_max) {
+                if (!fprefetch) {
+                    fown = a.f_clip_max[tc.b];
+                    fref = a.f_ref ? a.f_ref[tc.b] : fown;
+                }
+                dbs = db_scale_make(fown, fref);
+            }
             if (fprefetch) {
+                // opaque copy of the thread index: the (row, column) of the FPRE cells are tile-invariant, and hoisted out of the
+                // persistent loop they sit in registers next to the stationary weights and spill (a scratch reload = vmcnt(0) =
+                // a wait for the previous tile's stores at every tile top)
+                int tid_f = tid;
+                asm volatile("" : "+v"(tid_f));
 #pragma unroll
                 for (int n = 0; n < FPRE; ++n) {
-                    const int it = tid + NTH * n;
+                    const int it = tid_f + NTH * n;
                     const int fi = it / fcols, fj = it - fi * fcols;
-                    if (it < fitems) ftile[fi * FW + fj] = fpre[n];
+                    float v = fpre[n];
+                    if (a.f_clip_max) {
+                        const float sv = db_scale_apply(v, dbs);   // branch-free: a handful of instructions, the select drops the padding
+                        v = v < 0.f ? 0.f : sv;
+                    }
+                    if (it < fitems) ftile[fi * FW + fj] = v;
                 }
             } else {
                 const float* fb = a.feats + (int64_t)tc.b * a.f_stride_b;
@@ -359,7 +378,10 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
                     const int fi = r / fcols, fj = r - fi * fcols;
                     const int t = t0 - 2 + fi, f = f0 - 2 + fj;
                     float v = 0.f;
-                    if (t >= 0 && t < a.T && f >= 0 && f < a.F) v = fb[ci * a.f_stride_c + t * a.f_stride_t + f * a.f_stride_f];
+                    if (t >= 0 && t < a.T && f >= 0 && f < a.F) {
+                        v = fb[ci * a.f_stride_c + t * a.f_stride_t + f * a.f_stride_f];
+                        if (a.f_clip_max) v = db_scale_apply(v, dbs);
+                    }
                     ftile[(ci * FROWS + fi) * FW + fj] = v;
                 }
             }
@@ -769,7 +791,6 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
                     if (PREFETCH) stores_since += NTW / 2;
 #pragma unroll
                     for (int q = 0; q < NTW / 2; ++q)
-                        if (!(AMTX_CONV_EXP & 8) || v[8 * q] == 123.456f)   // experiment switch: no stores
                         dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
                                             pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
                 } else {

@@ -395,11 +395,15 @@ static GemmArgs gemm_args(const void* A, int64_t lda, int a_type, const LinearPa
     return g;
 }
 
-extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
-                               int64_t stride_f, int batch, int num_frames, void* workspace, size_t workspace_bytes,
-                               float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
-                               float* logits_pitch_head, void* stream_) {
+extern "C" int amtx_of_fuses_db_scale(const amtx_of_model* m);
+
+// clip_max != null: `feats` are raw power values, dB-scaled by the conv kernel while it stages them (amtx_of_forward_power)
+static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+                           int64_t stride_f, const float* clip_max, const float* ref, int batch, int num_frames, void* workspace,
+                           size_t workspace_bytes, float* out_onsets, float* out_multi_pitch, float* logits_onsets,
+                           float* logits_multi_pitch, float* logits_pitch_head, void* stream_) {
     AMTX_REQUIRE(m && m->finalized, "amtx_of_forward: model not finalized");
+    AMTX_REQUIRE(!clip_max || amtx_of_fuses_db_scale(m), "amtx_of_forward_power: this model does not stage its features in the conv kernel");
     AMTX_REQUIRE(feats && workspace, "amtx_of_forward: null pointer");
     AMTX_REQUIRE(batch > 0 && num_frames > 0, "amtx_of_forward: bad batch/num_frames");
     const int B = batch, T = num_frames;
@@ -441,6 +445,7 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
         c2.feats = feats; c2.f_stride_b = stride_b; c2.f_stride_c = stride_c; c2.f_stride_t = stride_t; c2.f_stride_f = stride_f;
         c2.c_in = m->in_channels; c2.w1frag = (const bf16_t*)m->conv1_frag.p; c2.shift1 = (const float*)m->conv1_s.p;
         c2.w1_gs = (int64_t)(m->gen_conv2 ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, pl) : amtx_conv1_wfrag_elems(m->in_channels, pl));
+        c2.f_clip_max = clip_max; c2.f_ref = ref;
     }
     if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
     mark();
@@ -525,6 +530,27 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
 
 // OnsetsFrames2: the offset head's LogisticBank output of the LAST amtx_of_forward on this workspace
 // (onsetsframes.py:256-261,323-325: finalize_output without a threshold = sigmoid probabilities, (B, n_out, T)).
+extern "C" int amtx_of_fuses_db_scale(const amtx_of_model* m) {
+    return m && m->finalized && m->fuse_conv1 && !m->gen_conv2 && m->in_channels == 1;
+}
+
+extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+                               int64_t stride_f, int batch, int num_frames, void* workspace, size_t workspace_bytes,
+                               float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
+                               float* logits_pitch_head, void* stream_) {
+    return of_forward_impl(m, feats, stride_b, stride_c, stride_t, stride_f, nullptr, nullptr, batch, num_frames, workspace, workspace_bytes,
+                           out_onsets, out_multi_pitch, logits_onsets, logits_multi_pitch, logits_pitch_head, stream_);
+}
+
+extern "C" int amtx_of_forward_power(const amtx_of_model* m, const float* power, int64_t stride_b, int64_t stride_t, int64_t stride_f,
+                                     const float* clip_max, const float* ref, int batch, int num_frames, void* workspace,
+                                     size_t workspace_bytes, float* out_onsets, float* out_multi_pitch, float* logits_onsets,
+                                     float* logits_multi_pitch, float* logits_pitch_head, void* stream_) {
+    AMTX_REQUIRE(clip_max, "amtx_of_forward_power: clip_max is null");
+    return of_forward_impl(m, power, stride_b, 0, stride_t, stride_f, clip_max, ref, batch, num_frames, workspace, workspace_bytes,
+                           out_onsets, out_multi_pitch, logits_onsets, logits_multi_pitch, logits_pitch_head, stream_);
+}
+
 extern "C" int amtx_of_offsets(const amtx_of_model* m, void* workspace, size_t workspace_bytes, int batch, int num_frames, float* out_offsets,
                                float* logits_offsets, void* stream_) {
     AMTX_REQUIRE(m && m->finalized, "amtx_of_offsets: model not finalized");

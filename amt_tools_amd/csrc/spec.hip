@@ -450,13 +450,10 @@ __global__ __launch_bounds__(256) void spec_scale_kernel(const float* __restrict
     const int f0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
 
-    float offs = 0.0f, floor_db = 0.0f;
+    DbScale dbs = {0.0f, 0.0f};
     if (transform == AMTX_SCALE_DB) {
-        const float amin = 1e-10f;
         const float own = clip_max[b];
-        const float r = ref ? ref[b] : own;
-        offs = 10.0f * log10f(fmaxf(amin, r));
-        floor_db = (10.0f * log10f(fmaxf(amin, own)) - offs) - 80.0f;   // log_spec.max() - top_db
+        dbs = db_scale_make(own, ref ? ref[b] : own);
     }
     const float* src = power + (int64_t)b * num_frames * n_bins;
 #pragma unroll
@@ -467,9 +464,7 @@ __global__ __launch_bounds__(256) void spec_scale_kernel(const float* __restrict
         if (t < num_frames && f < n_bins) {
             const float s = src[t * n_bins + f];
             if (transform == AMTX_SCALE_DB) {
-                float db = 10.0f * log10f(fmaxf(1e-10f, s)) - offs;
-                db = fmaxf(db, floor_db);
-                v = db / 80.0f + 1.0f;
+                v = db_scale_apply(s, dbs);
             } else if (transform == AMTX_SCALE_MAGNITUDE) {
                 v = sqrtf(s);
             } else {

@@ -25,6 +25,8 @@ accuracy) selects the engine's dense arithmetic.
 import ctypes as C
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -247,6 +249,23 @@ class SpectralFrontend(nn.Module):
         return self.module.process_batch(audio[:, 0].float())                            # CQT family: (B,C,F,T)
 
 
+class PendingFeatures(object):
+    """What OnsetsFrames.pre_proc puts under KEY_FEATS inside run_on_batch when the dB scaling of the front-end is deferred into the
+    engine's first conv kernel (amtx_of_forward_power): the raw power mel spectrogram (B,T,F), the clips' own maxima (B,) and the
+    FeatureModule that would finish them.  `materialize()` is the ordinary feature tensor (B,1,T,F), bit-identical to what the conv
+    kernel stages."""
+
+    def __init__(self, module, power, clip_max):
+        self.module, self.power, self.clip_max = module, power, clip_max
+
+    @property
+    def device(self):
+        return self.power.device
+
+    def materialize(self):
+        return self.module.scale_batch(self.power, self.clip_max, None, model_layout=True)
+
+
 class _OFEngine(object):
     """ctypes handle of an amtx_of_model + its workspace, bound to one device."""
 
@@ -279,9 +298,15 @@ class _OFEngine(object):
             _lib.check(L.amtx_of_model_finalize(self.handle), 'amtx_of_model_finalize')
         self.version = version
 
+    def fuses_db_scale(self):
+        return bool(_lib.lib().amtx_of_fuses_db_scale(self.handle))
+
     def forward(self, feats, want_logits=True):
-        """feats: (B,C,T,F) fp32 CUDA tensor (any strides).  Returns binary maps + raw logits."""
+        """feats: (B,C,T,F) fp32 CUDA tensor (any strides), or PendingFeatures.  Returns binary maps + raw logits."""
         L = _lib.lib()
+        pending = feats if isinstance(feats, PendingFeatures) else None
+        if pending is not None:
+            feats = pending.power.unsqueeze(1)
         B, Cc, T, Fd = feats.shape
         need = L.amtx_of_workspace_bytes(self.handle, B, T)
         if self.workspace is None or self.workspace.numel() < need:
@@ -296,9 +321,15 @@ class _OFEngine(object):
         lp = torch.empty((B, T, n_out), **opts) if want_logits else None
         sb, sc, st, sf = feats.stride()
         with torch.cuda.device(feats.device):
-            _lib.check(L.amtx_of_forward(self.handle, _lib.ptr(feats), sb, sc, st, sf, B, T, _lib.ptr(self.workspace),
-                                         self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch), _lib.ptr(lo),
-                                         _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)), 'amtx_of_forward')
+            if pending is not None:
+                _lib.check(L.amtx_of_forward_power(self.handle, _lib.ptr(feats), sb, st, sf, _lib.ptr(pending.clip_max), None, B, T,
+                                                   _lib.ptr(self.workspace), self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch),
+                                                   _lib.ptr(lo), _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)),
+                           'amtx_of_forward_power')
+            else:
+                _lib.check(L.amtx_of_forward(self.handle, _lib.ptr(feats), sb, sc, st, sf, B, T, _lib.ptr(self.workspace),
+                                             self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch), _lib.ptr(lo),
+                                             _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)), 'amtx_of_forward')
         self._last = (B, T)
         return onsets, multi_pitch, lo, lm, lp
 
@@ -360,9 +391,39 @@ class OnsetsFrames(TranscriptionModel):
         return eng
 
     def pre_proc(self, batch):
+        pending = self._deferred_scale(batch) if self.__dict__.get('_in_run_on_batch') else None
+        if pending is not None:
+            return pending
         batch = super().pre_proc(batch)
         # frequency <-> time (onsetsframes.py:90); a view, the engine takes strides
         batch[tools.KEY_FEATS] = batch[tools.KEY_FEATS].transpose(-1, -2)
+        return batch
+
+    def _deferred_scale(self, batch):
+        """Inside run_on_batch, eval mode, raw audio only, a dB-scaled log-mel / STFT front-end of this package on the GPU and an engine
+        whose first conv stages the features itself: the front-end stops after its power kernel and the dB scaling happens inside the
+        conv kernel (PendingFeatures; one kernel launch and one write + read of the feature tensor less per batch).  Returns the
+        pre-processed batch, or None when any of that does not hold (the ordinary path then runs)."""
+        if self.training or len(self.frontend) != 1 or not isinstance(self.frontend[0], SpectralFrontend):
+            return None
+        if os.environ.get('AMTX_DEFER_DB_SCALE', '1') == '0':     # A/B switch: front-end writes finished features (amtx_spec_scale)
+            return None
+        from .features import _SpecPlanOwner
+        module = self.frontend[0].module
+        if not isinstance(module, _SpecPlanOwner) or not getattr(module, 'decibels', False):
+            return None
+        if tools.query_dict(batch, tools.KEY_FEATS) or not tools.query_dict(batch, tools.KEY_AUDIO):
+            return None
+        if torch.device(self.device).type != 'cuda':
+            return None
+        batch = tools.dict_to_device(batch, self.device)
+        audio = batch[tools.KEY_AUDIO]
+        if not (torch.is_tensor(audio) and audio.is_cuda and audio.dim() == 2):
+            return None
+        if not self._get_engine(audio.device).fuses_db_scale():
+            return None
+        power, clip_max = module.power_batch(audio.float())
+        batch[tools.KEY_FEATS] = PendingFeatures(module, power, clip_max)
         return batch
 
     def run_on_batch(self, batch):
@@ -371,19 +432,24 @@ class OnsetsFrames(TranscriptionModel):
         # instead of being copied out into three (B,T,O) tensors.  forward() called on its own always returns logits.
         labelled = any(tools.query_dict(batch, k) for k in (tools.KEY_MULTIPITCH, tools.KEY_ONSETS, tools.KEY_OFFSETS))
         self.__dict__['_logits_wanted'] = labelled
+        self.__dict__['_in_run_on_batch'] = True
         try:
             return super().run_on_batch(batch)
         finally:
             self.__dict__.pop('_logits_wanted', None)
+            self.__dict__.pop('_in_run_on_batch', None)
 
     def forward(self, feats):
         """feats (B,C,T,F) -> dict of raw logits (B,T,O) under 'onsets' and 'multi_pitch'."""
-        if feats.is_cuda and not self.training:
+        pending = isinstance(feats, PendingFeatures)
+        if pending and self.training:
+            feats, pending = feats.materialize(), False
+        if pending or (feats.is_cuda and not self.training):
             eng = self._get_engine(feats.device)
-            if feats.dtype != torch.float32:
+            if not pending and feats.dtype != torch.float32:
                 feats = feats.float()
             want = self.__dict__.get('_logits_wanted', True)
-            onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats.detach(), want_logits=want)
+            onsets_bin, mp_bin, lo, lm, lp = eng.forward(feats if pending else feats.detach(), want_logits=want)
             if not want:
                 # label-free run_on_batch: the entries are the final piano rolls already (post_proc passes them through)
                 lo, lm = onsets_bin, mp_bin

@@ -97,6 +97,18 @@ int amtx_of_forward(const amtx_of_model* model, const float* feats, int64_t stri
                     float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                     float* logits_pitch_head, void* stream);
 
+/* The same forward pass fed with the front-end's RAW POWER mel spectrogram (amtx_spec_power's output, power[b*stride_b + t*stride_t +
+ * f*stride_f]) instead of finished features: the dB scaling of amtx_spec_scale(AMTX_SCALE_DB) (amt_tools/features/common.py:199,
+ * 218-228: power_to_db relative to `ref`, top_db = 80 below the clip's own maximum, / 80 + 1) is applied by the first conv kernel while
+ * it stages the values, bit-identical to amtx_spec_scale, so the feature tensor never exists in HBM.  clip_max: [batch] own maxima
+ * (amtx_spec_power), ref: [batch] reference powers or NULL (= own maximum).  Only for models where amtx_of_fuses_db_scale() is 1
+ * (one input channel, first conv fused into conv2); AMTX_ERR_ARG otherwise -- callers then run amtx_spec_scale + amtx_of_forward. */
+int amtx_of_fuses_db_scale(const amtx_of_model* model);
+int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_t stride_b, int64_t stride_t, int64_t stride_f,
+                          const float* clip_max, const float* ref, int batch, int num_frames, void* workspace, size_t workspace_bytes,
+                          float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
+                          float* logits_pitch_head, void* stream);
+
 /* OnsetsFrames2 (has_offsets = 1; amt_tools/models/onsetsframes.py:199-327): the offset head's output of the last amtx_of_forward
  * that used this workspace: out_offsets (B, n_out, T) sigmoid probabilities (finalize_output without threshold, :323-325),
  * logits_offsets optional (B, T, n_out). */

@@ -253,6 +253,49 @@ def test_fused_frontend_audio_to_pianoroll(precision):
         assert out[key].shape == (2, 88, 24)
 
 
+@pytest.mark.parametrize('precision', ['x3', 'bf16'])
+@pytest.mark.parametrize('frontend', ['mel', 'stft'])
+def test_db_scaling_deferred_into_the_conv_kernel_is_bit_identical(frontend, precision):
+    """run_on_batch on raw audio defers the dB scaling into the first conv kernel (amtx_of_forward_power): the logits must be the
+    SAME BITS as for the feature tensor the front-end would have written (amtx_spec_scale + amtx_of_forward), also for clips of
+    very different level (per-clip reference and top_db floor), a silent clip and a ragged last tile."""
+    from amt_tools_amd.features import MelSpec, STFT
+    from amt_tools_amd.models import OnsetsFrames, PendingFeatures
+    if frontend == 'mel':
+        mod, dim_in = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048), 229
+    else:
+        mod, dim_in = STFT(sample_rate=16000, hop_length=512, n_fft=256), 129
+    sd = synth_state_dict(5, dim_in=dim_in, in_channels=1, model_complexity=2)
+    model = OnsetsFrames(dim_in, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.frontend = torch.nn.Sequential(mod.frontend())
+    model.change_device()
+    model.eval()
+    audio = np.stack([synth_clip(i, num_samples=512 * 37 + 11) for i in range(4)])
+    audio[1] *= 1e-3
+    audio[2] *= 30.0
+    audio[3] = 0.0
+    a = torch.from_numpy(audio).cuda()
+    with torch.no_grad():
+        batch = {tools.KEY_AUDIO: a}
+        model.__dict__['_in_run_on_batch'] = True
+        try:
+            pre = model.pre_proc(batch)
+        finally:
+            model.__dict__.pop('_in_run_on_batch')
+        assert isinstance(pre[tools.KEY_FEATS], PendingFeatures)                     # the deferred path is the one that runs
+        assert torch.is_tensor(model.pre_proc(batch)[tools.KEY_FEATS])               # pre_proc on its own still returns features
+        fused = model(pre[tools.KEY_FEATS])
+        feats = pre[tools.KEY_FEATS].materialize()
+        np.testing.assert_array_equal(feats.cpu().numpy(), model.pre_proc(batch)[tools.KEY_FEATS].cpu().numpy())
+        plain = model(feats)
+        out = model.run_on_batch(batch)
+    for key in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
+        np.testing.assert_array_equal(fused[key].cpu().numpy(), plain[key].cpu().numpy())
+        assert out[key].shape == (4, 88, 38)
+        np.testing.assert_array_equal(out[key].cpu().numpy(), (plain[key].transpose(-1, -2) > 0).float().cpu().numpy())
+
+
 def test_of2_experiment_shape_audio_to_notes():
     """The reference's OnsetsFrames2 experiment end to end (scripts of_2.py:87-110,157-175): audio -> HTK log-mel front-end fused
     into the model -> OnsetsFrames2 as shipped (model_complexity 3, offset head) -> piano rolls + offset probabilities -> notes.
