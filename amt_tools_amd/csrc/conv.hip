@@ -124,8 +124,6 @@ __device__ __forceinline__ TileCoord tile_coord(int tile, int ntf, int ntt, int 
 // SIMD do not pay on gfx950: eight per block need <= 128 VGPRs and spill (72 weight + 48 fragment-ring + 16 accumulator registers
 // alone), six (168 VGPRs) leave one block resident per CU (measured 5.9 vs 2.85 ms for the fused c_in = 1 kernel).
 constexpr int conv_threads(bool fuse1, int ks, int ns) { return 256; }
-__device__ uint4 g_conv_zero16;              // zero-initialised: source of padded positions (DMA staging)
-__device__ uint4 g_conv_trash[4];            // sink of masked stores (kernels that count their store instructions)
 
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS>
 __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_threads(FUSE1, KS, NS) / 128 : 1)) void conv3x3_kernel(ConvArgs a, int ft, int ntf, int ntt, int inv_cols, int ntiles) {
@@ -135,22 +133,17 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     constexpr int PB = FUSE1 ? CM_BYTES : PLANE_BYTES;      // bytes of one input-tile plane in LDS
     constexpr int FW = fw_pitch(KS);
     // next-tile register prefetch only where the register budget keeps 2 waves per SIMD (C_out = 32)
-    // C_out = 64, bf16: the two halves of C_out go to two wave pairs (each wave keeps 9 x 2 weight fragments instead of 9 x 4 and
-    // walks every second column pair), which frees the registers the next-tile prefetch needs
-    constexpr int CSPLIT = (NT == 4 && NS == 1 && !FUSE1 && IN_TYPE == AMTX_T_BF16 && OUT_TYPE == AMTX_T_BF16) ? 2 : 1;
-    constexpr int NTW = NT / CSPLIT;                     // C_out tiles per wave
-    constexpr int NWP = conv_threads(FUSE1, KS, NS) / 64 / CSPLIT;   // waves that share the column pairs of one C_out half
-    constexpr bool PREFETCH = (IN_TYPE == AMTX_T_BF16) && !FUSE1 && NTW <= 2;
+    constexpr bool PREFETCH = (IN_TYPE == AMTX_T_BF16) && !FUSE1 && NT <= 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // dB staging of raw power features (ConvArgs::f_clip_max): c_in = 1 kernels only (compiled out elsewhere: those are out of registers)
+    const float* const f_clip_max = (FUSE1 && KS == 1) ? a.f_clip_max : nullptr;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // the same value, provably uniform: scalar loop counters
     const int grp = blockIdx.y;
     const int g = lane >> 4, trow = lane & 15;
-    const int chalf = CSPLIT == 2 ? wave_u / NWP : 0;    // which half of C_out this wave computes
-    const int pair0 = CSPLIT == 2 ? wave_u % NWP : wave_u;   // its first column pair
 
-    // ---- stationary weights: 9 taps x NTW tiles (x NS planes), one 16-byte fragment per lane each
-    uint4 wf[9][NTW][NS];
-    if constexpr (CSPLIT == 1) {
+    // ---- stationary weights: 9 taps x NT tiles (x NS planes), one 16-byte fragment per lane each
+    uint4 wf[9][NT][NS];
+    {
         const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
@@ -158,34 +151,23 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int p = 0; p < NS; ++p) wf[tap][nt][p] = w[((tap * NT + nt) * NS + p) * 64];
-    } else {
-        // The packed order gives row (4 gp + r) of tile ntp the channel 16 gp + 4 ntp + r.  This wave wants row (4 gr + r) of its
-        // tile nt to be channel 32 chalf + 8 gr + 4 nt + r (then a lane's two tiles are 8 consecutive channels and the four lane
-        // groups of a position store 64 contiguous bytes): a per-lane gather of rows out of the packed fragments, done once.
-        const int gr = (lane & 15) >> 2;
-        const int src_lane = (lane & 48) + 4 * (2 * chalf + (gr >> 1)) + (lane & 3);
-        const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + src_lane;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) wf[tap][nt][0] = w[(tap * NT + 2 * (gr & 1) + nt) * 64];
     }
     // folded BN shift: a C_out-float table at the end of LDS; the accumulators of every column pair are initialised
     // from it (lane -> its 4*NT consecutive channels), so the epilogue is max3(y0, y1, 0) only
-    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + (chalf * 4 + g) * NTW;
+    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + g * NT;
     if (tid < COUT) reinterpret_cast<float*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
 
     // C_out = 32: the shift also sits in 8 registers and is the C operand of each pair's first MFMAs directly (the LDS table read
     // at the top of every column pair put ~100 cycles of LDS latency in front of the first MFMA); C_out = 64 has no registers left
-    constexpr bool SH_REGS = (NTW == 2 && NS == 1 && KS <= 1);   // not the c_in > 1 variant: it is out of registers already
-    f32x4_t shr[NTW];
+    constexpr bool SH_REGS = (NT == 2 && NS == 1 && KS <= 1);   // not the c_in > 1 variant: it is out of registers already
+    f32x4_t shr[NT];
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) shr[nt][r] = SH_REGS ? a.shift[(int64_t)grp * a.shift_gs + ((chalf * 4 + g) * NTW + nt) * 4 + r] : 0.f;
+        for (int r = 0; r < 4; ++r) shr[nt][r] = SH_REGS ? a.shift[(int64_t)grp * a.shift_gs + (g * NT + nt) * 4 + r] : 0.f;
     if (SH_REGS) {
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) settle(shr[nt][r]);
     }
@@ -198,6 +180,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     // ---- constants of the fused first conv
     float* ftile = reinterpret_cast<float*>(smem + NS * PB);
     const int fcols = ft + 4;
+    const int inv_fcols = 65536 / fcols + 1;            // c_in = 1: it / fcols == (it * inv_fcols) >> 16 for it < FPRE * NTH (checked at launch)
     const int fitems = FUSE1 ? a.c_in * FROWS * fcols : 0;
     const bool fprefetch = FUSE1 && fitems <= FPRE * NTH;
     constexpr int KSA = KS > 0 ? KS : 1;
@@ -254,15 +237,13 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     }
 
     uint4 pre[PREFETCH ? ITEMS : 1];
-    unsigned premask = 0;        // PREFETCH: bit n = item n of the tile in flight is inside the image
-    int stores_since = 0;        // PREFETCH: store instructions this wave issued after the loads in flight (uniform)
     float fpre[FPRE];
-    float fown = 0.f, fref = 0.f;   // dB staging (a.f_clip_max): the prefetched tile's clip maximum and reference power
+    float fown = 0.f, fref = 0.f;   // dB staging (f_clip_max): the prefetched tile's clip maximum and reference power
     int tile = blockIdx.x;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int p = 0; p < NS; ++p) settle(wf[tap][nt][p]);
     if constexpr (FUSE1 && KS == 1) {
@@ -286,38 +267,34 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             for (int r = 0; r < 4; ++r) settle(sh1[nt][r]);
     }
 
-#define CONV_ISSUE_ITEM(TC, N)                                                                             \
-    do {                                                                                                   \
-        const int pos = (tid >> 2) + 64 * (N);                                                             \
-        const int i = (pos * inv_cols) >> 16;                                                              \
-        const int j = pos - i * cols;                                                                      \
-        const int t = (TC).t0 - 1 + i, f = (TC).f0 - 1 + j;                                                \
-        if (pos < npos && t >= 0 && t < a.T && f >= 0 && f < a.F) premask |= 1u << (N);                    \
-        const char* src = in_grp + ((((int64_t)(TC).b * a.T + min(max(t, 0), a.T - 1)) * a.F + min(max(f, 0), a.F - 1)) * CIN + c * 8) * 2; \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre[N]) : "v"(src));                         \
-    } while (0)
-// The loads are inline assembly so that the compiler does not track them: it would put s_waitcnt vmcnt(0) in front of the LDS
-// writes one tile later, which also waits for the C stores issued in between, i.e. for the write latency of the last column pair
-// every tile.  The wait is explicit instead (CONV_WAIT_TILE_LOADS: everything older than the stores counted since); padding
-// positions load a clamped address and are zeroed from `premask` at the LDS write.
 #define CONV_ISSUE_TILE_LOADS(TC)                                                                          \
     do {                                                                                                   \
-        premask = 0;                                                                                       \
-        _Pragma("unroll") for (int n = 0; n < ITEMS; ++n) CONV_ISSUE_ITEM(TC, n);                          \
-        stores_since = 0;                                                                                  \
+        const char* inb = in_grp + (int64_t)(TC).b * a.T * a.F * CIN * 2;                                  \
+        _Pragma("unroll") for (int n = 0; n < ITEMS; ++n) {                                                \
+            const int pos = (tid >> 2) + 64 * n;                                                           \
+            const int i = (pos * inv_cols) >> 16;                                                          \
+            const int j = pos - i * cols;                                                                  \
+            const int t = (TC).t0 - 1 + i, f = (TC).f0 - 1 + j;                                            \
+            pre[n] = make_uint4(0, 0, 0, 0);                                                               \
+            if (pos < npos && t >= 0 && t < a.T && f >= 0 && f < a.F)                                      \
+                pre[n] = *reinterpret_cast<const uint4*>(inb + (((int64_t)t * a.F + f) * CIN + c * 8) * 2); \
+        }                                                                                                  \
     } while (0)
 #define CONV_ISSUE_FEAT_LOADS(TC)                                                                          \
     do {                                                                                                   \
         const float* fb = a.feats + (int64_t)(TC).b * a.f_stride_b;                                        \
+        int tid_l = tid;                                                                                   \
+        asm volatile("" : "+v"(tid_l)); /* the (row, column) of the FPRE cells: recomputed per tile, not kept in registers */ \
+        const bool c1ch = a.c_in == 1;                                                                     \
         _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                                 \
-            const int it = tid + NTH * n;                                                                  \
-            const int fi = it / fcols, fj = it - fi * fcols;                                               \
+            const int it = tid_l + NTH * n;                                                                \
+            const int fi = c1ch ? (it * inv_fcols) >> 16 : it / fcols, fj = it - fi * fcols;               \
             const int t = (TC).t0 - 2 + fi, f = (TC).f0 - 2 + fj;                                          \
-            fpre[n] = a.f_clip_max ? -1.f : 0.f; /* power is never negative: -1 marks the zero padding */  \
+            fpre[n] = f_clip_max ? -1.f : 0.f; /* power is never negative: -1 marks the zero padding */  \
             if (it < fitems && t >= 0 && t < a.T && f >= 0 && f < a.F) fpre[n] = fb[t * a.f_stride_t + f * a.f_stride_f]; \
         }                                                                                                  \
-        if (a.f_clip_max) {                                                                                \
-            fown = a.f_clip_max[(TC).b];                                                                   \
+        if (f_clip_max) {                                                                                \
+            fown = f_clip_max[(TC).b];                                                                   \
             fref = a.f_ref ? a.f_ref[(TC).b] : fown;                                                       \
         }                                                                                                  \
     } while (0)
@@ -346,10 +323,12 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             // ---- fused first conv: features (c_in, 20 x (ft+4)) -> LDS, then Conv(c_in->32)+BN+ReLU on the matrix cores
             // (K = 9*c_in in steps of 16, im2col patches gathered from LDS as the MFMA B operand), written straight
             // into this kernel's input tile in fragment order.  a1 never touches HBM.
+            // raw power values are dB-scaled here, while they are staged (amtx_of_forward_power; db_scale_apply is the function
+            // spec_scale_kernel uses, so the staged values are the bits amtx_spec_scale would have written)
             DbScale dbs = {0.f, 0.f};
-            if (a.f_clip_max) {
+            if (f_clip_max) {
                 if (!fprefetch) {
-                    fown = a.f_clip_max[tc.b];
+                    fown = f_clip_max[tc.b];
                     fref = a.f_ref ? a.f_ref[tc.b] : fown;
                 }
                 dbs = db_scale_make(fown, fref);
@@ -363,9 +342,9 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 #pragma unroll
                 for (int n = 0; n < FPRE; ++n) {
                     const int it = tid_f + NTH * n;
-                    const int fi = it / fcols, fj = it - fi * fcols;
+                    const int fi = a.c_in == 1 ? (it * inv_fcols) >> 16 : it / fcols, fj = it - fi * fcols;
                     float v = fpre[n];
-                    if (a.f_clip_max) {
+                    if (f_clip_max) {
                         const float sv = db_scale_apply(v, dbs);   // branch-free: a handful of instructions, the select drops the padding
                         v = v < 0.f ? 0.f : sv;
                     }
@@ -380,7 +359,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
                     float v = 0.f;
                     if (t >= 0 && t < a.T && f >= 0 && f < a.F) {
                         v = fb[ci * a.f_stride_c + t * a.f_stride_t + f * a.f_stride_f];
-                        if (a.f_clip_max) v = db_scale_apply(v, dbs);
+                        if (f_clip_max) v = db_scale_apply(v, dbs);
                     }
                     ftile[(ci * FROWS + fi) * FW + fj] = v;
                 }
@@ -639,29 +618,12 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             CONV_TICK(2);
         } else if constexpr (PREFETCH) {
             // ---- the tile was fetched while the previous one was computed: registers -> LDS
-            switch (stores_since) {
-                case 0: wait_vm<0>(); break;
-                case 1: wait_vm<1>(); break;
-                case 2: wait_vm<2>(); break;
-                case 3: wait_vm<3>(); break;
-                case 4: wait_vm<4>(); break;
-                case 5: wait_vm<5>(); break;
-                case 6: wait_vm<6>(); break;
-                case 7: wait_vm<7>(); break;
-                case 8: wait_vm<8>(); break;
-                case 9: wait_vm<9>(); break;
-                case 10: wait_vm<10>(); break;
-                case 11: wait_vm<11>(); break;
-                default: wait_vm<12>(); break;          // more stores than that: waiting for a few of them too is harmless
-            }
 #pragma unroll
             for (int n = 0; n < ITEMS; ++n) {
                 const int pos = (tid >> 2) + 64 * n;
                 const int i = (pos * inv_cols) >> 16;
                 const int j = pos - i * cols;
-                asm volatile("" : "+v"(pre[n].x), "+v"(pre[n].y), "+v"(pre[n].z), "+v"(pre[n].w));   // not before the wait
-                const uint4 v = (premask >> n) & 1 ? pre[n] : make_uint4(0, 0, 0, 0);
-                if (pos < npos) *reinterpret_cast<uint4*>(smem + tile_off(i, j, c)) = v;
+                if (pos < npos) *reinterpret_cast<uint4*>(smem + tile_off(i, j, c)) = pre[n];
             }
         } else {
             // ---- stage the (TT+2) x (ft+2) x 32 tile in two batches (all loads of a batch issued before the first
@@ -734,39 +696,36 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
             x[KH][cc][0] = *reinterpret_cast<const uint4*>(smem + off);                                    \
             if (NS == 2) x[KH][cc][1] = *reinterpret_cast<const uint4*>(smem + PB + off);         \
         }
-        if (pair0 < npairs) {
-            CONV_LOAD_ROW(0, pair0)
-            CONV_LOAD_ROW(1, pair0)
-            CONV_LOAD_ROW(2, pair0)
+        if (wave_u < npairs) {
+            CONV_LOAD_ROW(0, wave_u)
+            CONV_LOAD_ROW(1, wave_u)
+            CONV_LOAD_ROW(2, wave_u)
         }
-        for (int jp = pair0; jp < npairs; jp += NWP) {
-            const int jn = min(jp + NWP, npairs - 1);    // past the end: re-read a valid pair, never used
-            f32x4_t acc[2][NTW];
+        for (int jp = wave_u; jp < npairs; jp += NW) {
+            const int jn = min(jp + NW, npairs - 1);     // past the end: re-read a valid pair, never used
+            f32x4_t acc[2][NT];
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[e][nt] = SH_REGS ? shr[nt] : shl[nt];
+                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = SH_REGS ? shr[nt] : shl[nt];
 
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {        // kw outermost: every accumulator is touched once per 2 NT products
-                    const int tap = kh * 3 + kw;
+                for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int cc = kw + e;
+                        const int kw = cc - e;
+                        if (kw < 0 || kw > 2) continue;
+                        const int tap = kh * 3 + kw;
 #pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt) acc[e][nt] = mfma16(wf[tap][nt][0], x[kh][cc][0], acc[e][nt]);
-                    }
-                    if (NS == 2) {
-#pragma unroll
-                        for (int e = 0; e < 2; ++e)
-#pragma unroll
-                            for (int nt = 0; nt < NTW; ++nt) acc[e][nt] = mfma16(wf[tap][nt][0], x[kh][kw + e][1], acc[e][nt]);
-#pragma unroll
-                        for (int e = 0; e < 2; ++e)
-#pragma unroll
-                            for (int nt = 0; nt < NTW; ++nt) acc[e][nt] = mfma16(wf[tap][nt][1], x[kh][kw + e][0], acc[e][nt]);
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[e][nt] = mfma16(wf[tap][nt][0], x[kh][cc][0], acc[e][nt]);
+                            if (NS == 2) {
+                                acc[e][nt] = mfma16(wf[tap][nt][0], x[kh][cc][1], acc[e][nt]);
+                                acc[e][nt] = mfma16(wf[tap][nt][1], x[kh][cc][0], acc[e][nt]);
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -776,27 +735,24 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 
             // ---- + shift, ReLU, MaxPool(1,2) over the (f, f+1) pair, channels-last store
             const int fo = (f0 >> 1) + jp;
-            const bool inside = t < a.T && fo < Fo;
-            if (PREFETCH || inside) {       // PREFETCH counts its store instructions: every one issues, masked lanes write a scratch line
-                float v[NTW * 4];
+            if (t < a.T && fo < Fo) {
+                float v[NT * 4];
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
                     }
                 if (OUT_TYPE == AMTX_T_BF16) {
-                    uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + (chalf * 4 + g) * 4 * NTW) * 2);
-                    if (PREFETCH && !inside) dst = g_conv_trash;
-                    if (PREFETCH) stores_since += NTW / 2;
+                    uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
 #pragma unroll
-                    for (int q = 0; q < NTW / 2; ++q)
+                    for (int q = 0; q < NT / 2; ++q)
                         dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
                                             pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
                 } else {
-                    float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + (chalf * 4 + g) * 4 * NTW) * 4);
+                    float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 4);
 #pragma unroll
-                    for (int q = 0; q < NTW; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+                    for (int q = 0; q < NT; ++q) dst[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
                 }
             }
         }
@@ -812,7 +768,6 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     }
 #endif
 #undef CONV_ISSUE_TILE_LOADS
-#undef CONV_ISSUE_ITEM
 #undef CONV_ISSUE_FEAT_LOADS
 }
 
@@ -828,6 +783,8 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 // an exact vmcnt (its own C stores issued since are counted: every store instruction always issues, masked
 // positions go to a scratch line), then the LDS-only barrier publishes the plane.
 constexpr int DMA_FT_MAX = 30;
+__device__ uint4 g_conv_zero16;              // zero-initialised: source of padded positions
+__device__ uint4 g_conv_trash[4];            // sink of masked stores
 
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft, int ntf, int ntt, int pitch, int inv_pitch, int plane_bytes,
@@ -858,19 +815,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
 
     const int cols = ft + 2;
     const int npairs = ft >> 1;
-    const int my_pairs = max(1, (npairs - wave_u + 3) >> 2);       // column pairs this wave owns (wave_u, +4, ...)
+    const int my_pairs = (npairs - wave_u + 3) >> 2;               // column pairs this wave owns (wave_u, +4, ...)
     const int Fo = a.F >> 1;
     const int ninstr = plane_bytes >> 10;                          // DMA instructions per plane (16 positions each)
-    const int dma_per_round = (((ninstr - wave_u + 3) >> 2) + my_pairs - 1) / my_pairs;   // this wave's share, spread over its rounds
     const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * 2;
     const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem);
 
-#define CONV_DMA_ISSUE(TC, BUF, N0, N1)                                                                          \
+#define CONV_DMA_ISSUE(TC, BUF)                                                                            \
     do {                                                                                                   \
         const char* inb = in_grp + (int64_t)(TC).b * a.T * a.F * CIN * 2;                                  \
         int lane_o = lane;                                                                                 \
         asm volatile("" : "+v"(lane_o)); /* keep the per-instruction index math out of the live ranges */ \
-        for (int n = (N0); n < (N1); n += 4) {                                                             \
+        for (int n = wave_u; n < ninstr; n += 4) {                                                         \
             const int q = n * 16 + (lane_o >> 2);                                                          \
             const int i = (q * inv_pitch) >> 16;                                                           \
             const int j = q - i * pitch;                                                                   \
@@ -887,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
     if (tile >= ntiles) return;
     {
         const TileCoord tc0 = tile_coord(tile, ntf, ntt, ft, ntiles);
-        CONV_DMA_ISSUE(tc0, 0, wave_u, ninstr);
+        CONV_DMA_ISSUE(tc0, 0);
     }
     wait_vm<0>();
     __syncthreads();                                               // first plane + shift table visible
@@ -896,11 +852,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
     for (; tile < ntiles; tile += gridDim.x) {
         const TileCoord tc = tile_coord(tile, ntf, ntt, ft, ntiles);
         const bool has_next = tile + (int)gridDim.x < ntiles;
-        const TileCoord tn = tile_coord(has_next ? tile + (int)gridDim.x : tile, ntf, ntt, ft, ntiles);
-        // The next plane's DMA instructions go out a few per column-pair round: issued in one burst they queue behind each other in
-        // the memory pipeline and the wave sits at the issue instead of feeding the matrix cores.
-        int dma_n = has_next ? wave_u : ninstr;                    // this wave's next DMA instruction of the next plane
-        int younger = 0;                                           // C stores issued after the most recent DMA instruction
+        if (has_next) {
+            const TileCoord tn = tile_coord(tile + (int)gridDim.x, ntf, ntt, ft, ntiles);
+            CONV_DMA_ISSUE(tn, cur ^ 1);
+        }
 
         const char* plane = smem + cur * plane_bytes;
         const int t = tc.t0 + trow;
@@ -919,12 +874,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
         }
         for (int jp = wave_u; jp < npairs; jp += 4) {
             const int jn = min(jp + 4, npairs - 1);
-            if (dma_n < ninstr) {
-                const int n1 = min(dma_n + 4 * dma_per_round, ninstr);
-                CONV_DMA_ISSUE(tn, cur ^ 1, dma_n, n1);
-                dma_n += 4 * dma_per_round;
-                younger = 0;
-            }
             f32x4_t acc[2][NT];
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -933,11 +882,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
+                for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < 2; ++e) {
+                        const int kw = cc - e;
+                        if (kw < 0 || kw > 2) continue;
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[e][nt] = mfma16(wf[kh * 3 + kw][nt], x[kh][kw + e], acc[e][nt]);
+                        for (int nt = 0; nt < NT; ++nt) acc[e][nt] = mfma16(wf[kh * 3 + kw][nt], x[kh][cc], acc[e][nt]);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 if (kh == 0) { CONV_DMA_LOAD_ROW(0, jn) } else if (kh == 1) { CONV_DMA_LOAD_ROW(1, jn) } else { CONV_DMA_LOAD_ROW(2, jn) }
                 __builtin_amdgcn_sched_barrier(0);
@@ -954,16 +907,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
             for (int q = 0; q < SPP; ++q)
                 dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
                                     pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
-            younger += SPP;
         }
 #undef CONV_DMA_LOAD_ROW
-        if (dma_n < ninstr) {                                      // fewer rounds than planned (narrow last tile)
-            CONV_DMA_ISSUE(tn, cur ^ 1, dma_n, ninstr);
-            younger = 0;
-        }
-        // ---- the next plane must have landed: everything older than the stores issued after its last DMA instruction
+        // ---- the next plane must have landed: everything older than this tile's my_pairs * SPP stores
         if (has_next) {
-            switch (younger) {
+            switch (my_pairs * SPP) {
                 case 0: wait_vm<0>(); break;
                 case 1: wait_vm<1>(); break;
                 case 2: wait_vm<2>(); break;
@@ -971,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft,
                 case 4: wait_vm<4>(); break;
                 case 6: wait_vm<6>(); break;
                 case 8: wait_vm<8>(); break;
-                default: wait_vm<0>(); break;
+                default: wait_vm<0>(); break;          // DMA_FT_MAX = 30 -> at most 4 pairs per wave
             }
         }
         lds_only_barrier();
@@ -1027,6 +975,14 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
             amtx_set_error("conv3x3: internal: reciprocal division inexact for cols=%d", cols);
             return AMTX_ERR_ARG;
         }
+    if (FUSE1 && a.c_in == 1) {
+        const int fcols = ft + 4, inv_fcols = 65536 / fcols + 1;
+        for (int it = 0; it < FPRE * 256; ++it)
+            if (((it * inv_fcols) >> 16) != it / fcols) {
+                amtx_set_error("conv3x3: internal: reciprocal division inexact for fcols=%d", fcols);
+                return AMTX_ERR_ARG;
+            }
+    }
     // persistent grid: two resident blocks per CU in total
     int64_t gx = nblocks;
     const int64_t per_group = std::max<int64_t>(1, 512 / std::max(1, a.groups));
