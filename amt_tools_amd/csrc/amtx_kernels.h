@@ -21,8 +21,15 @@ struct GemmArgs {
     // m < pair_rows[pair_map[p].y]; C is not written.
     const int2* pair_map = nullptr; float* pair_out = nullptr; int64_t pair_gs = 0, pair_pitch = 0;
     int pair_rows[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // optional with the magnitude epilogue: running maximum of the stored magnitudes per (group, pair_map[p].y): pair_max[grp * pair_nh + y]
+    // (atomic max on the float bits; the caller zeroes it first)
+    float* pair_max = nullptr; int pair_nh = 0;
 };
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);
+// several fp32-A / fp32-C / two-plane problems with one group count in one launch (generic 128 x 128 kernel)
+constexpr int AMTX_GEMM_MULTI_MAX = 10;
+struct GemmMulti { GemmArgs p[AMTX_GEMM_MULTI_MAX]; int n; };
+int amtx_launch_gemm_multi(const GemmArgs* gs, int n, hipStream_t stream);
 void amtx_gemm_pack_dims(int N, int K, int* n_pad, int* k_pad);
 // host packing: W (N x K fp32 row-major, leading dim ldw) -> [planes][n_pad][k_pad] bf16
 void amtx_gemm_pack_host(const float* W, int64_t ldw, int N, int K, int planes, bf16_t* out);

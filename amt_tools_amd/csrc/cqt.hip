@@ -35,7 +35,7 @@ constexpr double HANN_BW = 1.50018310546875;
 
 struct BankDev { int col0, nf, harm, bin0, frames; };
 struct LevelDev { int nbanks; int ncols; BankDev b[MAX_BANKS]; };
-struct HarmFrames { int f[MAX_BANKS]; };
+
 
 double bessel_i0(double x) {
     double s = 1.0, t = 1.0;
@@ -48,12 +48,28 @@ double bessel_i0(double x) {
 }
 
 // ---------------------------------------------------------------- kernels
+// level 0 of the pyramid: the clip copied between its centre paddings.  `zero_pads`: the paddings are written here too (zeros, librosa
+// >= 0.10; the reflecting pad of 0.9 keeps its own kernel); the per-(clip, harmonic) maxima the basis products accumulate are reset.
 __global__ __launch_bounds__(256) void cqt_level0_kernel(const float* __restrict__ audio, int64_t n, int64_t astride, float* __restrict__ pyr,
-                                                         int64_t pstride, int pad) {
+                                                         int64_t pstride, int pad, int zero_pads, float* __restrict__ maxbuf, int n_harm) {
     const int b = blockIdx.y;
     const float* src = audio + (int64_t)b * astride;
-    float* dst = pyr + (int64_t)b * pstride + pad;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+    float* row = pyr + (int64_t)b * pstride;
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_harm) maxbuf[b * n_harm + threadIdx.x] = 0.f;
+    if (zero_pads) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pstride; i += (int64_t)gridDim.x * 256)
+            row[i] = (i >= pad && i < pad + n) ? src[i - pad] : 0.f;
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) row[pad + i] = src[i];
+    }
+}
+
+// zero centre paddings of a decimated level, written by the first / last block of the kernel that produces the level
+__device__ __forceinline__ void cqt_zero_pads(float* __restrict__ row, int64_t n_out, int64_t out_stride, int pad) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < pad; i += 256) row[i] = 0.f;
+    if (blockIdx.x == gridDim.x - 1)
+        for (int64_t i = pad + n_out + threadIdx.x; i < out_stride; i += 256) row[i] = 0.f;
 }
 
 // out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in).
@@ -69,9 +85,10 @@ constexpr int DEC_XS = 2 * DEC_CH + DEC_TAPS_PAD + 16;
 __device__ __forceinline__ int dec_pidx(int p) { return p + (p >> 4); }
 
 __global__ __launch_bounds__(256) void cqt_decimate_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
-                                                           int64_t n_out, int64_t out_stride, int pad, const float* __restrict__ taps) {
+                                                           int64_t n_out, int64_t out_stride, int pad, const float* __restrict__ taps, int zero_pads) {
     __shared__ float xs[DEC_XS + (DEC_XS >> 4) + 1];
     const int b = blockIdx.y;
+    if (zero_pads) cqt_zero_pads(out + (int64_t)b * out_stride, n_out, out_stride, pad);
     const int64_t m0 = (int64_t)blockIdx.x * DEC_CH;
     const float* src = in + (int64_t)b * in_stride + pad;
     const int64_t base = 2 * m0 - DEC_HALF;
@@ -143,10 +160,11 @@ __device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
 }
 
 __global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
-                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag) {
+                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag, int zero_pads) {
     __shared__ __attribute__((aligned(16))) unsigned short xh[DEC_MXS + 8], xm[DEC_MXS + 8], xl[DEC_MXS + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
+    if (zero_pads) cqt_zero_pads(out + (int64_t)b * out_stride, n_out, out_stride, pad);
     const int64_t m0 = (int64_t)blockIdx.x * DEC_MCH;
     const float* src = in + (int64_t)b * in_stride + pad;
     const int64_t base = 2 * m0 - DEC_HALF;
@@ -228,24 +246,6 @@ __global__ __launch_bounds__(256) void cqt_pad_kernel(float* __restrict__ pyr, i
             row[pad + n + j] = v;
         }
     }
-}
-
-// max over one (clip, harmonic) map [n_bins][frames_h] (row pitch t_buf)
-__global__ __launch_bounds__(256) void cqt_max_kernel(const float* __restrict__ mag, HarmFrames frames_h, int n_harm, int n_bins,
-                                                      int64_t t_buf, float* __restrict__ maxbuf) {
-    __shared__ float red[4];
-    const int bh = blockIdx.x;
-    const int frames = frames_h.f[bh % n_harm];
-    const float* m = mag + (int64_t)bh * n_bins * t_buf;
-    float v = 0.f;
-    for (int64_t i = threadIdx.x; i < (int64_t)n_bins * frames; i += 256) {
-        const int k = (int)(i / frames);
-        v = fmaxf(v, m[(int64_t)k * t_buf + (i - (int64_t)k * frames)]);
-    }
-    v = wave_max_f32(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) maxbuf[bh] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // amplitude_to_db(ref = max) -> clamp -80 -> /80 + 1 (or plain magnitude), truncated to t_out frames
@@ -610,33 +610,38 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
     hipStream_t s = (hipStream_t)stream_;
     char* ws = (char*)workspace;
     const int B = batch, nl = (int)p->levels.size();
-    HarmFrames hf;
-    for (int h = 0; h < MAX_BANKS; ++h) hf.f[h] = h < p->n_harm ? d.frames_h[h] : 0;
+    float* mag = (float*)(ws + d.off_mag);
+    float* maxbuf = (float*)(ws + d.off_max);
+    const int zero_pads = p->lib09 ? 0 : 1;
 
     for (int l = 0; l < nl; ++l) {
         float* pyr = (float*)(ws + d.pyr_off[l]);
         if (l == 0) {
             const unsigned nb = (unsigned)std::min<int64_t>((num_samples + 255) / 256, 4096);
-            hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad);
+            hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad,
+                               zero_pads, maxbuf, p->n_harm);
         } else {
             // AMTX_CQT_VALU_DECIMATE=1: the vector-ALU FIR (kept as the A/B reference: 1.62 vs 0.x ms per HCQT call, see DESIGN)
             static const bool valu = getenv("AMTX_CQT_VALU_DECIMATE") != nullptr;
             if (valu) {
                 const unsigned nb = (unsigned)((d.len[l] + DEC_CH - 1) / DEC_CH);
                 hipLaunchKernelGGL(cqt_decimate_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
-                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps);
+                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps, zero_pads);
             } else {
                 const unsigned nb = (unsigned)((d.len[l] + DEC_MCH - 1) / DEC_MCH);
                 hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
-                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag);
+                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag, zero_pads);
             }
         }
         AMTX_CHECK_LAUNCH();
-        hipLaunchKernelGGL(cqt_pad_kernel, dim3(8, B), dim3(256), 0, s, pyr, d.len[l], d.stride[l], p->pad, p->lib09);
-        AMTX_CHECK_LAUNCH();
+        if (!zero_pads) {      // librosa 0.9: reflecting centre pad, from the level's own samples
+            hipLaunchKernelGGL(cqt_pad_kernel, dim3(8, B), dim3(256), 0, s, pyr, d.len[l], d.stride[l], p->pad, p->lib09);
+            AMTX_CHECK_LAUNCH();
+        }
     }
-    float* mag = (float*)(ws + d.off_mag);
-    float* maxbuf = (float*)(ws + d.off_max);
+    // the basis products of ALL levels in one launch (same kernel, per-level A / W / sizes; 8 launches before)
+    GemmArgs gs[AMTX_GEMM_MULTI_MAX];
+    int ng = 0;
     for (int l = 0; l < nl; ++l) {
         const Level& L = p->levels[l];
         if (L.banks.empty()) continue;
@@ -651,12 +656,18 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
         g.groups = B; g.a_gs = d.stride[l]; g.w_gs = 0; g.bias_gs = 0; g.c_gs = 0;
         g.pair_map = L.d_map; g.pair_out = mag; g.pair_gs = (int64_t)p->n_harm * p->n_bins * d.t_buf; g.pair_pitch = d.t_buf;
         for (int h = 0; h < p->n_harm && h < 16; ++h) g.pair_rows[h] = d.frames_h[h];
-        int rc = amtx_launch_gemm(g, s);
+        g.pair_max = maxbuf; g.pair_nh = p->n_harm;       // the per-(clip, harmonic) maxima of the dB reference, kept by the epilogue
+        if (ng == AMTX_GEMM_MULTI_MAX) {
+            int rc = amtx_launch_gemm_multi(gs, ng, s);
+            if (rc != AMTX_OK) return rc;
+            ng = 0;
+        }
+        gs[ng++] = g;
+    }
+    if (ng) {
+        int rc = amtx_launch_gemm_multi(gs, ng, s);
         if (rc != AMTX_OK) return rc;
     }
-    hipLaunchKernelGGL(cqt_max_kernel, dim3(B * p->n_harm), dim3(256), 0, s, (const float*)mag, hf, p->n_harm, p->n_bins,
-                       d.t_buf, maxbuf);
-    AMTX_CHECK_LAUNCH();
     hipLaunchKernelGGL(cqt_scale_kernel, dim3(8, B * p->n_harm), dim3(256), 0, s, (const float*)mag, (const float*)maxbuf, p->n_bins, d.t_buf,
                        d.t_out, decibels, out);
     AMTX_CHECK_LAUNCH();

@@ -62,16 +62,15 @@ struct AStage {
     }
 };
 
+// one 128 x 128 output tile (bx, by) of group grp; the body of gemm_kernel (one problem) and gemm_multi_kernel (several)
 template <int A_TYPE, int C_TYPE, int NS>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, int by, char* smem) {
     // layout: [buf][A planes NS][W planes NS] x TILE_BYTES
     constexpr int BUF_BYTES = 2 * NS * TILE_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int grp = blockIdx.z;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * BN;
 
     const char* Abase = reinterpret_cast<const char*>(g.A) + (int64_t)grp * g.a_gs * (A_TYPE == AMTX_T_BF16 ? 2 : 4);
     const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
@@ -161,6 +160,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     // epilogue: lane holds D'[n = 4*(lane>>4) + r][m = lane&15] of every 16x16 tile
     const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
     char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+    // magnitude epilogue with a running maximum per (group, harmonic): block-local maxima in LDS (the tile buffers are free after
+    // the loop's last barrier), then one global atomic per harmonic and block.  Magnitudes are >= 0: uint order == float order.
+    unsigned* lmax = reinterpret_cast<unsigned*>(smem);
+    const bool want_max = C_TYPE == AMTX_T_F32 && g.pair_map && g.pair_max;
+    if (want_max) {
+        if (tid < 16) lmax[tid] = 0u;
+        __syncthreads();
+    }
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
@@ -175,12 +182,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             // bytes of the transposed (pair-major) output
             const int2 pa = g.pair_map[n >> 1], pb = g.pair_map[(n >> 1) + (n + 2 < g.N ? 1 : 0)];
             float* po = g.pair_out + (int64_t)grp * g.pair_gs;
+            float ma = 0.f, mb = 0.f;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
                 const f32x4_t v = acc[nt][mt];
-                if (m < g.pair_rows[pa.y & 15]) po[(int64_t)pa.x * g.pair_pitch + m] = sqrtf(v[0] * v[0] + v[1] * v[1]);
-                if (n + 2 < g.N && m < g.pair_rows[pb.y & 15]) po[(int64_t)pb.x * g.pair_pitch + m] = sqrtf(v[2] * v[2] + v[3] * v[3]);
+                if (m < g.pair_rows[pa.y & 15]) {
+                    const float a = sqrtf(v[0] * v[0] + v[1] * v[1]);
+                    po[(int64_t)pa.x * g.pair_pitch + m] = a;
+                    ma = fmaxf(ma, a);
+                }
+                if (n + 2 < g.N && m < g.pair_rows[pb.y & 15]) {
+                    const float a = sqrtf(v[2] * v[2] + v[3] * v[3]);
+                    po[(int64_t)pb.x * g.pair_pitch + m] = a;
+                    mb = fmaxf(mb, a);
+                }
+            }
+            if (want_max) {
+                if (ma > 0.f) atomicMax(lmax + (pa.y & 15), __float_as_uint(ma));
+                if (mb > 0.f) atomicMax(lmax + (pb.y & 15), __float_as_uint(mb));
             }
             continue;
         }
@@ -197,6 +217,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
             }
         }
     }
+    if (want_max) {
+        __syncthreads();
+        if (tid < 16 && lmax[tid] != 0u) atomicMax(reinterpret_cast<unsigned*>(g.pair_max) + (int64_t)grp * g.pair_nh + tid, lmax[tid]);
+    }
+}
+
+template <int A_TYPE, int C_TYPE, int NS>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_tile<A_TYPE, C_TYPE, NS>(g, blockIdx.z, blockIdx.x, blockIdx.y, smem);
+}
+
+// Several problems of one kind in ONE launch (the CQT basis products of all pyramid levels: same types, same group count, their own
+// A / W / sizes): blockIdx.z = problem * groups + group, the grid covers the largest problem and the other problems' surplus blocks leave.
+template <int A_TYPE, int C_TYPE, int NS>
+__global__ __launch_bounds__(256) void gemm_multi_kernel(GemmMulti mm) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int groups = mm.p[0].groups;
+    const int pi = blockIdx.z / groups, grp = blockIdx.z - pi * groups;
+    const GemmArgs& g = mm.p[pi];
+    if ((int64_t)blockIdx.x * BM >= g.M || (int)blockIdx.y * BN >= g.n_pad) return;
+    gemm_tile<A_TYPE, C_TYPE, NS>(g, grp, blockIdx.x, blockIdx.y, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -699,6 +741,39 @@ void amtx_gemm_pack_host(const float* W, int64_t ldw, int N, int K, int planes, 
             out[(size_t)n * k_pad + k] = hi;
             if (planes == 2) out[plane + (size_t)n * k_pad + k] = f32_to_bf16_rn(w - bf16_to_f32(hi));
         }
+}
+
+static int check_generic(const GemmArgs& g) {
+    AMTX_REQUIRE(g.A && g.W && (g.C || g.pair_map), "gemm: null pointer");
+    AMTX_REQUIRE(!g.pair_map || (g.a_type == AMTX_T_F32 && g.c_type == AMTX_T_F32 && g.pair_out && g.N % 2 == 0), "gemm: the magnitude epilogue needs fp32 A / C, an output and an even N");
+    AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
+    AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
+    AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
+    AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
+    AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
+    AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
+    return AMTX_OK;
+}
+
+int amtx_launch_gemm_multi(const GemmArgs* gs, int n, hipStream_t stream) {
+    AMTX_REQUIRE(gs && n >= 1 && n <= AMTX_GEMM_MULTI_MAX, "gemm_multi: 1 .. %d problems", AMTX_GEMM_MULTI_MAX);
+    GemmMulti mm;
+    unsigned gx = 0, gy = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs& g = gs[i];
+        int rc = check_generic(g);
+        if (rc != AMTX_OK) return rc;
+        AMTX_REQUIRE(g.a_type == AMTX_T_F32 && g.c_type == AMTX_T_F32 && g.planes == 2 && g.groups == gs[0].groups,
+                     "gemm_multi: fp32 A / C, two weight planes and one group count for all problems");
+        mm.p[i] = g;
+        gx = std::max(gx, (unsigned)((g.M + BM - 1) / BM));
+        gy = std::max(gy, (unsigned)(g.n_pad / BN));
+    }
+    mm.n = n;
+    const size_t lds = 2 * 2 * 2 * TILE_BYTES;
+    hipLaunchKernelGGL((gemm_multi_kernel<AMTX_T_F32, AMTX_T_F32, 2>), dim3(gx, gy, (unsigned)(n * gs[0].groups)), dim3(256), lds, stream, mm);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
 }
 
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {

@@ -528,8 +528,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     return AMTX_OK;
 }
 
-// OnsetsFrames2: the offset head's LogisticBank output of the LAST amtx_of_forward on this workspace
-// (onsetsframes.py:256-261,323-325: finalize_output without a threshold = sigmoid probabilities, (B, n_out, T)).
+// 1 when amtx_of_forward_power applies: one input channel and the first conv fused into the C_out = 32 conv kernel (conv.hip, KS = 1)
 extern "C" int amtx_of_fuses_db_scale(const amtx_of_model* m) {
     return m && m->finalized && m->fuse_conv1 && !m->gen_conv2 && m->in_channels == 1;
 }
@@ -551,6 +550,8 @@ extern "C" int amtx_of_forward_power(const amtx_of_model* m, const float* power,
                            out_onsets, out_multi_pitch, logits_onsets, logits_multi_pitch, logits_pitch_head, stream_);
 }
 
+// OnsetsFrames2: the offset head's LogisticBank output of the LAST amtx_of_forward on this workspace
+// (onsetsframes.py:256-261,323-325: finalize_output without a threshold = sigmoid probabilities, (B, n_out, T)).
 extern "C" int amtx_of_offsets(const amtx_of_model* m, void* workspace, size_t workspace_bytes, int batch, int num_frames, float* out_offsets,
                                float* logits_offsets, void* stream_) {
     AMTX_REQUIRE(m && m->finalized, "amtx_of_offsets: model not finalized");
