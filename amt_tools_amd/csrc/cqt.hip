@@ -657,6 +657,12 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
         g.pair_map = L.d_map; g.pair_out = mag; g.pair_gs = (int64_t)p->n_harm * p->n_bins * d.t_buf; g.pair_pitch = d.t_buf;
         for (int h = 0; h < p->n_harm && h < 16; ++h) g.pair_rows[h] = d.frames_h[h];
         g.pair_max = maxbuf; g.pair_nh = p->n_harm;       // the per-(clip, harmonic) maxima of the dB reference, kept by the epilogue
+        static const bool per_level = getenv("AMTX_CQT_PER_LEVEL_GEMM") != nullptr;   // A/B switch: one launch per level
+        if (per_level) {
+            int rc = amtx_launch_gemm(g, s);
+            if (rc != AMTX_OK) return rc;
+            continue;
+        }
         if (ng == AMTX_GEMM_MULTI_MAX) {
             int rc = amtx_launch_gemm_multi(gs, ng, s);
             if (rc != AMTX_OK) return rc;
