@@ -46,8 +46,6 @@ struct SpecDev {
     int n_fft;               // frame length; the tuned kernel below is n_fft = 2048 only, spec_power_pow2_kernel takes 128 .. 4096
 };
 
-struct __attribute__((packed, aligned(4))) f32pair_a4 { float x, y; };   // two floats at a 4-byte aligned address: global_load_dwordx2
-
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -194,9 +192,8 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     do {                                                                                                 \
         const int64_t s0_ = (T_) * p.hop - half;                                                         \
         if (s0_ >= 0 && s0_ + NFFT <= num_samples) {                                                     \
-            /* one 8-byte load per complex point; the address is only 4-byte aligned (odd clip lengths, odd strides) */ \
-            const f32pair_a4* src_ = reinterpret_cast<const f32pair_a4*>(clip + s0_ + 2 * lane);           \
-            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) { const f32pair_a4 v_ = src_[64 * n1]; xr[n1] = v_.x; xi[n1] = v_.y; } \
+            const float* src_ = clip + s0_ + 2 * lane;                                                   \
+            _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) { xr[n1] = src_[128 * n1]; xi[n1] = src_[128 * n1 + 1]; } \
         } else {                                                                                         \
             _Pragma("unroll") for (int n1 = 0; n1 < 16; ++n1) {                                          \
                 const int64_t idx_ = s0_ + 2 * (n1 * 64 + lane);                                         \
@@ -210,17 +207,6 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         const int64_t tfirst = (int64_t)chunk * FPB + wave;
         if (tfirst < num_frames) SPEC_LOAD_FRAME(tfirst);
     }
-    float res_prev[MAX_MEL_ROUNDS];     // MEL: the mel row of the frame before, stored one frame late (see the loop)
-    float* out_prev = nullptr;
-#pragma unroll
-    for (int r = 0; r < MAX_MEL_ROUNDS; ++r) res_prev[r] = 0.0f;
-#define SPEC_STORE_PREV()                                                                                \
-    do {                                                                                                 \
-        if (out_prev) {                                                                                  \
-            _Pragma("unroll") for (int r = 0; r < MAX_MEL_ROUNDS; ++r)                                   \
-                if (r < rounds && r * 64 + lane < p.n_mels) out_prev[r * 64 + lane] = res_prev[r];       \
-        }                                                                                                \
-    } while (0)
 
 #ifdef AMTX_SPEC_TIMING
     unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -239,10 +225,6 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         float2 v[16];
 #pragma unroll
         for (int n1 = 0; n1 < 16; ++n1) v[n1] = make_float2(xr[n1] * wre[n1], xi[n1] * wim[n1]);
-        // The PREVIOUS frame's mel row is stored here, before the next frame's samples are requested: vmcnt retires in order and
-        // hipcc waits with vmcnt(0) for the samples at the top of the next iteration -- stores issued after the loads (at the end of
-        // the frame that produced them) made that wait include the write acknowledgement of four fresh stores, every frame.
-        if (MEL) SPEC_STORE_PREV();
         {
             const int64_t tnext = t + WAVES;
             if (i + 1 < FPW && tnext < num_frames) SPEC_LOAD_FRAME(tnext);
@@ -354,10 +336,12 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
             }
 #pragma unroll
             for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
-                res_prev[r] = res[r];
-                if (r < rounds && r * 64 + lane < p.n_mels) run_max = fmaxf(run_max, res[r]);
+                const int row = r * 64 + lane;
+                if (r < rounds && row < p.n_mels) {
+                    out_row[row] = res[r];
+                    run_max = fmaxf(run_max, res[r]);
+                }
             }
-            out_prev = out_row;
         } else {
             for (int k = lane; k < p.n_out; k += 64) {
                 const float val = pb[pidx(k)];
@@ -368,8 +352,6 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         wave_lds_sync();   // pb / xb are rewritten by the next frame
         SPEC_TICK(4);
     }
-    if (MEL) SPEC_STORE_PREV();
-#undef SPEC_STORE_PREV
 #undef SPEC_LOAD_FRAME
 #ifdef AMTX_SPEC_TIMING
     if (threadIdx.x == 0)
