@@ -30,7 +30,7 @@ constexpr int XB_PITCH = 68;         // LDS row pitch (complex) of the exchange 
 constexpr int XB_ELEMS = 16 * XB_PITCH;
 constexpr int PB_BINS = 1025 + 128;  // bins a padded mel row may touch: the last real bin is 1024, the rest stays zero
 constexpr int PB_ELEMS = 1232;       // power row: bin k lives at k + (k >> 4) (PB_BINS bins -> 1225 slots), see pidx()
-constexpr int MEL_UNROLL = 8;        // taps per batch of the mel gather (loads in flight per lane)
+constexpr int MEL_UNROLL = 4;        // taps per batch of the mel gather (loads in flight per lane); round tap counts are padded to it
 constexpr int WAVES = 4;
 constexpr int MAX_MEL_ROUNDS = 8;    // up to 512 output rows
 
@@ -45,6 +45,8 @@ struct SpecDev {
     int hop, n_out, n_mels, center, pad_mode;
     int n_fft;               // frame length; the tuned kernel below is n_fft = 2048 only, spec_power_pow2_kernel takes 128 .. 4096
 };
+
+struct __attribute__((packed, aligned(4))) f32pair_a4 { float x, y; };   // two floats at a 4-byte aligned address: one global_load_dwordx2
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -118,14 +120,87 @@ __device__ __forceinline__ void untangle_pair(float2 zk, float2 zp, float2 w, fl
     pmk = br * br + bi * bi;
 }
 
+// 1024-point complex FFT of the windowed frame (v[n1] = z[64 n1 + lane]) + real-FFT untangling -> |X[k]|^2, k = 0 .. 1024, in the
+// wave-private LDS power row pb.  xb: the wave's exchange buffer; twp / tw2l: block-shared twiddle tables; tw1: per-lane pass-A twiddles.
+__device__ __forceinline__ void fft_power_row(float2 (&v)[16], float2* __restrict__ xb, float* __restrict__ pb, const float2* __restrict__ twp,
+                                              const float2* __restrict__ tw2l, const float2 (&tw1)[16], int lane) {
+    // ---- pass A: DFT-16 over n1, twiddle W_1024^(lane*k1), exchange 1
+    dft16(v);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        const float2 y = cmul(v[4 * (k1 & 3) + (k1 >> 2)], tw1[k1]);
+        xb[k1 * XB_PITCH + lane] = y;
+    }
+    wave_lds_sync();
+    // lane = (k1 = lane>>2, b = lane&3) gathers B[k1][4a + b], a = 0..15
+    {
+        const float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) v[a] = row[4 * a];
+    }
+    wave_lds_sync();
+    // ---- pass B: DFT-16 over a, twiddle W_64^(b*c), exchange 2 into [k1][c][b]
+    dft16(v);
+    {
+        float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
+        const float2* t2 = tw2l + (lane & 3) * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[4 * c] = cmul(v[4 * (c & 3) + (c >> 2)], t2[c]);
+    }
+    wave_lds_sync();
+
+    // ---- radix-4 tail merged with the real-FFT untangling: 128 tasks = exactly two full-wave iterations.
+    // A task takes a 4-point group (k1, c) and its partner group ((16 - k1) & 15, 15 - c), runs the two DFT-4s and
+    // untangles the four bin pairs (k, M - k), k = k1 + 16 c + 256 d.  The two self-paired groups (0,0) and (0,8) would be
+    // a 129th task (and a third, one-lane iteration): they are merged into ONE task (q = 127) whose four untangle slots
+    // are (Z0,Z0) -> bins 0 / 1024, (Z1,Z3) -> 256 / 768 of group (0,0) and (Z0,Z3) -> 128 / 896, (Z1,Z2) -> 384 / 640 of
+    // group (0,8); the one bin left over, 512, is its own partner: X[512] = conj(Z[512]), power |Z2|^2.
+#pragma unroll
+    for (int q = lane; q < 128; q += 64) {
+        int k1, c, pk1, pc;
+        const bool sp = q == 127;
+        if (q < 112) { c = (q * 9363) >> 16; k1 = 1 + q - 7 * c; pk1 = 16 - k1; pc = 15 - c; }   // c = q / 7, k1 = 1 + q % 7: k1-major lanes
+        else if (q < 120) { k1 = 8; c = q - 112; pk1 = 8; pc = 15 - c; }
+        else if (q < 127) { k1 = 0; c = q - 119; pk1 = 0; pc = 16 - c; }                          // c = 1..7 with 15..9
+        else { k1 = 0; c = 0; pk1 = 0; pc = 8; }
+        const float4* ga = reinterpret_cast<const float4*>(xb + k1 * XB_PITCH + 4 * c);
+        const float4* gb = reinterpret_cast<const float4*>(xb + pk1 * XB_PITCH + 4 * pc);
+        float4 a01 = ga[0], a23 = ga[1], b01 = gb[0], b23 = gb[1];
+        float2 za[4] = {make_float2(a01.x, a01.y), make_float2(a01.z, a01.w), make_float2(a23.x, a23.y), make_float2(a23.z, a23.w)};
+        float2 zb[4] = {make_float2(b01.x, b01.y), make_float2(b01.z, b01.w), make_float2(b23.x, b23.y), make_float2(b23.z, b23.w)};
+        dft4(za[0], za[1], za[2], za[3]);
+        dft4(zb[0], zb[1], zb[2], zb[3]);
+        const int kbase = k1 + 16 * c;
+        // slot d untangles (A[d], P[d]) into bins (ks[d], M - ks[d]); the merged task re-routes slots by select
+        const float2 A[4] = {za[0], za[1], sp ? zb[0] : za[2], sp ? zb[1] : za[3]};
+        const float2 P[4] = {sp ? za[0] : zb[3], sp ? za[3] : zb[2], sp ? zb[3] : zb[1], sp ? zb[2] : zb[0]};
+        const int ks[4] = {kbase, kbase + 256, sp ? 128 : kbase + 512, sp ? 384 : kbase + 768};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            float pk, pmk;
+            float2 w = twp[ks[d] & (M / 2 - 1)];
+            if (d >= 2) {                                  // ks >= 512 unless this is the merged task (128, 384)
+                const float2 wr = make_float2(w.y, -w.x);  // times -i
+                w = sp ? w : wr;
+            }
+            untangle_pair(A[d], P[d], w, pk, pmk);
+            pb[pidx(ks[d])] = pk;
+            pb[pidx(M - ks[d])] = pmk;
+        }
+        if (sp) pb[pidx(M / 2)] = za[2].x * za[2].x + za[2].y * za[2].y;
+    }
+    wave_lds_sync();
+
+}
+
 // MELLDS: the tap-major mel table (slots x 64 lanes) is copied into LDS once per block and the gather reads its weights from
 // there: per frame 72 global loads per lane (L1/L2 hits, but nine dependent batches of load latency with only two waves per SIMD
 // to cover them) become conflict-free LDS reads.  Plans whose table does not leave room for two blocks per CU keep it in memory.
 constexpr int MEL_LDS_MAX_SLOTS = 80;
 
 #ifdef AMTX_SPEC_TIMING
-// debug build only: cycles wave 0 of every block spends per section of a frame, summed: [0] window + next-frame load issue, [1] pass A +
-// exchange 1, [2] pass B + exchange 2, [3] radix-4 tail + untangling, [4] mel gather + stores, [5] frames
+// debug build only (general kernel): cycles wave 0 of every block spends per section of a frame, summed: [0] window + next-frame load
+// issue, [3] FFT + untangling (fft_power_row), [4] mel gather + stores, [5] frames
 __device__ unsigned long long g_spec_prof[8];
 #define SPEC_TICK(SLOT)                                                    \
     do {                                                                   \
@@ -231,75 +306,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         }
 
         SPEC_TICK(0);
-        // ---- pass A: DFT-16 over n1, twiddle W_1024^(lane*k1), exchange 1
-        dft16(v);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) {
-            const float2 y = cmul(v[4 * (k1 & 3) + (k1 >> 2)], tw1[k1]);
-            xb[k1 * XB_PITCH + lane] = y;
-        }
-        wave_lds_sync();
-        // lane = (k1 = lane>>2, b = lane&3) gathers B[k1][4a + b], a = 0..15
-        {
-            const float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
-#pragma unroll
-            for (int a = 0; a < 16; ++a) v[a] = row[4 * a];
-        }
-        wave_lds_sync();
-        SPEC_TICK(1);
-        // ---- pass B: DFT-16 over a, twiddle W_64^(b*c), exchange 2 into [k1][c][b]
-        dft16(v);
-        {
-            float2* row = xb + (lane >> 2) * XB_PITCH + (lane & 3);
-            const float2* t2 = tw2l + (lane & 3) * 16;
-#pragma unroll
-            for (int c = 0; c < 16; ++c) row[4 * c] = cmul(v[4 * (c & 3) + (c >> 2)], t2[c]);
-        }
-        wave_lds_sync();
-
-        SPEC_TICK(2);
-        // ---- radix-4 tail merged with the real-FFT untangling: 128 tasks = exactly two full-wave iterations.
-        // A task takes a 4-point group (k1, c) and its partner group ((16 - k1) & 15, 15 - c), runs the two DFT-4s and
-        // untangles the four bin pairs (k, M - k), k = k1 + 16 c + 256 d.  The two self-paired groups (0,0) and (0,8) would be
-        // a 129th task (and a third, one-lane iteration): they are merged into ONE task (q = 127) whose four untangle slots
-        // are (Z0,Z0) -> bins 0 / 1024, (Z1,Z3) -> 256 / 768 of group (0,0) and (Z0,Z3) -> 128 / 896, (Z1,Z2) -> 384 / 640 of
-        // group (0,8); the one bin left over, 512, is its own partner: X[512] = conj(Z[512]), power |Z2|^2.
-#pragma unroll 1
-        for (int q = lane; q < 128; q += 64) {
-            int k1, c, pk1, pc;
-            const bool sp = q == 127;
-            if (q < 112) { c = (q * 9363) >> 16; k1 = 1 + q - 7 * c; pk1 = 16 - k1; pc = 15 - c; }   // c = q / 7, k1 = 1 + q % 7: k1-major lanes
-            else if (q < 120) { k1 = 8; c = q - 112; pk1 = 8; pc = 15 - c; }
-            else if (q < 127) { k1 = 0; c = q - 119; pk1 = 0; pc = 16 - c; }                          // c = 1..7 with 15..9
-            else { k1 = 0; c = 0; pk1 = 0; pc = 8; }
-            const float4* ga = reinterpret_cast<const float4*>(xb + k1 * XB_PITCH + 4 * c);
-            const float4* gb = reinterpret_cast<const float4*>(xb + pk1 * XB_PITCH + 4 * pc);
-            float4 a01 = ga[0], a23 = ga[1], b01 = gb[0], b23 = gb[1];
-            float2 za[4] = {make_float2(a01.x, a01.y), make_float2(a01.z, a01.w), make_float2(a23.x, a23.y), make_float2(a23.z, a23.w)};
-            float2 zb[4] = {make_float2(b01.x, b01.y), make_float2(b01.z, b01.w), make_float2(b23.x, b23.y), make_float2(b23.z, b23.w)};
-            dft4(za[0], za[1], za[2], za[3]);
-            dft4(zb[0], zb[1], zb[2], zb[3]);
-            const int kbase = k1 + 16 * c;
-            // slot d untangles (A[d], P[d]) into bins (ks[d], M - ks[d]); the merged task re-routes slots by select
-            const float2 A[4] = {za[0], za[1], sp ? zb[0] : za[2], sp ? zb[1] : za[3]};
-            const float2 P[4] = {sp ? za[0] : zb[3], sp ? za[3] : zb[2], sp ? zb[3] : zb[1], sp ? zb[2] : zb[0]};
-            const int ks[4] = {kbase, kbase + 256, sp ? 128 : kbase + 512, sp ? 384 : kbase + 768};
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                float pk, pmk;
-                float2 w = twp[ks[d] & (M / 2 - 1)];
-                if (d >= 2) {                                  // ks >= 512 unless this is the merged task (128, 384)
-                    const float2 wr = make_float2(w.y, -w.x);  // times -i
-                    w = sp ? w : wr;
-                }
-                untangle_pair(A[d], P[d], w, pk, pmk);
-                pb[pidx(ks[d])] = pk;
-                pb[pidx(M - ks[d])] = pmk;
-            }
-            if (sp) pb[pidx(M / 2)] = za[2].x * za[2].x + za[2].y * za[2].y;
-        }
-        wave_lds_sync();
-
+        fft_power_row(v, xb, pb, twp, tw2l, tw1, lane);
         SPEC_TICK(3);
         float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
         if (MEL) {
@@ -360,6 +367,148 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
 
     run_max = wave_max_f32(run_max);
     if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));   // values >= 0: uint order == float order
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same frame pipeline specialised for the BASELINE log-mel front-end (n_fft 2048, hop 512, a mel table whose four rounds of 64
+// rows need S0 / S1 / S2 / S3 tap slots): measured on the general kernel, a quarter of its time went into fetching every sample
+// four times (each wave loads the whole 2048-sample frame, the four frames of a block overlap by 75 %: 0.40 of 2.00 ms with the
+// loads compiled out) and another quarter into the mel gather's two LDS reads per tap.  Here
+//   * the block keeps a 4096-sample RING of the clip in LDS: per iteration (four adjacent frames, one per wave) the block fetches
+//     only the 2048 NEW samples (8 per thread, prefetched a whole iteration ahead in registers) and every wave reads its frame from
+//     the ring -- 3.7 x fewer global load instructions, two block barriers per four frames;
+//   * the mel weights are STATIONARY IN REGISTERS (slot q of lane l = weight q of row 64 r + l, exactly the tap-major table): the
+//     gather is one LDS read + one FMA per tap, and the 18 KB the table took in LDS pay for the ring.
+// Arithmetic and summation order are those of spec_power_kernel: the two kernels return the same bits (tests/test_gpu_frontend.py).
+constexpr int RING_HOP = 512;
+constexpr int RING_ELEMS = 4096;                 // floats; window of an iteration: 3 hops + 2048 = 3584, new per iteration: 2048
+
+template <int FPW, int S0, int S1, int S2, int S3>
+__global__ __launch_bounds__(256, 2) void spec_power_ring_kernel(SpecDev p, const float* __restrict__ audio, int64_t num_samples,
+                                                              int64_t audio_stride, int64_t num_frames, float* __restrict__ power,
+                                                              unsigned* __restrict__ clip_max) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NSLOT = S0 + S1 + S2 + S3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* xb = reinterpret_cast<float2*>(smem) + wave * XB_ELEMS;
+    float* pb = reinterpret_cast<float*>(smem + WAVES * XB_ELEMS * sizeof(float2)) + wave * PB_ELEMS;
+    float2* twp = reinterpret_cast<float2*>(smem + WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float));
+    float2* tw2l = twp + M / 2;
+    int* mstart = reinterpret_cast<int*>(tw2l + 64);                       // [4][64]
+    float* ring = reinterpret_cast<float*>(mstart + 64 * 4);               // [RING_ELEMS]
+
+    constexpr int FPB = FPW * WAVES;
+    const unsigned chunks = (unsigned)((num_frames + FPB - 1) / FPB);
+    const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned clip_idx = logical / chunks, chunk = logical % chunks;
+    const float* clip = audio + (int64_t)clip_idx * audio_stride;
+
+    for (int i = tid; i < M / 2; i += 256) twp[i] = p.tw_post[i];
+    if (tid < 64) tw2l[tid] = p.tw_fft[(16 * (tid >> 4) * (tid & 15)) & (M - 1)];
+    for (int i = tid; i < 64 * 4; i += 256) mstart[i] = p.mel_start[i];
+    float wre[16], wim[16];
+    float2 tw1[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int m = n1 * 64 + lane;
+        wre[n1] = p.window[2 * m];
+        wim[n1] = p.window[2 * m + 1];
+        tw1[n1] = p.tw_fft[(lane * n1) & (M - 1)];
+    }
+    float mw[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) mw[q] = p.mel_wt[q * 64 + lane];
+    for (int i = pidx(M + 1) + lane; i < PB_ELEMS; i += 64) pb[i] = 0.0f;
+
+    // ---- sample staging.  sb = first sample of the block's first frame; sample s lives at ring[(s - sb) & (RING_ELEMS - 1)].
+    const int64_t half = p.center ? NFFT / 2 : 0;
+    const int64_t sb = (int64_t)chunk * FPB * RING_HOP - half;
+    // 2048 samples starting at s0: thread tid takes the pairs (2 tid + 512 m, + 1), m = 0..3 (consecutive lanes, consecutive 8 bytes)
+    float2 pre[4];
+#define RING_FETCH(S0_)                                                                                  \
+    do {                                                                                                 \
+        const int64_t s0_ = (S0_);                                                                       \
+        if (s0_ >= 0 && s0_ + 2048 <= num_samples) {                                                     \
+            const f32pair_a4* src_ = reinterpret_cast<const f32pair_a4*>(clip + s0_ + 2 * tid);          \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) { const f32pair_a4 v_ = src_[256 * m]; pre[m] = make_float2(v_.x, v_.y); } \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                              \
+                const int64_t idx_ = s0_ + 2 * tid + 512 * m;                                            \
+                pre[m] = make_float2(fetch_padded(clip, idx_, num_samples, p.pad_mode), fetch_padded(clip, idx_ + 1, num_samples, p.pad_mode)); \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+#define RING_STORE(S0_)                                                                                  \
+    do {                                                                                                 \
+        const int r0_ = (int)(((S0_) - sb) & (RING_ELEMS - 1));                                          \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                    \
+            *reinterpret_cast<float2*>(ring + ((r0_ + 2 * tid + 512 * m) & (RING_ELEMS - 1))) = pre[m];  \
+    } while (0)
+    // window 0 = [sb, sb + 3584): 2048 + 1536 samples (the second fetch brings 2048, of which the last 512 belong to window 1)
+    RING_FETCH(sb);
+    RING_STORE(sb);
+    RING_FETCH(sb + 2048);
+    RING_STORE(sb + 2048);
+    if (FPW > 1) RING_FETCH(sb + 4096);                       // the rest of window 1's new samples: [sb + 4096, sb + 6144)
+
+    float run_max = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < FPW; ++i) {
+        const int64_t t = (int64_t)chunk * FPB + i * WAVES + wave;
+        const bool active = t < num_frames;
+        __syncthreads();                                      // window i is in the ring (and the tables, first time round)
+        float2 v[16];
+        {
+            const int r0 = (2048 * i + RING_HOP * wave + 2 * lane) & (RING_ELEMS - 1);
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                const float2 x = *reinterpret_cast<const float2*>(ring + ((r0 + 128 * n1) & (RING_ELEMS - 1)));
+                v[n1] = make_float2(x.x * wre[n1], x.y * wim[n1]);
+            }
+        }
+        __syncthreads();                                      // every wave has its frame: the oldest 2048 ring slots are free
+        if (i + 1 < FPW) {
+            // window i + 1 = [sb + 2048 (i + 1), + 3584): its last 1536 ... the ring holds up to sb + 2048 i + 4096, `pre` brings
+            // [sb + 2048 i + 4096, + 2048)
+            RING_STORE(sb + 2048 * (int64_t)i + 4096);
+            if (i + 2 < FPW) RING_FETCH(sb + 2048 * (int64_t)(i + 1) + 4096);
+        }
+        if (!active) continue;
+
+        fft_power_row(v, xb, pb, twp, tw2l, tw1, lane);
+
+        // ---- sparse mel, weights in registers; same accumulation order as the general kernel (even taps -> acc0, odd -> acc1)
+        float res[4];
+#define RING_MEL_ROUND(R, OFF, N)                                                                        \
+        {                                                                                                \
+            const int start_ = mstart[(R) * 64 + lane];                                                  \
+            float acc0 = 0.0f, acc1 = 0.0f;                                                              \
+            _Pragma("unroll") for (int j = 0; j < (N); j += 2) {                                         \
+                acc0 = fmaf(mw[(OFF) + j], pb[pidx(start_ + j)], acc0);                                  \
+                acc1 = fmaf(mw[(OFF) + j + 1], pb[pidx(start_ + j + 1)], acc1);                          \
+            }                                                                                            \
+            res[R] = acc0 + acc1;                                                                        \
+        }
+        RING_MEL_ROUND(0, 0, S0)
+        RING_MEL_ROUND(1, S0, S1)
+        RING_MEL_ROUND(2, S0 + S1, S2)
+        RING_MEL_ROUND(3, S0 + S1 + S2, S3)
+#undef RING_MEL_ROUND
+        float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = r * 64 + lane;
+            if (row < p.n_mels) {
+                out_row[row] = res[r];
+                run_max = fmaxf(run_max, res[r]);
+            }
+        }
+        wave_lds_sync();   // pb / xb are rewritten by the next frame
+    }
+#undef RING_FETCH
+#undef RING_STORE
+    run_max = wave_max_f32(run_max);
+    if (lane == 0 && run_max > 0.0f) atomicMax(clip_max + clip_idx, __float_as_uint(run_max));
 }
 
 // Any other power-of-two frame length (128 .. 4096; amt_tools/features/stft.py:15-40 and mel.py:15-38 take any n_fft): one wave per
@@ -698,6 +847,21 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
                            (unsigned*)clip_max);
         return AMTX_OK;
     };
+    // the BASELINE log-mel shape (hop 512, four mel rounds of 4 / 8 / 20 / 32 tap slots = librosa's 229 Slaney rows at 22.05 kHz) has its own
+    // kernel: clip ring in LDS + mel weights in registers; AMTX_SPEC_NO_RING=1 keeps the general kernel (A/B and the bit-equality test)
+    static const bool no_ring = getenv("AMTX_SPEC_NO_RING") != nullptr;
+    const auto& dv = plan->dev;
+    if (!no_ring && plan->hop == RING_HOP && mel_rounds == 4 && dv.round_max[0] == 4 && dv.round_max[1] == 8 && dv.round_max[2] == 20 &&
+        dv.round_max[3] == 32 && dv.round_off[1] == 4 && dv.round_off[2] == 12 && dv.round_off[3] == 32) {
+        auto kern = spec_power_ring_kernel<FPW, 4, 8, 20, 32>;
+        const size_t lds_r = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M / 2 + 64) * sizeof(float2) +
+                             64 * 4 * sizeof(int) + RING_ELEMS * sizeof(float);
+        AMTX_GRANT_LDS(kern, lds_r);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_r, stream, plan->dev, audio, num_samples, audio_stride, T, power,
+                           (unsigned*)clip_max);
+        AMTX_CHECK_LAUNCH();
+        return AMTX_OK;
+    }
     int rc;
     if (mel_lds) rc = launch(spec_power_kernel<FPW, true, true>);
     else if (plan->n_mels > 0) rc = launch(spec_power_kernel<FPW, true, false>);

@@ -3,6 +3,8 @@
 Tolerance: the scaled features live in [0, 1]; the fp32 on-device FFT differs from the fp64 oracle by
 rounding noise that is largest (in dB) in bins near the -80 dB floor.  Bound: 1e-4 absolute in the
 scaled domain (SURVEY 8(c) suggests 1e-5..1e-4), 2e-6 relative on linear power."""
+import os
+
 import numpy as np
 import pytest
 
@@ -197,3 +199,43 @@ def test_short_window_not_centered_stft_is_the_bookkeeping_goldens_module():
     y = synth_clip(2, num_samples=20000)
     wide = STFT(sample_rate=22050, hop_length=512, n_fft=2048, win_length=1500)
     assert np.abs(wide.process_audio(y) - fe.stft_process_audio(y, 512, 2048, win_length=1500)).max() < TOL_SCALED
+
+
+_RING_VS_GENERAL = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd.features import MelSpec
+from amt_tools_amd.synth import synth_clip
+mod = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048, librosa_version=sys.argv[2])
+outs = []
+for n in (319999, 512 * 37 + 11, 2049, 70001, 1025):
+    a = np.stack([synth_clip(i, num_samples=n) for i in range(5)])
+    a[1] *= 1e-3
+    a[3] = 0
+    power, cmax = mod.power_batch(torch.from_numpy(a).cuda())
+    outs += [power.cpu().numpy(), cmax.cpu().numpy()]
+np.savez(sys.argv[1], *outs)
+'''
+
+
+@pytest.mark.parametrize('lv', ['0.10', '0.9'])
+def test_ring_kernel_returns_the_bits_of_the_general_kernel(tmp_path, lv):
+    """The BASELINE log-mel shape (n_fft 2048, hop 512, 229 Slaney rows at 22.05 kHz) runs on spec_power_ring_kernel (clip ring in LDS, mel
+    weights in registers); AMTX_SPEC_NO_RING=1 keeps the general spec_power_kernel.  Same arithmetic, same order: the power mel
+    spectrograms and the clip maxima must be IDENTICAL, for full-size clips, ragged lengths (frames that straddle the clip end,
+    chunks with inactive waves), both padding modes (zeros / reflection), a silent clip and clips 60 dB apart."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('ring', {}), ('general', {'AMTX_SPEC_NO_RING': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _RING_VS_GENERAL, files[tag], lv], env=env, cwd=root)
+    ring, general = np.load(files['ring']), np.load(files['general'])
+    assert len(ring.files) == 10
+    for k in ring.files:
+        np.testing.assert_array_equal(ring[k], general[k])
+    assert ring['arr_0'].shape == (5, 625, 229) and ring['arr_0'].max() > 0

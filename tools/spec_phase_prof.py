@@ -10,6 +10,7 @@ from amt_tools_amd import _lib
 from amt_tools_amd.features import MelSpec
 from amt_tools_amd.synth import synth_clip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+os.environ.setdefault('AMTX_SPEC_NO_RING', '1')   # the counters live in the general kernel
 mel = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048)
 audio = torch.from_numpy(np.stack([synth_clip(i) for i in range(4)])).cuda().repeat((B + 3) // 4, 1)[:B].contiguous()
 L = C.CDLL(_lib.LIB_PATH)
@@ -21,7 +22,7 @@ assert L.amtxdbg_spec_prof(buf, 1) == 0
 mel.power_batch(audio)
 torch.cuda.synchronize()
 assert L.amtxdbg_spec_prof(buf, 1) == 0
-names = ['window + next-frame load issue', 'pass A (DFT-16, twiddle, exchange 1)', 'pass B (DFT-16, twiddle, exchange 2)', 'radix-4 tail + untangling', 'mel gather + stores']
+names = ['window + next-frame load issue', '-', '-', 'FFT (two DFT-16 passes, two exchanges) + radix-4 tail + untangling', 'mel gather + stores']
 tot = sum(buf[i] for i in range(5))
 for i, n in enumerate(names):
     print(f'   {n:<40} {buf[i] / max(1, buf[5]):8.0f} cycles / frame  ({100.0 * buf[i] / tot:4.1f} %)')
