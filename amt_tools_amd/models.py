@@ -255,15 +255,16 @@ class PendingFeatures(object):
     FeatureModule that would finish them.  `materialize()` is the ordinary feature tensor (B,1,T,F), bit-identical to what the conv
     kernel stages."""
 
-    def __init__(self, module, power, clip_max):
-        self.module, self.power, self.clip_max = module, power, clip_max
+    def __init__(self, module, power, clip_max, ref=None):
+        # ref: optional (B,) reference powers for the dB scale (track-level reference, SURVEY F7); None = each clip's own maximum
+        self.module, self.power, self.clip_max, self.ref = module, power, clip_max, ref
 
     @property
     def device(self):
         return self.power.device
 
     def materialize(self):
-        return self.module.scale_batch(self.power, self.clip_max, None, model_layout=True)
+        return self.module.scale_batch(self.power, self.clip_max, self.ref, model_layout=True)
 
 
 class _OFEngine(object):
@@ -322,7 +323,7 @@ class _OFEngine(object):
         sb, sc, st, sf = feats.stride()
         with torch.cuda.device(feats.device):
             if pending is not None:
-                _lib.check(L.amtx_of_forward_power(self.handle, _lib.ptr(feats), sb, st, sf, _lib.ptr(pending.clip_max), None, B, T,
+                _lib.check(L.amtx_of_forward_power(self.handle, _lib.ptr(feats), sb, st, sf, _lib.ptr(pending.clip_max), _lib.ptr(pending.ref), B, T,
                                                    _lib.ptr(self.workspace), self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch),
                                                    _lib.ptr(lo), _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)),
                            'amtx_of_forward_power')

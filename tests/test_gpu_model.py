@@ -290,8 +290,14 @@ def test_db_scaling_deferred_into_the_conv_kernel_is_bit_identical(frontend, pre
         np.testing.assert_array_equal(feats.cpu().numpy(), model.pre_proc(batch)[tools.KEY_FEATS].cpu().numpy())
         plain = model(feats)
         out = model.run_on_batch(batch)
+        # a caller-supplied reference power per clip (track-level dB reference) goes through the same kernel argument
+        pf = pre[tools.KEY_FEATS]
+        with_ref = PendingFeatures(pf.module, pf.power, pf.clip_max, ref=(pf.clip_max * 3.0 + 1e-3).contiguous())
+        fused_ref, plain_ref = model(with_ref), model(with_ref.materialize())
     for key in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
         np.testing.assert_array_equal(fused[key].cpu().numpy(), plain[key].cpu().numpy())
+        np.testing.assert_array_equal(fused_ref[key].cpu().numpy(), plain_ref[key].cpu().numpy())
+        assert not np.array_equal(fused_ref[key].cpu().numpy(), fused[key].cpu().numpy())      # the reference really changes the features
         assert out[key].shape == (4, 88, 38)
         np.testing.assert_array_equal(out[key].cpu().numpy(), (plain[key].transpose(-1, -2) > 0).float().cpu().numpy())
 
