@@ -143,7 +143,20 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 
     // ---- stationary weights: 9 taps x NT tiles (x NS planes), one 16-byte fragment per lane each
     uint4 wf[9][NT][NS];
-    {
+    // C_out = 64, bf16 out: the packed order gives a lane 16 consecutive channels (two 16-byte stores 32 bytes apart per position, four
+    // lane groups interleaved).  WIDE_ST re-deals the weight rows once at load so that store q of the four lane groups covers 64
+    // CONTIGUOUS bytes (channels 32 q + 8 g ..): row (4 gr + r) of tile nt <- row (4 (2 (nt >> 1) + (gr >> 1)) + r) of packed tile 2 (gr & 1) + (nt & 1)
+    constexpr bool WIDE_ST = NT == 4 && NS == 1 && OUT_TYPE == AMTX_T_BF16 && !FUSE1;
+    if constexpr (WIDE_ST) {
+        const int gr = (lane & 15) >> 2;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int src_lane = (lane & 48) + 4 * (2 * (nt >> 1) + (gr >> 1)) + (lane & 3);
+            const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + src_lane;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) wf[tap][nt][0] = w[(tap * NT + 2 * (gr & 1) + (nt & 1)) * 64];
+        }
+    } else {
         const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
@@ -154,7 +167,8 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     }
     // folded BN shift: a C_out-float table at the end of LDS; the accumulators of every column pair are initialised
     // from it (lane -> its 4*NT consecutive channels), so the epilogue is max3(y0, y1, 0) only
-    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0)) + g * NT;
+    const f32x4_t* shl0 = reinterpret_cast<const f32x4_t*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0));
+    const f32x4_t* shl = shl0 + g * NT;
     if (tid < COUT) reinterpret_cast<float*>(smem + NS * PB + (FUSE1 ? (a.c_in * FROWS * FW + FSLACK) * 4 : 0))[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
 
     // C_out = 32: the shift also sits in 8 registers and is the C operand of each pair's first MFMAs directly (the LDS table read
@@ -707,7 +721,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = SH_REGS ? shr[nt] : shl[nt];
+                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = SH_REGS ? shr[nt] : (WIDE_ST ? shl0[(nt >> 1) * 8 + g * 2 + (nt & 1)] : shl[nt]);
 
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
@@ -744,10 +758,10 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
                         v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
                     }
                 if (OUT_TYPE == AMTX_T_BF16) {
-                    uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
+                    uint4* dst = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + (WIDE_ST ? g * 8 : g * 4 * NT)) * 2);
 #pragma unroll
                     for (int q = 0; q < NT / 2; ++q)
-                        dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
+                        dst[WIDE_ST ? 4 * q : q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
                                             pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
                 } else {
                     float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 4);
