@@ -230,10 +230,14 @@ __device__ __forceinline__ void load_x4(const char* xbase, int64_t row_off, type
     }
 }
 
-template <int NS, int X_TYPE, int OUT_TYPE, bool FAST>
-__device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf)[4][4][NS], const typename XScalar<X_TYPE>::type (&xcur)[4],
-                                           typename XScalar<X_TYPE>::type (&xnext)[4], float& c, const char* xbase, char* obase, int t, int tnext,
-                                           int lane, int hwoff, bool clip_ok, float* save) {
+// NC = clips per lane: 1 -> four clips per block in rows 0 / 4 / 8 / 12 of the h tile (accumulator register 0), 2 -> eight clips in
+// rows 0 / 2 / ... / 14 (registers 0 and 2): the same 16 MFMAs per wave and step serve twice the clips.
+template <int NS, int X_TYPE, int OUT_TYPE, bool FAST, int NC>
+__device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf)[4][4][NS], const typename XScalar<X_TYPE>::type (&xcur)[NC][4],
+                                           typename XScalar<X_TYPE>::type (&xnext)[NC][4], float (&c)[NC], const char* const (&xbase)[NC],
+                                           char* const (&obase)[NC], int t, int tnext, int lane, const int (&hwoff)[NC], const bool (&clip_ok)[NC],
+                                           float* save) {
+    constexpr int RSTEP = 4 / NC;                 // accumulator register (= h tile row inside the lane group) of clip j: RSTEP * j
     const char* hb = smem + cur * NS * HBUF_BYTES;
     uint4 hf[4][NS];
 #pragma unroll
@@ -242,11 +246,16 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
         for (int p = 0; p < NS; ++p)
             hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBUF_BYTES + ((lane & 15) * HP + 32 * ks + 8 * (lane >> 4)) * 2);
 
-    load_x4<X_TYPE>(xbase, (int64_t)tnext * 1024, xnext);     // unconditional, see lstm_step
+#pragma unroll
+    for (int j = 0; j < NC; ++j) load_x4<X_TYPE>(xbase[j], (int64_t)tnext * 1024, xnext[j]);     // unconditional, see lstm_step
 
     f32x4_t acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (f32x4_t){unpack_xs(xcur[q], lane & 1), 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q) {
+        acc[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NC; ++j) acc[q][RSTEP * j] = unpack_xs(xcur[j][q], lane & 1);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -258,39 +267,39 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
             }
         }
 
-    const float ig = sigmoid_f<FAST>(acc[0][0]);
-    const float fg = sigmoid_f<FAST>(acc[1][0]);
-    const float gg = tanh_f<FAST>(acc[2][0]);
-    const float og = sigmoid_f<FAST>(acc[3][0]);
-    c = fg * c + ig * gg;
-    const float h = og * tanh_f<FAST>(c);
-    if (save && clip_ok) {     // training: post-activation gates and the new cell state, [b][t][dir][5][128] (save points at [b][0][dir][0][unit])
-        float* sv = save + (int64_t)t * (2 * 5 * H);
-        sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c;
-    }
-
     char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
-    uint32_t hiw, low = 0;
-    if (NS == 2) split_bf16x2(h, 0.f, hiw, low);
-    else hiw = pack_bf16x2(h, 0.f);
-    *reinterpret_cast<unsigned short*>(hn + hwoff) = (unsigned short)hiw;
-    if (NS == 2) *reinterpret_cast<unsigned short*>(hn + HBUF_BYTES + hwoff) = (unsigned short)low;
-    if (clip_ok) {
-        if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<unsigned short*>(obase + (int64_t)t * 256 * 2) = (unsigned short)hiw;
-        else *reinterpret_cast<float*>(obase + (int64_t)t * 256 * 4) = h;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const float ig = sigmoid_f<FAST>(acc[0][RSTEP * j]);
+        const float fg = sigmoid_f<FAST>(acc[1][RSTEP * j]);
+        const float gg = tanh_f<FAST>(acc[2][RSTEP * j]);
+        const float og = sigmoid_f<FAST>(acc[3][RSTEP * j]);
+        c[j] = fg * c[j] + ig * gg;
+        const float h = og * tanh_f<FAST>(c[j]);
+        if (NC == 1 && save && clip_ok[j]) {     // training: post-activation gates and the new cell state, [b][t][dir][5][128] (save points at [b][0][dir][0][unit])
+            float* sv = save + (int64_t)t * (2 * 5 * H);
+            sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c[j];
+        }
+        uint32_t hiw, low = 0;
+        if (NS == 2) split_bf16x2(h, 0.f, hiw, low);
+        else hiw = pack_bf16x2(h, 0.f);
+        *reinterpret_cast<unsigned short*>(hn + hwoff[j]) = (unsigned short)hiw;
+        if (NS == 2) *reinterpret_cast<unsigned short*>(hn + HBUF_BYTES + hwoff[j]) = (unsigned short)low;
+        if (clip_ok[j]) {
+            if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<unsigned short*>(obase[j] + (int64_t)t * 256 * 2) = (unsigned short)hiw;
+            else *reinterpret_cast<float*>(obase[j] + (int64_t)t * 256 * 4) = h;
+        }
     }
     lds_barrier();
 }
 
-template <int NS, int X_TYPE, int OUT_TYPE>
+template <int NS, int X_TYPE, int OUT_TYPE, int NC = 1>
 __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16, rows 0/4/8/12 used
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HP] bf16, rows 0/4/8/12 (NC = 2: every second row) used
     constexpr bool FAST = true;   // v_exp_f32 / v_rcp_f32 are ~1 ulp: also fine for the fp32-class (two-plane) mode, checked at 1e-4 / 2e-4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int unit = 16 * wave + (lane & 15), cg = lane >> 4;
     const int dir = blockIdx.y, grp = blockIdx.z;
-    const int b = blockIdx.x * 4 + cg;
-    const bool clip_ok = b < a.B;
     const int T = a.T;
 
     uint4 wf[4][4][NS];
@@ -305,28 +314,45 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_kernel(LstmArgs a) {
     }
     for (int i = tid; i < 2 * NS * HBUF_BYTES / 16; i += LTHREADS) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
 
-    float c = 0.f;
-    const char* xbase = reinterpret_cast<const char*>(a.xproj) +
-                        ((int64_t)grp * a.x_gs + (int64_t)(clip_ok ? b : 0) * T * 1024 + dir * 512 + (X_TYPE == AMTX_T_BF16 ? (unit & ~1) : unit)) *
-                            (X_TYPE == AMTX_T_BF16 ? 2 : 4);
-    char* obase = reinterpret_cast<char*>(a.out) +
-                  ((int64_t)grp * a.out_gs + (int64_t)(clip_ok ? b : 0) * T * 256 + dir * 128 + unit) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
-    const int hwoff = (4 * cg * HP + unit) * 2;
-    float* save = a.save ? a.save + (((int64_t)grp * a.B + (clip_ok ? b : 0)) * T * 2 + dir) * (5 * H) + unit : nullptr;
+    float c[NC];
+    bool clip_ok[NC];
+    const char* xbase[NC];
+    char* obase[NC];
+    int hwoff[NC];
+    float* save = nullptr;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int b = (blockIdx.x * 4 + cg) * NC + j;
+        clip_ok[j] = b < a.B;
+        c[j] = 0.f;
+        xbase[j] = reinterpret_cast<const char*>(a.xproj) +
+                   ((int64_t)grp * a.x_gs + (int64_t)(clip_ok[j] ? b : 0) * T * 1024 + dir * 512 + (X_TYPE == AMTX_T_BF16 ? (unit & ~1) : unit)) *
+                       (X_TYPE == AMTX_T_BF16 ? 2 : 4);
+        obase[j] = reinterpret_cast<char*>(a.out) +
+                   ((int64_t)grp * a.out_gs + (int64_t)(clip_ok[j] ? b : 0) * T * 256 + dir * 128 + unit) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+        hwoff[j] = ((4 * cg + (4 / NC) * j) * HP + unit) * 2;
+        if (NC == 1) save = a.save ? a.save + (((int64_t)grp * a.B + (clip_ok[j] ? b : 0)) * T * 2 + dir) * (5 * H) + unit : nullptr;
+    }
 
-    typename XScalar<X_TYPE>::type x0[4], x1[4], x2[4], x3[4];
+    typename XScalar<X_TYPE>::type x0[NC][4], x1[NC][4], x2[NC][4], x3[NC][4];
     auto tidx = [&](int s) { s = s < T ? s : T - 1; return (int64_t)(dir == 0 ? s : T - 1 - s); };
-    load_x4<X_TYPE>(xbase, tidx(0) * 1024, x0);
-    load_x4<X_TYPE>(xbase, tidx(1) * 1024, x1);
-    load_x4<X_TYPE>(xbase, tidx(2) * 1024, x2);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        load_x4<X_TYPE>(xbase[j], tidx(0) * 1024, x0[j]);
+        load_x4<X_TYPE>(xbase[j], tidx(1) * 1024, x1[j]);
+        load_x4<X_TYPE>(xbase[j], tidx(2) * 1024, x2[j]);
+    }
     __syncthreads();
 
     for (int s = 0; s < T; s += 4) {
         // straight-line body, stores of the steps past T masked (see bilstm_kernel)
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), lane, hwoff, clip_ok, save);
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, clip_ok && s + 1 < T, save);
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, clip_ok && s + 2 < T, save);
-        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, clip_ok && s + 3 < T, save);
+        bool ok1[NC], ok2[NC], ok3[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) { ok1[j] = clip_ok[j] && s + 1 < T; ok2[j] = clip_ok[j] && s + 2 < T; ok3[j] = clip_ok[j] && s + 3 < T; }
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST, NC>(smem, 0, wf, x0, x3, c, xbase, obase, (int)tidx(s), (int)tidx(s + 3), lane, hwoff, clip_ok, save);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST, NC>(smem, 1, wf, x1, x0, c, xbase, obase, (int)tidx(s + 1), (int)tidx(s + 4), lane, hwoff, ok1, save);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST, NC>(smem, 0, wf, x2, x1, c, xbase, obase, (int)tidx(s + 2), (int)tidx(s + 5), lane, hwoff, ok2, save);
+        lstm4_step<NS, X_TYPE, OUT_TYPE, FAST, NC>(smem, 1, wf, x3, x2, c, xbase, obase, (int)tidx(s + 3), (int)tidx(s + 6), lane, hwoff, ok3, save);
     }
 }
 
@@ -920,7 +946,15 @@ inline bool use_four_clip_blocks(const LstmArgs& a) { return (int64_t)((a.B + 3)
 template <int NS, int X_TYPE, int OUT_TYPE>
 int launch(const LstmArgs& a, hipStream_t stream) {
     const size_t lds = 2 * NS * HBUF_BYTES;
-    if (use_four_clip_blocks(a) || a.save) {     // the training forward (save != null) exists for the 4-clip mapping only
+    // Eight clips per block once four-clip blocks would outnumber the CUs: two co-resident blocks share a SIMD's matrix pipe and issue
+    // slots and a step takes 1650 cycles instead of the 1070 a block has to itself (0.54 vs 0.35 ms per 625 steps, measured at 1024 and
+    // 512 clips); the eight-clip block does the same 16 MFMAs per wave and step for twice the clips, one block per CU.
+    static const bool no8 = getenv("AMTX_LSTM_NO8") != nullptr;       // A/B switch
+    const int64_t blocks4 = (int64_t)((a.B + 3) / 4) * 2 * a.groups;
+    if (!a.save && !no8 && blocks4 > 256 && use_four_clip_blocks(a)) {
+        dim3 grid((unsigned)((a.B + 7) / 8), 2, (unsigned)a.groups);
+        hipLaunchKernelGGL((bilstm4_kernel<NS, X_TYPE, OUT_TYPE, 2>), grid, dim3(LTHREADS), lds, stream, a);
+    } else if (use_four_clip_blocks(a) || a.save) {     // the training forward (save != null) exists for the 4-clip mapping only
         dim3 grid((unsigned)((a.B + 3) / 4), 2, (unsigned)a.groups);
         hipLaunchKernelGGL((bilstm4_kernel<NS, X_TYPE, OUT_TYPE>), grid, dim3(LTHREADS), lds, stream, a);
     } else {
