@@ -24,7 +24,12 @@ struct GemmArgs {
     // optional with the magnitude epilogue: running maximum of the stored magnitudes per (group, pair_map[p].y): pair_max[grp * pair_nh + y]
     // (atomic max on the float bits; the caller zeroes it first)
     float* pair_max = nullptr; int pair_nh = 0;
+    // optional piano-roll epilogue (bf16-A / fp32-C direct-to-LDS kernel, amtx_gemm_has_roll_epilogue): rows are (clip, frame) with roll_T
+    // frames per clip; group roll_group also writes roll_out[clip][n][frame] = sigmoid(c) (roll_thr < 0) or sigmoid(c) < roll_thr ? 0 : 1.
+    // C may then be null (logits not wanted).
+    float* roll_out = nullptr; int roll_T = 0; float roll_thr = 0.5f; int roll_group = 0;
 };
+bool amtx_gemm_has_roll_epilogue(const GemmArgs& g);
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);
 // several fp32-A / fp32-C / two-plane problems with one group count in one launch (generic 128 x 128 kernel)
 constexpr int AMTX_GEMM_MULTI_MAX = 10;

@@ -396,9 +396,26 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[nt][r] = acc[nt][mt][r] + bv[nt][r];
                 if (C_TYPE == AMTX_T_F32) {
+                    if (g.C) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        if (wide || nb + 4 * nt < g.N) reinterpret_cast<float4*>(dst)[nt] = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+                        for (int nt = 0; nt < 4; ++nt)
+                            if (wide || nb + 4 * nt < g.N) reinterpret_cast<float4*>(dst)[nt] = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+                    }
+                    if (g.roll_out && grp == g.roll_group) {
+                        // piano-roll epilogue (LogisticBank.finalize_output, amt_tools/models/common.py:586-620): the row is frame
+                        // t of clip b, its logits become sigmoid -> threshold in out[b][key][t]; the 16 lanes of a lane group hold 16
+                        // consecutive frames of one key: 64-byte stores.  Same expression as pianoroll_kernel (head.hip): same bits.
+                        const unsigned bclip = (unsigned)m / (unsigned)g.roll_T, tfrm = (unsigned)m - bclip * (unsigned)g.roll_T;
+                        float* ro = g.roll_out + ((int64_t)bclip * g.N + nb) * g.roll_T + tfrm;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (nb + 4 * nt + r < g.N) {
+                                    const float sg = 1.0f / (1.0f + expf(-o[nt][r]));
+                                    ro[(int64_t)(4 * nt + r) * g.roll_T] = g.roll_thr < 0.f ? sg : (sg < g.roll_thr ? 0.f : 1.f);
+                                }
+                    }
                 } else if (wide) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
@@ -776,8 +793,14 @@ int amtx_launch_gemm_multi(const GemmArgs* gs, int n, hipStream_t stream) {
     return AMTX_OK;
 }
 
+// the shapes amtx_launch_gemm sends to gemm_glds_kernel<fp32 C> (not the two-group ring, whose epilogue has no roll code)
+bool amtx_gemm_has_roll_epilogue(const GemmArgs& g) {
+    return g.a_type == AMTX_T_BF16 && g.c_type == AMTX_T_F32 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0 &&
+           !(g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256);
+}
+
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
-    AMTX_REQUIRE(g.A && g.W && (g.C || g.pair_map), "gemm: null pointer");
+    AMTX_REQUIRE(g.A && g.W && (g.C || g.pair_map || g.roll_out), "gemm: null pointer");
     AMTX_REQUIRE(!g.pair_map || (g.a_type == AMTX_T_F32 && g.c_type == AMTX_T_F32 && g.pair_out && g.N % 2 == 0), "gemm: the magnitude epilogue needs fp32 A / C, an output and an even N");
     AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
     AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
@@ -785,6 +808,8 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
+    AMTX_REQUIRE(!g.roll_out || amtx_gemm_has_roll_epilogue(g), "gemm: the piano-roll epilogue exists on the bf16 direct-to-LDS path with fp32 C only");
+    AMTX_REQUIRE(!g.roll_out || (g.roll_T > 0 && g.M % g.roll_T == 0 && g.M < (1ll << 31)), "gemm: piano-roll epilogue: M must be clips x frames");
     if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {
         // A/B switches for tools/bench_gemm.py / tools/check_gemm_pp.py: AMTX_GEMM_PP=1 forces the two-group ring for any K,
         // AMTX_GEMM_NO_PP=1 disables it

@@ -484,6 +484,11 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     mark();
     // LogisticBank of each recurrent head -> joint[:, r*n_out : (r+1)*n_out]; group stride of C = n_out columns
     g = gemm_args(w.l1, m->dim_lm, at, m->rec_out, pl, w.joint, m->dim_aj, AMTX_T_F32, BT, m->n_rec, BT * m->dim_lm, m->n_out);
+    // piano rolls (LogisticBank.finalize_output with threshold 0.5) come out of the LogisticBank GEMMs' epilogues where that kernel has
+    // one (bf16 mode); otherwise amtx_launch_pianoroll below reads the logits back
+    static const bool no_roll_epi = getenv("AMTX_OF_NO_ROLL_EPILOGUE") != nullptr;     // A/B switch: separate pianoroll launches
+    const bool roll_on = out_onsets && !no_roll_epi && amtx_gemm_has_roll_epilogue(g);
+    if (roll_on) { g.roll_out = out_onsets; g.roll_T = T; g.roll_thr = 0.5f; g.roll_group = 0; }
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     // pitch head: (fc1 . LogisticBank) folded, straight from its conv3 map -> last n_out columns of joint
@@ -508,12 +513,17 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
     mark();
     g = gemm_args(w.l2, m->dim_lm, at, m->adj_out, pl, w.mp, m->n_out, AMTX_T_F32, BT, 1, 0, 0);
+    const bool roll_mp = out_multi_pitch && !no_roll_epi && amtx_gemm_has_roll_epilogue(g);
+    if (roll_mp) {
+        g.roll_out = out_multi_pitch; g.roll_T = T; g.roll_thr = 0.5f; g.roll_group = 0;
+        if (!logits_multi_pitch) g.C = nullptr;            // nobody reads the refined logits then: only the roll is written
+    }
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
-    // piano rolls (LogisticBank.finalize_output with threshold 0.5)
-    if (out_onsets && (rc = amtx_launch_pianoroll((const float*)w.joint, m->dim_aj, 0, B, T, m->n_out, 0.5f, out_onsets, s)) != AMTX_OK) return rc;
-    if (out_multi_pitch && (rc = amtx_launch_pianoroll((const float*)w.mp, m->n_out, 0, B, T, m->n_out, 0.5f, out_multi_pitch, s)) != AMTX_OK) return rc;
+    // piano rolls of the modes whose LogisticBank GEMM has no roll epilogue (x3)
+    if (out_onsets && !roll_on && (rc = amtx_launch_pianoroll((const float*)w.joint, m->dim_aj, 0, B, T, m->n_out, 0.5f, out_onsets, s)) != AMTX_OK) return rc;
+    if (out_multi_pitch && !roll_mp && (rc = amtx_launch_pianoroll((const float*)w.mp, m->n_out, 0, B, T, m->n_out, 0.5f, out_multi_pitch, s)) != AMTX_OK) return rc;
 
     mark();
     // optional raw logits, contiguous (B, T, n_out)
