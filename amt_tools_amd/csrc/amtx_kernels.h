@@ -28,6 +28,9 @@ struct GemmArgs {
     // frames per clip; group roll_group also writes roll_out[clip][n][frame] = sigmoid(c) (roll_thr < 0) or sigmoid(c) < roll_thr ? 0 : 1.
     // C may then be null (logits not wanted).
     float* roll_out = nullptr; int roll_T = 0; float roll_thr = 0.5f; int roll_group = 0;
+    // optional, same kernel: a bf16 copy of the output rows into copy16[m * copy16_ld + copy16_col0 + grp * copy16_gs + n] with copy16_pad zero
+    // columns behind column N - 1 (N + copy16_pad <= n_pad); C may be null
+    bf16_t* copy16 = nullptr; int64_t copy16_ld = 0; int copy16_col0 = 0, copy16_gs = 0, copy16_pad = 0;
 };
 bool amtx_gemm_has_roll_epilogue(const GemmArgs& g);
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);

@@ -401,6 +401,17 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
                         for (int nt = 0; nt < 4; ++nt)
                             if (wide || nb + 4 * nt < g.N) reinterpret_cast<float4*>(dst)[nt] = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
                     }
+                    if (g.copy16) {
+                        // bf16 copy of the row into a second matrix (the refinement stage's K-padded input): columns
+                        // copy16_col0 + grp * copy16_gs + n, plus copy16_pad zero columns behind the last valid one
+                        bf16_t* cp = g.copy16 + m * g.copy16_ld + g.copy16_col0 + (int64_t)grp * g.copy16_gs + nb;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int n4 = nb + 4 * nt;
+                            if (n4 < g.N) reinterpret_cast<uint2*>(cp)[nt] = make_uint2(pack_bf16x2(o[nt][0], o[nt][1]), pack_bf16x2(o[nt][2], o[nt][3]));
+                            else if (n4 < g.N + g.copy16_pad) reinterpret_cast<uint2*>(cp)[nt] = make_uint2(0u, 0u);
+                        }
+                    }
                     if (g.roll_out && grp == g.roll_group) {
                         // piano-roll epilogue (LogisticBank.finalize_output, amt_tools/models/common.py:586-620): the row is frame
                         // t of clip b, its logits become sigmoid -> threshold in out[b][key][t]; the 16 lanes of a lane group hold 16
@@ -800,7 +811,7 @@ bool amtx_gemm_has_roll_epilogue(const GemmArgs& g) {
 }
 
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
-    AMTX_REQUIRE(g.A && g.W && (g.C || g.pair_map || g.roll_out), "gemm: null pointer");
+    AMTX_REQUIRE(g.A && g.W, "gemm: null pointer");
     AMTX_REQUIRE(!g.pair_map || (g.a_type == AMTX_T_F32 && g.c_type == AMTX_T_F32 && g.pair_out && g.N % 2 == 0), "gemm: the magnitude epilogue needs fp32 A / C, an output and an even N");
     AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
     AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
@@ -808,6 +819,10 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
+    AMTX_REQUIRE(!g.copy16 || (amtx_gemm_has_roll_epilogue(g) && g.copy16_pad % 4 == 0 && g.N + g.copy16_pad <= g.n_pad &&
+                               (g.copy16_ld % 4) == 0 && ((g.copy16_col0 | g.copy16_gs) % 4) == 0 && ((uintptr_t)g.copy16 % 8) == 0),
+                 "gemm: bad bf16-copy epilogue arguments");
+    AMTX_REQUIRE(g.C || g.pair_map || g.roll_out || g.copy16, "gemm: no output");
     AMTX_REQUIRE(!g.roll_out || amtx_gemm_has_roll_epilogue(g), "gemm: the piano-roll epilogue exists on the bf16 direct-to-LDS path with fp32 C only");
     AMTX_REQUIRE(!g.roll_out || (g.roll_T > 0 && g.M % g.roll_T == 0 && g.M < (1ll << 31)), "gemm: piano-roll epilogue: M must be clips x frames");
     if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {

@@ -489,19 +489,29 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     static const bool no_roll_epi = getenv("AMTX_OF_NO_ROLL_EPILOGUE") != nullptr;     // A/B switch: separate pianoroll launches
     const bool roll_on = out_onsets && !no_roll_epi && amtx_gemm_has_roll_epilogue(g);
     if (roll_on) { g.roll_out = out_onsets; g.roll_T = T; g.roll_thr = 0.5f; g.roll_group = 0; }
+    // bf16 mode: the refinement stage's input (the joint logits rounded to bf16, K zero-padded to the DMA GEMM's 64-deep k-tile) is
+    // written by the same two epilogues instead of a conversion pass over the fp32 joint buffer; the fp32 joint logits themselves are
+    // only written when something reads them (logit outputs, the offset head's probabilities, the modes without these epilogues)
+    const int kp = (m->dim_aj + 63) / 64 * 64;
+    GemmArgs gp = gemm_args(w.a3 + (size_t)(m->n_heads - 1) * BT * m->kfc_pad * amtx_tsize(at), m->kfc_pad, at, m->pitch_out, pl,
+                            w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
+    const bool copy_on = pl == 1 && !no_roll_epi && amtx_gemm_has_roll_epilogue(g) && amtx_gemm_has_roll_epilogue(gp) && m->n_out % 4 == 0 &&
+                         (kp - m->dim_aj) % 4 == 0 && gp.N + (kp - m->dim_aj) <= gp.n_pad;
+    if (copy_on) {
+        g.copy16 = (bf16_t*)w.joint16; g.copy16_ld = kp; g.copy16_col0 = 0; g.copy16_gs = m->n_out; g.copy16_pad = 0;
+        gp.copy16 = (bf16_t*)w.joint16; gp.copy16_ld = kp; gp.copy16_col0 = m->n_rec * m->n_out; gp.copy16_gs = 0; gp.copy16_pad = kp - m->dim_aj;
+        if (roll_on && !logits_onsets && !logits_pitch_head && !m->has_offsets) { g.C = nullptr; gp.C = nullptr; }
+    }
     if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     // pitch head: (fc1 . LogisticBank) folded, straight from its conv3 map -> last n_out columns of joint
-    g = gemm_args(w.a3 + (size_t)(m->n_heads - 1) * BT * m->kfc_pad * amtx_tsize(at), m->kfc_pad, at, m->pitch_out, pl,
-                  w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
-    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    if ((rc = amtx_launch_gemm(gp, s)) != AMTX_OK) return rc;
     mark();
 
     // adjoin
     if (pl == 1) {
-        // bf16 mode: round the joint logits to bf16 once (zero-padded to a 64-multiple K) and use the direct-to-LDS GEMM
-        const int kp = (m->dim_aj + 63) / 64 * 64;
-        if ((rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s)) != AMTX_OK) return rc;
+        // bf16 mode: the joint logits rounded to bf16 (zero-padded to a 64-multiple K) feed the direct-to-LDS GEMM
+        if (!copy_on && (rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s)) != AMTX_OK) return rc;
         g = gemm_args(w.joint16, kp, AMTX_T_BF16, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
         g.K = kp;
     } else {
