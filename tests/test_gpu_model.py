@@ -495,3 +495,53 @@ def test_bench_workload_parity_of_both_precisions_against_the_cpu_oracle(capsys)
     assert el < 2e-4 and ea < 1e-4 and rate < 1e-4, report['x3']
     rate, el, ea = report['bf16']
     assert rate < 5e-3 and el < 0.12, report['bf16']
+
+
+_EPILOGUE_AB = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd import tools
+from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
+from amt_tools_amd.synth import synth_state_dict
+outs = {}
+for name, cls, mc, T in (('of1', OnsetsFrames, 2, 70), ('of1_long', OnsetsFrames, 2, 333), ('of2', OnsetsFrames2, 2, 70)):
+    sd = synth_state_dict(11, dim_in=229, in_channels=1, model_complexity=mc, offsets=(cls is OnsetsFrames2))
+    model = cls(229, tools.PianoProfile(), 1, mc, device='cuda:0', precision='bf16')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    rng = np.random.default_rng(3)
+    feats = torch.from_numpy(rng.random((5, 1, 229, T)).astype(np.float32))
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_FEATS: feats})                          # label-free: rolls only, logits stay in the engine
+        lg = model.engine_logits(feats.cuda())                                        # logits wanted: every buffer is written
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            outs[f'{name}_roll_{k}'] = v.cpu().numpy()
+    for k, v in lg.items():
+        outs[f'{name}_logit_{k}'] = v.cpu().numpy()
+np.savez(sys.argv[1], **outs)
+'''
+
+
+def test_head_gemm_epilogues_return_the_bits_of_the_separate_kernels(tmp_path):
+    """bf16 mode writes the piano rolls and the refinement stage's bf16 input from the LogisticBank GEMMs' epilogues and skips buffers
+    nobody reads; AMTX_OF_NO_ROLL_EPILOGUE=1 runs the separate pianoroll / conversion kernels.  Rolls (label-free run_on_batch),
+    logits and offset probabilities (engine_logits) must be identical, for frame counts that put clip boundaries inside a 128-row
+    GEMM tile, with and without the offset head."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('epilogue', {}), ('separate', {'AMTX_OF_NO_ROLL_EPILOGUE': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _EPILOGUE_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['epilogue']), np.load(files['separate'])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 12
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert set(np.unique(a['of1_roll_' + tools.KEY_ONSETS])) <= {0.0, 1.0}
