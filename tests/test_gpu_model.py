@@ -192,6 +192,33 @@ def test_unbuilt_model_complexity_is_rejected_loudly_by_the_engine():
         model.run_on_batch({tools.KEY_FEATS: torch.zeros(1, 1, 229, 8)})
 
 
+def test_forward_power_is_refused_loudly_where_the_conv_kernel_does_not_stage_features():
+    """amtx_of_forward_power exists for one-channel models whose first conv is fused into conv.hip's kernel; model_complexity 3 (convg.hip)
+    and multi-channel inputs answer amtx_of_fuses_db_scale() = 0, run_on_batch takes the ordinary feature path for them, and a direct
+    call with pending power features raises instead of computing on unscaled values."""
+    from amt_tools_amd._lib import AmtxError
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.models import OnsetsFrames, PendingFeatures
+    mod = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048)
+    audio = torch.from_numpy(np.stack([synth_clip(i, num_samples=512 * 20) for i in range(2)])).cuda()
+    for mc, fuses in ((2, True), (3, False)):
+        sd = synth_state_dict(3, dim_in=229, in_channels=1, model_complexity=mc)
+        model = OnsetsFrames(229, tools.PianoProfile(), 1, mc, device='cuda:0')
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        model.frontend = torch.nn.Sequential(mod.frontend())
+        model.change_device()
+        model.eval()
+        eng = model._get_engine(torch.device('cuda:0'))
+        assert eng.fuses_db_scale() == fuses
+        with torch.no_grad():
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})                      # both complexities: fine through run_on_batch
+            assert out[tools.KEY_ONSETS].shape == (2, 88, 21)
+            power, cmax = mod.power_batch(audio)
+            if not fuses:
+                with pytest.raises(AmtxError):
+                    model(PendingFeatures(mod, power, cmax))
+
+
 def test_engine_ragged_batch_and_single_frame():
     from oracle import model_ref
     g = load_golden('of1_eval.npz')
