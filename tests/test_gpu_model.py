@@ -161,6 +161,39 @@ def test_complexity_2_engine_vs_oracle_feature_sizes_and_ragged_batches(dim_in):
                     assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize('precision', ['x3', 'bf16'])
+@pytest.mark.parametrize('cls,B,T', [('OnsetsFrames', 523, 33), ('OnsetsFrames', 1024, 40), ('OnsetsFrames2', 261, 33)])
+def test_engine_at_batch_sizes_that_take_the_eight_clip_recurrence(cls, B, T, precision):
+    """DESIGN rule: every batch-size-dependent dispatch has a test on each side of its threshold.  lstm.hip switches to eight clips per
+    block (bilstm4_kernel<.., NC = 2>) once four-clip blocks would outnumber the 256 CUs: more than 512 clips with one recurrent head,
+    more than 256 with the two grouped recurrences of OnsetsFrames2 -- the mapping the headline bench (1024 clips) runs.  Whole engine
+    against the CPU oracle for clips of the first block, blocks in the middle and the ragged last block (523 = 65 x 8 + 3, 261 = 32 x 8
+    + 5), every clip distinct; x3: logits within 3e-4 and activations within 1e-4 (the parity gate), bf16: the 6e-2 logit bound."""
+    from oracle import model_ref
+    import amt_tools_amd.models as M
+    offsets = cls == 'OnsetsFrames2'
+    sd = synth_state_dict(23, dim_in=229, in_channels=1, model_complexity=2, offsets=offsets)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model = getattr(M, cls)(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+    model.load_state_dict(sdt)
+    model.change_device()
+    model.eval()
+    rng = np.random.default_rng(B + T)
+    feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32))
+    pick = sorted({0, 1, 7, 8, 9, B // 2, B // 2 + 1, B // 2 + 5, B - 9, B - 8, B - 4, B - 3, B - 2, B - 1})
+    with torch.no_grad():
+        got = model.engine_logits(feats.cuda())
+        ref = model_ref.run_on_batch(feats[pick], sdt)
+    tol = 3e-4 if precision == 'x3' else TOL['bf16']
+    keys = ('onsets', 'multi_pitch', 'pitch_head') + (('offsets',) if offsets else ())
+    for key in keys:
+        g = got[key].cpu()[pick]
+        err = (g - ref['logits'][key]).abs().max().item()
+        assert err < tol, (key, err)
+        if precision == 'x3':
+            assert (torch.sigmoid(g) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4, key
+
+
 @pytest.mark.parametrize('mc', [2, 3])
 @pytest.mark.parametrize('precision', ['bf16', 'x3'])
 def test_engine_is_deterministic_run_to_run(mc, precision):

@@ -204,7 +204,11 @@ def test_bilstm_h_entry_runs_hidden_128_like_the_fixed_entry():
 
 @pytest.mark.parametrize('planes', [1, 2])
 # b <= 2048 runs the four-clips-per-block kernel, larger batches the sixteen-clip one (lstm.hip: use_four_clip_blocks)
-@pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (32, 200), (2049, 7), (2063, 3)])
+# and from 513 clips on (four-clip blocks would outnumber the 256 CUs) the eight-clips-per-block mapping bilstm4_kernel<.., NC = 2>: both
+# sides of every batch-size threshold of the dispatch are here (512 | 513, 2048 | 2049), with ragged last blocks (521 = 65 x 8 + 1,
+# 2047) and the clip_ok[1] = false tail (513, 521: the last block holds one clip)
+@pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (32, 200), (512, 7), (513, 7), (521, 40), (1024, 7), (1030, 40), (2047, 5),
+                                 (2048, 7), (2049, 7), (2063, 3)])
 def test_bilstm(planes, b, t):
     L = _lib.lib()
     g = torch.Generator().manual_seed(b * 100 + t)
