@@ -69,6 +69,13 @@ size_t amtx_conv3x3_wfrag_elems(int c_out, int planes);
 // host packing: weight (c_out, 32, 3, 3) fp32 * scale[c_out] -> fragment order
 void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int planes, bf16_t* out);
 
+// the whole stack layer1 -> layer2 -> layer3 of a one-channel, 32/32/64-channel, bf16 model in one kernel (convf.hip): `c2` as for
+// amtx_launch_conv3x3 with the fused first conv (feats, w1frag, shift1, wfrag, shift; `out` ignored), plus layer3's packed weights and
+// shift; out = [groups][B][T][F / 4][64] bf16.  amtx_conv_stack_fused_ok: the batch is large enough for its one-strip-per-CU granularity.
+bool amtx_conv_stack_fused_ok(int B, int T, int F, int groups);
+int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_gs, const float* shift3, void* out, int64_t out_gs,
+                           hipStream_t stream);
+
 // general channel counts (convg.hip): C_in a multiple of 16, weights staged in LDS per C_out chunk; `a.in` is [B][T][F][c_in]
 int amtx_conv3x3_gen_ntc(int c_in, int c_out);           // 0 = this pair of channel counts is not built
 size_t amtx_conv3x3_gen_wfrag_elems(int c_in, int c_out, int planes);

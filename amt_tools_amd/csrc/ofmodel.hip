@@ -61,6 +61,7 @@ struct amtx_of_model {
     // packed device weights (group-major)
     DevBuf conv1_w, conv1_s, conv1_frag, conv2_w, conv2_s, conv3_w, conv3_s;
     bool fuse_conv1 = false;                   // first conv computed inside the conv2 kernel (9*C_in <= 64)
+    bool fuse_stack = false;                   // layer1 -> layer2 -> layer3 in one kernel (convf.hip) for batches that fill the chip with strips
     LinearPack fc1;                            // groups = n_heads
     LinearPack rec_ih;                         // groups = n_rec, N = 1024
     DevBuf rec_hh;                             // groups = n_rec
@@ -170,7 +171,8 @@ Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
     w.a1 = take(m->fuse_conv1 ? 256 : BT * F * m->nf1 * es * m->n_heads);
-    w.a2 = take(BT * F2 * m->nf2 * es * m->n_heads);
+    // the 32-channel map behind layer2 only exists in HBM on the two-kernel path
+    w.a2 = take(m->fuse_stack && amtx_conv_stack_fused_ok(B, T, F, m->n_heads) ? 256 : BT * F2 * m->nf2 * es * m->n_heads);
     w.a3 = take(BT * m->kfc_pad * es * m->n_heads);
     w.e = take(BT * m->dim_am * es * m->n_heads);
     w.xp = take(BT * m->xw * es * m->n_rec);
@@ -221,6 +223,8 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->n_heads = (int)m->head_names.size();
     m->dim_aj = (m->n_rec + 1) * n_out;
     m->fuse_conv1 = m->gen_conv2 ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
+    // A/B switch: AMTX_NO_CONV_FUSE=1 keeps conv.hip's two kernels (conv1+conv2, conv3) at every batch size
+    m->fuse_stack = !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && m->planes == 1 && getenv("AMTX_NO_CONV_FUSE") == nullptr;
     *out = m;
     return AMTX_OK;
 }
@@ -447,7 +451,12 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         c2.w1_gs = (int64_t)(m->gen_conv2 ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, pl) : amtx_conv1_wfrag_elems(m->in_channels, pl));
         c2.f_clip_max = clip_max; c2.f_ref = ref;
     }
-    if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
+    const bool fused_stack = m->fuse_stack && amtx_conv_stack_fused_ok(B, T, F, m->n_heads);
+    if (fused_stack) {
+        // layer1 -> layer2 -> layer3 in one kernel: neither intermediate map reaches HBM (stage timer: all of it under conv2_pool)
+        if ((rc = amtx_launch_conv_stack(c2, (const bf16_t*)m->conv3_w.p, (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl), (const float*)m->conv3_s.p,
+                                         w.a3, BT * m->kfc_pad, s)) != AMTX_OK) return rc;
+    } else if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c3 = c2;
@@ -464,7 +473,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         if ((rc = amtx_launch_zero_cols(w.a3 + (size_t)m->kfc * es, (int64_t)m->kfc_pad * es, (int)((m->kfc_pad - m->kfc) * es),
                                         BT * m->n_heads, s)) != AMTX_OK) return rc;
     }
-    if ((rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
+    if (!fused_stack && (rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
     mark();
 
     // fc1 of the recurrent heads (heads 0..n_rec-1 of a3); the pitch head's fc1 is folded into its output layer below

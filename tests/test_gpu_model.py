@@ -194,6 +194,73 @@ def test_engine_at_batch_sizes_that_take_the_eight_clip_recurrence(cls, B, T, pr
             assert (torch.sigmoid(g) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4, key
 
 
+def _of1_bf16(seed, dim_in, cls='OnsetsFrames'):
+    import amt_tools_amd.models as M
+    sd = synth_state_dict(seed, dim_in=dim_in, in_channels=1, model_complexity=2, offsets=cls == 'OnsetsFrames2')
+    model = getattr(M, cls)(dim_in, tools.PianoProfile(), 1, 2, device='cuda:0', precision='bf16')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    return model
+
+
+@pytest.mark.parametrize('dim_in', [229, 40, 88, 54, 192, 8, 5])
+def test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path(dim_in, monkeypatch):
+    """convf.hip (layer1 -> layer2 -> layer3 in one kernel, both intermediate maps in LDS only) accumulates every output in the order
+    conv.hip's two kernels do, so the engine's logits must be the SAME BITS with and without it (AMTX_NO_CONV_FUSE=1 is read when the
+    engine is created).  Feature sizes that need 1 .. 15 frequency steps and end inside a step, frame counts that end inside the first /
+    second / third 16-row tile of a 46-frame strip, one and several strips per clip, two and three heads; batch sizes on BOTH sides of the
+    dispatch threshold (heads x clips x strips >= 256: DESIGN rule), checked through the workspace size (the 32-channel map behind layer2
+    has no HBM buffer on the fused path)."""
+    from amt_tools_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(dim_in)
+    cases = [('OnsetsFrames', 128, 33), ('OnsetsFrames', 127, 33), ('OnsetsFrames', 43, 140), ('OnsetsFrames', 130, 47),
+             ('OnsetsFrames', 260, 1), ('OnsetsFrames', 129, 17), ('OnsetsFrames2', 86, 46), ('OnsetsFrames2', 44, 93)]
+    for cls, B, T in cases:
+        feats = torch.from_numpy(rng.random((B, 1, dim_in, T)).astype(np.float32)).cuda()
+        got = {}
+        for mode in ('fused', 'two-kernel'):
+            if mode == 'two-kernel':
+                monkeypatch.setenv('AMTX_NO_CONV_FUSE', '1')
+            else:
+                monkeypatch.delenv('AMTX_NO_CONV_FUSE', raising=False)
+            model = _of1_bf16(31, dim_in, cls)
+            with torch.no_grad():
+                got[mode] = {k: v.clone() for k, v in model.engine_logits(feats).items()}
+            got[mode + '_ws'] = L.amtx_of_workspace_bytes(model._get_engine(feats.device).handle, B, T)
+            del model
+        heads = 3 if cls == 'OnsetsFrames2' else 2
+        expect_fused = heads * B * ((T + 45) // 46) >= 256
+        assert (got['fused_ws'] < got['two-kernel_ws']) == expect_fused, (cls, B, T, got['fused_ws'], got['two-kernel_ws'])
+        for k in got['fused']:
+            assert torch.equal(got['fused'][k], got['two-kernel'][k]), (cls, B, T, k, (got['fused'][k] - got['two-kernel'][k]).abs().max().item())
+
+
+def test_fused_conv_stack_on_raw_power_features_is_bit_identical(monkeypatch):
+    """The same, entered through amtx_of_forward_power (audio -> log-mel power -> engine, dB scaling applied while the features are staged):
+    piano rolls of run_on_batch on audio with and without the fused stack."""
+    from amt_tools_amd.features import MelSpec
+    mod = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048)
+    audio = torch.from_numpy(np.stack([synth_clip(i, num_samples=512 * 60) for i in range(140)])).cuda()
+    outs = []
+    for mode in ('fused', 'two-kernel'):
+        if mode == 'two-kernel':
+            monkeypatch.setenv('AMTX_NO_CONV_FUSE', '1')
+        else:
+            monkeypatch.delenv('AMTX_NO_CONV_FUSE', raising=False)
+        model = _of1_bf16(3, 229)
+        model.frontend = torch.nn.Sequential(mod.frontend())
+        model.change_device()
+        model.eval()
+        with torch.no_grad():
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})
+        outs.append({k: out[k].clone() for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH)})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert outs[0][tools.KEY_ONSETS].shape == (140, 88, 61)
+
+
 @pytest.mark.parametrize('mc', [2, 3])
 @pytest.mark.parametrize('precision', ['bf16', 'x3'])
 def test_engine_is_deterministic_run_to_run(mc, precision):
