@@ -50,6 +50,7 @@ _SIGNATURES = {
     'amtx_of_workspace_bytes': (C.c_size_t, [_P, _I, _I]),
     'amtx_of_forward': (_I, [_P, _P, _L, _L, _L, _L, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
     'amtx_of_fuses_db_scale': (_I, [_P]),
+    'amtx_of_conv_stack_fused': (_I, [_P, _I, _I]),
     'amtx_of_forward_power': (_I, [_P, _P, _L, _L, _L, _P, _P, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
     'amtx_of_offsets': (_I, [_P, _P, C.c_size_t, _I, _I, _P, _P, _P]),
     'amtx_of_num_stages': (_I, []),

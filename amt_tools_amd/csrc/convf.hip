@@ -164,7 +164,23 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         const int c1l = CS * (P).j - 1 + 4 * xb;                /* first a1 column of this lane's four positions */ \
         const int slotl = base1 + 4 * xb;                                                                   \
         const int dst_row = A1_OFF + g1 * PLANE1 + row1 * ROWB1;                                            \
-        const int dst_scratch = SLAB_OFF + 2 * SLAB_BYTES + 128 + (lane_o & 63) * 16;
+        const int dst_scratch = SLAB_OFF + 2 * SLAB_BYTES + 128 + (lane_o & 63) * 16;                       \
+        /* scalar: no position of the unit is padding -> the lean epilogue (a unit is ~50 instead of ~140 vector instructions, and */ \
+        /* a wave's instruction stream, not the matrix pipe, is what a step of this kernel waits for) */    \
+        const int tu_ = (P).r0 - 2 + 16 * (u >> 1), cu_ = CS * (P).j - 1 + 4 * (u & 1);                     \
+        const bool lean = mainu && tu_ >= 0 && tu_ + 15 < a.T && cu_ >= 0 && cu_ + 3 < a.F;                 \
+        const int slots_ = base1 + 4 * (u & 1);                 /* scalar ring slot of a main unit's first column */
+#define CONVF_L1_STORE_LEAN(Q, ACC0, ACC1)                                                                  \
+        do {                                                                                                \
+            uint32_t pk[4];                                                                                 \
+            pk[0] = pack_bf16x2((ACC0)[0], (ACC0)[1]); pk[1] = pack_bf16x2((ACC0)[2], (ACC0)[3]);           \
+            pk[2] = pack_bf16x2((ACC1)[0], (ACC1)[1]); pk[3] = pack_bf16x2((ACC1)[2], (ACC1)[3]);           \
+            _Pragma("unroll") for (int h = 0; h < 4; ++h)                                                   \
+                pk[h] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pk[h]), (s16x2){0, 0})); \
+            int sq = slots_ + (Q);                                                                          \
+            sq = sq >= RC1 ? sq - RC1 : sq;                                                                 \
+            *reinterpret_cast<uint4*>(smem + dst_row + sq * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);   \
+        } while (0)
 #define CONVF_L1_STORE(Q, ACC0, ACC1)                                                                       \
         do {                                                                                                \
             /* round first, then ReLU on the packed pairs as a signed 16-bit max with 0 (a negative bf16 is a negative int16), then the padding */ \
@@ -274,13 +290,23 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         const int lane_a2 = A2_OFF + g * PLANE2 + trow * ROWB2;     // lane part of an a2 store address
         const int n16 = trow, g1 = g, gg = min(g, 2), lane_o = lane;
         const int lane_a1 = A1_OFF + g * PLANE1 + trow * ROWB1;     // lane part of an a1 address (fragment reads and layer1 stores)
-#define CONVF_L1_PRODUCER(P)                                                                                \
+#define CONVF_L1_PUNIT(P, U)                                                                                \
         do {                                                                                                \
-            CONVF_L1_BEGIN(P, wave)                                                                         \
+            CONVF_L1_BEGIN(P, U)                                                                            \
             f32x4_t acc1[4][2];                                                                             \
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc1[q][nt] = mfma16(w1t[q][nt], bh, sh1[nt]); \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) CONVF_L1_STORE(q, acc1[q][0], acc1[q][1]);        \
+            if (lean) {                                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) CONVF_L1_STORE_LEAN(q, acc1[q][0], acc1[q][1]); \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) CONVF_L1_STORE(q, acc1[q][0], acc1[q][1]);    \
+            }                                                                                               \
+        } while (0)
+        // a producer wave's units: u = wave (0 .. 3) of every step, and unit 8 when it is its turn (weights in registers: no LDS round trip)
+#define CONVF_L1_PRODUCER(P)                                                                                \
+        do {                                                                                                \
+            CONVF_L1_PUNIT(P, wave);                                                                        \
+            if (((P).kk & 3) == wave) CONVF_L1_PUNIT(P, NUNITS - 1);                                        \
         } while (0)
 
         Pos pl = pos_first(first, ntt), p1 = pl, p0 = pl;
@@ -305,6 +331,9 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         unsigned long long prof_acc[4] = {0, 0, 0, 0};
         unsigned long long prof_t = __builtin_readcyclecounter();
 #endif
+        // static priority for the producer waves' matrix loop: their path through a step (layer2, staging, one or two layer1 units) is the
+        // longer one, the consumer waves' layer3 takes the issue slots that are left (8.9 -> 8.6 ms per 1024 clips; the other way round: 9.3)
+        __builtin_amdgcn_s_setprio(2);
         for (int kk = 0; kk <= K; ++kk) {
             if (kk < K) {
                 // ---------------------------------------------------------------- layer2 + MaxPool(1,2): a1 ring -> a2 ring
@@ -390,7 +419,7 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
                     if (!CONVF_DBG(1)) CONVF_L1_PRODUCER(p1);
                     pos_next(p1, nstep, ntt);
                 }
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(2);
                 CONVF_TICK(1);
             }
             lds_only_barrier();
@@ -405,6 +434,7 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
 #undef CONVF_ISSUE_LOADS
 #undef CONVF_WRITE_SLAB
 #undef CONVF_L1_PRODUCER
+#undef CONVF_L1_PUNIT
     } else {
         // =================================================================== consumers: layer3 + MaxPool(1,2) -> HBM
         // weight rows re-dealt at load (conv.hip WIDE_ST): store q of the four lane groups covers 64 CONTIGUOUS bytes
@@ -430,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
             reinterpret_cast<uint4*>(smem + W1_OFF)[i] = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs)[i];
         const f32x4_t* shl0 = reinterpret_cast<const f32x4_t*>(smem + SH3_OFF);
         __syncthreads();
-        // this wave's layer1 units: u = wave (4 .. 7) of every step, and unit 8 when it is its turn
+        // this wave's layer1 unit: u = wave (4 .. 7) of every step
         // (fragments from LDS, two columns in flight: the registers next to layer3's 144 weight registers do not hold all eight)
 #define CONVF_L1_CUNIT(P, U)                                                                                \
         do {                                                                                                \
@@ -447,12 +477,15 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
             f32x4_t acc1[4][2];                                                                             \
             _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                   \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) acc1[q][nt] = mfma16(w1l[q][nt], bh, sh1l[nt]); \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) CONVF_L1_STORE(q, acc1[q][0], acc1[q][1]);        \
+            if (lean) {                                                                                     \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) CONVF_L1_STORE_LEAN(q, acc1[q][0], acc1[q][1]); \
+            } else {                                                                                        \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) CONVF_L1_STORE(q, acc1[q][0], acc1[q][1]);    \
+            }                                                                                               \
         } while (0)
 #define CONVF_L1_CONSUMER(P)                                                                                \
         do {                                                                                                \
             CONVF_L1_CUNIT(P, wave);                                                                        \
-            if (((P).kk & 3) == wave - 4) CONVF_L1_CUNIT(P, NUNITS - 1);                                    \
         } while (0)
         Pos pc1 = pos_first(first, ntt);
         CONVF_L1_CONSUMER(pc1);
@@ -558,6 +591,7 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
 
 #undef CONVF_L1_BEGIN
 #undef CONVF_L1_STORE
+#undef CONVF_L1_STORE_LEAN
 
 }  // namespace
 

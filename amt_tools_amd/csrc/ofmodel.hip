@@ -562,6 +562,10 @@ extern "C" int amtx_of_fuses_db_scale(const amtx_of_model* m) {
     return m && m->finalized && m->fuse_conv1 && !m->gen_conv2 && m->in_channels == 1;
 }
 
+extern "C" int amtx_of_conv_stack_fused(const amtx_of_model* m, int batch, int num_frames) {
+    return m && m->fuse_stack && amtx_conv_stack_fused_ok(batch, num_frames, m->dim_in, m->n_heads);
+}
+
 extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
                                int64_t stride_f, int batch, int num_frames, void* workspace, size_t workspace_bytes,
                                float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,

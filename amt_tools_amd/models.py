@@ -302,6 +302,10 @@ class _OFEngine(object):
     def fuses_db_scale(self):
         return bool(_lib.lib().amtx_of_fuses_db_scale(self.handle))
 
+    def conv_stack_fused(self, batch, num_frames):
+        """True when a forward pass of this shape runs the three convolution layers as one kernel (csrc/convf.hip)."""
+        return bool(_lib.lib().amtx_of_conv_stack_fused(self.handle, int(batch), int(num_frames)))
+
     def forward(self, feats, want_logits=True):
         """feats: (B,C,T,F) fp32 CUDA tensor (any strides), or PendingFeatures.  Returns binary maps + raw logits."""
         L = _lib.lib()

@@ -109,6 +109,12 @@ int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_
                           float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                           float* logits_pitch_head, void* stream);
 
+/* 1 when amtx_of_forward / amtx_of_forward_power at this batch and frame count run the acoustic heads' three convolution layers
+ * (amt_tools/models/onsetsframes.py:375-412) as ONE kernel whose intermediate maps stay in LDS (convf.hip: one-channel bf16 models at
+ * model_complexity 2, batches of at least 256 head x clip x 62-frame strips; AMTX_NO_CONV_FUSE=1 at model creation turns it off), 0 when
+ * they run as the two kernels of conv.hip.  The results are the same bits either way; amtx_of_workspace_bytes accounts for it. */
+int amtx_of_conv_stack_fused(const amtx_of_model* model, int batch, int num_frames);
+
 /* OnsetsFrames2 (has_offsets = 1; amt_tools/models/onsetsframes.py:199-327): the offset head's output of the last amtx_of_forward
  * that used this workspace: out_offsets (B, n_out, T) sigmoid probabilities (finalize_output without threshold, :323-325),
  * logits_offsets optional (B, T, n_out). */

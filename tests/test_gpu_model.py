@@ -229,10 +229,12 @@ def test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path(dim_in, monkey
             with torch.no_grad():
                 got[mode] = {k: v.clone() for k, v in model.engine_logits(feats).items()}
             got[mode + '_ws'] = L.amtx_of_workspace_bytes(model._get_engine(feats.device).handle, B, T)
+            got[mode + '_q'] = model._get_engine(feats.device).conv_stack_fused(B, T)
             del model
         heads = 3 if cls == 'OnsetsFrames2' else 2
         expect_fused = heads * B * ((T + 61) // 62) >= 256
         assert (got['fused_ws'] < got['two-kernel_ws']) == expect_fused, (cls, B, T, got['fused_ws'], got['two-kernel_ws'])
+        assert got['fused_q'] == expect_fused and not got['two-kernel_q']
         for k in got['fused']:
             assert torch.equal(got['fused'][k], got['two-kernel'][k]), (cls, B, T, k, (got['fused'][k] - got['two-kernel'][k]).abs().max().item())
 
