@@ -403,12 +403,16 @@ def run_infer(args, rank, world, device):
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
             pmc = json.load(f)
         src = pmc.get('_source', 'profiles/pmc_traffic.json')
-        if dom in pmc:
-            roof['traffic'] = pmc[dom]['hbm_bytes_corrected'] * B / pmc[dom]['clips']
+        kernels = {k: v for k, v in pmc.items() if isinstance(v, dict) and 'hbm_bytes_corrected' in v}
+        # the dominant stage's own kernel (entries are per kernel; a kernel that serves several stages cannot be attributed to one)
+        own = [v for v in kernels.values() if v.get('stages') == [dom]]
+        if own:
+            roof['traffic'] = own[0]['hbm_bytes_corrected'] * B / own[0]['clips']
             roof['traffic_unit'] = 'bytes per launch'
             roof['traffic_source'] = src
             roof['algorithmic_bytes'] = ALGO_BYTES.get(dom, 0) * frames_per_launch or None
-        tot = sum(v['hbm_bytes_corrected'] / v['clips'] for k, v in pmc.items() if isinstance(v, dict) and 'hbm_bytes_corrected' in v)
+        # every kernel of a step (tools/pmc_traffic.py), launches per step included
+        tot = sum(v['hbm_bytes_corrected'] * v.get('launches_per_step', 1) / v['clips'] for v in kernels.values())
         hbm_measured = (tot * B, src)
     except (OSError, ValueError, KeyError):
         pass
