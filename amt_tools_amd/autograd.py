@@ -37,9 +37,11 @@ _WS = {}
 
 
 def _workspace(nbytes, device):
-    """Grow-only scratch buffer per device (split-contraction partials, permuted conv weights).  Stream-ordered reuse: every
+    """Grow-only scratch buffer per device and stream (split-contraction partials, permuted conv weights).  Stream-ordered reuse: every
     consumer is enqueued on the current stream right behind its producer."""
-    key = (device.type, device.index)
+    # one buffer per (device, stream): the reuse is only ordered within a stream, so two streams (or two threads on their own streams)
+    # training on one GPU each get their own scratch instead of silently sharing split-contraction partials
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = _WS[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

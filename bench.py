@@ -92,10 +92,12 @@ def parse(argv=None):
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3'])
     ap.add_argument('--of2', action='store_true', help='train mode: OnsetsFrames2 as shipped (model_complexity 3, offset head)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time budget of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--no-train-probe', action='store_true', help='skip the one-GPU training-step time (BASELINE metric ii) appended to the default line')
     ap.add_argument('--no-parity', action='store_true', help='skip the bf16-vs-x3 / oracle cell-mismatch count and the x3 throughput leg')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only for the "
                                                       "single-GPU smoke test of the multi-process path)")
     ap.add_argument('--share-device', action='store_true', help='test only: every rank uses cuda:0')
+    ap.add_argument('--fail-rank', type=int, default=-1, help='test only (with --dry-run): this rank exits with an error before the rendezvous')
     ap.add_argument('--dry-run', action='store_true', help='test only (CPU): ranks rendezvous over gloo and rank 0 prints a line '
                                                            'without touching a GPU -- exercises the launcher and the relay')
     args = ap.parse_args(argv)
@@ -123,19 +125,50 @@ def launch(args, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    line = None
-    for out in procs[0].stdout:
-        out = out.rstrip('\n')
-        if out.startswith('{') and '"metric"' in out:
-            line = out
-        elif out:
-            print(out, file=sys.stderr, flush=True)
-    rcs = [p.wait() for p in procs]
-    if any(rcs) or line is None:
+    # rank 0's pipe is drained on a thread while every child is polled: one rank dying before or at the rendezvous (out of memory, bad
+    # device) must end the run at once -- its peers would otherwise sit in init_process_group / barrier until the store times out
+    import threading
+    got = {'line': None}
+
+    def drain():
+        for out in procs[0].stdout:
+            out = out.rstrip('\n')
+            if out.startswith('{') and '"metric"' in out:
+                got['line'] = out
+            elif out:
+                print(out, file=sys.stderr, flush=True)
+
+    th = threading.Thread(target=drain, daemon=True)
+    th.start()
+    deadline = time.time() + float(os.environ.get('AMTX_BENCH_LAUNCH_TIMEOUT', '3000'))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs):
+            failed = 'a rank exited with an error'
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() > deadline:
+            failed = 'timeout'
+            break
+        time.sleep(0.05)
+    if failed:
         for p in procs:
             if p.poll() is None:
+                p.terminate()
+        t_kill = time.time() + 5
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
                 p.kill()
-        print(f'bench.py launcher: rank exit codes {rcs}, result line {"present" if line else "missing"}', file=sys.stderr, flush=True)
+    rcs = [p.wait() for p in procs]
+    th.join(timeout=5)
+    line = got['line']
+    if failed or any(rcs) or line is None:
+        print(f'bench.py launcher: {failed or "failure"}: rank exit codes {rcs}, result line {"present" if line else "missing"}',
+              file=sys.stderr, flush=True)
         return 1
     print(line, flush=True)
     return 0
@@ -176,6 +209,17 @@ def max_over_ranks(elapsed, world, device, backend):
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(elapsed, world, device, backend):
+    """Every rank's own elapsed time (list, rank order): the first SCALE record is then diagnosable without a second run."""
+    if world == 1:
+        return [elapsed]
+    import torch.distributed as dist
+    t = torch.zeros(world, dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+    t[dist.get_rank()] = elapsed
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
 
 
 def barrier(world):
@@ -241,7 +285,18 @@ def cpu_baseline(budget_s, sd, keep=8):
             break
     rec = {'value': n * CLIP_FRAMES / t_total, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
            'sample': f'{n} synthetic clips x {CLIP_FRAMES} frames in {t_total:.1f} s of oracle time (clip synthesis excluded), one clip per '
-                     f'call, fp32, numpy front-end (share {t_fe / t_total:.2f}) + torch-CPU model restatement with ATen nn.LSTM recurrences'}
+                     f'call, fp32, numpy front-end (share {t_fe / t_total:.2f}) + torch-CPU model restatement with ATen nn.LSTM recurrences',
+           # the front-end / model split, and the batch-of-8 call next to the one-clip-per-call pattern
+           'frontend_frames_per_s': n * CLIP_FRAMES / max(t_fe, 1e-9), 'model_frames_per_s': n * CLIP_FRAMES / max(t_total - t_fe, 1e-9),
+           'frontend_share': t_fe / t_total}
+    nb = min(8, n)
+    if nb >= 2:
+        fb = np.stack([fe.melspec_process_audio(clips[i], SR, HOP, N_MELS, N_FFT, dtype=np.float32) for i in range(nb)]).astype(np.float32)
+        a = time.perf_counter()
+        with torch.no_grad():
+            model_ref.run_on_batch(torch.from_numpy(fb), sdt)
+        rec['model_frames_per_s_batch8'] = nb * CLIP_FRAMES / (time.perf_counter() - a)
+        rec['batch8_note'] = f'{nb} clips in ONE call of the model restatement (front-end excluded)'
     return rec, rolls
 
 
@@ -272,9 +327,12 @@ def cpu_train_baseline(budget_s):
         opt.step()
         times.append(time.perf_counter() - a)
     step_s = min(times[1:]) if len(times) > 1 else times[0]
-    return {'value': step_s * 1e3 * 8 / Bc, 'unit': 'ms/step', 'cores': cores, 'kind': 'port',
+    # `value` is what was measured (a 2-clip step); the linear extrapolation to the 8-clip batch over-states the CPU time (the LSTM time
+    # steps amortise over the batch) and lives in its own, clearly named field
+    return {'value': step_s * 1e3, 'unit': f'ms/step at {Bc} clips per step', 'cores': cores, 'kind': 'port', 'clips_per_step': Bc,
+            'extrapolated_8clip_ms': step_s * 1e3 * 8 / Bc,
             'sample': f'torch-CPU fp32 fwd+bwd+Adam on {Bc} clips x {CLIP_FRAMES} frames of oracle features: {step_s:.2f} s per step '
-                      f'(best of {max(1, len(times) - 1)} after one warm-up step), scaled x{8 // Bc} to the 8-clip batch'}
+                      f'(best of {max(1, len(times) - 1)} after one warm-up step); extrapolated_8clip_ms = x{8 // Bc}, an upper bound'}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -299,6 +357,16 @@ def parity_leg(model, audio, out_bf16, device, oracle_rolls):
         res['x3_frames_per_s'] = 3 * Bx * CLIP_FRAMES / (time.perf_counter() - t0)
         res['x3_clips_per_step'] = Bx
     nd = min(8, Bx)       # distinct clips (the batch tiles 8)
+    # every clip of the batch against the distinct clip it is a copy of: a block- or tail-dependent indexing error in any kernel of the
+    # 1024-clip run would show here (clips 0 .. 7 alone are block 0 of most grids)
+    Bfull = out_bf16[tools.KEY_ONSETS].shape[0]
+    same = True
+    for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
+        o = out_bf16[k]
+        idx = torch.arange(Bfull, device=o.device) % 8
+        same = same and bool(torch.equal(o, o[idx]))
+    res['tiled_clips_equal_their_source_clip'] = same
+    res['tiled_clips_compared'] = Bfull
     cells, diff = 0, 0
     for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
         a, b = out_bf16[k][:nd], ox[k][:nd]
@@ -364,6 +432,7 @@ def run_infer(args, rank, world, device):
     barrier(world)
     elapsed = time.perf_counter() - t0
     gc.enable()
+    per_rank = gather_over_ranks(elapsed, world, device, args.backend)
     elapsed = max_over_ranks(elapsed, world, device, args.backend)
 
     stage_ms = (C.c_double * L.amtx_of_num_stages())()
@@ -423,7 +492,7 @@ def run_infer(args, rank, world, device):
     config = {'workload': 'OnsetsFrames(mc=2)+MelSpec(229 bins, n_fft 2048, hop 512) inference, synthetic 22.05 kHz clips of 319999 '
                           'samples (625 frames; 8 distinct clips per rank tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
               'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
-              'rccl_ranks': world,
+              'rccl_ranks': world, 'per_rank_frames_per_s': [B * CLIP_FRAMES * args.steps / t for t in per_rank],
               'whole_path_frac_of_mfma_roof': fps / world * MODEL_FLOPS_PER_FRAME / 2.5e15,
               'whole_path_frac_of_mfma_roof_executed_flops': fps / world * EXECUTED_FLOPS_PER_FRAME / 2.5e15,
               'flops_per_frame': {'reference_algorithmic': MODEL_FLOPS_PER_FRAME, 'executed': EXECUTED_FLOPS_PER_FRAME,
@@ -446,13 +515,20 @@ def run_infer(args, rank, world, device):
         res['cpu_baseline'], oracle_rolls = cpu_baseline(args.cpu_seconds, sd)
     if world == 1 and not args.no_parity and args.precision == 'bf16':
         config.update(parity_leg(model, audio, out, device, oracle_rolls))
+    if world == 1 and not args.no_train_probe:
+        # BASELINE metric (ii), train step time, at N = 1 (the DP = 8 figure needs the 8-GPU node: python bench.py --mode train --gpus 8)
+        del model, out
+        torch.cuda.empty_cache()
+        config['train_step_ms_1gpu'] = train_step_probe(device)
+        config['train_step_workload'] = 'OnsetsFrames(mc=2)+MelSpec(229) fwd+bwd+Adam, 8 clips x 625 frames per GPU, 10 steps after 3 warm-up steps (python bench.py --mode train)'
     return res
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
 # training mode (BASELINE metric ii)
 # ------------------------------------------------------------------------------------------------------------------------------
-def run_train(args, rank, world, device):
+def _train_setup(device, rank, B, of2):
+    """Model, optimizer and one synthetic labelled batch of the training step (amt_tools/train.py:122-141); returns step()."""
     from amt_tools_amd import tools
     from amt_tools_amd.dp import DataParallelOptimizer, broadcast_parameters
     from amt_tools_amd.features import MelSpec
@@ -460,7 +536,7 @@ def run_train(args, rank, world, device):
     from amt_tools_amd.synth import synth_clip, synth_labels
 
     torch.manual_seed(0)
-    if args.of2:
+    if of2:
         model = OnsetsFrames2(N_MELS, tools.PianoProfile(), 1, device=device)
     else:
         model = OnsetsFrames(N_MELS, tools.PianoProfile(), 1, 2, device=device)
@@ -469,13 +545,12 @@ def run_train(args, rank, world, device):
     broadcast_parameters(model)
     model.train()
     opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4, buffers=model.buffers())   # BatchNorm policy: amt_tools_amd/dp.py
-    B = args.clips
     audio = torch.from_numpy(np.stack([synth_clip(rank * B + i) for i in range(B)])).to(device)
     lab = [synth_labels(rank * B + i) for i in range(B)]
     batch = {tools.KEY_AUDIO: audio,
              tools.KEY_MULTIPITCH: torch.from_numpy(np.stack([l[0] for l in lab])).to(device),
              tools.KEY_ONSETS: torch.from_numpy(np.stack([l[1] for l in lab])).to(device)}
-    if args.of2:
+    if of2:
         batch[tools.KEY_OFFSETS] = torch.from_numpy(np.stack([l[1][:, ::-1].copy() for l in lab])).to(device)   # any sparse binary map
 
     def step():       # amt_tools/train.py:122-141
@@ -484,6 +559,26 @@ def run_train(args, rank, world, device):
         loss.backward()
         opt.step()
         return loss
+
+    return step, opt
+
+
+def train_step_probe(device, steps=10, warmup=3):
+    """BASELINE metric (ii) at N = 1 inside the default line: ms per fwd + bwd + Adam step, 8 clips x 625 frames."""
+    step, _ = _train_setup(device, 0, 8, False)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def run_train(args, rank, world, device):
+    B = args.clips
+    step, opt = _train_setup(device, rank, B, args.of2)
 
     for _ in range(args.warmup):
         loss = step()
@@ -496,7 +591,18 @@ def run_train(args, rank, world, device):
     barrier(world)
     elapsed = time.perf_counter() - t0
     gc.enable()
+    per_rank = gather_over_ranks(elapsed, world, device, args.backend)
     elapsed = max_over_ranks(elapsed, world, device, args.backend)
+    # the gradient all-reduce on its own (flatten + RCCL all-reduce + unflatten, what DataParallelOptimizer.step() adds to an optimizer step),
+    # timed after the run on this rank's last gradients
+    allreduce_ms = None
+    if world > 1:
+        barrier(world)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            opt.allreduce_gradients()
+        barrier(world)
+        allreduce_ms = max_over_ranks((time.perf_counter() - t1) / 5 * 1e3, world, device, args.backend)
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -512,6 +618,7 @@ def run_train(args, rank, world, device):
         'config': {'workload': f'{name}+MelSpec(229) training step, {B} clips x {CLIP_FRAMES} frames per GPU, Adam lr 6e-4, labels Bernoulli '
                                f'(synth_labels), audio resident in HBM', 'clips_per_gpu_per_step': B, 'global_batch': world * B,
                    'frames_per_s': fps, 'parallelism': f'dp{world}: one flat fp32 gradient all-reduce per step', 'rccl_ranks': world,
+                   'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank], 'allreduce_ms_per_step': allreduce_ms,
                    'loss': float(loss), 'backward': training_backend()},
         'roofline': {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None,
@@ -528,6 +635,8 @@ def main(argv=None):
     args = parse(argv)
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(launch(args, argv))            # nothing above has touched the GPU
+    if args.dry_run and args.fail_rank >= 0 and int(os.environ.get('RANK', '0')) == args.fail_rank:
+        sys.exit(3)
     rank, world, device = init_ranks(args)
     if args.dry_run:
         import torch.distributed as dist

@@ -38,6 +38,17 @@ def test_failing_rank_fails_the_launcher():
     assert p.returncode != 0
 
 
+def test_one_failing_rank_ends_the_run_at_once():
+    """Only rank 1 fails (before the rendezvous): the launcher must terminate rank 0, which is waiting for its peer in
+    init_process_group, and fail within seconds -- not after the store's rendezvous timeout."""
+    import time
+    t0 = time.time()
+    p = _run(['--gpus', '2', '--dry-run', '--fail-rank', '1'], timeout=120)
+    assert p.returncode != 0
+    assert time.time() - t0 < 60
+    assert 'a rank exited with an error' in p.stderr
+
+
 def test_train_mode_shim_passes_through_the_same_launcher():
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_train.py'), '--gpus', '2', '--dry-run'],
                        env={k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')},

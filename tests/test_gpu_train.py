@@ -274,7 +274,9 @@ def test_linear_fwd_bwd_matches_float64(M, N, K):
 
 
 @pytest.mark.parametrize('ci,co', [(1, 32), (32, 32), (32, 64), (48, 96), (16, 16)])
-@pytest.mark.parametrize('B,T,F', [(1, 1, 2), (2, 7, 13), (3, 20, 57), (1, 33, 229)])
+# (3, 64, 229) = 43 968 positions: more than the 24 576 that one xwgrad_kernel step per block covers (several steps per block, the per-step
+# advance of the x / dy strips and the clip wrap inside the loop: ADVICE r02), several clips
+@pytest.mark.parametrize('B,T,F', [(1, 1, 2), (2, 7, 13), (3, 20, 57), (1, 33, 229), (3, 64, 229)])
 def test_conv3x3_fwd_bwd_matches_float64(ci, co, B, T, F):
     """autograd.conv3x3 (implicit GEMMs of csrc/train.hip) against torch's float64 Conv2d: output, input gradient (where the layer
     has one: not the one-channel first layer), weight and bias gradients; zero padding at clip boundaries in time and at the band
