@@ -32,12 +32,17 @@ def _deps():
 FILE_FLAGS = {'spec.hip': ['-fno-slp-vectorize'], 'convg.hip': ['-fno-slp-vectorize']}
 
 
-def _compile(src, hdr_mtime, verbose):
-    obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
+# Compiled a second time with -DAMTX_F16 (IEEE half operands instead of bf16, public functions suffixed _f16: csrc/amtx_f16_names.h):
+# the engine's precision 'f16'
+F16_TWINS = ('conv.hip', 'convf.hip', 'gemm.hip', 'lstm.hip')
+
+
+def _compile(src, hdr_mtime, verbose, f16=False):
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ('_f16.o' if f16 else '.o'))
     path = os.path.join(CSRC, src)
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_mtime):
         return obj
-    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', path, '-o', obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + (['-DAMTX_F16'] if f16 else []) + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', path, '-o', obj]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -48,7 +53,8 @@ def build(verbose=True, jobs=4):
     """Compile + link; rebuilds only what changed.  Returns the path of libamtx.so."""
     hdr_mtime = _deps()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, hdr_mtime, verbose), _sources()))
+        jobs_ = [(s, False) for s in _sources()] + [(s, True) for s in F16_TWINS]
+        objs = list(ex.map(lambda j: _compile(j[0], hdr_mtime, verbose, j[1]), jobs_))
     if not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

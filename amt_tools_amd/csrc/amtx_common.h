@@ -44,9 +44,27 @@ int amtx_grant_lds(const void* kernel, size_t bytes);
         }                                                                                \
     } while (0)
 
-// ------------------------------------------------------------------ bf16 helpers
-typedef uint16_t bf16_t;   // raw bf16 bits
+// ------------------------------------------------------------------ 16-bit operand format of this translation unit
+// conv.hip, convf.hip, gemm.hip and lstm.hip are compiled TWICE (amt_tools_amd/build.py): as they are, with bf16 operands, and with
+// -DAMTX_F16 into a second object whose public functions carry the suffix _f16 (amtx_f16_names.h) and whose 16-bit values are IEEE
+// half precision: the same matrix rate on gfx950 (v_mfma_f32_16x16x32_f16), three more mantissa bits -- the engine's precision 'f16'.
+// In that build every name below that says "bf16" means "the 16-bit operand format of this build": bf16_t is a raw 16-bit pattern
+// either way, and no kernel touches the bits except through these helpers.
+typedef uint16_t bf16_t;   // raw 16-bit operand bits (bf16, or half in an AMTX_F16 build)
 
+#ifdef AMTX_F16
+static inline __host__ __device__ bf16_t f32_to_bf16_rn(float f) {      // round to nearest even (hardware or compiler conversion)
+    const _Float16 h = (_Float16)f;
+    bf16_t u;
+    __builtin_memcpy(&u, &h, 2);
+    return u;
+}
+static inline __host__ __device__ float bf16_to_f32(bf16_t u) {
+    _Float16 h;
+    __builtin_memcpy(&h, &u, 2);
+    return (float)h;
+}
+#else
 static inline __host__ __device__ bf16_t f32_to_bf16_rn(float f) {
     uint32_t u;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -69,6 +87,7 @@ static inline __host__ __device__ float bf16_to_f32(bf16_t h) {
     return f;
 #endif
 }
+#endif
 
 #if defined(__HIPCC__)
 // vector types matching MFMA operand register counts
@@ -77,20 +96,60 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4_t;   // 4 bf16 = 2 VGPR
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // C/D of 16x16
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // C/D of 32x32
 
-// pack two floats into one dword of 2 x bf16 (round to nearest even); lo -> bits 0..15.
-// gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32), reached through the native __bf16 type.
+// pack two floats into one dword of two 16-bit operands (round to nearest even); lo -> bits 0..15.  gfx950 has both conversions in
+// hardware (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32), reached through the native __bf16 / _Float16 types.
 typedef __attribute__((ext_vector_type(2))) float amtx_f32x2;
+#ifdef AMTX_F16
+typedef __attribute__((ext_vector_type(2))) _Float16 amtx_bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 amtx_mfma_x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 amtx_mfma_x4;
+#else
 typedef __attribute__((ext_vector_type(2))) __bf16 amtx_bf16x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 amtx_mfma_x8;
+typedef __attribute__((ext_vector_type(4))) short amtx_mfma_x4;
+#endif
 static __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const amtx_f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, amtx_bf16x2));
 }
+// the two halves of a packed dword back as floats
+static __device__ __forceinline__ float unpack16_lo(uint32_t v) {
+#ifdef AMTX_F16
+    return (float)__builtin_bit_cast(amtx_bf16x2, v)[0];
+#else
+    return __uint_as_float(v << 16);
+#endif
+}
+static __device__ __forceinline__ float unpack16_hi(uint32_t v) {
+#ifdef AMTX_F16
+    return (float)__builtin_bit_cast(amtx_bf16x2, v)[1];
+#else
+    return __uint_as_float(v & 0xffff0000u);
+#endif
+}
+// D = A (16 x 32) . B (32 x 16) + C on the matrix cores, operands in the build's 16-bit format, fp32 accumulate
+typedef __attribute__((ext_vector_type(4))) float amtx_f32x4;
+static __device__ __forceinline__ amtx_f32x4 amtx_mfma_16x16x32(uint4 a, uint4 b, amtx_f32x4 c) {
+#ifdef AMTX_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(amtx_mfma_x8, a), __builtin_bit_cast(amtx_mfma_x8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(amtx_mfma_x8, a), __builtin_bit_cast(amtx_mfma_x8, b), c, 0, 0, 0);
+#endif
+}
+// the legacy 16-deep form (conv.hip's multi-channel fused first conv)
+static __device__ __forceinline__ amtx_f32x4 amtx_mfma_16x16x16(uint2 a, uint2 b, amtx_f32x4 c) {
+#ifdef AMTX_F16
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(amtx_mfma_x4, a), __builtin_bit_cast(amtx_mfma_x4, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(amtx_mfma_x4, a), __builtin_bit_cast(amtx_mfma_x4, b), c, 0, 0, 0);
+#endif
+}
 
-// split x = hi + lo with hi = bf16(x), lo = bf16(x - hi): the two planes of the "x3" (split-bf16,
-// fp32-class accuracy) MFMA path.  Pairs at a time: one packed dword per plane.
+// split x = hi + lo with hi = 16-bit(x), lo = 16-bit(x - hi): the two planes of the "x3" (split-bf16, fp32-class accuracy) MFMA path.
+// Pairs at a time: one packed dword per plane.
 static __device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf16x2(a, b);
-    lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+    lo = pack_bf16x2(a - unpack16_lo(hi), b - unpack16_hi(hi));
 }
 
 static __device__ __forceinline__ float wave_max_f32(float v) {

@@ -128,5 +128,6 @@ int amtx_launch_bce_loss(const float* logits, int64_t ld, const float* labels, c
 int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int T, int keys, float threshold, float* out,
                           hipStream_t stream);
 
-int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream);
+int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream,
+                             bool f16 = false /* IEEE half instead of bf16 (AMTX_PREC_F16) */);
 int amtx_launch_zero_cols(void* base, int64_t pitch_bytes, int width_bytes, int64_t rows, hipStream_t stream);

@@ -12,6 +12,7 @@
 // Eval-mode BatchNorm is folded on the host: scale into the weights, shift (+ conv bias) into `shift`.
 // Algorithmic HBM bytes per output position: 32 ch in + C_out/2 ch out (pooled), element size of the mode.
 
+#include "amtx_f16_names.h"
 #include "amtx_kernels.h"
 
 #include <algorithm>
@@ -37,7 +38,7 @@ constexpr int CM_BYTES = 3 * CM_PLANE + ROWS * PITCH * 16;   // the last chunk p
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+    return amtx_mfma_16x16x32(a, b, c);
 }
 
 // Byte offset of 16-byte chunk c of tile position (row i, column j).  A fragment read takes, per lane,
@@ -47,7 +48,7 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
 // (found by exhaustive search, tools/lds_swizzle_search.py).
 typedef __attribute__((ext_vector_type(4))) short mfma_s16x4;
 __device__ __forceinline__ f32x4_t mfma16k16(uint2 a, uint2 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(mfma_s16x4, a), __builtin_bit_cast(mfma_s16x4, b), c, 0, 0, 0);
+    return amtx_mfma_16x16x16(a, b, c);
 }
 
 __device__ __forceinline__ int tile_off(int i, int j, int c) { return ((i * PITCH + j) * 4 + (c ^ (((i >> 2) & 1) << 1))) * 16; }

@@ -31,6 +31,7 @@
 // hit 16 distinct 16-byte bank groups, and the 8 rows of a ds_write_b128 lane group 8 distinct ones), two bf16 feature slabs (68 rows x
 // 12 columns, dB-scaled while they are staged: amtx_of_forward_power), layer3's shift table.
 
+#include "amtx_f16_names.h"
 #include "amtx_kernels.h"
 
 #include <algorithm>
@@ -72,7 +73,7 @@ static_assert(CP == 4 && XB == 2, "wave roles below are written for 8 layer2 col
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+    return amtx_mfma_16x16x32(a, b, c);
 }
 __device__ __forceinline__ void settle(const uint4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 __device__ __forceinline__ void settle(float v) { asm volatile("" ::"v"(v)); }

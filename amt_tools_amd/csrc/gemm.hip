@@ -10,6 +10,7 @@
 // * 128x128x32 block tile, 4 waves (2x2) of 64x64, register-staged double-buffered LDS with an XOR chunk
 //   swizzle so the 16 rows of a fragment read hit 16 distinct 16-byte slots.
 
+#include "amtx_f16_names.h"
 #include "amtx_kernels.h"
 
 #include <algorithm>
@@ -30,7 +31,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 
 __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+    return amtx_mfma_16x16x32(a, b, c);
 }
 
 template <int A_TYPE, int NS>

@@ -37,6 +37,12 @@ __global__ __launch_bounds__(256) void pianoroll_kernel(const float* __restrict_
 
 // fp32 rows [M][ld_src] (n_src valid columns) -> bf16 rows [M][ld_dst], zero padded: lets the adjoin input projection
 // (A = joint logits) run on the direct-to-LDS bf16 GEMM path.
+typedef __attribute__((ext_vector_type(2))) _Float16 head_f16x2;
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {       // the AMTX_PREC_F16 engine: IEEE half instead of bf16
+    const amtx_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, head_f16x2));
+}
+template <bool F16>
 __global__ __launch_bounds__(256) void cvt_pad_bf16_kernel(const float* __restrict__ src, int64_t ld_src, int n_src, bf16_t* __restrict__ dst,
                                                            int ld_dst, int64_t rows) {
     const int groups = ld_dst >> 2;                                   // 4 columns per thread
@@ -46,7 +52,8 @@ __global__ __launch_bounds__(256) void cvt_pad_bf16_kernel(const float* __restri
         const int c = (int)(i - r * groups) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c + 3 < n_src) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
-        *reinterpret_cast<uint2*>(dst + r * ld_dst + c) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        *reinterpret_cast<uint2*>(dst + r * ld_dst + c) = F16 ? make_uint2(pack_f16x2(v.x, v.y), pack_f16x2(v.z, v.w))
+                                                              : make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
     }
 }
 
@@ -69,11 +76,12 @@ int amtx_launch_zero_cols(void* base, int64_t pitch_bytes, int width_bytes, int6
     return AMTX_OK;
 }
 
-int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream) {
+int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream, bool f16) {
     AMTX_REQUIRE(src && dst && rows > 0 && n_src % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0 && ld_dst >= n_src, "cvt_pad_bf16: bad argument");
     int64_t nb = (rows * (ld_dst >> 2) + 255) / 256;
     if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(cvt_pad_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, rows);
+    if (f16) hipLaunchKernelGGL(cvt_pad_bf16_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, rows);
+    else hipLaunchKernelGGL(cvt_pad_bf16_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, rows);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

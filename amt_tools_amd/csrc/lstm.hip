@@ -19,6 +19,7 @@
 // The recurrence is a dependency chain (latency-bound, not roofline-bound): throughput comes from running
 // ceil(B/16) x 2 directions x groups blocks concurrently.
 
+#include "amtx_f16_names.h"
 #include "amtx_kernels.h"
 
 #include <type_traits>
@@ -34,7 +35,7 @@ constexpr int HBUF_BYTES = 16 * HP * 2;      // one plane of one buffer
 
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
 __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a), __builtin_bit_cast(mfma_bf16x8, b), c, 0, 0, 0);
+    return amtx_mfma_16x16x32(a, b, c);
 }
 
 // FAST (bf16 mode): v_exp_f32 + v_rcp_f32 (1 ulp each) -- far below the bf16 rounding of h.
@@ -66,8 +67,7 @@ __device__ __forceinline__ void load_x(const char* xbase, int64_t row_off, typen
 }
 __device__ __forceinline__ f32x4_t unpack_x(float4 v) { return (f32x4_t){v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ f32x4_t unpack_x(uint2 v) {
-    return (f32x4_t){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u), __uint_as_float(v.y << 16),
-                     __uint_as_float(v.y & 0xffff0000u)};
+    return (f32x4_t){unpack16_lo(v.x), unpack16_hi(v.x), unpack16_lo(v.y), unpack16_hi(v.y)};
 }
 
 // LDS-only workgroup barrier: waits for this wave's LDS traffic, NOT for its global loads/stores (the
@@ -218,7 +218,7 @@ template <int X_TYPE> struct XScalar { typedef float type; };
 // zero-extension / pair-packing instruction right behind it, which drags the wait for the prefetch to the load)
 template <> struct XScalar<AMTX_T_BF16> { typedef unsigned int type; };
 __device__ __forceinline__ float unpack_xs(float v, bool) { return v; }
-__device__ __forceinline__ float unpack_xs(unsigned int v, bool odd) { return __uint_as_float(odd ? (v & 0xffff0000u) : (v << 16)); }
+__device__ __forceinline__ float unpack_xs(unsigned int v, bool odd) { return odd ? unpack16_hi(v) : unpack16_lo(v); }
 
 template <int X_TYPE>
 __device__ __forceinline__ void load_x4(const char* xbase, int64_t row_off, typename XScalar<X_TYPE>::type (&dst)[4]) {

@@ -15,6 +15,7 @@
 //   piano-roll finalize (sigmoid, threshold 0.5, transpose) x2
 
 #include "amtx_kernels.h"
+#include "amtx_kernels_f16.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -48,6 +49,7 @@ struct LinearPack { DevBuf w, b; int N = 0, K = 0, n_pad = 0, k_pad = 0; };
 struct amtx_of_model {
     int dim_in, in_channels, mc, n_out, has_offsets, precision;
     int planes, act_type;
+    bool f16 = false;                          // AMTX_PREC_F16: the half-operand builds of the conv / GEMM / BiLSTM kernels, weights packed as half
     int nf1, nf2, nf3, dim_am, dim_lm, fq, kfc;
     int kfc_pad;                               // fc1's K rounded up to the DMA GEMM's 64-deep k-tile (rows of a3 are this long)
     int hid, xw;                               // LSTM hidden size per direction, width of an x-projection row (2 dirs x 4 gates x hid)
@@ -129,7 +131,7 @@ int pack_linear_groups(amtx_of_model* m, LinearPack& lp, const std::vector<std::
     std::vector<bf16_t> packed(per * Ws.size());
     std::vector<float> bias((size_t)N * Ws.size());
     for (size_t g = 0; g < Ws.size(); ++g) {
-        amtx_gemm_pack_host(Ws[g].data(), K, N, K, m->planes, packed.data() + g * per);
+        (m->f16 ? amtx_gemm_pack_host_f16 : amtx_gemm_pack_host)(Ws[g].data(), K, N, K, m->planes, packed.data() + g * per);
         memcpy(bias.data() + g * N, bs[g].data(), sizeof(float) * N);
     }
     int rc = lp.w.upload(packed.data(), packed.size() * sizeof(bf16_t));
@@ -154,7 +156,7 @@ int pack_lstm(amtx_of_model* m, const std::string& prefix, int dim_in, std::vect
     b.resize(2 * G);
     for (int i = 0; i < G; ++i) { b[i] = bif[i] + bhf[i]; b[G + i] = bib[i] + bhb[i]; }
     hh.resize(amtx_bilstm_wfrag_elems_h(H, m->planes));
-    amtx_bilstm_pack_host_h(whf, whb, H, m->planes, hh.data());
+    (m->f16 ? amtx_bilstm_pack_host_h_f16 : amtx_bilstm_pack_host_h)(whf, whb, H, m->planes, hh.data());
     return AMTX_OK;
 }
 
@@ -192,7 +194,7 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
                                     int has_offsets, int precision) {
     AMTX_REQUIRE(out, "amtx_of_model_create: null model pointer");
     *out = nullptr;
-    AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3, "amtx_of_model_create: bad precision");
+    AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3 || precision == AMTX_PREC_F16, "amtx_of_model_create: bad precision");
     AMTX_REQUIRE(dim_in >= 4 && in_channels >= 1 && n_out > 0 && n_out % 4 == 0, "amtx_of_model_create: bad dims");
     if (model_complexity != 2 && model_complexity != 3) {
         amtx_set_error("amtx_of_model_create: model_complexity 2 (32/32/64-channel convolutions, LSTM hidden 128) and 3 (48/48/96, hidden 256) "
@@ -203,7 +205,8 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->dim_in = dim_in; m->in_channels = in_channels; m->mc = model_complexity; m->n_out = n_out;
     m->has_offsets = has_offsets; m->precision = precision;
     m->planes = precision == AMTX_PREC_X3 ? 2 : 1;
-    m->act_type = precision == AMTX_PREC_X3 ? AMTX_T_F32 : AMTX_T_BF16;
+    m->act_type = precision == AMTX_PREC_X3 ? AMTX_T_F32 : AMTX_T_BF16;      // AMTX_T_BF16 = "16-bit operand format": half in the f16 mode
+    m->f16 = precision == AMTX_PREC_F16;
     m->nf1 = 16 * model_complexity; m->nf2 = m->nf1; m->nf3 = 32 * model_complexity;
     m->dim_am = 256 * model_complexity; m->dim_lm = 256 * (model_complexity - 1);
     m->fq = dim_in / 4;                      // two MaxPool(1,2): floor(floor(F/2)/2) == F//4
@@ -223,6 +226,12 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->n_heads = (int)m->head_names.size();
     m->dim_aj = (m->n_rec + 1) * n_out;
     m->fuse_conv1 = m->gen_conv2 ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
+    if (m->f16 && (m->gen_conv || m->gen_conv2)) {
+        amtx_set_error("amtx_of_model_create: precision f16 is built for one-channel models at model_complexity 2 (conv.hip / convf.hip); "
+                       "this model needs the general-channel kernels of convg.hip, which exist for bf16 and x3 only");
+        delete m;
+        return AMTX_ERR_UNSUPPORTED;
+    }
     // A/B switch: AMTX_NO_CONV_FUSE=1 keeps conv.hip's two kernels (conv1+conv2, conv3) at every batch size
     m->fuse_stack = !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && m->planes == 1 && getenv("AMTX_NO_CONV_FUSE") == nullptr;
     *out = m;
@@ -276,20 +285,20 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
                 c1w[((size_t)h * m->nf1 + co) * m->in_channels * 9 + i] = w[(size_t)co * m->in_channels * 9 + i] * scale[co];
         memcpy(c1s.data() + (size_t)h * m->nf1, shift.data(), sizeof(float) * m->nf1);
         if (m->fuse_conv1 && m->gen_conv2) amtx_conv1g_pack_host(w, scale.data(), m->in_channels, m->nf1, m->planes, c1f.data() + c1f_per * h);
-        else if (m->fuse_conv1) amtx_conv1_pack_host(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
+        else if (m->fuse_conv1) (m->f16 ? amtx_conv1_pack_host_f16 : amtx_conv1_pack_host)(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
 
         rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
         if (m->gen_conv2) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
-        else amtx_conv3x3_pack_host(w, scale.data(), m->nf2, m->planes, c2w.data() + c2w_per * h);
+        else (m->f16 ? amtx_conv3x3_pack_host_f16 : amtx_conv3x3_pack_host)(w, scale.data(), m->nf2, m->planes, c2w.data() + c2w_per * h);
         memcpy(c2s.data() + (size_t)h * m->nf2, shift.data(), sizeof(float) * m->nf2);
 
         rc = fold_bn(m, am + ".layer3.0", am + ".layer3.1", m->nf3, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
         if (m->gen_conv) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf2, m->nf3, m->planes, c3w.data() + c3w_per * h);
-        else amtx_conv3x3_pack_host(w, scale.data(), m->nf3, m->planes, c3w.data() + c3w_per * h);
+        else (m->f16 ? amtx_conv3x3_pack_host_f16 : amtx_conv3x3_pack_host)(w, scale.data(), m->nf3, m->planes, c3w.data() + c3w_per * h);
         memcpy(c3s.data() + (size_t)h * m->nf3, shift.data(), sizeof(float) * m->nf3);
 
         // fc1: reference column index c*fq + f  ->  ours f*nf3 + c
@@ -418,6 +427,11 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     const int64_t BT = (int64_t)B * T;
     const int F = m->dim_in, F2 = F / 2, at = m->act_type, pl = m->planes;
     int rc;
+    // the kernels of this model's 16-bit operand format (bf16, or IEEE half: the second build of conv / convf / gemm / lstm.hip)
+    const bool f16 = m->f16;
+    auto launch_gemm = [f16](const GemmArgs& ga, hipStream_t st) { return f16 ? amtx_launch_gemm_f16(ga, st) : amtx_launch_gemm(ga, st); };
+    auto launch_conv = [f16](const ConvArgs& ca, hipStream_t st) { return f16 ? amtx_launch_conv3x3_f16(ca, st) : amtx_launch_conv3x3(ca, st); };
+    auto launch_bilstm = [f16](const LstmArgs& la, hipStream_t st) { return f16 ? amtx_launch_bilstm_f16(la, st) : amtx_launch_bilstm(la, st); };
     std::vector<hipEvent_t>* evs = nullptr;
     if (m->prof) {
         m->prof_events.emplace_back();
@@ -454,9 +468,9 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     const bool fused_stack = m->fuse_stack && amtx_conv_stack_fused_ok(B, T, F, m->n_heads);
     if (fused_stack) {
         // layer1 -> layer2 -> layer3 in one kernel: neither intermediate map reaches HBM (stage timer: all of it under conv2_pool)
-        if ((rc = amtx_launch_conv_stack(c2, (const bf16_t*)m->conv3_w.p, (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl), (const float*)m->conv3_s.p,
+        if ((rc = (f16 ? amtx_launch_conv_stack_f16 : amtx_launch_conv_stack)(c2, (const bf16_t*)m->conv3_w.p, (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl), (const float*)m->conv3_s.p,
                                          w.a3, BT * m->kfc_pad, s)) != AMTX_OK) return rc;
-    } else if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : amtx_launch_conv3x3(c2, s)) != AMTX_OK) return rc;
+    } else if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : launch_conv(c2, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c3 = c2;
@@ -473,23 +487,23 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         if ((rc = amtx_launch_zero_cols(w.a3 + (size_t)m->kfc * es, (int64_t)m->kfc_pad * es, (int)((m->kfc_pad - m->kfc) * es),
                                         BT * m->n_heads, s)) != AMTX_OK) return rc;
     }
-    if (!fused_stack && (rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : amtx_launch_conv3x3(c3, s)) != AMTX_OK) return rc;
+    if (!fused_stack && (rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : launch_conv(c3, s)) != AMTX_OK) return rc;
     mark();
 
     // fc1 of the recurrent heads (heads 0..n_rec-1 of a3); the pitch head's fc1 is folded into its output layer below
     GemmArgs g = gemm_args(w.a3, m->kfc_pad, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_rec, BT * m->kfc_pad, BT * m->dim_am);
-    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
     // recurrent heads: heads 0..n_rec-1 of `e`
     g = gemm_args(w.e, m->dim_am, at, m->rec_ih, pl, w.xp, m->xw, at, BT, m->n_rec, BT * m->dim_am, BT * m->xw);
-    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     LstmArgs l;
     l.xproj = w.xp; l.x_type = at; l.whh = (const bf16_t*)m->rec_hh.p; l.planes = pl; l.out = w.l1; l.out_type = at;
     l.B = B; l.T = T; l.groups = m->n_rec; l.x_gs = BT * m->xw; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems_h(m->hid, pl); l.out_gs = BT * m->dim_lm;
     l.hidden = m->hid;
-    if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
+    if ((rc = launch_bilstm(l, s)) != AMTX_OK) return rc;
     mark();
     // LogisticBank of each recurrent head -> joint[:, r*n_out : (r+1)*n_out]; group stride of C = n_out columns
     g = gemm_args(w.l1, m->dim_lm, at, m->rec_out, pl, w.joint, m->dim_aj, AMTX_T_F32, BT, m->n_rec, BT * m->dim_lm, m->n_out);
@@ -511,25 +525,25 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         gp.copy16 = (bf16_t*)w.joint16; gp.copy16_ld = kp; gp.copy16_col0 = m->n_rec * m->n_out; gp.copy16_gs = 0; gp.copy16_pad = kp - m->dim_aj;
         if (roll_on && !logits_onsets && !logits_pitch_head && !m->has_offsets) { g.C = nullptr; gp.C = nullptr; }
     }
-    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     // pitch head: (fc1 . LogisticBank) folded, straight from its conv3 map -> last n_out columns of joint
-    if ((rc = amtx_launch_gemm(gp, s)) != AMTX_OK) return rc;
+    if ((rc = launch_gemm(gp, s)) != AMTX_OK) return rc;
     mark();
 
     // adjoin
     if (pl == 1) {
         // bf16 mode: the joint logits rounded to bf16 (zero-padded to a 64-multiple K) feed the direct-to-LDS GEMM
-        if (!copy_on && (rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s)) != AMTX_OK) return rc;
+        if (!copy_on && (rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s, f16)) != AMTX_OK) return rc;
         g = gemm_args(w.joint16, kp, AMTX_T_BF16, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
         g.K = kp;
     } else {
         g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
     }
-    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     l.xproj = w.xp2; l.whh = (const bf16_t*)m->adj_hh.p; l.out = w.l2; l.groups = 1;
-    if ((rc = amtx_launch_bilstm(l, s)) != AMTX_OK) return rc;
+    if ((rc = launch_bilstm(l, s)) != AMTX_OK) return rc;
     mark();
     g = gemm_args(w.l2, m->dim_lm, at, m->adj_out, pl, w.mp, m->n_out, AMTX_T_F32, BT, 1, 0, 0);
     const bool roll_mp = out_multi_pitch && !no_roll_epi && amtx_gemm_has_roll_epilogue(g);
@@ -537,7 +551,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         g.roll_out = out_multi_pitch; g.roll_T = T; g.roll_thr = 0.5f; g.roll_group = 0;
         if (!logits_multi_pitch) g.C = nullptr;            // nobody reads the refined logits then: only the roll is written
     }
-    if ((rc = amtx_launch_gemm(g, s)) != AMTX_OK) return rc;
+    if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
     // piano rolls of the modes whose LogisticBank GEMM has no roll epilogue (x3)

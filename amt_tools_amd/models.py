@@ -273,7 +273,7 @@ class _OFEngine(object):
     def __init__(self, model, device):
         self.device = device
         self.handle = C.c_void_p()
-        prec = {'bf16': 0, 'x3': 1}[model.precision]
+        prec = {'bf16': 0, 'x3': 1, 'f16': 2}[model.precision]
         L = _lib.lib()
         with torch.cuda.device(device):
             _lib.check(L.amtx_of_model_create(C.byref(self.handle), int(model.dim_in), int(model.in_channels),
@@ -365,7 +365,7 @@ class OnsetsFrames(TranscriptionModel):
     def __init__(self, dim_in, profile, in_channels=1, model_complexity=2, detach_heads=False, device='cpu',
                  precision='bf16'):
         super().__init__(dim_in, profile, in_channels, model_complexity, 1, device)
-        assert precision in ('bf16', 'x3')
+        assert precision in ('bf16', 'x3', 'f16')
         self.detach_heads = detach_heads
         self.precision = precision
         self.dim_am = 256 * self.model_complexity

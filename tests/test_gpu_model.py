@@ -194,6 +194,71 @@ def test_engine_at_batch_sizes_that_take_the_eight_clip_recurrence(cls, B, T, pr
             assert (torch.sigmoid(g) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4, key
 
 
+@pytest.mark.parametrize('name', ['of1_eval.npz', 'of2_mc2_eval.npz'])
+def test_f16_precision_matches_reference_golden(name):
+    """precision 'f16': the bf16 engine with IEEE half operands (the second, -DAMTX_F16 build of conv / convf / gemm / lstm.hip: same
+    matrix rate, three more mantissa bits).  Logits within 1e-2 of the REAL reference classes' outputs (bf16: 6e-2, x3: 1e-4) and several
+    times closer to them than the bf16 mode's on the same input; piano rolls identical outside the tolerance band."""
+    import amt_tools_amd.models as M
+    g = load_golden(name)
+    cls = M.OnsetsFrames2 if name.startswith('of2') else M.OnsetsFrames
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=int(g['in_channels']), model_complexity=int(g['model_complexity']),
+                          offsets=name.startswith('of2'))
+    errs = {}
+    for precision in ('f16', 'bf16'):
+        model = cls(int(g['dim_in']), tools.PianoProfile(), int(g['in_channels']), int(g['model_complexity']), device='cuda:0', precision=precision)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        model.change_device()
+        model.eval()
+        with torch.no_grad():
+            out = model.run_on_batch({tools.KEY_FEATS: torch.from_numpy(g['feats'])})
+            logits = model.engine_logits(torch.from_numpy(g['feats']).cuda())
+        errs[precision] = max(np.abs(logits[key].cpu().numpy() - g['logits_' + key]).max() for key in ('onsets', 'multi_pitch', 'pitch_head'))
+        if precision == 'f16':
+            for key in ('onsets', 'multi_pitch'):
+                near = np.abs(np.swapaxes(g['logits_' + key], -1, -2)) < 1e-2
+                assert np.all((out[key].cpu().numpy() == g['out_' + key]) | near)
+    assert errs['f16'] < 1e-2, errs
+    assert errs['f16'] < 0.4 * errs['bf16'], errs
+
+
+@pytest.mark.parametrize('dim_in', [229, 40, 8])
+def test_f16_precision_vs_oracle_on_both_convolution_paths(dim_in):
+    """f16 on the two-kernel path (small batches) and on the fused stack (256 or more head x clip x strip), ragged shapes; against the CPU
+    oracle within 1e-2 (logits) / 2.5e-3 (activations)."""
+    from oracle import model_ref
+    import amt_tools_amd.models as M
+    sd = synth_state_dict(19, dim_in=dim_in, in_channels=1, model_complexity=2)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model = M.OnsetsFrames(dim_in, tools.PianoProfile(), 1, 2, device='cuda:0', precision='f16')
+    model.load_state_dict(sdt)
+    model.change_device()
+    model.eval()
+    rng = np.random.default_rng(dim_in + 1)
+    for B, T in ((3, 17), (1, 33), (130, 47), (44, 140)):
+        feats = torch.from_numpy(rng.random((B, 1, dim_in, T)).astype(np.float32))
+        pick = sorted({0, B // 2, B - 1})
+        with torch.no_grad():
+            got = model.engine_logits(feats.cuda())
+            ref = model_ref.run_on_batch(feats[pick], sdt)
+        assert model._get_engine(torch.device('cuda:0')).conv_stack_fused(B, T) == (2 * B * ((T + 61) // 62) >= 256)
+        for key in ('onsets', 'multi_pitch', 'pitch_head'):
+            gk = got[key].cpu()[pick]
+            assert (gk - ref['logits'][key]).abs().max().item() < 1e-2, (B, T, key)
+            assert (torch.sigmoid(gk) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 2.5e-3, (B, T, key)
+
+
+def test_f16_precision_is_refused_where_the_general_conv_kernels_run():
+    from amt_tools_amd._lib import AmtxError
+    import amt_tools_amd.models as M
+    for kw in (dict(dim_in=229, in_channels=1, mc=3), dict(dim_in=72, in_channels=6, mc=2)):
+        model = M.OnsetsFrames(kw['dim_in'], tools.PianoProfile(), kw['in_channels'], kw['mc'], device='cuda:0', precision='f16')
+        model.change_device()
+        model.eval()
+        with pytest.raises(AmtxError), torch.no_grad():
+            model.run_on_batch({tools.KEY_FEATS: torch.zeros(1, kw['in_channels'], kw['dim_in'], 8)})
+
+
 def _of1_bf16(seed, dim_in, cls='OnsetsFrames'):
     import amt_tools_amd.models as M
     sd = synth_state_dict(seed, dim_in=dim_in, in_channels=1, model_complexity=2, offsets=cls == 'OnsetsFrames2')
