@@ -147,3 +147,35 @@ def ptr(t):
 def current_stream(device=None):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# kernel workspaces with guard bands (tests/test_gpu_guards.py)
+# ------------------------------------------------------------------------------------------------------------------------------
+GUARD_BYTES = 0        # > 0 (a multiple of 256): every workspace below gets this many pattern-filled bytes in front of and behind it
+_GUARD_PATTERN = 0xA5
+
+
+def alloc_workspace(nbytes, device):
+    """uint8 tensor of `nbytes` for a kernel workspace.  With GUARD_BYTES set it is the middle of a larger allocation whose first and last
+    GUARD_BYTES hold a pattern: several kernels issue masked stores to scratch lines and loads from clamped addresses, and a store that
+    leaves its workspace must not go unnoticed (guards_intact)."""
+    import torch
+    nbytes = int(nbytes)
+    g = int(GUARD_BYTES)
+    if g <= 0:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    assert g % 256 == 0
+    full = torch.empty(nbytes + 2 * g, dtype=torch.uint8, device=device)
+    full[:g] = _GUARD_PATTERN
+    full[g + nbytes:] = _GUARD_PATTERN
+    return full[g:g + nbytes]                      # a view: keeps `full` alive, data_ptr() is 256-byte aligned like the allocation
+
+
+def guards_intact(ws):
+    """True when the bands around a workspace from alloc_workspace still hold the pattern (or there are none)."""
+    base = getattr(ws, '_base', None)
+    if base is None:
+        return True
+    g = (base.numel() - ws.numel()) // 2
+    return bool((base[:g] == _GUARD_PATTERN).all().item()) and bool((base[g + ws.numel():] == _GUARD_PATTERN).all().item())

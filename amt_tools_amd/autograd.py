@@ -44,7 +44,7 @@ def _workspace(nbytes, device):
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _WS[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        ws = _WS[key] = _lib.alloc_workspace(max(int(nbytes), 1 << 20), device)
     return ws
 
 

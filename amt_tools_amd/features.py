@@ -433,7 +433,7 @@ class _CqtPlanOwner(object):
         ws = self.__dict__.get('_workspace')
         if ws is None or ws.numel() < need or ws.device != audio.device:
             self.__dict__['_workspace'] = None
-            ws = self.__dict__['_workspace'] = torch.empty(int(need), dtype=torch.uint8, device=audio.device)
+            ws = self.__dict__['_workspace'] = _lib.alloc_workspace(need, audio.device)
         out = torch.empty((B, H, self.n_bins, T), dtype=torch.float32, device=audio.device)
         with torch.cuda.device(audio.device):
             _lib.check(L.amtx_cqt_forward(plan, _lib.ptr(audio), N, audio.stride(0), B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),

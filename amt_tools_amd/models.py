@@ -316,7 +316,7 @@ class _OFEngine(object):
         need = L.amtx_of_workspace_bytes(self.handle, B, T)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None
-            self.workspace = torch.empty(int(need), dtype=torch.uint8, device=feats.device)
+            self.workspace = _lib.alloc_workspace(need, feats.device)
         n_out = self.n_out
         opts = dict(dtype=torch.float32, device=feats.device)
         onsets = torch.empty((B, n_out, T), **opts)
