@@ -786,191 +786,6 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 #undef CONV_ISSUE_FEAT_LOADS
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// bf16 -> bf16 layers that read their input from HBM (conv3, and conv2 when the first conv is not fused): the input
-// tile goes HBM/L2 -> LDS by DMA (global_load_lds_dwordx4) into the second of two LDS planes while the current plane is
-// on the matrix cores.  No staging registers, no staging instructions, no exposed load latency: in the register-staged
-// kernel above a C_out = 64 block spends as long waiting for its tile (two dependent batches of loads, ~4 us) as
-// computing on it.  Planes are sized to the tile (row pitch = columns + 1 or + 3, always 1 mod 4, so tile_off's
-// swizzle argument holds): with <= 30 output columns two blocks x two planes fit one CU's 160 KiB.
-// The DMA writes 16 consecutive tile positions (4 chunks each) per instruction; the chunk XOR and the zero padding
-// (out-of-image positions read a 16-byte zero line) live on the SOURCE address.  Ordering: the issuing wave waits with
-// an exact vmcnt (its own C stores issued since are counted: every store instruction always issues, masked
-// positions go to a scratch line), then the LDS-only barrier publishes the plane.
-constexpr int DMA_FT_MAX = 30;
-__device__ uint4 g_conv_zero16;              // zero-initialised: source of padded positions
-__device__ uint4 g_conv_trash[4];            // sink of masked stores
-
-template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3x3_dma_kernel(ConvArgs a, int ft, int ntf, int ntt, int pitch, int inv_pitch, int plane_bytes,
-                                                             int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 planes][plane_bytes] | shift[C_out]
-    constexpr int COUT = NT * 16;
-    constexpr int SPP = NT / 2;                                    // 16-byte store instructions per column pair
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = blockIdx.y;
-    const int g = lane >> 4, trow = lane & 15;
-
-    uint4 wf[9][NT];
-    {
-        const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wf[tap][nt] = w[(tap * NT + nt) * 64];
-    }
-    float* sh_w = reinterpret_cast<float*>(smem + 2 * plane_bytes);
-    const f32x4_t* shl = reinterpret_cast<const f32x4_t*>(sh_w) + g * NT;
-    if (tid < COUT) sh_w[tid] = a.shift[(int64_t)grp * a.shift_gs + tid];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) settle(wf[tap][nt]);
-
-    const int cols = ft + 2;
-    const int npairs = ft >> 1;
-    const int my_pairs = (npairs - wave_u + 3) >> 2;               // column pairs this wave owns (wave_u, +4, ...)
-    const int Fo = a.F >> 1;
-    const int ninstr = plane_bytes >> 10;                          // DMA instructions per plane (16 positions each)
-    const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * 2;
-    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem);
-
-#define CONV_DMA_ISSUE(TC, BUF)                                                                            \
-    do {                                                                                                   \
-        const char* inb = in_grp + (int64_t)(TC).b * a.T * a.F * CIN * 2;                                  \
-        int lane_o = lane;                                                                                 \
-        asm volatile("" : "+v"(lane_o)); /* keep the per-instruction index math out of the live ranges */ \
-        for (int n = wave_u; n < ninstr; n += 4) {                                                         \
-            const int q = n * 16 + (lane_o >> 2);                                                          \
-            const int i = (q * inv_pitch) >> 16;                                                           \
-            const int j = q - i * pitch;                                                                   \
-            const int t = (TC).t0 - 1 + i, f = (TC).f0 - 1 + j;                                            \
-            const int ch = (lane_o & 3) ^ (((i >> 2) & 1) << 1);                                           \
-            const bool ok = i < ROWS && j < cols && t >= 0 && t < a.T && f >= 0 && f < a.F;                \
-            const void* src = ok ? static_cast<const void*>(inb + (((int64_t)t * a.F + f) * CIN + ch * 8) * 2) \
-                                 : static_cast<const void*>(&g_conv_zero16);                               \
-            glds16(src, lds_base + (BUF) * plane_bytes + n * 1024);                                        \
-        }                                                                                                  \
-    } while (0)
-
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    {
-        const TileCoord tc0 = tile_coord(tile, ntf, ntt, ft, ntiles);
-        CONV_DMA_ISSUE(tc0, 0);
-    }
-    wait_vm<0>();
-    __syncthreads();                                               // first plane + shift table visible
-
-    int cur = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
-        const TileCoord tc = tile_coord(tile, ntf, ntt, ft, ntiles);
-        const bool has_next = tile + (int)gridDim.x < ntiles;
-        if (has_next) {
-            const TileCoord tn = tile_coord(tile + (int)gridDim.x, ntf, ntt, ft, ntiles);
-            CONV_DMA_ISSUE(tn, cur ^ 1);
-        }
-
-        const char* plane = smem + cur * plane_bytes;
-        const int t = tc.t0 + trow;
-        char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)tc.b * a.T + t) * Fo * COUT) * 2;
-        int rbase[3];
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) rbase[kh] = (((trow + kh) * pitch) * 4 + (g ^ ((((trow + kh) >> 2) & 1) << 1))) * 16;
-        uint4 x[3][4];
-#define CONV_DMA_LOAD_ROW(KH, JP)                                                                          \
-        _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                                   \
-            x[KH][cc] = *reinterpret_cast<const uint4*>(plane + rbase[KH] + (2 * (JP) + cc) * 64);
-        if (wave_u < npairs) {
-            CONV_DMA_LOAD_ROW(0, wave_u)
-            CONV_DMA_LOAD_ROW(1, wave_u)
-            CONV_DMA_LOAD_ROW(2, wave_u)
-        }
-        for (int jp = wave_u; jp < npairs; jp += 4) {
-            const int jn = min(jp + 4, npairs - 1);
-            f32x4_t acc[2][NT];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[e][nt] = shl[nt];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int kw = cc - e;
-                        if (kw < 0 || kw > 2) continue;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[e][nt] = mfma16(wf[kh * 3 + kw][nt], x[kh][cc], acc[e][nt]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (kh == 0) { CONV_DMA_LOAD_ROW(0, jn) } else if (kh == 1) { CONV_DMA_LOAD_ROW(1, jn) } else { CONV_DMA_LOAD_ROW(2, jn) }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- ReLU + MaxPool(1,2) over the (f, f+1) pair (shift is in the accumulator), channels-last store
-            const int fo = (tc.f0 >> 1) + jp;
-            float v[NT * 4];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
-            uint4* dst = (t < a.T && fo < Fo) ? reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2) : g_conv_trash;
-#pragma unroll
-            for (int q = 0; q < SPP; ++q)
-                dst[q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
-                                    pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
-        }
-#undef CONV_DMA_LOAD_ROW
-        // ---- the next plane must have landed: everything older than this tile's my_pairs * SPP stores
-        if (has_next) {
-            switch (my_pairs * SPP) {
-                case 0: wait_vm<0>(); break;
-                case 1: wait_vm<1>(); break;
-                case 2: wait_vm<2>(); break;
-                case 3: wait_vm<3>(); break;
-                case 4: wait_vm<4>(); break;
-                case 6: wait_vm<6>(); break;
-                case 8: wait_vm<8>(); break;
-                default: wait_vm<0>(); break;          // DMA_FT_MAX = 30 -> at most 4 pairs per wave
-            }
-        }
-        lds_only_barrier();
-        cur ^= 1;
-    }
-#undef CONV_DMA_ISSUE
-}
-
-template <int NT>
-int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
-    const int fe = (a.F + 1) & ~1;
-    const int ntf = (fe + DMA_FT_MAX - 1) / DMA_FT_MAX;
-    const int ft = 2 * (((fe >> 1) + ntf - 1) / ntf);
-    const int ntt = (a.T + TT - 1) / TT;
-    const int64_t ntiles = (int64_t)ntf * ntt * a.B;
-    AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
-    const int cols = ft + 2;
-    const int pitch = cols + ((cols & 3) == 0 ? 1 : 3);            // cols is even: pitch = 1 (mod 4)
-    const int plane_bytes = ((ROWS * pitch + 15) / 16) * 1024;
-    const size_t lds = 2 * (size_t)plane_bytes + (size_t)NT * 16 * sizeof(float);
-    const int inv_pitch = 65536 / pitch + 1;
-    for (int q = 0; q < plane_bytes / 64; ++q)
-        if (((q * inv_pitch) >> 16) != q / pitch) {
-            amtx_set_error("conv3x3: internal: reciprocal division inexact for pitch=%d", pitch);
-            return AMTX_ERR_ARG;
-        }
-    auto kern = conv3x3_dma_kernel<NT>;
-    AMTX_GRANT_LDS(kern, 80 * 1024);
-    int64_t gx = ntiles;
-    const int64_t per_group = std::max<int64_t>(1, 512 / std::max(1, a.groups));
-    if (gx > per_group) gx = per_group;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(256), lds, stream, a, ft, ntf, ntt, pitch, inv_pitch, plane_bytes, (int)ntiles);
-    AMTX_CHECK_LAUNCH();
-    return AMTX_OK;
-}
-
 template <int NT, int NS, int IN_TYPE, int OUT_TYPE, bool FUSE1, int KS = 0>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     const int fe = (a.F + 1) & ~1;
@@ -1022,12 +837,8 @@ int dispatch_types(const ConvArgs& a, hipStream_t s) {
         return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true, 4>(a, s);
     }
     if (a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) {
-        // Measured on MI355X (conv3 of the bench workload): DMA staging 2.28 ms, register staging 2.19 ms.  The layer moves
-        // ~10.9 GB per launch (4.7 in + halo re-reads, 4.7 out), i.e. it already runs at ~5 TB/s of HBM traffic, so hiding the
-        // staging latency buys nothing and the narrower DMA tiles re-read more halo.  Kept as an opt-in for layers that are not
-        // HBM-bound (AMTX_CONV_DMA=1).
-        static const bool use_dma = getenv("AMTX_CONV_DMA") != nullptr;
-        if (NS == 1 && use_dma) return launch_conv_dma<NT>(a, s);
+        // (an LDS-DMA double-buffered variant of this layer was measured in rounds 1 - 2: 4 % slower on conv3, which is bandwidth-bound,
+        // and never the default; it and its AMTX_CONV_DMA switch are gone)
         return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16, false>(a, s);
     }
     if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32, false>(a, s);

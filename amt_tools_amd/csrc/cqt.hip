@@ -72,74 +72,8 @@ __device__ __forceinline__ void cqt_zero_pads(float* __restrict__ row, int64_t n
         for (int64_t i = pad + n_out + threadIdx.x; i < out_stride; i += 256) row[i] = 0.f;
 }
 
-// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in).
-// Register-blocked FIR: a thread owns DEC_OPT = 8 consecutive outputs, i.e. the input window e[p] = in[2 m0 + p - DEC_HALF],
-// p = 0 .. 2*8 - 2 + DEC_TAPS - 1.  For tap k output i needs e[2 i + k]: every loaded sample feeds 8 FMAs (one per output, with a
-// different tap), so the loop is 16 LDS reads per 128 FMAs; the taps are wave-uniform and come in through scalar loads (an SGPR
-// operand of v_fma), not through LDS.  The LDS tile is stored with one pad word per 16 samples so that the threads' windows
-// (16 samples apart) start in distinct banks.  k ascends per output exactly as in a plain loop: same rounding.
-constexpr int DEC_OPT = 8;                          // outputs per thread
-constexpr int DEC_CH = 256 * DEC_OPT;               // outputs per block
-constexpr int DEC_TAPS_PAD = 304;                   // 19 chunks of 16 taps, zero padded
-constexpr int DEC_XS = 2 * DEC_CH + DEC_TAPS_PAD + 16;
-__device__ __forceinline__ int dec_pidx(int p) { return p + (p >> 4); }
-
-__global__ __launch_bounds__(256) void cqt_decimate_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
-                                                           int64_t n_out, int64_t out_stride, int pad, const float* __restrict__ taps, int zero_pads) {
-    __shared__ float xs[DEC_XS + (DEC_XS >> 4) + 1];
-    const int b = blockIdx.y;
-    if (zero_pads) cqt_zero_pads(out + (int64_t)b * out_stride, n_out, out_stride, pad);
-    const int64_t m0 = (int64_t)blockIdx.x * DEC_CH;
-    const float* src = in + (int64_t)b * in_stride + pad;
-    const int64_t base = 2 * m0 - DEC_HALF;
-    for (int i = threadIdx.x; i < DEC_XS; i += 256) {
-        const int64_t g = base + i;
-        xs[dec_pidx(i)] = (g >= 0 && g < n_in) ? src[g] : 0.f;
-    }
-    __syncthreads();
-    const int j = threadIdx.x;
-    const float* e = xs + 17 * j;                                   // dec_pidx(16 j + p) = 17 j + p + (p >> 4)
-    float acc[DEC_OPT];
-#pragma unroll
-    for (int i = 0; i < DEC_OPT; ++i) acc[i] = 0.f;
-    float w0[16], w1[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) w0[p] = e[p];                      // p >> 4 = 0
-#pragma unroll 1
-    for (int kb = 0; kb < DEC_TAPS_PAD; kb += 32) {
-        // two 16-tap chunks per iteration so the two register windows swap roles by name
-#pragma unroll
-        for (int p = 0; p < 16; ++p) w1[p] = e[kb + 16 + p + ((kb + 16 + p) >> 4)];
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float h = taps[kb + kk];                          // uniform: scalar load
-#pragma unroll
-            for (int i = 0; i < DEC_OPT; ++i) {
-                const int idx = 2 * i + kk;
-                acc[i] = fmaf(h, idx < 16 ? w0[idx] : w1[idx - 16], acc[i]);
-            }
-        }
-        if (kb + 16 < DEC_TAPS_PAD) {
-#pragma unroll
-            for (int p = 0; p < 16; ++p) w0[p] = e[kb + 32 + p + ((kb + 32 + p) >> 4)];
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const float h = taps[kb + 16 + kk];
-#pragma unroll
-                for (int i = 0; i < DEC_OPT; ++i) {
-                    const int idx = 2 * i + kk;
-                    acc[i] = fmaf(h, idx < 16 ? w1[idx] : w0[idx - 16], acc[i]);
-                }
-            }
-        }
-    }
-    float* dst = out + (int64_t)b * out_stride + pad;
-#pragma unroll
-    for (int i = 0; i < DEC_OPT; ++i) {
-        const int64_t m = m0 + (int64_t)DEC_OPT * j + i;
-        if (m < n_out) dst[m] = 1.41421356237309505f * acc[i];
-    }
-}
+// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in): the half-band decimation of the pyramid.  (A register-blocked
+// vector-ALU FIR did this until round 2, 1.62 ms per HCQT call; the matrix-core kernel below replaced it and its A/B switch is gone.)
 
 // The same decimation on the matrix cores.  For a block of 16 consecutive outputs y[16 q + i] = sum_k h[k] in[32 q + 2 i + k - HALF]
 // is a 16 x KW Toeplitz matrix T[i][j] = h[j - 2 i] (constant: fragments built once per plan) times the window
@@ -290,7 +224,6 @@ struct amtx_cqt_plan {
     std::vector<int> early;           // early-downsample count per harmonic
     std::vector<Level> levels;
     int pad = 0;                      // centre padding of every pyramid level (max n_fft / 2)
-    float* d_taps = nullptr;
     void* d_tfrag = nullptr;                       // Toeplitz fragments of the decimator for cqt_decimate_mfma_kernel
 };
 
@@ -372,7 +305,6 @@ extern "C" int amtx_cqt_plan_destroy(amtx_cqt_plan* p) {
         if (l.d_w) (void)hipFree(l.d_w);
         if (l.d_map) (void)hipFree(l.d_map);
     }
-    if (p->d_taps) (void)hipFree(p->d_taps);
     if (p->d_tfrag) (void)hipFree(p->d_tfrag);
     delete p;
     return AMTX_OK;
@@ -477,7 +409,7 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
     }
     p->pad = (p->pad + 3) & ~3;
     // decimator taps
-    std::vector<float> taps(DEC_TAPS_PAD + 16, 0.0f);      // zero padded: the kernel walks whole 16-tap chunks
+    std::vector<float> taps(DEC_TAPS, 0.0f);
     {
         std::vector<double> h(DEC_TAPS);
         double sum = 0;
@@ -503,9 +435,7 @@ extern "C" int amtx_cqt_plan_create(amtx_cqt_plan** out, int sample_rate, int ho
                 tfrag[((size_t)(ks * 3 + 1) * 64 + l) * 8 + j] = mid;
                 tfrag[((size_t)(ks * 3 + 2) * 64 + l) * 8 + j] = f32_to_bf16_rn(r1 - bf16_to_f32(mid));
             }
-    hipError_t e = hipMalloc(&p->d_taps, taps.size() * sizeof(float));
-    if (e == hipSuccess) e = hipMemcpy(p->d_taps, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&p->d_tfrag, tfrag.size() * sizeof(bf16_t));
+    hipError_t e = hipMalloc(&p->d_tfrag, tfrag.size() * sizeof(bf16_t));
     if (e == hipSuccess) e = hipMemcpy(p->d_tfrag, tfrag.data(), tfrag.size() * sizeof(bf16_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         amtx_set_error("amtx_cqt_plan_create: device allocation failed: %s", hipGetErrorString(e));
@@ -621,17 +551,9 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
             hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad,
                                zero_pads, maxbuf, p->n_harm);
         } else {
-            // AMTX_CQT_VALU_DECIMATE=1: the vector-ALU FIR (kept as the A/B reference: 1.62 vs 0.x ms per HCQT call, see DESIGN)
-            static const bool valu = getenv("AMTX_CQT_VALU_DECIMATE") != nullptr;
-            if (valu) {
-                const unsigned nb = (unsigned)((d.len[l] + DEC_CH - 1) / DEC_CH);
-                hipLaunchKernelGGL(cqt_decimate_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
-                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const float*)p->d_taps, zero_pads);
-            } else {
-                const unsigned nb = (unsigned)((d.len[l] + DEC_MCH - 1) / DEC_MCH);
-                hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
-                                   d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag, zero_pads);
-            }
+            const unsigned nb = (unsigned)((d.len[l] + DEC_MCH - 1) / DEC_MCH);
+            hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
+                               d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag, zero_pads);
         }
         AMTX_CHECK_LAUNCH();
         if (!zero_pads) {      // librosa 0.9: reflecting centre pad, from the level's own samples
@@ -657,12 +579,6 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
         g.pair_map = L.d_map; g.pair_out = mag; g.pair_gs = (int64_t)p->n_harm * p->n_bins * d.t_buf; g.pair_pitch = d.t_buf;
         for (int h = 0; h < p->n_harm && h < 16; ++h) g.pair_rows[h] = d.frames_h[h];
         g.pair_max = maxbuf; g.pair_nh = p->n_harm;       // the per-(clip, harmonic) maxima of the dB reference, kept by the epilogue
-        static const bool per_level = getenv("AMTX_CQT_PER_LEVEL_GEMM") != nullptr;   // A/B switch: one launch per level
-        if (per_level) {
-            int rc = amtx_launch_gemm(g, s);
-            if (rc != AMTX_OK) return rc;
-            continue;
-        }
         if (ng == AMTX_GEMM_MULTI_MAX) {
             int rc = amtx_launch_gemm_multi(gs, ng, s);
             if (rc != AMTX_OK) return rc;

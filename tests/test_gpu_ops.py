@@ -246,41 +246,3 @@ def test_pianoroll_threshold_and_probabilities():
     assert out[0, 0, 0] == 1 and out[0, 0, 1] == 1 and out[0, 0, 2] == 0
     _lib.check(L.amtx_pianoroll_fwd(_lib.ptr(ld_d), ld, col0, b, t, keys, -1.0, _lib.ptr(out), _stream()))
     assert (out.cpu() - act).abs().max().item() < 1e-6
-
-
-def test_conv3x3_dma_variant_is_bit_identical():
-    """The opt-in LDS-DMA (double-buffered tile) conv kernel (AMTX_CONV_DMA=1, read once per process) against the default
-    register-staged one: same fragments, same MFMA order -> identical bits.  Runs both in child processes."""
-    import subprocess, sys, os, tempfile
-    code = r'''
-import sys, numpy as np, torch
-sys.path.insert(0, %r)
-from amt_tools_amd import _lib
-L = _lib.lib()
-g = torch.Generator().manual_seed(5)
-outs = []
-for (b, t, f, cout) in [(2, 40, 114, 64), (1, 37, 229, 32), (3, 16, 30, 64)]:
-    x = torch.rand(b, t, f, 32, generator=g)
-    w = torch.randn(cout, 32, 3, 3, generator=g) / 17.0
-    scale = torch.rand(cout, generator=g) + 0.5
-    shift = (torch.randn(cout, generator=g) * 0.1).cuda()
-    packed = np.zeros(L.amtx_conv3x3_packed_elems(cout, 1), dtype=np.uint16)
-    _lib.check(L.amtx_conv3x3_pack(_lib.ptr(w.numpy()), _lib.ptr(scale.numpy()), cout, 1, _lib.ptr(packed)))
-    wp = torch.from_numpy(packed.view(np.int16)).cuda()
-    xd = x.cuda().bfloat16().contiguous()
-    out = torch.zeros((b, t, f // 2, cout), dtype=torch.bfloat16, device='cuda')
-    _lib.check(L.amtx_conv3x3_fwd(_lib.ptr(xd), 0, _lib.ptr(wp), 1, _lib.ptr(shift), _lib.ptr(out), b, t, f, cout, _lib.current_stream()))
-    outs.append(out.view(torch.int16).cpu().numpy().ravel())
-np.save(sys.argv[1], np.concatenate(outs))
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = []
-    with tempfile.TemporaryDirectory() as d:
-        for dma in ('0', '1'):
-            env = dict(os.environ)
-            env.pop('AMTX_CONV_DMA', None)
-            if dma == '1':
-                env['AMTX_CONV_DMA'] = '1'
-            path = os.path.join(d, f'o{dma}.npy')
-            subprocess.run([sys.executable, '-c', code, path], check=True, env=env, timeout=300)
-            res.append(np.load(path))
-    assert res[0].size > 0 and np.array_equal(res[0], res[1])
