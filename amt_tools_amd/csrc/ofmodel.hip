@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -33,9 +34,11 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int upload(const void* host, size_t n) {
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = n;
-        AMTX_CHECK_HIP(hipMalloc(&p, n));
+        if (!p || bytes != n) {        // a weight re-sync (validate() inside train()) keeps its allocations: same model, same sizes
+            if (p) (void)hipFree(p);
+            p = nullptr; bytes = n;
+            AMTX_CHECK_HIP(hipMalloc(&p, n));
+        }
         AMTX_CHECK_HIP(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
         return AMTX_OK;
     }
@@ -358,19 +361,30 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
         std::vector<std::vector<float>> W(1), Bv(1);
         W[0].assign((size_t)m->n_out * m->kfc_pad, 0.0f);
         Bv[0].assign(m->n_out, 0.0f);
-        std::vector<double> rowacc(m->kfc_pad);
-        for (int o = 0; o < m->n_out; ++o) {
-            std::fill(rowacc.begin(), rowacc.end(), 0.0);
-            double bacc = b[o];
-            for (int j = 0; j < m->dim_am; ++j) {
-                const double wo = w[(size_t)o * m->dim_am + j];
-                const float* frow = fw.data() + (size_t)j * m->kfc_pad;
-                for (int k = 0; k < m->kfc_pad; ++k) rowacc[k] += wo * frow[k];
-                bacc += wo * fb1[j];
+        // n_out x dim_am x kfc double-precision multiply-adds (164 M at model_complexity 2): output rows dealt to a few host threads, each
+        // row summed in the same order as before (the result does not depend on the thread count)
+        auto fold_rows = [&](int o0, int o1) {
+            std::vector<double> rowacc(m->kfc_pad);
+            for (int o = o0; o < o1; ++o) {
+                std::fill(rowacc.begin(), rowacc.end(), 0.0);
+                double bacc = b[o];
+                for (int j = 0; j < m->dim_am; ++j) {
+                    const double wo = w[(size_t)o * m->dim_am + j];
+                    const float* frow = fw.data() + (size_t)j * m->kfc_pad;
+                    for (int k = 0; k < m->kfc_pad; ++k) rowacc[k] += wo * frow[k];
+                    bacc += wo * fb1[j];
+                }
+                for (int k = 0; k < m->kfc_pad; ++k) W[0][(size_t)o * m->kfc_pad + k] = (float)rowacc[k];
+                Bv[0][o] = (float)bacc;
             }
-            for (int k = 0; k < m->kfc_pad; ++k) W[0][(size_t)o * m->kfc_pad + k] = (float)rowacc[k];
-            Bv[0][o] = (float)bacc;
-        }
+        };
+        const int nthreads = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        const int per = (m->n_out + nthreads - 1) / nthreads;
+        for (int t = 1; t < nthreads; ++t)
+            if (t * per < m->n_out) pool.emplace_back(fold_rows, t * per, std::min(m->n_out, (t + 1) * per));
+        fold_rows(0, std::min(m->n_out, per));
+        for (auto& th : pool) th.join();
         if ((rc = pack_linear_groups(m, m->pitch_out, W, Bv, m->n_out, m->kfc_pad)) != AMTX_OK) return rc;
     }
     // ---- adjoin: LSTM over the joint logits + LogisticBank

@@ -288,13 +288,16 @@ class _OFEngine(object):
         if version == self.version:
             return
         L = _lib.lib()
-        keep = []
-        for k, v in sd.items():
-            if not v.dtype.is_floating_point or k.startswith('frontend.'):
-                continue
-            arr = v.detach().to('cpu', torch.float32).contiguous().numpy()
-            keep.append(arr)
-            _lib.check(L.amtx_of_model_set_tensor(self.handle, k.encode(), _lib.ptr(arr), arr.size), 'amtx_of_model_set_tensor')
+        items = [(k, v) for k, v in sd.items() if v.dtype.is_floating_point and not k.startswith('frontend.') and v.numel() > 0]
+        # ONE device-to-host copy of all parameters and buffers (a copy per tensor is ~60 synchronisations per re-sync: validate()
+        # inside train() pays this at every checkpoint); the library packs from host memory
+        flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for _, v in items]).cpu().numpy()
+        off = 0
+        for k, v in items:
+            n = v.numel()
+            arr = flat[off:off + n]
+            off += n
+            _lib.check(L.amtx_of_model_set_tensor(self.handle, k.encode(), _lib.ptr(arr), n), 'amtx_of_model_set_tensor')
         with torch.cuda.device(self.device):
             _lib.check(L.amtx_of_model_finalize(self.handle), 'amtx_of_model_finalize')
         self.version = version
