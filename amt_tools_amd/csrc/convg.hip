@@ -18,6 +18,7 @@
 //   * x3 precision: hi/lo planes of both operands, 3 MFMAs per product (as everywhere else in this library).
 // Algorithmic HBM bytes per output position: C_in in + C_out / 2 out, element size of the mode.
 
+#include "amtx_f16_names.h"
 #include "amtx_kernels.h"
 
 #include <algorithm>
@@ -31,7 +32,7 @@ constexpr int GROWS = GTT + 2;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 g_bf16x8;
 __device__ __forceinline__ f32x4_t gm32(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g_bf16x8, a), __builtin_bit_cast(g_bf16x8, b), c, 0, 0, 0);
+    return amtx_mfma_16x16x32(a, b, c);
 }
 
 // compile-time loop: the body sees its index as a constant expression, so register arrays indexed through it stay in registers

@@ -229,12 +229,6 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->n_heads = (int)m->head_names.size();
     m->dim_aj = (m->n_rec + 1) * n_out;
     m->fuse_conv1 = m->gen_conv2 ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
-    if (m->f16 && (m->gen_conv || m->gen_conv2)) {
-        amtx_set_error("amtx_of_model_create: precision f16 is built for one-channel models at model_complexity 2 (conv.hip / convf.hip); "
-                       "this model needs the general-channel kernels of convg.hip, which exist for bf16 and x3 only");
-        delete m;
-        return AMTX_ERR_UNSUPPORTED;
-    }
     // A/B switch: AMTX_NO_CONV_FUSE=1 keeps conv.hip's two kernels (conv1+conv2, conv3) at every batch size
     m->fuse_stack = !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && m->planes == 1 && getenv("AMTX_NO_CONV_FUSE") == nullptr;
     *out = m;
@@ -287,20 +281,20 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
             for (int i = 0; i < m->in_channels * 9; ++i)
                 c1w[((size_t)h * m->nf1 + co) * m->in_channels * 9 + i] = w[(size_t)co * m->in_channels * 9 + i] * scale[co];
         memcpy(c1s.data() + (size_t)h * m->nf1, shift.data(), sizeof(float) * m->nf1);
-        if (m->fuse_conv1 && m->gen_conv2) amtx_conv1g_pack_host(w, scale.data(), m->in_channels, m->nf1, m->planes, c1f.data() + c1f_per * h);
+        if (m->fuse_conv1 && m->gen_conv2) (m->f16 ? amtx_conv1g_pack_host_f16 : amtx_conv1g_pack_host)(w, scale.data(), m->in_channels, m->nf1, m->planes, c1f.data() + c1f_per * h);
         else if (m->fuse_conv1) (m->f16 ? amtx_conv1_pack_host_f16 : amtx_conv1_pack_host)(w, scale.data(), m->in_channels, m->planes, c1f.data() + c1f_per * h);
 
         rc = fold_bn(m, am + ".layer2.0", am + ".layer2.1", m->nf2, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
-        if (m->gen_conv2) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
+        if (m->gen_conv2) (m->f16 ? amtx_conv3x3_gen_pack_host_f16 : amtx_conv3x3_gen_pack_host)(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
         else (m->f16 ? amtx_conv3x3_pack_host_f16 : amtx_conv3x3_pack_host)(w, scale.data(), m->nf2, m->planes, c2w.data() + c2w_per * h);
         memcpy(c2s.data() + (size_t)h * m->nf2, shift.data(), sizeof(float) * m->nf2);
 
         rc = fold_bn(m, am + ".layer3.0", am + ".layer3.1", m->nf3, scale, shift);
         if (rc != AMTX_OK) return rc;
         NEED(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
-        if (m->gen_conv) amtx_conv3x3_gen_pack_host(w, scale.data(), m->nf2, m->nf3, m->planes, c3w.data() + c3w_per * h);
+        if (m->gen_conv) (m->f16 ? amtx_conv3x3_gen_pack_host_f16 : amtx_conv3x3_gen_pack_host)(w, scale.data(), m->nf2, m->nf3, m->planes, c3w.data() + c3w_per * h);
         else (m->f16 ? amtx_conv3x3_pack_host_f16 : amtx_conv3x3_pack_host)(w, scale.data(), m->nf3, m->planes, c3w.data() + c3w_per * h);
         memcpy(c3s.data() + (size_t)h * m->nf3, shift.data(), sizeof(float) * m->nf3);
 
@@ -445,6 +439,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     const bool f16 = m->f16;
     auto launch_gemm = [f16](const GemmArgs& ga, hipStream_t st) { return f16 ? amtx_launch_gemm_f16(ga, st) : amtx_launch_gemm(ga, st); };
     auto launch_conv = [f16](const ConvArgs& ca, hipStream_t st) { return f16 ? amtx_launch_conv3x3_f16(ca, st) : amtx_launch_conv3x3(ca, st); };
+    auto launch_convg = [f16](const ConvArgs& ca, int ci, hipStream_t st) { return f16 ? amtx_launch_conv3x3_gen_f16(ca, ci, st) : amtx_launch_conv3x3_gen(ca, ci, st); };
     auto launch_bilstm = [f16](const LstmArgs& la, hipStream_t st) { return f16 ? amtx_launch_bilstm_f16(la, st) : amtx_launch_bilstm(la, st); };
     std::vector<hipEvent_t>* evs = nullptr;
     if (m->prof) {
@@ -463,7 +458,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     c1.w = (const float*)m->conv1_w.p; c1.shift = (const float*)m->conv1_s.p; c1.out = w.a1; c1.out_type = at;
     c1.B = B; c1.T = T; c1.F = F; c1.c_in = m->in_channels; c1.c_out = m->nf1;
     c1.groups = m->n_heads; c1.w_gs = (int64_t)m->nf1 * m->in_channels * 9; c1.shift_gs = m->nf1; c1.out_gs = BT * F * m->nf1;
-    if (!m->fuse_conv1 && (rc = amtx_launch_conv1(c1, s)) != AMTX_OK) return rc;
+    if (!m->fuse_conv1 && (rc = (f16 ? amtx_launch_conv1_f16 : amtx_launch_conv1)(c1, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c2;
@@ -484,7 +479,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         // layer1 -> layer2 -> layer3 in one kernel: neither intermediate map reaches HBM (stage timer: all of it under conv2_pool)
         if ((rc = (f16 ? amtx_launch_conv_stack_f16 : amtx_launch_conv_stack)(c2, (const bf16_t*)m->conv3_w.p, (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl), (const float*)m->conv3_s.p,
                                          w.a3, BT * m->kfc_pad, s)) != AMTX_OK) return rc;
-    } else if ((rc = m->gen_conv2 ? amtx_launch_conv3x3_gen(c2, m->nf1, s) : launch_conv(c2, s)) != AMTX_OK) return rc;
+    } else if ((rc = m->gen_conv2 ? launch_convg(c2, m->nf1, s) : launch_conv(c2, s)) != AMTX_OK) return rc;
     mark();
 
     ConvArgs c3 = c2;
@@ -501,7 +496,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         if ((rc = amtx_launch_zero_cols(w.a3 + (size_t)m->kfc * es, (int64_t)m->kfc_pad * es, (int)((m->kfc_pad - m->kfc) * es),
                                         BT * m->n_heads, s)) != AMTX_OK) return rc;
     }
-    if (!fused_stack && (rc = m->gen_conv ? amtx_launch_conv3x3_gen(c3, m->nf2, s) : launch_conv(c3, s)) != AMTX_OK) return rc;
+    if (!fused_stack && (rc = m->gen_conv ? launch_convg(c3, m->nf2, s) : launch_conv(c3, s)) != AMTX_OK) return rc;
     mark();
 
     // fc1 of the recurrent heads (heads 0..n_rec-1 of a3); the pitch head's fc1 is folded into its output layer below

@@ -30,8 +30,8 @@ extern "C" {
 /* precision of the dense (MFMA) stages */
 #define AMTX_PREC_BF16 0   /* bf16 operands, fp32 accumulate (headline mode)                     */
 #define AMTX_PREC_X3 1     /* split-bf16 (hi+lo) operands, 3 MFMAs per product: fp32-class parity */
-#define AMTX_PREC_F16 2    /* IEEE half operands, fp32 accumulate: the bf16 mode's speed, 3 more mantissa bits (engine only: one-channel
-                            * models at model_complexity 2; values beyond +-65504 would overflow -- log-mel features and BatchNorm'd maps do not) */
+#define AMTX_PREC_F16 2    /* IEEE half operands, fp32 accumulate: the bf16 mode's speed, 3 more mantissa bits (engine only; values beyond
+                            * +-65504 would overflow -- log-mel / CQT features in [0, 1] and BatchNorm'd maps do not) */
 
 const char* amtx_last_error(void);   /* thread-local message of the last failing call */
 int amtx_version(void);

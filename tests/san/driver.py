@@ -67,7 +67,7 @@ for planes in (1, 2):
 # ---------------------------------------------------------------- engine: create / set_tensor / finalize / workspace / argument checks
 configs = [dict(dim_in=229, ch=1, mc=2, off=0, prec=0), dict(dim_in=229, ch=1, mc=2, off=0, prec=1), dict(dim_in=229, ch=1, mc=2, off=0, prec=2),
            dict(dim_in=229, ch=1, mc=3, off=1, prec=0), dict(dim_in=229, ch=1, mc=3, off=0, prec=1), dict(dim_in=72, ch=6, mc=2, off=0, prec=0),
-           dict(dim_in=72, ch=6, mc=3, off=1, prec=1), dict(dim_in=8, ch=1, mc=2, off=1, prec=0), dict(dim_in=40, ch=1, mc=2, off=0, prec=2),
+           dict(dim_in=72, ch=6, mc=3, off=1, prec=1), dict(dim_in=72, ch=6, mc=2, off=0, prec=2), dict(dim_in=229, ch=1, mc=3, off=1, prec=2), dict(dim_in=8, ch=1, mc=2, off=1, prec=0), dict(dim_in=40, ch=1, mc=2, off=0, prec=2),
            dict(dim_in=5, ch=1, mc=2, off=0, prec=0), dict(dim_in=192, ch=2, mc=2, off=0, prec=0)]
 for cfg in configs:
     h = C.c_void_p()

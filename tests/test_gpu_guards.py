@@ -19,7 +19,7 @@ def guards(monkeypatch):
 
 
 @pytest.mark.parametrize('cls,mc,ch,dim_in,precision', [('OnsetsFrames', 2, 1, 229, 'bf16'), ('OnsetsFrames', 2, 1, 229, 'x3'), ('OnsetsFrames', 2, 1, 229, 'f16'),
-                                                        ('OnsetsFrames2', 3, 1, 229, 'bf16'), ('OnsetsFrames', 2, 6, 72, 'bf16'), ('OnsetsFrames', 2, 1, 54, 'bf16'),
+                                                        ('OnsetsFrames2', 3, 1, 229, 'bf16'), ('OnsetsFrames2', 3, 1, 229, 'f16'), ('OnsetsFrames', 2, 6, 72, 'bf16'), ('OnsetsFrames', 2, 6, 72, 'f16'), ('OnsetsFrames', 2, 1, 54, 'bf16'),
                                                         ('OnsetsFrames', 2, 1, 8, 'x3')])
 def test_engine_workspace_guard_bands_survive_ragged_forwards(guards, cls, mc, ch, dim_in, precision):
     import amt_tools_amd.models as M
