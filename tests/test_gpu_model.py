@@ -272,7 +272,11 @@ def test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path(dim_in, monkey
     L = _lib.lib()
     rng = np.random.default_rng(dim_in)
     cases = [('OnsetsFrames', 128, 33), ('OnsetsFrames', 127, 33), ('OnsetsFrames', 43, 140), ('OnsetsFrames', 130, 47),
-             ('OnsetsFrames', 260, 1), ('OnsetsFrames', 129, 17), ('OnsetsFrames2', 86, 46), ('OnsetsFrames2', 44, 93)]
+             ('OnsetsFrames', 260, 1), ('OnsetsFrames', 129, 17), ('OnsetsFrames2', 86, 46), ('OnsetsFrames2', 44, 93),
+             # frame counts on both sides of the 62-frame strip boundaries (one strip exactly full, one frame into the next, two strips, ...)
+             ('OnsetsFrames', 130, 62), ('OnsetsFrames', 66, 63), ('OnsetsFrames', 65, 124), ('OnsetsFrames', 44, 125), ('OnsetsFrames', 33, 187)]
+    if dim_in == 229:
+        cases.append(('OnsetsFrames', 12, 625))             # the BASELINE clip length: eleven strips, the last one five frames long
     for cls, B, T in cases:
         feats = torch.from_numpy(rng.random((B, 1, dim_in, T)).astype(np.float32)).cuda()
         got = {}
