@@ -87,8 +87,8 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
-    ap.add_argument('--clips', type=int, default=None, help='clips per GPU per step (default 1024 for infer -- sweep on MI355X, round 2: 512: 33.3, '
-                                                            '1024: 36.0, 2048: 35.3, 3072: 35.3 M frames/s -- and 8 for train, the reference batch)')
+    ap.add_argument('--clips', type=int, default=None, help='clips per GPU per step (default 1024 for infer -- sweep on MI355X, round 3: 512: 37.7, '
+                                                            '768: 38.6, 1024: 40.2, 1536: 39.5, 2048: 40.4 M frames/s -- and 8 for train, the reference batch)')
     ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3'])
     ap.add_argument('--of2', action='store_true', help='train mode: OnsetsFrames2 as shipped (model_complexity 3, offset head)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time budget of the CPU-baseline sample (0 = skip)')
