@@ -4,11 +4,11 @@ writes of the untangling pass), per MI355X_MICROARCH.md's LDS rules (ds_read_b32
 mod 32, one extra cycle per extra distinct address on a bank, 2-way free on ds_write_b32).  CPU only; prints LDS cycles per frame for a few
 power-row layouts and for a permuted row -> lane assignment.  Used to decide (round 3) that neither a padded power-row layout nor a
 permutation of the mel rows inside their rounds removes the gather's conflicts: they come from the mel rows' irregular first bins.
-    python tools/spec_lds_model.py"""
+    python tests/spec_lds_model.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import frontend_np as fe          # (a tool, not the product: the filterbank geometry is all it takes from the oracle)
+from oracle import frontend_np as fe          # (under tests/: only tests, smoke() and the CPU baseline may import the oracle)
 
 fb = fe.mel_filterbank(22050, 2048, 229)
 starts = [int(np.nonzero(fb[r])[0][0]) for r in range(229)] + [0] * (256 - 229)
