@@ -6,18 +6,20 @@
 // HBM by one kernel and read back by the next: 37 % of all bytes a forward pass moves, and the kernels run power-managed at
 // 1.8 GHz under that traffic.  Here neither intermediate map exists outside LDS.
 //
-// Shape of the kernel.  One 512-thread block per CU, wave-specialised: waves 0-3 ("producers") run layer1 + layer2, waves
-// 4-7 ("consumers") run layer3, so that each SIMD hosts one wave of either kind and their (equal) matrix work shares the SIMD's
-// matrix pipe; every wave keeps ITS layers' folded weights stationary in registers (producer 104, consumer 144 VGPRs), which is
-// why the split is by layer: one wave cannot hold both sets.
+// Shape of the kernel.  One 512-thread block per CU, wave-specialised: waves 0-3 ("producers") run layer2, waves 4-7 ("consumers")
+// run layer3, so that each SIMD hosts one wave of either kind and their (equal) matrix work shares the SIMD's matrix pipe; every wave
+// keeps ITS layer's folded weights stationary in registers (producer 72 + layer1's 32, consumer 144 VGPRs), which is why the split is
+// by layer: one wave cannot hold both sets.
 // A block owns "strips" = (head, clip, 62 consecutive frames) and STREAMS each strip along the frequency axis in steps of 8
 // layer2 columns (= 4 pooled columns = 2 output columns), ONE barrier per step:
-//     step k:   producers   layer1 of step k + 1 -> a1 ring (66 rows x 18 columns x 32 ch)      | consumers   layer3 on the pooled columns of
-//                           layer2 of step k (a1 ring) -> a2 ring (64 rows x 10 pooled columns)  |             step k - 1 -> 64-byte stores
+//     step k:   producers   layer2 of step k (a1 ring, 66 rows x 18 columns x 32 ch) -> a2 ring (64 rows x 10 pooled columns),
+//                           then the feature staging of step k + 2 and their layer1 unit(s) of step k + 1
+//               consumers   their layer1 unit of step k + 1, then layer3 on the pooled columns of step k - 1 -> 64-byte stores
 //               barrier
-// layer1 is a latency chain (LDS read -> 8 small MFMAs -> convert / clamp -> LDS write) with 3 % of the flops: run a step AHEAD
-// inside the producer wave it sits in the shadow of the consumer wave's dense MFMA stream on the same SIMD (as a phase of its own,
-// behind a barrier, it was a third of the step with the matrix pipe idle).
+// layer1 is a latency chain (LDS read -> 8 small MFMAs -> convert / clamp -> LDS write) with 3 % of the flops.  It runs a step AHEAD,
+// dealt in 16-row x 4-column units to all eight waves (the consumers read its Toeplitz fragments from LDS; the ninth unit, rows 64 - 65,
+// goes to a producer wave in turn), and each role does its vector work while the OTHER role's wave on the same SIMD is in its matrix loop
+// (as a phase of its own, behind a barrier, layer1 was a third of the step with the matrix pipe idle).
 // Rings are indexed by a running column counter (mod 18 / mod 10), so the two columns a 3x3 window needs from the previous step are
 // simply still there, and a strip's last step flows into the next strip's first one without a drain.  Streaming along frequency means
 // there is NO halo in frequency at all (the zero padding at both ends is the real padding); in time a strip computes 64 layer2
@@ -25,11 +27,12 @@
 // D = W . X^T exactly as in conv.hip (a lane ends up with consecutive channels of one position: MaxPool over the frequency pair,
 // ReLU and the channels-last store are lane-local); the accumulation order of every output equals conv.hip's, so the result is
 // BIT-IDENTICAL to the two-kernel path (tests/test_gpu_model.py::test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path).
+// DESIGN.md ("Measured (round 3)") has the history of the structure, the ablation numbers and what was tried and rejected.
 //
-// LDS (127 KB of the CU's 160): a1 ring 4 chunk planes x 66 x 19 x 16 B, a2 ring 4 x 64 x 11 x 16 B (chunk-major: 16-byte chunk c of
+// LDS (137 KB of the CU's 160): a1 ring 4 chunk planes x 66 x 19 x 16 B, a2 ring 4 x 64 x 11 x 16 B (chunk-major: 16-byte chunk c of
 // position (row, slot) at c * PLANE + (row * pitch + slot) * 16; both row pitches are odd, so the 16 rows of a ds_read_b128 lane group
 // hit 16 distinct 16-byte bank groups, and the 8 rows of a ds_write_b128 lane group 8 distinct ones), two bf16 feature slabs (68 rows x
-// 12 columns, dB-scaled while they are staged: amtx_of_forward_power), layer3's shift table.
+// 12 columns, dB-scaled while they are staged: amtx_of_forward_power) + scratch lines, layer1's Toeplitz fragments, the shift tables.
 
 #include "amtx_f16_names.h"
 #include "amtx_kernels.h"
