@@ -20,6 +20,9 @@ class AmtxError(RuntimeError):
     pass
 
 
+ERR_UNSUPPORTED = -3       # AMTX_ERR_UNSUPPORTED (include/amtx.h)
+
+
 def declared_symbols():
     """Every function name include/amtx.h declares."""
     with open(HEADER_PATH) as f:
@@ -47,6 +50,8 @@ _SIGNATURES = {
     'amtx_of_model_destroy': (_I, [_P]),
     'amtx_of_model_set_tensor': (_I, [_P, C.c_char_p, _P, _L]),
     'amtx_of_model_finalize': (_I, [_P]),
+    'amtx_of_model_set_tensor_device': (_I, [_P, C.c_char_p, _P, _L]),
+    'amtx_of_model_finalize_device': (_I, [_P, _P]),
     'amtx_of_workspace_bytes': (C.c_size_t, [_P, _I, _I]),
     'amtx_of_forward': (_I, [_P, _P, _L, _L, _L, _L, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
     'amtx_of_fuses_db_scale': (_I, [_P]),

@@ -34,7 +34,7 @@ FILE_FLAGS = {'spec.hip': ['-fno-slp-vectorize'], 'convg.hip': ['-fno-slp-vector
 
 # Compiled a second time with -DAMTX_F16 (IEEE half operands instead of bf16, public functions suffixed _f16: csrc/amtx_f16_names.h):
 # the engine's precision 'f16'
-F16_TWINS = ('conv.hip', 'convf.hip', 'convg.hip', 'gemm.hip', 'lstm.hip')
+F16_TWINS = ('conv.hip', 'convf.hip', 'convg.hip', 'gemm.hip', 'lstm.hip', 'pack.hip')
 
 
 def _compile(src, hdr_mtime, verbose, f16=False):

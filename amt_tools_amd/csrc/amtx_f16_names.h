@@ -1,4 +1,4 @@
-// Included FIRST by the files that amt_tools_amd/build.py compiles twice (conv.hip, convf.hip, convg.hip, gemm.hip, lstm.hip).  In the second
+// Included FIRST by the files that amt_tools_amd/build.py compiles twice (conv.hip, convf.hip, convg.hip, gemm.hip, lstm.hip, pack.hip).  In the second
 // build (-DAMTX_F16: IEEE half operands instead of bf16, see amtx_common.h) every public function of those files gets the suffix _f16,
 // declarations in amtx_kernels.h included, so that both objects link into one libamtx.so.  The engine (ofmodel.hip) picks the variant by
 // the model's precision; the prototypes it needs are in amtx_kernels_f16.h.
@@ -22,6 +22,12 @@
 #define amtx_conv3x3_gen_can_fuse1 amtx_conv3x3_gen_can_fuse1_f16
 #define amtx_launch_conv3x3_gen amtx_launch_conv3x3_gen_f16
 #define amtxdbg_convg_prof amtxdbg_convg_prof_f16
+#define amtx_pack_bn_fold_dev amtx_pack_bn_fold_dev_f16
+#define amtx_pack_conv3x3_dev amtx_pack_conv3x3_dev_f16
+#define amtx_pack_conv1_dev amtx_pack_conv1_dev_f16
+#define amtx_pack_linear_dev amtx_pack_linear_dev_f16
+#define amtx_pack_head_fold_dev amtx_pack_head_fold_dev_f16
+#define amtx_pack_vec_add_dev amtx_pack_vec_add_dev_f16
 #define amtx_gemm_pack_dims amtx_gemm_pack_dims_f16
 #define amtx_gemm_pack_host amtx_gemm_pack_host_f16
 #define amtx_launch_gemm_multi amtx_launch_gemm_multi_f16

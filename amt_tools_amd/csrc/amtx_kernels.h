@@ -131,3 +131,15 @@ int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int 
 int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream,
                              bool f16 = false /* IEEE half instead of bf16 (AMTX_PREC_F16) */);
 int amtx_launch_zero_cols(void* base, int64_t pitch_bytes, int width_bytes, int64_t rows, hipStream_t stream);
+
+// ---------------------------------------------------------------- device-side weight packing (pack.hip): the host packers' layouts and
+// arithmetic as kernels, for a weight re-sync that does not leave the GPU (amtx_of_model_finalize_device)
+int amtx_pack_bn_fold_dev(const float* conv_bias, const float* gamma, const float* beta, const float* mean, const float* var, int c_out, float* scale,
+                          float* shift, hipStream_t s);
+int amtx_pack_conv3x3_dev(const float* w, const float* scale, int c_out, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_conv1_dev(const float* w, const float* scale, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_linear_dev(const float* W, int64_t ldw, int N, int K, int planes, int n_pad, int k_pad, int row0, int rows_owned, int perm_c, int perm_f,
+                         bf16_t* out, hipStream_t s);
+int amtx_pack_head_fold_dev(const float* w_out, const float* w_fc1, const float* b_fc1, const float* b_out, int n_out, int dim_am, int kfc, int kfc_pad,
+                            int nf3, int fq, float* wfold, float* bfold, hipStream_t s);
+int amtx_pack_vec_add_dev(const float* a, const float* b, int n, float* out, hipStream_t s);

@@ -62,6 +62,8 @@ struct amtx_of_model {
     int n_rec;                                 // recurrent heads feeding the joint: onset, (offset)
     std::vector<std::string> head_names;       // state_dict prefixes of the acoustic models, group order
     std::map<std::string, Tensor> tensors;
+    std::map<std::string, std::pair<const float*, int64_t>> dev_tensors;   // amtx_of_model_set_tensor_device: borrowed device pointers
+    DevBuf pack_scratch;                       // device re-sync: BatchNorm scale / shift, the folded pitch head, the unused backward LSTM fragments
     bool finalized = false;
     // packed device weights (group-major)
     DevBuf conv1_w, conv1_s, conv1_frag, conv2_w, conv2_s, conv3_w, conv3_s;
@@ -239,7 +241,7 @@ extern "C" int amtx_of_model_destroy(amtx_of_model* m) {
     if (!m) return AMTX_OK;
     DevBuf* bufs[] = {&m->conv1_w, &m->conv1_s, &m->conv1_frag, &m->conv2_w, &m->conv2_s, &m->conv3_w, &m->conv3_s, &m->fc1.w, &m->fc1.b,
                       &m->rec_ih.w, &m->rec_ih.b, &m->rec_hh, &m->rec_out.w, &m->rec_out.b, &m->pitch_out.w, &m->pitch_out.b,
-                      &m->adj_ih.w, &m->adj_ih.b, &m->adj_hh, &m->adj_out.w, &m->adj_out.b};
+                      &m->adj_ih.w, &m->adj_ih.b, &m->adj_hh, &m->adj_out.w, &m->adj_out.b, &m->pack_scratch};
     for (DevBuf* b : bufs) b->release();
     delete m;
     return AMTX_OK;
@@ -396,6 +398,149 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     }
     m->tensors.clear();
     m->finalized = true;
+    return AMTX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight RE-SYNC without leaving the GPU.  After one host-side amtx_of_model_finalize (which sizes and allocates every packed
+// buffer), later weight versions can be handed over as device pointers under the same state_dict names and packed by the kernels of
+// pack.hip -- the host packers' arithmetic and layouts, bit for bit.  Built for the configuration that trains under train.py with
+// the engine validating at every checkpoint (amt_tools/train.py:183-189): one input channel, model_complexity 2 (conv.hip / convf.hip
+// fragment layouts, hidden-128 recurrences), any precision; other configurations answer AMTX_ERR_UNSUPPORTED and callers keep the
+// host path.
+extern "C" int amtx_of_model_set_tensor_device(amtx_of_model* m, const char* name, const float* device_data, int64_t numel) {
+    AMTX_REQUIRE(m && name && device_data && numel > 0, "amtx_of_model_set_tensor_device: bad argument");
+    m->dev_tensors[name] = std::make_pair(device_data, numel);
+    return AMTX_OK;
+}
+
+namespace {
+int need_dev(const amtx_of_model* m, const std::string& name, size_t numel, const float** out) {
+    auto it = m->dev_tensors.find(name);
+    if (it == m->dev_tensors.end()) {
+        amtx_set_error("of_model: device tensor '%s' was not provided", name.c_str());
+        return AMTX_ERR_ARG;
+    }
+    if ((size_t)it->second.second != numel) {
+        amtx_set_error("of_model: device tensor '%s' has %lld elements, expected %zu", name.c_str(), (long long)it->second.second, numel);
+        return AMTX_ERR_ARG;
+    }
+    *out = it->second.first;
+    return AMTX_OK;
+}
+#define NEED_DEV(name, numel, ptr)                                     \
+    do {                                                               \
+        int _rc = need_dev(m, name, numel, &(ptr));                    \
+        if (_rc != AMTX_OK) return _rc;                                \
+    } while (0)
+#define PACK_TRY(expr)                                                 \
+    do {                                                               \
+        int _rc = (expr);                                              \
+        if (_rc != AMTX_OK) return _rc;                                \
+    } while (0)
+}  // namespace
+
+extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
+    AMTX_REQUIRE(m, "amtx_of_model_finalize_device: null model");
+    AMTX_REQUIRE(m->finalized, "amtx_of_model_finalize_device: the first sync goes through amtx_of_model_finalize (it allocates the packed buffers)");
+    if (m->gen_conv || m->gen_conv2 || !m->fuse_conv1 || m->in_channels != 1 || m->hid != 128) {
+        amtx_set_error("amtx_of_model_finalize_device: built for one-channel models at model_complexity 2; use amtx_of_model_finalize");
+        return AMTX_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const int nh = m->n_heads, pl = m->planes, H = m->hid, G = 4 * H;
+    const bool f16 = m->f16;
+    auto pack_conv = [f16](const float* w, const float* sc, int c_out, int planes, bf16_t* out, hipStream_t st) {
+        return f16 ? amtx_pack_conv3x3_dev_f16(w, sc, c_out, planes, out, st) : amtx_pack_conv3x3_dev(w, sc, c_out, planes, out, st);
+    };
+    auto pack_lin = [f16](const float* W, int64_t ldw, int N, int K, int planes, int n_pad, int k_pad, int row0, int rows, int pc, int pf, bf16_t* out,
+                          hipStream_t st) {
+        return f16 ? amtx_pack_linear_dev_f16(W, ldw, N, K, planes, n_pad, k_pad, row0, rows, pc, pf, out, st)
+                   : amtx_pack_linear_dev(W, ldw, N, K, planes, n_pad, k_pad, row0, rows, pc, pf, out, st);
+    };
+    // scratch: scale[64] | shift[64] | folded pitch head (n_out x kfc_pad) | folded bias | backward LSTM fragments (written by the shared
+    // pack kernel, not used by inference)
+    const size_t hh_elems = amtx_bilstm_wfrag_elems_h(H, pl);
+    const size_t sc_bytes = (size_t)(128 + (size_t)m->n_out * m->kfc_pad + m->n_out) * sizeof(float) + hh_elems * sizeof(bf16_t) + 256;
+    if (!m->pack_scratch.p || m->pack_scratch.bytes < sc_bytes) {
+        m->pack_scratch.release();
+        AMTX_CHECK_HIP(hipMalloc(&m->pack_scratch.p, sc_bytes));
+        m->pack_scratch.bytes = sc_bytes;
+    }
+    float* scale = (float*)m->pack_scratch.p;
+    float* shift_tmp = scale + 64;
+    float* wfold = scale + 128;
+    float* bfold = wfold + (size_t)m->n_out * m->kfc_pad;
+    bf16_t* hh_bwd = (bf16_t*)(((uintptr_t)(bfold + m->n_out) + 255) & ~(uintptr_t)255);
+    (void)shift_tmp;
+
+    const size_t c1f_per = amtx_conv1_wfrag_elems(1, pl), c2w_per = amtx_conv3x3_wfrag_elems(m->nf2, pl), c3w_per = amtx_conv3x3_wfrag_elems(m->nf3, pl);
+    const size_t fc_per = (size_t)m->fc1.n_pad * m->fc1.k_pad * pl;
+    for (int h = 0; h < nh; ++h) {
+        const std::string am = m->head_names[h] + ".0";
+        const float *w, *cb, *g, *be, *mu, *var;
+        // layer1: scale folded into the Toeplitz fragments, shift kept fp32 (conv1_s); the fp32 copy conv1_w feeds only the unfused first conv
+        NEED_DEV(am + ".layer1.0.weight", (size_t)m->nf1 * 9, w);
+        NEED_DEV(am + ".layer1.0.bias", (size_t)m->nf1, cb); NEED_DEV(am + ".layer1.1.weight", (size_t)m->nf1, g); NEED_DEV(am + ".layer1.1.bias", (size_t)m->nf1, be);
+        NEED_DEV(am + ".layer1.1.running_mean", (size_t)m->nf1, mu); NEED_DEV(am + ".layer1.1.running_var", (size_t)m->nf1, var);
+        PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf1, scale, (float*)m->conv1_s.p + (size_t)h * m->nf1, s));
+        PACK_TRY((f16 ? amtx_pack_conv1_dev_f16 : amtx_pack_conv1_dev)(w, scale, pl, (bf16_t*)m->conv1_frag.p + c1f_per * h, s));
+        NEED_DEV(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
+        NEED_DEV(am + ".layer2.0.bias", (size_t)m->nf2, cb); NEED_DEV(am + ".layer2.1.weight", (size_t)m->nf2, g); NEED_DEV(am + ".layer2.1.bias", (size_t)m->nf2, be);
+        NEED_DEV(am + ".layer2.1.running_mean", (size_t)m->nf2, mu); NEED_DEV(am + ".layer2.1.running_var", (size_t)m->nf2, var);
+        PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf2, scale, (float*)m->conv2_s.p + (size_t)h * m->nf2, s));
+        PACK_TRY(pack_conv(w, scale, m->nf2, pl, (bf16_t*)m->conv2_w.p + c2w_per * h, s));
+        NEED_DEV(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
+        NEED_DEV(am + ".layer3.0.bias", (size_t)m->nf3, cb); NEED_DEV(am + ".layer3.1.weight", (size_t)m->nf3, g); NEED_DEV(am + ".layer3.1.bias", (size_t)m->nf3, be);
+        NEED_DEV(am + ".layer3.1.running_mean", (size_t)m->nf3, mu); NEED_DEV(am + ".layer3.1.running_var", (size_t)m->nf3, var);
+        PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf3, scale, (float*)m->conv3_s.p + (size_t)h * m->nf3, s));
+        PACK_TRY(pack_conv(w, scale, m->nf3, pl, (bf16_t*)m->conv3_w.p + c3w_per * h, s));
+        // fc1 of the recurrent heads, columns permuted (channel, freq) -> (freq, channel)
+        if (h < m->n_rec) {
+            const float* fb;
+            NEED_DEV(am + ".fc1.0.weight", (size_t)m->dim_am * m->kfc, w);
+            NEED_DEV(am + ".fc1.0.bias", (size_t)m->dim_am, fb);
+            PACK_TRY(pack_lin(w, m->kfc, m->dim_am, m->kfc, pl, m->fc1.n_pad, m->fc1.k_pad, 0, m->fc1.n_pad, m->nf3, m->fq, (bf16_t*)m->fc1.w.p + fc_per * h, s));
+            AMTX_CHECK_HIP(hipMemcpyAsync((float*)m->fc1.b.p + (size_t)h * m->dim_am, fb, sizeof(float) * m->dim_am, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    // LSTM + LogisticBank of a recurrent stage: input projection rows [fwd | reverse], merged biases, W_hh fragments, output layer
+    auto pack_rec = [&](const std::string& lstm, const std::string& bank, int dim_in, LinearPack& ih, DevBuf& hh, LinearPack& outp, int grp) -> int {
+        const float *wif, *wib, *whf, *whb, *bif, *bib, *bhf, *bhb, *wo, *bo;
+        const std::string p = lstm + ".mlm.";
+        NEED_DEV(p + "weight_ih_l0", (size_t)G * dim_in, wif); NEED_DEV(p + "weight_ih_l0_reverse", (size_t)G * dim_in, wib);
+        NEED_DEV(p + "weight_hh_l0", (size_t)G * H, whf); NEED_DEV(p + "weight_hh_l0_reverse", (size_t)G * H, whb);
+        NEED_DEV(p + "bias_ih_l0", (size_t)G, bif); NEED_DEV(p + "bias_ih_l0_reverse", (size_t)G, bib);
+        NEED_DEV(p + "bias_hh_l0", (size_t)G, bhf); NEED_DEV(p + "bias_hh_l0_reverse", (size_t)G, bhb);
+        bf16_t* ihw = (bf16_t*)ih.w.p + (size_t)ih.n_pad * ih.k_pad * pl * grp;
+        PACK_TRY(pack_lin(wif, dim_in, G, dim_in, pl, ih.n_pad, ih.k_pad, 0, G, 0, 0, ihw, s));
+        PACK_TRY(pack_lin(wib, dim_in, G, dim_in, pl, ih.n_pad, ih.k_pad, G, ih.n_pad - G, 0, 0, ihw, s));
+        float* ihb = (float*)ih.b.p + (size_t)ih.N * grp;
+        PACK_TRY(amtx_pack_vec_add_dev(bif, bhf, G, ihb, s));
+        PACK_TRY(amtx_pack_vec_add_dev(bib, bhb, G, ihb + G, s));
+        PACK_TRY((f16 ? amtx_launch_bilstm_pack_dev_f16 : amtx_launch_bilstm_pack_dev)(whf, whb, pl, (bf16_t*)hh.p + hh_elems * grp, hh_bwd, s));
+        NEED_DEV(bank + ".output_layer.weight", (size_t)m->n_out * m->dim_lm, wo);
+        NEED_DEV(bank + ".output_layer.bias", (size_t)m->n_out, bo);
+        PACK_TRY(pack_lin(wo, m->dim_lm, m->n_out, m->dim_lm, pl, outp.n_pad, outp.k_pad, 0, outp.n_pad, 0, 0,
+                          (bf16_t*)outp.w.p + (size_t)outp.n_pad * outp.k_pad * pl * grp, s));
+        AMTX_CHECK_HIP(hipMemcpyAsync((float*)outp.b.p + (size_t)outp.N * grp, bo, sizeof(float) * m->n_out, hipMemcpyDeviceToDevice, s));
+        return AMTX_OK;
+    };
+    for (int r = 0; r < m->n_rec; ++r) PACK_TRY(pack_rec(m->head_names[r] + ".1", m->head_names[r] + ".2", m->dim_am, m->rec_ih, m->rec_hh, m->rec_out, r));
+    PACK_TRY(pack_rec("adjoin.0", "adjoin.1", m->dim_aj, m->adj_ih, m->adj_hh, m->adj_out, 0));
+    // pitch head: LogisticBank folded into fc1 in double precision, then packed like any Linear layer
+    {
+        const float *wo, *bo, *w1, *b1;
+        NEED_DEV("pitch_head.1.output_layer.weight", (size_t)m->n_out * m->dim_am, wo);
+        NEED_DEV("pitch_head.1.output_layer.bias", (size_t)m->n_out, bo);
+        NEED_DEV("pitch_head.0.fc1.0.weight", (size_t)m->dim_am * m->kfc, w1);
+        NEED_DEV("pitch_head.0.fc1.0.bias", (size_t)m->dim_am, b1);
+        PACK_TRY(amtx_pack_head_fold_dev(wo, w1, b1, bo, m->n_out, m->dim_am, m->kfc, m->kfc_pad, m->nf3, m->fq, wfold, bfold, s));
+        PACK_TRY(pack_lin(wfold, m->kfc_pad, m->n_out, m->kfc_pad, pl, m->pitch_out.n_pad, m->pitch_out.k_pad, 0, m->pitch_out.n_pad, 0, 0,
+                          (bf16_t*)m->pitch_out.w.p, s));
+        AMTX_CHECK_HIP(hipMemcpyAsync(m->pitch_out.b.p, bfold, sizeof(float) * m->n_out, hipMemcpyDeviceToDevice, s));
+    }
+    m->dev_tensors.clear();
     return AMTX_OK;
 }
 

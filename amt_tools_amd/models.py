@@ -281,6 +281,7 @@ class _OFEngine(object):
                                               int(model.has_offsets), prec), 'amtx_of_model_create')
         self.version = None
         self.workspace = None
+        self.device_sync = os.environ.get('AMTX_HOST_WEIGHT_SYNC') is None     # A/B switch: always pack on the host
 
     def sync_weights(self, model):
         sd = model.state_dict()
@@ -289,8 +290,21 @@ class _OFEngine(object):
             return
         L = _lib.lib()
         items = [(k, v) for k, v in sd.items() if v.dtype.is_floating_point and not k.startswith('frontend.') and v.numel() > 0]
-        # ONE device-to-host copy of all parameters and buffers (a copy per tensor is ~60 synchronisations per re-sync: validate()
-        # inside train() pays this at every checkpoint); the library packs from host memory
+        # A RE-sync (validate() inside train() pays one at every checkpoint) stays on the GPU where the library can pack there: the
+        # tensors are handed over as device pointers and folded / packed by kernels -- the same bits as the host path.
+        if self.version is not None and self.device_sync and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for _, v in items):
+            for k, v in items:
+                _lib.check(L.amtx_of_model_set_tensor_device(self.handle, k.encode(), _lib.ptr(v), v.numel()), 'amtx_of_model_set_tensor_device')
+            with torch.cuda.device(self.device):
+                rc = L.amtx_of_model_finalize_device(self.handle, _lib.current_stream(self.device))
+            if rc == 0:
+                self.version = version
+                return
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, 'amtx_of_model_finalize_device')
+            self.device_sync = False                    # this configuration packs on the host
+        # ONE device-to-host copy of all parameters and buffers (a copy per tensor is ~60 synchronisations per re-sync); the library packs
+        # from host memory
         flat = torch.cat([v.detach().reshape(-1).to(torch.float32) for _, v in items]).cpu().numpy()
         off = 0
         for k, v in items:

@@ -111,6 +111,13 @@ int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_
                           float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                           float* logits_pitch_head, void* stream);
 
+/* Weight RE-SYNC without leaving the GPU (validate() inside train(), amt_tools/train.py:183-189): after one amtx_of_model_finalize, later
+ * weight versions can be handed over as DEVICE pointers (fp32, contiguous, same state_dict names, borrowed until finalize_device returns)
+ * and are folded / packed by kernels into the model's existing buffers -- the same bits the host path produces.  One-channel models at
+ * model_complexity 2 (any precision); AMTX_ERR_UNSUPPORTED otherwise (callers then use set_tensor + finalize). */
+int amtx_of_model_set_tensor_device(amtx_of_model* model, const char* name, const float* device_data, int64_t numel);
+int amtx_of_model_finalize_device(amtx_of_model* model, void* stream);
+
 /* 1 when amtx_of_forward / amtx_of_forward_power at this batch and frame count run the acoustic heads' three convolution layers
  * (amt_tools/models/onsetsframes.py:375-412) as ONE kernel whose intermediate maps stay in LDS (convf.hip: one-channel bf16 models at
  * model_complexity 2, batches of at least 256 head x clip x 62-frame strips; AMTX_NO_CONV_FUSE=1 at model creation turns it off), 0 when

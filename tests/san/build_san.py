@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, '_build')
 LIB = os.path.join(OUT, 'libamtx_san.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 SAN = ['-fsanitize=address,undefined', '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer', '-g', '-O1']
-F16_TWINS = ('conv.hip', 'convf.hip', 'convg.hip', 'gemm.hip', 'lstm.hip')
+F16_TWINS = ('conv.hip', 'convf.hip', 'convg.hip', 'gemm.hip', 'lstm.hip', 'pack.hip')
 
 
 def asan_runtime():

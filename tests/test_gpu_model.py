@@ -250,6 +250,61 @@ def test_f16_precision_vs_oracle_on_both_convolution_paths(dim_in):
             assert (torch.sigmoid(gk) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 2.5e-3, (B, T, key)
 
 
+@pytest.mark.parametrize('precision', ['bf16', 'x3', 'f16'])
+@pytest.mark.parametrize('cls', ['OnsetsFrames', 'OnsetsFrames2'])
+def test_device_side_weight_sync_equals_the_host_path(cls, precision, monkeypatch):
+    """A weight RE-sync packs on the GPU (pack.hip, amtx_of_model_finalize_device) with the host packers' arithmetic: after the same
+    parameter update, an engine re-synced on the device and one re-synced through the host (AMTX_HOST_WEIGHT_SYNC=1) return identical
+    bits -- BatchNorm statistics, every convolution / Linear / LSTM tensor and the fp64-folded pitch head included."""
+    import amt_tools_amd.models as M
+    offsets = cls == 'OnsetsFrames2'
+    sd = synth_state_dict(9, dim_in=229, in_channels=1, model_complexity=2, offsets=offsets)
+    feats = torch.from_numpy(np.random.default_rng(4).random((3, 1, 229, 40)).astype(np.float32)).cuda()
+    outs = {}
+    for mode in ('device', 'host'):
+        if mode == 'host':
+            monkeypatch.setenv('AMTX_HOST_WEIGHT_SYNC', '1')
+        else:
+            monkeypatch.delenv('AMTX_HOST_WEIGHT_SYNC', raising=False)
+        model = getattr(M, cls)(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        model.change_device()
+        model.eval()
+        with torch.no_grad():
+            first = model.engine_logits(feats)                       # the first sync always goes through the host
+            g = torch.Generator(device='cuda').manual_seed(1)
+            for p_ in model.parameters():                            # "an optimizer step"
+                p_.add_(torch.randn(p_.shape, generator=g, device='cuda') * 0.01 * p_.abs().mean())
+            for b_ in model.buffers():
+                if b_.dtype.is_floating_point:
+                    b_.mul_(1.05)
+            eng = model._get_engine(feats.device)
+            assert eng.device_sync == (mode == 'device')
+            got = model.engine_logits(feats)
+            assert eng.device_sync == (mode == 'device')             # the device path was not refused
+        assert not torch.equal(first['multi_pitch'], got['multi_pitch'])
+        outs[mode] = got
+    for k in outs['host']:
+        assert torch.equal(outs['device'][k], outs['host'][k]), (k, (outs['device'][k] - outs['host'][k]).abs().max().item())
+
+
+def test_device_side_weight_sync_falls_back_where_it_is_not_built():
+    """model_complexity 3 (convg.hip fragment layouts, hidden-256 recurrence) re-syncs through the host: amtx_of_model_finalize_device answers
+    AMTX_ERR_UNSUPPORTED, the engine notes it and the results follow the new weights all the same."""
+    import amt_tools_amd.models as M
+    model = M.OnsetsFrames2(229, tools.PianoProfile(), 1, 3, device='cuda:0')
+    model.change_device()
+    model.eval()
+    feats = torch.rand(2, 1, 229, 20, device='cuda')
+    with torch.no_grad():
+        a = model.engine_logits(feats)['multi_pitch'].clone()
+        for p_ in model.parameters():
+            p_.mul_(1.1)
+        b = model.engine_logits(feats)['multi_pitch']
+    assert not model._get_engine(feats.device).device_sync
+    assert not torch.equal(a, b)
+
+
 def _of1_bf16(seed, dim_in, cls='OnsetsFrames'):
     import amt_tools_amd.models as M
     sd = synth_state_dict(seed, dim_in=dim_in, in_channels=1, model_complexity=2, offsets=cls == 'OnsetsFrames2')
