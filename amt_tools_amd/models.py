@@ -282,6 +282,7 @@ class _OFEngine(object):
         self.version = None
         self.workspace = None
         self.device_sync = os.environ.get('AMTX_HOST_WEIGHT_SYNC') is None     # A/B switch: always pack on the host
+        self.device_syncs = 0                            # re-syncs that stayed on the GPU (tests)
 
     def sync_weights(self, model):
         sd = model.state_dict()
@@ -292,13 +293,21 @@ class _OFEngine(object):
         items = [(k, v) for k, v in sd.items() if v.dtype.is_floating_point and not k.startswith('frontend.') and v.numel() > 0]
         # A RE-sync (validate() inside train() pays one at every checkpoint) stays on the GPU where the library can pack there: the
         # tensors are handed over as device pointers and folded / packed by kernels -- the same bits as the host path.
-        if self.version is not None and self.device_sync and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for _, v in items):
+        if self.version is not None and self.device_sync and all(v.is_cuda and v.dtype == torch.float32 for _, v in items):
+            keep = []                                   # channels-last convolution weights (the GPU training layout) go through a dense device copy
             for k, v in items:
-                _lib.check(L.amtx_of_model_set_tensor_device(self.handle, k.encode(), _lib.ptr(v), v.numel()), 'amtx_of_model_set_tensor_device')
+                t = v.detach()
+                t = t if t.is_contiguous() else t.contiguous()
+                keep.append(t)
+                _lib.check(L.amtx_of_model_set_tensor_device(self.handle, k.encode(), _lib.ptr(t), t.numel()), 'amtx_of_model_set_tensor_device')
             with torch.cuda.device(self.device):
                 rc = L.amtx_of_model_finalize_device(self.handle, _lib.current_stream(self.device))
+                if keep and rc == 0:
+                    torch.cuda.current_stream(self.device).synchronize()     # the borrowed copies may go once the pack kernels have read them
+            del keep
             if rc == 0:
                 self.version = version
+                self.device_syncs += 1
                 return
             if rc != _lib.ERR_UNSUPPORTED:
                 _lib.check(rc, 'amtx_of_model_finalize_device')

@@ -281,7 +281,7 @@ def test_device_side_weight_sync_equals_the_host_path(cls, precision, monkeypatc
             eng = model._get_engine(feats.device)
             assert eng.device_sync == (mode == 'device')
             got = model.engine_logits(feats)
-            assert eng.device_sync == (mode == 'device')             # the device path was not refused
+            assert eng.device_sync == (mode == 'device') and eng.device_syncs == (1 if mode == 'device' else 0)   # the device path really ran
         assert not torch.equal(first['multi_pitch'], got['multi_pitch'])
         outs[mode] = got
     for k in outs['host']:
