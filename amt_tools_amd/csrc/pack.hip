@@ -15,6 +15,10 @@
 namespace {
 
 __device__ __forceinline__ void put16(bf16_t* out, size_t hi_index, size_t plane_stride, int planes, float v) {
+    // v is often a product (weight x BatchNorm scale).  In the half-precision build hipcc would fuse multiply and conversion into one
+    // v_fma_mixlo_f16, i.e. round the exact product ONCE to half, where the host packers round it to fp32 first: rare last-bit
+    // differences between a device-synced and a host-synced model (seen as 3e-5 ... 4e-4 on f16 logits).  Keep the fp32 product.
+    asm volatile("" : "+v"(v));
     const bf16_t hi = f32_to_bf16_rn(v);
     out[hi_index] = hi;
     if (planes == 2) out[hi_index + plane_stride] = f32_to_bf16_rn(v - bf16_to_f32(hi));
