@@ -15,7 +15,7 @@ from . import _lib
 __all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction',
            'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend']
 
-HIDDEN_SIZES = (128, 256)       # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3)
+HIDDEN_SIZES = (128, 256, 384)  # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3, 4)
 
 
 USE_HIP_DENSE = True            # False: nn.Conv2d / nn.Linear / the LSTM's matmuls through ATen (MIOpen / hipBLASLt) -- the A/B switch of the tests

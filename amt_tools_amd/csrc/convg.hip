@@ -569,6 +569,7 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
 int amtx_conv3x3_gen_ntc(int c_in, int c_out) {
     if (c_in == 48 && c_out % 48 == 0) return 3;
     if (c_in == 32 && c_out == 32) return 2;          // model_complexity 2 with a multi-channel first conv (HCQT), see ofmodel.hip
+    if (c_in == 64 && c_out % 32 == 0) return 2;      // model_complexity 4 (64 -> 64, 64 -> 128): 36 KiB of weights per chunk and plane
     return 0;
 }
 
@@ -645,6 +646,7 @@ int amtx_launch_conv3x3_gen(const ConvArgs& a, int c_in, hipStream_t stream) {
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3 (general): planes must be 1 or 2");
     if (c_in == 48 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 3) return dispatch_gen<3, 3>(a, stream);
     if (c_in == 32 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 2) return dispatch_gen<2, 2>(a, stream);
+    if (c_in == 64 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 2) return dispatch_gen<4, 2>(a, stream);
     amtx_set_error("conv3x3 (general): unsupported channel counts %d -> %d", c_in, a.c_out);
     return AMTX_ERR_UNSUPPORTED;
 }

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
                                                   // the stream is bound by the 64 B/clk a CU's vector memory path takes, not by latency)
     // Of every four consecutive groups of a wave, group 0 is held in registers and group 1 in LDS for the whole launch (bf16
     // mode: 64 spare VGPRs, 128 KiB of LDS per block), the other two are streamed: half the bytes per step.
-    constexpr bool PIN = NS == 1;
+    constexpr bool PIN = NS == 1 && HH == 256;   // (HH = 384: 9 groups per kind would be 144 VGPRs / 288 KiB of LDS: all streamed)
     constexpr int NPIN = PIN ? NG / 4 : 0;        // groups pinned per kind (registers, LDS) and wave
     constexpr int NSG = NG - 2 * NPIN;            // streamed groups per step and wave
     static_assert(NU % 8 == 0 && KSN % SGK == 0 && NG % 4 == 0 && NSG % RS == 0, "hidden size must be a multiple of 128");
@@ -628,11 +628,15 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
         wb = (gchar_p)wbase;
         asm volatile("" : "+s"(wb));
         const char* hb = smem + cur * NS * HBG;
-        uint4 hf[KSN][NS];
+        // the h fragments of a step: in registers while they are at most 64 (HH = 384 in two planes would be 96: read at their use)
+        constexpr bool HF_REG = KSN * NS <= 16;
+        uint4 hf[HF_REG ? KSN : 1][NS];
+        if constexpr (HF_REG) {
 #pragma unroll
-        for (int ks = 0; ks < KSN; ++ks)
+            for (int ks = 0; ks < KSN; ++ks)
 #pragma unroll
-            for (int p = 0; p < NS; ++p) hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBG + (clip * HPG + 32 * ks + 8 * g) * 2);
+                for (int p = 0; p < NS; ++p) hf[ks][p] = *reinterpret_cast<const uint4*>(hb + p * HBG + (clip * HPG + 32 * ks + 8 * g) * 2);
+        }
 
         f32x4_t acc[UPW][4];
 #pragma unroll
@@ -668,10 +672,17 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
                 } else {
                     w0 = w[si % RS][k][0]; w1 = w[si % RS][k][NS - 1];
                 }
-                d = mfma16(w0, hf[ks][0], d);
+                uint4 h0, h1;
+                if constexpr (HF_REG) {
+                    h0 = hf[ks][0]; h1 = hf[ks][NS - 1];
+                } else {
+                    h0 = *reinterpret_cast<const uint4*>(hb + (clip * HPG + 32 * ks + 8 * g) * 2);
+                    h1 = *reinterpret_cast<const uint4*>(hb + (NS - 1) * HBG + (clip * HPG + 32 * ks + 8 * g) * 2);
+                }
+                d = mfma16(w0, h0, d);
                 if constexpr (NS == 2) {
-                    d = mfma16(w0, hf[ks][1], d);
-                    d = mfma16(w1, hf[ks][0], d);
+                    d = mfma16(w0, h1, d);
+                    d = mfma16(w1, h0, d);
                 }
             });
             acc[ub][q] = d;
@@ -740,7 +751,8 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
     constexpr int RS = 4;
     // every fourth group is pinned in registers for the whole launch (the kernel needs ~106 VGPRs of the 256 it may use), the
     // other three are streamed: a quarter fewer bytes per step
-    constexpr int NPINB = NG / 4, NSGB = NG - NPINB;
+    constexpr bool PINB = HH == 256;               // (HH = 384: 18 pinned groups would be 288 VGPRs: all streamed)
+    constexpr int NPINB = PINB ? NG / 4 : 0, NSGB = NG - NPINB;
     constexpr int GPH = 4 * HH + 8;                // bf16 elements per row of the dgates tile
     constexpr int GBH = 16 * GPH * 2;              // one plane of one buffer
     static_assert(NG % 4 == 0 && NSGB % RS == 0, "hidden size must be a multiple of 128");
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
         }
     };
     load_next(frame(0));
-    uint4 wpin[NPINB][SGK][NS];
+    uint4 wpin[PINB ? NPINB : 1][SGK][NS];
     static_for<0, NPINB>([&](auto gc) {
         static_for<0, SGK>([&](auto kc) {
             static_for<0, NS>([&](auto pc) { wpin[decltype(gc)::value][decltype(kc)::value][decltype(pc)::value] = load_frag(4 * decltype(gc)::value, decltype(kc)::value, decltype(pc)::value); });
@@ -798,7 +810,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
     });
     static_for<0, RS - 1>([&](auto sc) {
         constexpr int si = decltype(sc)::value;
-        constexpr int gi = (si / 3) * 4 + 1 + si % 3;        // streamed group si -> group index
+        constexpr int gi = PINB ? (si / 3) * 4 + 1 + si % 3 : si;        // streamed group si -> group index
         static_for<0, SGK>([&](auto kc) {
             static_for<0, NS>([&](auto pc) { w[si % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
         });
@@ -848,11 +860,11 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
         static_for<0, NG>([&](auto ic) {
             constexpr int gi = decltype(ic)::value;
             constexpr int ut = gi / (KSN / SGK), sub = gi % (KSN / SGK);
-            constexpr bool pinned = (gi & 3) == 0;
-            constexpr int si = (gi >> 2) * 3 + (gi & 3) - 1;                     // index among the streamed groups
+            constexpr bool pinned = PINB && (gi & 3) == 0;
+            constexpr int si = PINB ? (gi >> 2) * 3 + (gi & 3) - 1 : gi;         // index among the streamed groups
             if constexpr (!pinned) {
                 constexpr int sn = (si + RS - 1) % NSGB;                         // behind the last RS - 1 streamed groups
-                constexpr int gn = (sn / 3) * 4 + 1 + sn % 3;
+                constexpr int gn = PINB ? (sn / 3) * 4 + 1 + sn % 3 : sn;
                 static_for<0, SGK>([&](auto kc) {
                     static_for<0, NS>([&](auto pc) { w[sn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
                 });
@@ -923,7 +935,7 @@ __global__ void bilstm_pack_dev_h_kernel(const float* __restrict__ whh_fwd, cons
 template <int HH, int NS, int X_TYPE, int OUT_TYPE>
 int launch_stream(const LstmArgs& a, hipStream_t stream) {
     // h tiles + (bf16 mode) the LDS-resident quarter of W_hh: 8 waves x (groups / 4) x 4 KiB
-    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 ? (size_t)8 * ((HH / 128) * 4 * (HH / 32 / 4) / 4) * 4096 : 0);
+    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 && HH == 256 ? (size_t)8 * ((HH / 128) * 4 * (HH / 32 / 4) / 4) * 4096 : 0);
     auto kern = bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>;
     AMTX_GRANT_LDS(kern, lds);
     dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
@@ -1020,7 +1032,8 @@ int amtx_launch_bilstm(const LstmArgs& a, hipStream_t stream) {
     if (a.hidden != H) {
         AMTX_REQUIRE(!a.save || a.planes == 2, "bilstm: the training forward (save) is built for the two-plane precision");
         if (a.hidden == 256) return dispatch_stream<256>(a, stream);
-        amtx_set_error("bilstm: unsupported hidden size %d (128 and 256 are built)", a.hidden);
+        if (a.hidden == 384) return dispatch_stream<384>(a, stream);
+        amtx_set_error("bilstm: unsupported hidden size %d (128, 256 and 384 are built)", a.hidden);
         return AMTX_ERR_UNSUPPORTED;
     }
     if (a.planes == 1 && a.x_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch<1, AMTX_T_BF16, AMTX_T_BF16>(a, stream);
@@ -1057,7 +1070,7 @@ int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* w
 int amtx_launch_bilstm_pack_dev_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream) {
     AMTX_REQUIRE(whh_fwd && whh_bwd && frag_fwd && frag_bwd && (planes == 1 || planes == 2), "bilstm pack: bad argument");
     if (hidden == H) return amtx_launch_bilstm_pack_dev(whh_fwd, whh_bwd, planes, frag_fwd, frag_bwd, stream);
-    AMTX_REQUIRE(hidden == 256, "bilstm pack: hidden size %d is not built (128, 256)", hidden);
+    AMTX_REQUIRE(hidden == 256 || hidden == 384, "bilstm pack: hidden size %d is not built (128, 256, 384)", hidden);
     hipLaunchKernelGGL(bilstm_pack_dev_h_kernel, dim3(256), dim3(256), 0, stream, whh_fwd, whh_bwd, hidden, planes, frag_fwd, frag_bwd);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
@@ -1076,12 +1089,18 @@ int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t*
         return AMTX_OK;
     }
     AMTX_REQUIRE(dout && save && whh_t && dxproj, "bilstm backward: null pointer");
-    AMTX_REQUIRE(B > 0 && T > 0 && planes == 2 && hidden == 256, "bilstm backward: hidden 256 is built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
+    AMTX_REQUIRE(B > 0 && T > 0 && planes == 2 && (hidden == 256 || hidden == 384),
+                 "bilstm backward: hidden 256 / 384 are built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
     LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T, (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes)};
     dim3 grid((unsigned)((B + 3) / 4), 2, (unsigned)groups);
-    const size_t lds = 2 * (size_t)planes * 16 * (4 * 256 + 8) * 2;
-    AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<256, 2>), lds);
-    hipLaunchKernelGGL((bilstm_stream_bwd_kernel<256, 2>), grid, dim3(512), lds, stream, a);
+    const size_t lds = 2 * (size_t)planes * 16 * (4 * hidden + 8) * 2;
+    if (hidden == 256) {
+        AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<256, 2>), lds);
+        hipLaunchKernelGGL((bilstm_stream_bwd_kernel<256, 2>), grid, dim3(512), lds, stream, a);
+    } else {
+        AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<384, 2>), lds);
+        hipLaunchKernelGGL((bilstm_stream_bwd_kernel<384, 2>), grid, dim3(512), lds, stream, a);
+    }
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

@@ -89,13 +89,13 @@ extern "C" int amtx_bilstm_fwd(const void* xproj, const uint16_t* whh_packed, in
 }
 
 extern "C" int64_t amtx_bilstm_h_packed_elems(int hidden, int planes) {
-    if (hidden != 128 && hidden != 256) return 0;
+    if (hidden != 128 && hidden != 256 && hidden != 384) return 0;
     return (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes);
 }
 
 extern "C" int amtx_bilstm_h_pack(const float* host_whh_fwd, const float* host_whh_bwd, int hidden, int planes, uint16_t* host_out) {
     AMTX_REQUIRE(host_whh_fwd && host_whh_bwd && host_out && (planes == 1 || planes == 2), "amtx_bilstm_h_pack: bad argument");
-    AMTX_REQUIRE(hidden == 128 || hidden == 256, "amtx_bilstm_h_pack: hidden size %d is not built (128, 256)", hidden);
+    AMTX_REQUIRE(hidden == 128 || hidden == 256 || hidden == 384, "amtx_bilstm_h_pack: hidden size %d is not built (128, 256, 384)", hidden);
     amtx_bilstm_pack_host_h(host_whh_fwd, host_whh_bwd, hidden, planes, host_out);
     return AMTX_OK;
 }
@@ -145,7 +145,7 @@ extern "C" int amtx_bilstm_train_bwd(const float* dout, const float* save, const
     return amtx_launch_bilstm_bwd(dout, save, (const bf16_t*)whh_t_packed, planes, dxproj, batch, num_frames, (hipStream_t)stream);
 }
 
-// ---- training recurrences for any built hidden size (128: the register-stationary kernels, 256: the streaming ones)
+// ---- training recurrences for any built hidden size (128: the register-stationary kernels, 256 / 384: the streaming ones)
 extern "C" int amtx_bilstm_h_pack_device(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, uint16_t* frag_fwd, uint16_t* frag_bwd,
                                          void* stream) {
     return amtx_launch_bilstm_pack_dev_h(whh_fwd, whh_bwd, hidden, planes, frag_fwd, frag_bwd, (hipStream_t)stream);

@@ -108,6 +108,57 @@ def test_onsetsframes2_default_complexity_3_engine_matches_reference_golden(prec
         assert np.all((got == g['out_' + key]) | near)
 
 
+@pytest.mark.parametrize('precision', ['x3', 'bf16', 'f16'])
+@pytest.mark.parametrize('name', ['of1_mc4_eval.npz', 'of2_mc4_hcqt_eval.npz'])
+def test_complexity_4_engine_matches_reference_golden(name, precision):
+    """model_complexity 4 (onsetsframes.py:358-364, 40-41: 64/64/128-channel convolutions, fc 1024, LSTM hidden 384) through the HIP
+    engine against vectors recorded from the real reference classes: OnsetsFrames on one-channel mel features and OnsetsFrames2
+    (offset head) on a three-channel HCQT shape."""
+    import amt_tools_amd.models as M
+    g = load_golden(name)
+    assert int(g['model_complexity']) == 4
+    offsets = name.startswith('of2')
+    cls = M.OnsetsFrames2 if offsets else M.OnsetsFrames
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=int(g['in_channels']), model_complexity=4, offsets=offsets)
+    model = cls(int(g['dim_in']), tools.PianoProfile(), int(g['in_channels']), 4, device='cuda:0', precision=precision)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    tol = {'x3': 1e-4, 'bf16': 6e-2, 'f16': 1e-2}[precision]
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_TIMES: torch.from_numpy(g['out_times'])})
+        logits = model.engine_logits(torch.from_numpy(g['feats']).cuda())
+    for key in ('onsets', 'multi_pitch', 'pitch_head') + (('offsets',) if offsets else ()):
+        err = np.abs(logits[key].cpu().numpy() - g['logits_' + key]).max()
+        assert err < tol, (key, err)
+    if offsets:
+        assert np.abs(out[tools.KEY_OFFSETS].cpu().numpy() - g['out_offsets']).max() < (1e-4 if precision == 'x3' else 2e-2)
+    for key in ('onsets', 'multi_pitch'):
+        near = np.abs(np.swapaxes(g['logits_' + key], -1, -2)) < tol
+        assert np.all((out[key].cpu().numpy() == g['out_' + key]) | near)
+
+
+def test_complexity_4_engine_vs_oracle_on_ragged_batches():
+    """model_complexity 4 against the oracle on fresh inputs whose batch and frame counts do not fill the kernels' tiles (x3)."""
+    from oracle import model_ref
+    from amt_tools_amd.models import OnsetsFrames
+    sd = synth_state_dict(12, dim_in=229, in_channels=1, model_complexity=4)
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 4, device='cuda:0', precision='x3')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    sdt = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(7)
+    for B, T in ((1, 1), (3, 17), (17, 9), (2, 40)):
+        feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32))
+        with torch.no_grad():
+            ref = model_ref.run_on_batch(feats, sdt)
+            got = model.engine_logits(feats.cuda())
+        for key in ('onsets', 'multi_pitch'):
+            assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
+            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+
+
 @pytest.mark.parametrize('dim_in,in_channels', [(229, 1), (72, 6)])
 def test_complexity_3_engine_vs_oracle_on_ragged_batches(dim_in, in_channels):
     """OnsetsFrames (no offset head) at model_complexity 3 against the oracle on fresh inputs, batch and frame counts that do not
@@ -402,7 +453,7 @@ def test_engine_is_deterministic_run_to_run(mc, precision):
 def test_unbuilt_model_complexity_is_rejected_loudly_by_the_engine():
     from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd._lib import AmtxError
-    model = OnsetsFrames(229, tools.PianoProfile(), 1, 4, device='cuda:0')
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 5, device='cuda:0')        # 80 / 80 / 160 channels, hidden 512: not built
     model.change_device()
     model.eval()
     with pytest.raises(AmtxError), torch.no_grad():

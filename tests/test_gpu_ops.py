@@ -93,9 +93,10 @@ def test_conv3x3_bn_relu_pool(planes, b, t, f, cout):
 
 @pytest.mark.parametrize('planes', [1, 2])
 @pytest.mark.parametrize('b,t,f,cin,cout', [(2, 40, 229, 48, 48), (1, 17, 114, 48, 96), (3, 5, 36, 48, 48), (1, 33, 18, 48, 96),
-                                            (1, 1, 2, 48, 48), (2, 16, 33, 48, 96)])
+                                            (1, 1, 2, 48, 48), (2, 16, 33, 48, 96),
+                                            (2, 40, 229, 64, 64), (1, 17, 114, 64, 128), (3, 5, 36, 64, 64), (1, 33, 18, 64, 128), (1, 1, 2, 64, 64)])
 def test_conv3x3_general_channels(planes, b, t, f, cin, cout):
-    """convg.hip (weights staged in LDS): the 48 -> 48 and 48 -> 96 layers of model_complexity 3."""
+    """convg.hip (weights staged in LDS): the 48 -> 48 and 48 -> 96 layers of model_complexity 3, 64 -> 64 and 64 -> 128 of 4."""
     L = _lib.lib()
     g = torch.Generator().manual_seed(b * 1000 + t * 10 + f + cout)
     x = torch.rand(b, t, f, cin, generator=g)
@@ -119,7 +120,7 @@ def test_conv3x3_general_channels(planes, b, t, f, cin, cout):
 
 def test_conv3x3_general_rejects_unbuilt_channel_counts():
     L = _lib.lib()
-    assert L.amtx_conv3x3g_packed_elems(40, 48, 1) == 0 and L.amtx_conv3x3g_packed_elems(48, 80, 1) == 0
+    assert L.amtx_conv3x3g_packed_elems(40, 48, 1) == 0 and L.amtx_conv3x3g_packed_elems(48, 80, 1) == 0 and L.amtx_conv3x3g_packed_elems(64, 80, 1) == 0
     dummy = np.zeros(16, dtype=np.float32)
     assert L.amtx_conv3x3g_pack(_lib.ptr(dummy), None, 40, 48, 1, _lib.ptr(dummy)) < 0
     assert b'not built' in L.amtx_last_error()
@@ -163,10 +164,10 @@ def _lstm_ref(xproj, whh_f, whh_b, H=128):
 
 @pytest.mark.parametrize('planes', [1, 2])
 @pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (40, 120)])
-def test_bilstm_hidden_256(planes, b, t):
-    """lstm.hip bilstm_stream_kernel (W_hh streamed from L2): the recurrence of model_complexity 3 (hidden 256 per direction)."""
+@pytest.mark.parametrize('H', [256, 384])
+def test_bilstm_hidden_256_384(planes, b, t, H):
+    """lstm.hip bilstm_stream_kernel (W_hh streamed from L2): the recurrences of model_complexity 3 and 4 (hidden 256 / 384 per direction)."""
     L = _lib.lib()
-    H = 256
     g = torch.Generator().manual_seed(b * 100 + t)
     xproj = torch.randn(b, t, 2, 4 * H, generator=g)
     whh_f = (torch.rand(4 * H, H, generator=g) - 0.5) * 0.2

@@ -37,14 +37,15 @@ def test_eval_run_on_batch_matches_reference_on_cpu():
     assert batch[tools.KEY_FEATS].shape == (2, 1, 229, 40)            # caller's batch untouched
 
 
-@pytest.mark.parametrize('name', ['of2_eval.npz', 'of2_mc2_eval.npz'])
+@pytest.mark.parametrize('name', ['of2_eval.npz', 'of2_mc2_eval.npz', 'of2_mc4_hcqt_eval.npz'])
 def test_onsetsframes2_matches_reference_on_cpu(name):
     """OnsetsFrames2 (offset head, detach_heads, model_complexity 3 and 2): same state_dict keys as the reference, same logits,
     same outputs (offsets as probabilities, onsetsframes.py:323-325)."""
     g = load_golden(name)
     mc = int(g['model_complexity'])
-    model = OnsetsFrames2(int(g['dim_in']), tools.PianoProfile(), 1, mc)
-    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=1, model_complexity=mc, offsets=True)
+    ic = int(g['in_channels'])
+    model = OnsetsFrames2(int(g['dim_in']), tools.PianoProfile(), ic, mc)
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=ic, model_complexity=mc, offsets=True)
     assert list(model.state_dict().keys()) == list(sd.keys())
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model.eval()
@@ -74,8 +75,9 @@ def test_onsetsframes2_matches_reference_on_cpu(name):
     assert off.shape == mp.shape and off[..., -1].sum() == mp[..., -1].sum() and set(np.unique(off)) <= {0.0, 1.0}
 
 
-def test_training_step_matches_reference_losses_and_grads():
-    g = load_golden('of1_train.npz')
+@pytest.mark.parametrize('name', ['of1_train.npz', 'of1_mc4_train.npz'])
+def test_training_step_matches_reference_losses_and_grads(name):
+    g = load_golden(name)
     model = _model(g)
     for mod in model.modules():
         if isinstance(mod, torch.nn.Dropout):

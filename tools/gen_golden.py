@@ -131,7 +131,13 @@ def gen_of_eval(name, cls, seed, dim_in, in_channels, mc, B, T, offsets):
     print(name, {k: getattr(v, 'shape', v) for k, v in rec.items()})
 
 
-def gen_of_train(name, seed, dim_in, mc, B, T):
+# small tensors only: the recurrent matrices of model_complexity 4 are 1536 x 384
+MC4_GKEYS = ['onset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'onset_head.1.mlm.bias_hh_l0', 'onset_head.1.mlm.bias_ih_l0_reverse',
+             'pitch_head.0.fc1.0.bias', 'pitch_head.0.layer2.1.bias', 'adjoin.0.mlm.bias_hh_l0', 'adjoin.1.output_layer.weight',
+             'pitch_head.1.output_layer.bias']
+
+
+def gen_of_train(name, seed, dim_in, mc, B, T, gkeys=None):
     """Training-mode golden: BatchNorm batch statistics, Dropout disabled (p=0) so the result is
     deterministic; labels given -> the reference's losses and a few gradients."""
     profile = rtools.PianoProfile()
@@ -150,9 +156,9 @@ def gen_of_train(name, seed, dim_in, mc, B, T):
     loss = out[rtools.KEY_LOSS]
     loss[rtools.KEY_LOSS_TOTAL].backward()
     named = dict(model.named_parameters())
-    gkeys = ['onset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'onset_head.1.mlm.weight_hh_l0',
-             'pitch_head.0.fc1.0.bias', 'adjoin.0.mlm.weight_ih_l0_reverse', 'adjoin.1.output_layer.weight',
-             'pitch_head.1.output_layer.bias']
+    gkeys = gkeys or ['onset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'onset_head.1.mlm.weight_hh_l0',
+                      'pitch_head.0.fc1.0.bias', 'adjoin.0.mlm.weight_ih_l0_reverse', 'adjoin.1.output_layer.weight',
+                      'pitch_head.1.output_layer.bias']
     rec = dict(seed=seed, dim_in=dim_in, model_complexity=mc, feats=feats, multi_pitch=mp, onsets=on,
                wsum=weight_checksum(sd_np),
                loss_pitch=loss[rtools.KEY_LOSS_PITCH].item(), loss_onsets=loss[rtools.KEY_LOSS_ONSETS].item(),
@@ -359,7 +365,15 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'notes_f32':
         gen_notes('notes_f32times.npz', 35, 625, 0.01, 0.05, True, sr=16000, times_dtype=np.float32)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'mc4':
+        gen_of_eval('of1_mc4_eval.npz', OnsetsFrames, seed=15, dim_in=229, in_channels=1, mc=4, B=2, T=24, offsets=False)
+        gen_of_eval('of2_mc4_hcqt_eval.npz', OnsetsFrames2, seed=16, dim_in=72, in_channels=3, mc=4, B=1, T=20, offsets=True)
+        gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS)
+        sys.exit(0)
     gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
+    gen_of_eval('of1_mc4_eval.npz', OnsetsFrames, seed=15, dim_in=229, in_channels=1, mc=4, B=2, T=24, offsets=False)
+    gen_of_eval('of2_mc4_hcqt_eval.npz', OnsetsFrames2, seed=16, dim_in=72, in_channels=3, mc=4, B=1, T=20, offsets=True)
+    gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS)
     gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
     gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
