@@ -754,9 +754,11 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
     constexpr bool PINB = HH == 256;               // (HH = 384: 18 pinned groups would be 288 VGPRs: all streamed)
     constexpr int NPINB = PINB ? NG / 4 : 0, NSGB = NG - NPINB;
     constexpr int GPH = 4 * HH + 8;                // bf16 elements per row of the dgates tile
-    constexpr int GBH = 16 * GPH * 2;              // one plane of one buffer
+    // one plane of one buffer: the four clips' rows + ONE zero row that stands for the twelve unused rows of the 16-row MFMA operand
+    // (all 16 rows: 197 KiB at HH = 384 in two planes)
+    constexpr int GBH = 5 * GPH * 2;
     static_assert(NG % 4 == 0 && NSGB % RS == 0, "hidden size must be a multiple of 128");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][GPH] bf16, rows 0/4/8/12 used
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][5][GPH] bf16: clip rows 0..3, zero row 4
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cg = lane >> 4;
     const int dir = blockIdx.y;
@@ -785,7 +787,9 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
     const float* sv0 = a.save + ((bb * T) * 2 + dir) * (5 * HH) + unit0;          // + t * (2*5*HH) + 16 ut + q * HH
     const float* do0 = a.dout + (bb * T) * (2 * HH) + dir * HH + unit0;            // + t * 2 HH + 16 ut
     float* dx0 = a.dxproj + (bb * T) * (8 * HH) + dir * 4 * HH + unit0;            // + t * 8 HH + q * HH + 16 ut
-    const int gwoff = (4 * cg * GPH + unit0) * 2;                                   // byte offset of (slot, gate 0, ut 0) in a tile plane
+    const int gwoff = (cg * GPH + unit0) * 2;                                       // byte offset of (clip row, gate 0, ut 0) in a tile plane
+    // fragment row (lane & 15) of the operand: rows 0 / 4 / 8 / 12 are the clips, every other row reads the zero row
+    const int groff = ((((lane & 15) & 3) == 0 ? (lane & 15) >> 2 : 4) * GPH + 8 * (lane >> 4)) * 2;
 
     float dh_rec[UT], dc_rec[UT];
 #pragma unroll
@@ -875,7 +879,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_bwd_kernel(LstmBwdHArgs a) 
                 uint4 gf[NS];
 #pragma unroll
                 for (int p = 0; p < NS; ++p)
-                    gf[p] = *reinterpret_cast<const uint4*>(gt + p * GBH + ((lane & 15) * GPH + 32 * ks + 8 * (lane >> 4)) * 2);
+                    gf[p] = *reinterpret_cast<const uint4*>(gt + p * GBH + groff + 32 * ks * 2);
                 uint4 w0, w1;
                 if constexpr (pinned) { w0 = wpin[gi >> 2][k][0]; w1 = wpin[gi >> 2][k][NS - 1]; }
                 else { w0 = w[si % RS][k][0]; w1 = w[si % RS][k][NS - 1]; }
@@ -1093,7 +1097,7 @@ int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t*
                  "bilstm backward: hidden 256 / 384 are built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
     LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T, (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes)};
     dim3 grid((unsigned)((B + 3) / 4), 2, (unsigned)groups);
-    const size_t lds = 2 * (size_t)planes * 16 * (4 * hidden + 8) * 2;
+    const size_t lds = 2 * (size_t)planes * 5 * (4 * hidden + 8) * 2;
     if (hidden == 256) {
         AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<256, 2>), lds);
         hipLaunchKernelGGL((bilstm_stream_bwd_kernel<256, 2>), grid, dim3(512), lds, stream, a);

@@ -37,7 +37,14 @@ dt = (time.perf_counter() - t0) / N
 ms = (C.c_double * L.amtx_of_num_stages())(); n = C.c_int(0)
 _lib.check(L.amtx_of_profile_read(eng.handle, ms, C.byref(n)))
 T = out[tools.KEY_ONSETS].shape[-1]
-mac = {2: 13347648 + 6145000, 3: 46.8e6}.get(MC, 0)     # per clip-frame incl. the offset head (mc 3: SURVEY 8d 93.6 MFLOP)
+def _macs(mc, F=229, n_out=88):
+    # multiply-adds per clip-frame of the reference's layers (onsetsframes.py:375-427, 498-507, common.py:539): three acoustic models,
+    # two recurrent heads, the refinement stage
+    nf1, nf3, am, lm = 16 * mc, 32 * mc, 256 * mc, 256 * (mc - 1)
+    acoustic = 9 * nf1 * F + 9 * nf1 * nf1 * F + 9 * nf1 * nf3 * (F // 2) + nf3 * (F // 4) * am
+    lstm = lambda d_in: d_in * 4 * lm + (lm // 2) * 4 * lm + lm * n_out
+    return 3 * acoustic + 2 * lstm(am) + am * n_out + lstm(3 * n_out)
+mac = {2: 13347648 + 6145000, 3: 46.8e6}.get(MC) or _macs(MC)     # per clip-frame incl. the offset head (mc 3: SURVEY 8d 93.6 MFLOP)
 fps = B * T / dt
 print(f'OnsetsFrames2(mc={MC}) {B} clips x {T} frames: {dt * 1e3:.2f} ms/step = {fps / 1e6:.2f} M frames/s'
       + (f' = {2 * mac * fps / 1e12:.0f} TFLOP/s ({2 * mac * fps / 2.5e15:.1%} of the 2.5 PF dense bf16 peak)' if mac else '')
