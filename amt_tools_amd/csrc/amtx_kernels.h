@@ -138,6 +138,9 @@ int amtx_pack_bn_fold_dev(const float* conv_bias, const float* gamma, const floa
                           float* shift, hipStream_t s);
 int amtx_pack_conv3x3_dev(const float* w, const float* scale, int c_out, int planes, bf16_t* out, hipStream_t s);
 int amtx_pack_conv1_dev(const float* w, const float* scale, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_conv_gen_dev(const float* w, const float* scale, int c_in, int c_out, int ntc, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_conv1g_dev(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_scale_rows_dev(const float* w, const float* scale, int rows, int cols, float* out, hipStream_t s);
 int amtx_pack_linear_dev(const float* W, int64_t ldw, int N, int K, int planes, int n_pad, int k_pad, int row0, int rows_owned, int perm_c, int perm_f,
                          bf16_t* out, hipStream_t s);
 int amtx_pack_head_fold_dev(const float* w_out, const float* w_fc1, const float* b_fc1, const float* b_out, int n_out, int dim_am, int kfc, int kfc_pad,

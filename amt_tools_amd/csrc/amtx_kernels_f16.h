@@ -19,6 +19,9 @@ void amtx_bilstm_pack_host_h_f16(const float* whh_fwd, const float* whh_bwd, int
 int amtx_launch_bilstm_f16(const LstmArgs& l, hipStream_t stream);
 int amtx_pack_conv3x3_dev_f16(const float* w, const float* scale, int c_out, int planes, bf16_t* out, hipStream_t s);
 int amtx_pack_conv1_dev_f16(const float* w, const float* scale, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_conv_gen_dev_f16(const float* w, const float* scale, int c_in, int c_out, int ntc, int planes, bf16_t* out, hipStream_t s);
+int amtx_pack_conv1g_dev_f16(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out, hipStream_t s);
 int amtx_pack_linear_dev_f16(const float* W, int64_t ldw, int N, int K, int planes, int n_pad, int k_pad, int row0, int rows_owned, int perm_c, int perm_f,
                              bf16_t* out, hipStream_t s);
 int amtx_launch_bilstm_pack_dev_f16(const float* whh_fwd, const float* whh_bwd, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream);
+int amtx_launch_bilstm_pack_dev_h_f16(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream);

@@ -404,10 +404,10 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // Weight RE-SYNC without leaving the GPU.  After one host-side amtx_of_model_finalize (which sizes and allocates every packed
 // buffer), later weight versions can be handed over as device pointers under the same state_dict names and packed by the kernels of
-// pack.hip -- the host packers' arithmetic and layouts, bit for bit.  Built for the configuration that trains under train.py with
-// the engine validating at every checkpoint (amt_tools/train.py:183-189): one input channel, model_complexity 2 (conv.hip / convf.hip
-// fragment layouts, hidden-128 recurrences), any precision; other configurations answer AMTX_ERR_UNSUPPORTED and callers keep the
-// host path.
+// pack.hip -- the host packers' arithmetic and layouts, bit for bit.  Built for every configuration the engine runs (the engine
+// validates at every checkpoint of train.py, amt_tools/train.py:183-189): model_complexity 2, 3 and 4, one or several input channels,
+// any precision -- except a multi-channel first conv on conv.hip's kernel (only reachable with AMTX_NO_CONVG_MC2), which answers
+// AMTX_ERR_UNSUPPORTED and keeps the host path.
 extern "C" int amtx_of_model_set_tensor_device(amtx_of_model* m, const char* name, const float* device_data, int64_t numel) {
     AMTX_REQUIRE(m && name && device_data && numel > 0, "amtx_of_model_set_tensor_device: bad argument");
     m->dev_tensors[name] = std::make_pair(device_data, numel);
@@ -443,8 +443,8 @@ int need_dev(const amtx_of_model* m, const std::string& name, size_t numel, cons
 extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
     AMTX_REQUIRE(m, "amtx_of_model_finalize_device: null model");
     AMTX_REQUIRE(m->finalized, "amtx_of_model_finalize_device: the first sync goes through amtx_of_model_finalize (it allocates the packed buffers)");
-    if (m->gen_conv || m->gen_conv2 || !m->fuse_conv1 || m->in_channels != 1 || m->hid != 128) {
-        amtx_set_error("amtx_of_model_finalize_device: built for one-channel models at model_complexity 2; use amtx_of_model_finalize");
+    if (!m->gen_conv2 && m->in_channels != 1) {
+        amtx_set_error("amtx_of_model_finalize_device: no device packer for conv.hip's multi-channel first conv; use amtx_of_model_finalize");
         return AMTX_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream_;
@@ -458,43 +458,53 @@ extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
         return f16 ? amtx_pack_linear_dev_f16(W, ldw, N, K, planes, n_pad, k_pad, row0, rows, pc, pf, out, st)
                    : amtx_pack_linear_dev(W, ldw, N, K, planes, n_pad, k_pad, row0, rows, pc, pf, out, st);
     };
-    // scratch: scale[64] | shift[64] | folded pitch head (n_out x kfc_pad) | folded bias | backward LSTM fragments (written by the shared
-    // pack kernel, not used by inference)
+    // scratch: scale[256] | folded pitch head (n_out x kfc_pad) | folded bias | backward LSTM fragments (written by the shared pack
+    // kernel, not used by inference)
     const size_t hh_elems = amtx_bilstm_wfrag_elems_h(H, pl);
-    const size_t sc_bytes = (size_t)(128 + (size_t)m->n_out * m->kfc_pad + m->n_out) * sizeof(float) + hh_elems * sizeof(bf16_t) + 256;
+    const size_t sc_bytes = (size_t)(256 + (size_t)m->n_out * m->kfc_pad + m->n_out) * sizeof(float) + hh_elems * sizeof(bf16_t) + 256;
+    AMTX_REQUIRE(m->nf3 <= 256, "amtx_of_model_finalize_device: internal: scale scratch");
     if (!m->pack_scratch.p || m->pack_scratch.bytes < sc_bytes) {
         m->pack_scratch.release();
         AMTX_CHECK_HIP(hipMalloc(&m->pack_scratch.p, sc_bytes));
         m->pack_scratch.bytes = sc_bytes;
     }
     float* scale = (float*)m->pack_scratch.p;
-    float* shift_tmp = scale + 64;
-    float* wfold = scale + 128;
+    float* wfold = scale + 256;
     float* bfold = wfold + (size_t)m->n_out * m->kfc_pad;
     bf16_t* hh_bwd = (bf16_t*)(((uintptr_t)(bfold + m->n_out) + 255) & ~(uintptr_t)255);
-    (void)shift_tmp;
 
-    const size_t c1f_per = amtx_conv1_wfrag_elems(1, pl), c2w_per = amtx_conv3x3_wfrag_elems(m->nf2, pl), c3w_per = amtx_conv3x3_wfrag_elems(m->nf3, pl);
+    const int ic = m->in_channels;
+    const size_t c1f_per = m->gen_conv2 ? amtx_conv1g_wfrag_elems(ic, m->nf1, pl) : amtx_conv1_wfrag_elems(ic, pl);
+    const size_t c2w_per = m->gen_conv2 ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, pl) : amtx_conv3x3_wfrag_elems(m->nf2, pl);
+    const size_t c3w_per = m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, pl) : amtx_conv3x3_wfrag_elems(m->nf3, pl);
+    auto pack_conv_gen = [f16](const float* w, const float* sc, int c_in, int c_out, int planes, bf16_t* out, hipStream_t st) {
+        const int ntc = amtx_conv3x3_gen_ntc(c_in, c_out);
+        return f16 ? amtx_pack_conv_gen_dev_f16(w, sc, c_in, c_out, ntc, planes, out, st) : amtx_pack_conv_gen_dev(w, sc, c_in, c_out, ntc, planes, out, st);
+    };
     const size_t fc_per = (size_t)m->fc1.n_pad * m->fc1.k_pad * pl;
     for (int h = 0; h < nh; ++h) {
         const std::string am = m->head_names[h] + ".0";
         const float *w, *cb, *g, *be, *mu, *var;
         // layer1: scale folded into the Toeplitz fragments, shift kept fp32 (conv1_s); the fp32 copy conv1_w feeds only the unfused first conv
-        NEED_DEV(am + ".layer1.0.weight", (size_t)m->nf1 * 9, w);
+        NEED_DEV(am + ".layer1.0.weight", (size_t)m->nf1 * ic * 9, w);
         NEED_DEV(am + ".layer1.0.bias", (size_t)m->nf1, cb); NEED_DEV(am + ".layer1.1.weight", (size_t)m->nf1, g); NEED_DEV(am + ".layer1.1.bias", (size_t)m->nf1, be);
         NEED_DEV(am + ".layer1.1.running_mean", (size_t)m->nf1, mu); NEED_DEV(am + ".layer1.1.running_var", (size_t)m->nf1, var);
         PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf1, scale, (float*)m->conv1_s.p + (size_t)h * m->nf1, s));
-        PACK_TRY((f16 ? amtx_pack_conv1_dev_f16 : amtx_pack_conv1_dev)(w, scale, pl, (bf16_t*)m->conv1_frag.p + c1f_per * h, s));
+        PACK_TRY(amtx_pack_scale_rows_dev(w, scale, m->nf1, ic * 9, (float*)m->conv1_w.p + (size_t)h * m->nf1 * ic * 9, s));
+        if (m->fuse_conv1 && m->gen_conv2) PACK_TRY((f16 ? amtx_pack_conv1g_dev_f16 : amtx_pack_conv1g_dev)(w, scale, ic, m->nf1, pl, (bf16_t*)m->conv1_frag.p + c1f_per * h, s));
+        else if (m->fuse_conv1) PACK_TRY((f16 ? amtx_pack_conv1_dev_f16 : amtx_pack_conv1_dev)(w, scale, pl, (bf16_t*)m->conv1_frag.p + c1f_per * h, s));
         NEED_DEV(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
         NEED_DEV(am + ".layer2.0.bias", (size_t)m->nf2, cb); NEED_DEV(am + ".layer2.1.weight", (size_t)m->nf2, g); NEED_DEV(am + ".layer2.1.bias", (size_t)m->nf2, be);
         NEED_DEV(am + ".layer2.1.running_mean", (size_t)m->nf2, mu); NEED_DEV(am + ".layer2.1.running_var", (size_t)m->nf2, var);
         PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf2, scale, (float*)m->conv2_s.p + (size_t)h * m->nf2, s));
-        PACK_TRY(pack_conv(w, scale, m->nf2, pl, (bf16_t*)m->conv2_w.p + c2w_per * h, s));
+        if (m->gen_conv2) PACK_TRY(pack_conv_gen(w, scale, m->nf1, m->nf2, pl, (bf16_t*)m->conv2_w.p + c2w_per * h, s));
+        else PACK_TRY(pack_conv(w, scale, m->nf2, pl, (bf16_t*)m->conv2_w.p + c2w_per * h, s));
         NEED_DEV(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
         NEED_DEV(am + ".layer3.0.bias", (size_t)m->nf3, cb); NEED_DEV(am + ".layer3.1.weight", (size_t)m->nf3, g); NEED_DEV(am + ".layer3.1.bias", (size_t)m->nf3, be);
         NEED_DEV(am + ".layer3.1.running_mean", (size_t)m->nf3, mu); NEED_DEV(am + ".layer3.1.running_var", (size_t)m->nf3, var);
         PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf3, scale, (float*)m->conv3_s.p + (size_t)h * m->nf3, s));
-        PACK_TRY(pack_conv(w, scale, m->nf3, pl, (bf16_t*)m->conv3_w.p + c3w_per * h, s));
+        if (m->gen_conv) PACK_TRY(pack_conv_gen(w, scale, m->nf2, m->nf3, pl, (bf16_t*)m->conv3_w.p + c3w_per * h, s));
+        else PACK_TRY(pack_conv(w, scale, m->nf3, pl, (bf16_t*)m->conv3_w.p + c3w_per * h, s));
         // fc1 of the recurrent heads, columns permuted (channel, freq) -> (freq, channel)
         if (h < m->n_rec) {
             const float* fb;
@@ -518,7 +528,7 @@ extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
         float* ihb = (float*)ih.b.p + (size_t)ih.N * grp;
         PACK_TRY(amtx_pack_vec_add_dev(bif, bhf, G, ihb, s));
         PACK_TRY(amtx_pack_vec_add_dev(bib, bhb, G, ihb + G, s));
-        PACK_TRY((f16 ? amtx_launch_bilstm_pack_dev_f16 : amtx_launch_bilstm_pack_dev)(whf, whb, pl, (bf16_t*)hh.p + hh_elems * grp, hh_bwd, s));
+        PACK_TRY((f16 ? amtx_launch_bilstm_pack_dev_h_f16 : amtx_launch_bilstm_pack_dev_h)(whf, whb, H, pl, (bf16_t*)hh.p + hh_elems * grp, hh_bwd, s));
         NEED_DEV(bank + ".output_layer.weight", (size_t)m->n_out * m->dim_lm, wo);
         NEED_DEV(bank + ".output_layer.bias", (size_t)m->n_out, bo);
         PACK_TRY(pack_lin(wo, m->dim_lm, m->n_out, m->dim_lm, pl, outp.n_pad, outp.k_pad, 0, outp.n_pad, 0, 0,

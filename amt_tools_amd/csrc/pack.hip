@@ -109,6 +109,58 @@ __global__ void head_fold_kernel(const float* w_out, const float* w_fc1, const f
     }
 }
 
+// convg.hip amtx_conv3x3_gen_pack_host: [chunk][fragment][plane][lane][8]; fragments of a chunk: the full 32-deep steps in (tap, tile,
+// step) order, then (C_in with a 16-channel tail) the paired tails A (kw, tile): taps (0,kw) | (1,kw); B (tile): (2,0) | (2,1); C (tile): (2,2) | 0.
+// One thread per (chunk, tile, lane, j).
+__global__ void conv_gen_pack_kernel(const float* w, const float* scale, int c_in, int c_out, int ntc, int planes, bf16_t* out) {
+    const int ci16 = c_in / 16, n32 = ci16 / 2, n16 = ci16 % 2;
+    const int nmain = 9 * ntc * n32, nfrag = nmain + 5 * ntc * n16;
+    const int nchunks = c_out / (16 * ntc);
+    const int total = nchunks * ntc * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int j = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int nt = r % ntc;
+        const int ch = r / ntc;
+        const int row = l & 15, gq = l >> 4;
+        const int co = ch * 16 * ntc + (row >> 2) * (4 * ntc) + 4 * nt + (row & 3);
+        const float sc = scale ? scale[co] : 1.0f;
+        bf16_t* cbase = out + (size_t)ch * nfrag * planes * 512;
+        auto wv = [&](int ci, int tap) { return w[((size_t)co * c_in + ci) * 9 + tap] * sc; };
+        auto put = [&](int frag, float v) { put16(cbase, (size_t)frag * planes * 512 + (size_t)l * 8 + j, 512, planes, v); };
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ks = 0; ks < n32; ++ks) put((tap * ntc + nt) * n32 + ks, wv(32 * ks + 8 * gq + j, tap));
+        if (!n16) continue;
+        const int ct = 32 * n32 + 8 * (gq & 1);
+        for (int kw = 0; kw < 3; ++kw) put(nmain + kw * ntc + nt, wv(ct + j, (gq < 2 ? 0 : 3) + kw));
+        put(nmain + 3 * ntc + nt, wv(ct + j, gq < 2 ? 6 : 7));
+        put(nmain + 4 * ntc + nt, gq < 2 ? wv(ct + j, 8) : 0.0f);
+    }
+}
+
+// convg.hip amtx_conv1g_pack_host: [tile of 16 channels][k-step][plane][lane][8], k = 32 ks + 8 (lane >> 4) + j over (ci, kh, kw), zero past 9 c_in
+__global__ void conv1g_pack_kernel(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out) {
+    const int kvalid = 9 * c_in, ks1 = (kvalid + 31) / 32;
+    const int total = (c_mid / 16) * ks1 * 64 * 8;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int j = r & 7; r >>= 3;
+        const int l = r & 63; r >>= 6;
+        const int ks = r % ks1;
+        const int nt = r / ks1;
+        const int co = 16 * nt + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+        const float v = k < kvalid ? w[(size_t)co * kvalid + k] * (scale ? scale[co] : 1.0f) : 0.0f;
+        put16(out, ((size_t)(nt * ks1 + ks) * planes) * 512 + (size_t)l * 8 + j, 512, planes, v);
+    }
+}
+
+// ofmodel.hip: the fp32 weights of the unfused first convolution, out[row][i] = w[row][i] * scale[row]
+__global__ void scale_rows_kernel(const float* w, const float* scale, int rows, int cols, float* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < rows * cols) out[idx] = w[idx] * scale[idx / cols];
+}
+
 __global__ void vec_add_kernel(const float* a, const float* b, int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
@@ -125,6 +177,25 @@ int amtx_pack_bn_fold_dev(const float* conv_bias, const float* gamma, const floa
 
 int amtx_pack_conv3x3_dev(const float* w, const float* scale, int c_out, int planes, bf16_t* out, hipStream_t s) {
     hipLaunchKernelGGL(conv3x3_pack_kernel, dim3(64), dim3(256), 0, s, w, scale, c_out, planes, out);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_pack_conv_gen_dev(const float* w, const float* scale, int c_in, int c_out, int ntc, int planes, bf16_t* out, hipStream_t s) {
+    AMTX_REQUIRE(ntc > 0 && c_in % 16 == 0 && c_out % (16 * ntc) == 0, "conv pack (general): bad channel counts %d -> %d", c_in, c_out);
+    hipLaunchKernelGGL(conv_gen_pack_kernel, dim3(32), dim3(256), 0, s, w, scale, c_in, c_out, ntc, planes, out);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_pack_conv1g_dev(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(conv1g_pack_kernel, dim3(16), dim3(256), 0, s, w, scale, c_in, c_mid, planes, out);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_pack_scale_rows_dev(const float* w, const float* scale, int rows, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, s, w, scale, rows, cols, out);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

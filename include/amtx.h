@@ -115,8 +115,9 @@ int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_
 
 /* Weight RE-SYNC without leaving the GPU (validate() inside train(), amt_tools/train.py:183-189): after one amtx_of_model_finalize, later
  * weight versions can be handed over as DEVICE pointers (fp32, contiguous, same state_dict names, borrowed until finalize_device returns)
- * and are folded / packed by kernels into the model's existing buffers -- the same bits the host path produces.  One-channel models at
- * model_complexity 2 (any precision); AMTX_ERR_UNSUPPORTED otherwise (callers then use set_tensor + finalize). */
+ * and are folded / packed by kernels into the model's existing buffers -- the same bits the host path produces.  Every built
+ * configuration and precision; AMTX_ERR_UNSUPPORTED only for a multi-channel first conv forced onto conv.hip's kernel
+ * (AMTX_NO_CONVG_MC2): callers then use set_tensor + finalize. */
 int amtx_of_model_set_tensor_device(amtx_of_model* model, const char* name, const float* device_data, int64_t numel);
 int amtx_of_model_finalize_device(amtx_of_model* model, void* stream);
 

@@ -302,22 +302,26 @@ def test_f16_precision_vs_oracle_on_both_convolution_paths(dim_in):
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'x3', 'f16'])
-@pytest.mark.parametrize('cls', ['OnsetsFrames', 'OnsetsFrames2'])
-def test_device_side_weight_sync_equals_the_host_path(cls, precision, monkeypatch):
+@pytest.mark.parametrize('cls,mc,dim_in,ic', [('OnsetsFrames', 2, 229, 1), ('OnsetsFrames2', 2, 229, 1), ('OnsetsFrames2', 3, 229, 1), ('OnsetsFrames', 2, 72, 6),
+                                              ('OnsetsFrames', 3, 72, 6), ('OnsetsFrames', 4, 229, 1), ('OnsetsFrames2', 4, 72, 3)])
+def test_device_side_weight_sync_equals_the_host_path(cls, mc, dim_in, ic, precision, monkeypatch):
     """A weight RE-sync packs on the GPU (pack.hip, amtx_of_model_finalize_device) with the host packers' arithmetic: after the same
     parameter update, an engine re-synced on the device and one re-synced through the host (AMTX_HOST_WEIGHT_SYNC=1) return identical
-    bits -- BatchNorm statistics, every convolution / Linear / LSTM tensor and the fp64-folded pitch head included."""
+    bits -- BatchNorm statistics, every convolution / Linear / LSTM tensor and the fp64-folded pitch head included.  Every engine
+    configuration: conv.hip / convf.hip fragments (model_complexity 2, one channel), convg.hip's chunked fragments with and without a
+    16-channel tail and its fused first conv (3, 4, multi-channel input), hidden 128 / 256 / 384 recurrences, the unfused first conv
+    (x3 at model_complexity 4)."""
     import amt_tools_amd.models as M
     offsets = cls == 'OnsetsFrames2'
-    sd = synth_state_dict(9, dim_in=229, in_channels=1, model_complexity=2, offsets=offsets)
-    feats = torch.from_numpy(np.random.default_rng(4).random((3, 1, 229, 40)).astype(np.float32)).cuda()
+    sd = synth_state_dict(9, dim_in=dim_in, in_channels=ic, model_complexity=mc, offsets=offsets)
+    feats = torch.from_numpy(np.random.default_rng(4).random((3, ic, dim_in, 40)).astype(np.float32)).cuda()
     outs = {}
     for mode in ('device', 'host'):
         if mode == 'host':
             monkeypatch.setenv('AMTX_HOST_WEIGHT_SYNC', '1')
         else:
             monkeypatch.delenv('AMTX_HOST_WEIGHT_SYNC', raising=False)
-        model = getattr(M, cls)(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
+        model = getattr(M, cls)(dim_in, tools.PianoProfile(), ic, mc, device='cuda:0', precision=precision)
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         model.change_device()
         model.eval()
@@ -339,14 +343,16 @@ def test_device_side_weight_sync_equals_the_host_path(cls, precision, monkeypatc
         assert torch.equal(outs['device'][k], outs['host'][k]), (k, (outs['device'][k] - outs['host'][k]).abs().max().item())
 
 
-def test_device_side_weight_sync_falls_back_where_it_is_not_built():
-    """model_complexity 3 (convg.hip fragment layouts, hidden-256 recurrence) re-syncs through the host: amtx_of_model_finalize_device answers
-    AMTX_ERR_UNSUPPORTED, the engine notes it and the results follow the new weights all the same."""
+def test_device_side_weight_sync_falls_back_where_it_is_not_built(monkeypatch):
+    """A multi-channel first conv on conv.hip's kernel (AMTX_NO_CONVG_MC2: the A/B switch back from convg.hip's) has no device packer:
+    amtx_of_model_finalize_device answers AMTX_ERR_UNSUPPORTED, the engine notes it, re-syncs through the host and the results follow the
+    new weights all the same."""
     import amt_tools_amd.models as M
-    model = M.OnsetsFrames2(229, tools.PianoProfile(), 1, 3, device='cuda:0')
+    monkeypatch.setenv('AMTX_NO_CONVG_MC2', '1')
+    model = M.OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0')
     model.change_device()
     model.eval()
-    feats = torch.rand(2, 1, 229, 20, device='cuda')
+    feats = torch.rand(2, 6, 72, 20, device='cuda')
     with torch.no_grad():
         a = model.engine_logits(feats)['multi_pitch'].clone()
         for p_ in model.parameters():
