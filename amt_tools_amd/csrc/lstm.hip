@@ -268,26 +268,40 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
         }
 
     char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
+    // The cells of a lane are independent chains of ~12 dependent operations (five of them exp / rcp pairs): all arithmetic first, the
+    // (per-lane predicated) stores behind it -- with a predicated store between the cells hipcc runs the chains one after the other
+    // (a branch around each store), which is most of what a second clip per lane costs.
+    float ig[NC], fg[NC], gg[NC], og[NC], h[NC];
+    uint32_t hiw[NC], low[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-        const float ig = sigmoid_f<FAST>(acc[0][RSTEP * j]);
-        const float fg = sigmoid_f<FAST>(acc[1][RSTEP * j]);
-        const float gg = tanh_f<FAST>(acc[2][RSTEP * j]);
-        const float og = sigmoid_f<FAST>(acc[3][RSTEP * j]);
-        c[j] = fg * c[j] + ig * gg;
-        const float h = og * tanh_f<FAST>(c[j]);
+        ig[j] = sigmoid_f<FAST>(acc[0][RSTEP * j]);
+        fg[j] = sigmoid_f<FAST>(acc[1][RSTEP * j]);
+        gg[j] = tanh_f<FAST>(acc[2][RSTEP * j]);
+        og[j] = sigmoid_f<FAST>(acc[3][RSTEP * j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        c[j] = fg[j] * c[j] + ig[j] * gg[j];
+        h[j] = og[j] * tanh_f<FAST>(c[j]);
+        low[j] = 0;
+        if (NS == 2) split_bf16x2(h[j], 0.f, hiw[j], low[j]);
+        else hiw[j] = pack_bf16x2(h[j], 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        *reinterpret_cast<unsigned short*>(hn + hwoff[j]) = (unsigned short)hiw[j];
+        if (NS == 2) *reinterpret_cast<unsigned short*>(hn + HBUF_BYTES + hwoff[j]) = (unsigned short)low[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
         if (NC == 1 && save && clip_ok[j]) {     // training: post-activation gates and the new cell state, [b][t][dir][5][128] (save points at [b][0][dir][0][unit])
             float* sv = save + (int64_t)t * (2 * 5 * H);
-            sv[0] = ig; sv[H] = fg; sv[2 * H] = gg; sv[3 * H] = og; sv[4 * H] = c[j];
+            sv[0] = ig[j]; sv[H] = fg[j]; sv[2 * H] = gg[j]; sv[3 * H] = og[j]; sv[4 * H] = c[j];
         }
-        uint32_t hiw, low = 0;
-        if (NS == 2) split_bf16x2(h, 0.f, hiw, low);
-        else hiw = pack_bf16x2(h, 0.f);
-        *reinterpret_cast<unsigned short*>(hn + hwoff[j]) = (unsigned short)hiw;
-        if (NS == 2) *reinterpret_cast<unsigned short*>(hn + HBUF_BYTES + hwoff[j]) = (unsigned short)low;
         if (clip_ok[j]) {
-            if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<unsigned short*>(obase[j] + (int64_t)t * 256 * 2) = (unsigned short)hiw;
-            else *reinterpret_cast<float*>(obase[j] + (int64_t)t * 256 * 4) = h;
+            if (OUT_TYPE == AMTX_T_BF16) *reinterpret_cast<unsigned short*>(obase[j] + (int64_t)t * 256 * 2) = (unsigned short)hiw[j];
+            else *reinterpret_cast<float*>(obase[j] + (int64_t)t * 256 * 4) = h[j];
         }
     }
     lds_barrier();
