@@ -411,6 +411,46 @@ def test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path(dim_in, monkey
             assert torch.equal(got['fused'][k], got['two-kernel'][k]), (cls, B, T, k, (got['fused'][k] - got['two-kernel'][k]).abs().max().item())
 
 
+def test_whole_tracks_of_several_thousand_frames(monkeypatch):
+    """The reference transcribes WHOLE tracks in one forward pass (transcribe.py / evaluate.py feed run_on_batch a track's full feature
+    matrix: thousands of frames, batch 1 - 2).  2 tracks x 4001 frames (65 strips per track, the last one 33 frames long; 4001 dependent
+    recurrence steps): the fused stack (2 heads x 2 x 65 = 260 strips) returns the bits of the two-kernel path, and the x3 engine stays
+    within 3e-4 of the CPU oracle at the start, in the middle and at the end of the track."""
+    from oracle import model_ref
+    import amt_tools_amd.models as M
+    B, T, dim_in = 2, 4001, 229
+    feats = torch.from_numpy(np.random.default_rng(8).random((B, 1, dim_in, T)).astype(np.float32))
+    got = {}
+    for mode in ('fused', 'two-kernel'):
+        if mode == 'two-kernel':
+            monkeypatch.setenv('AMTX_NO_CONV_FUSE', '1')
+        else:
+            monkeypatch.delenv('AMTX_NO_CONV_FUSE', raising=False)
+        model = _of1_bf16(32, dim_in)
+        assert model._get_engine(torch.device('cuda:0')).conv_stack_fused(B, T) == (mode == 'fused')
+        with torch.no_grad():
+            got[mode] = {k: v.clone() for k, v in model.engine_logits(feats.cuda()).items()}
+        del model
+    for k in got['fused']:
+        assert torch.equal(got['fused'][k], got['two-kernel'][k]), k
+    monkeypatch.delenv('AMTX_NO_CONV_FUSE', raising=False)
+    sd = synth_state_dict(32, dim_in=dim_in, in_channels=1, model_complexity=2)
+    sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model = M.OnsetsFrames(dim_in, tools.PianoProfile(), 1, 2, device='cuda:0', precision='x3')
+    model.load_state_dict(sdt)
+    model.change_device()
+    model.eval()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        x3 = model.engine_logits(feats.cuda())
+        ref = model_ref.run_on_batch(feats[:1], sdt)          # the recurrences make every frame depend on the whole track: no cropping
+    for key in ('onsets', 'multi_pitch', 'pitch_head'):
+        for lo, hi in ((0, 64), (1970, 2034), (T - 64, T)):
+            err = (x3[key][0, lo:hi].cpu() - ref['logits'][key][0, lo:hi]).abs().max().item()
+            assert err < 3e-4, (key, lo, err)
+        assert (got['fused'][key][0].cpu() - ref['logits'][key][0]).abs().max().item() < 6e-2, key
+
+
 def test_fused_conv_stack_on_raw_power_features_is_bit_identical(monkeypatch):
     """The same, entered through amtx_of_forward_power (audio -> log-mel power -> engine, dB scaling applied while the features are staged):
     piano rolls of run_on_batch on audio with and without the fused stack."""
