@@ -23,6 +23,7 @@ python3 tools/pmc_summary.py $O/pmc_${TAG}_* > $O/${TAG}_pmc_counters.txt
 {
   echo "== tools/bench_hcqt.py 512 (BASELINE config 3)"; timeout 300 python3 tools/bench_hcqt.py 512 2>&1 | grep -v amdgpu.ids | tail -3
   echo "== tools/bench_of2.py 1024 (OnsetsFrames2 as shipped: model_complexity 3, offset head, HTK mel)"; timeout 300 python3 tools/bench_of2.py 1024 2>&1 | grep -v amdgpu.ids | tail -1
+  echo "== tools/bench_of2.py 512 3 | 256 4 (model_complexity 3 at 512 clips, model_complexity 4)"; timeout 300 python3 tools/bench_of2.py 512 3 2>&1 | grep -v amdgpu.ids | tail -1; timeout 300 python3 tools/bench_of2.py 256 4 2>&1 | grep -v amdgpu.ids | tail -1
   echo "== tools/bench_train.py (BASELINE config 4, one GPU)"; timeout 300 python3 tools/bench_train.py 2>&1 | grep -v amdgpu.ids | tail -1
   echo "== tools/bench_train.py --of2 (OnsetsFrames2 as shipped, one GPU)"; timeout 300 python3 tools/watchdog_run.py 250 tools/bench_train.py --of2 --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tail -1
   echo "== tools/latency.py"; timeout 300 python3 tools/latency.py 2>&1 | grep -v amdgpu.ids | tail -6
