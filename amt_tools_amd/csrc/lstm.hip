@@ -553,11 +553,13 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     constexpr bool FAST = true;
     constexpr int RS = 4;                         // ring slots: RS - 1 streamed groups (4 KiB each per wave) in flight (8 slots: no faster,
                                                   // the stream is bound by the 64 B/clk a CU's vector memory path takes, not by latency)
-    // Of every four consecutive groups of a wave, group 0 is held in registers and group 1 in LDS for the whole launch (bf16
-    // mode: 64 spare VGPRs, 128 KiB of LDS per block), the other two are streamed: half the bytes per step.
-    constexpr bool PIN = NS == 1 && HH == 256;   // (HH = 384: 9 groups per kind would be 144 VGPRs / 288 KiB of LDS: all streamed)
-    constexpr int NPIN = PIN ? NG / 4 : 0;        // groups pinned per kind (registers, LDS) and wave
-    constexpr int NSG = NG - 2 * NPIN;            // streamed groups per step and wave
+    // HH = 256, bf16: of every four consecutive groups of a wave, group 0 is held in registers and group 1 in LDS for the whole launch
+    // (64 spare VGPRs, 128 KiB of LDS per block), the other two are streamed: half the bytes per step.  HH = 384, bf16: 36 groups per
+    // wave, no spare registers; every ninth group (4 per wave, again 128 KiB per block) sits in LDS, 32 are streamed.
+    constexpr bool PIN = NS == 1 && HH == 256;    // register + LDS pinning, period 4
+    constexpr bool PINL = NS == 1 && HH == 384;   // LDS pinning only, period 9
+    constexpr int NPIN = PIN ? NG / 4 : (PINL ? NG / 9 : 0);   // groups pinned per kind and wave
+    constexpr int NSG = NG - (PIN ? 2 : (PINL ? 1 : 0)) * NPIN;   // streamed groups per step and wave
     static_assert(NU % 8 == 0 && KSN % SGK == 0 && NG % 4 == 0 && NSG % RS == 0, "hidden size must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HPG] bf16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -608,17 +610,19 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     auto load_frag = [&](int gi, int k, int p) {
         return __builtin_bit_cast(uint4, *reinterpret_cast<const gu4_t*>(wb + ((gi * SGK + k) * NS + p) * 1024 + wlane));
     };
-    if constexpr (PIN) {
+    if constexpr (PIN || PINL) {
         static_for<0, NG>([&](auto ic) {
             constexpr int gi = decltype(ic)::value;
-            if constexpr ((gi & 3) < 2) {
+            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : (gi % 9 == 0 ? 1 : 2);
+            constexpr int pidx = PIN ? gi >> 2 : gi / 9;
+            if constexpr (kind < 2) {
                 static_for<0, SGK>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
                     static_for<0, NS>([&](auto pc) {
                         constexpr int p = decltype(pc)::value;
                         const uint4 v = load_frag(gi, k, p);
-                        if constexpr ((gi & 3) == 0) wpin[gi >> 2][k][p] = v;
-                        else *reinterpret_cast<uint4*>(wlds + (((gi >> 2) * SGK + k) * NS + p) * 1024 + wlane) = v;
+                        if constexpr (kind == 0) wpin[pidx][k][p] = v;
+                        else *reinterpret_cast<uint4*>(wlds + ((pidx * SGK + k) * NS + p) * 1024 + wlane) = v;
                     });
                 });
             }
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     load_xrow(tidx(0), xn);
     static_for<0, RS - 1>([&](auto sc) {
         constexpr int si = decltype(sc)::value;
-        constexpr int gi = PIN ? (si >> 1) * 4 + 2 + (si & 1) : si;
+        constexpr int gi = PIN ? (si >> 1) * 4 + 2 + (si & 1) : (PINL ? si + si / 8 + 1 : si);
         static_for<0, SGK>([&](auto kc) {
             static_for<0, NS>([&](auto pc) { w[si % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
         });
@@ -663,12 +667,13 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
         static_for<0, NG>([&](auto ic) {
             constexpr int gi = decltype(ic)::value;
             constexpr int ub = gi / (4 * NSUB), q = (gi / NSUB) & 3, sub = gi % NSUB;
-            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : 2;     // 0 registers, 1 LDS, 2 streamed
-            constexpr int si = PIN ? (gi >> 2) * 2 + (gi & 3) - 2 : gi;                        // index among the streamed groups
+            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : (PINL ? (gi % 9 == 0 ? 1 : 2) : 2);     // 0 registers, 1 LDS, 2 streamed
+            constexpr int pidx = PIN ? gi >> 2 : gi / 9;                                        // index among the pinned groups of its kind
+            constexpr int si = PIN ? (gi >> 2) * 2 + (gi & 3) - 2 : (PINL ? gi - gi / 9 - 1 : gi);   // index among the streamed groups
             if constexpr (kind == 2) {
                 // behind the last RS - 1 streamed groups: the first ones of the next step
                 constexpr int sn = (si + RS - 1) % NSG;
-                constexpr int gn = PIN ? (sn >> 1) * 4 + 2 + (sn & 1) : sn;
+                constexpr int gn = PIN ? (sn >> 1) * 4 + 2 + (sn & 1) : (PINL ? sn + sn / 8 + 1 : sn);
                 static_for<0, SGK>([&](auto kc) {
                     static_for<0, NS>([&](auto pc) { w[sn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
                 });
@@ -679,9 +684,9 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
                 constexpr int ks = sub * SGK + k;
                 uint4 w0, w1;
                 if constexpr (kind == 0) {
-                    w0 = wpin[gi >> 2][k][0]; w1 = wpin[gi >> 2][k][NS - 1];
+                    w0 = wpin[pidx][k][0]; w1 = wpin[pidx][k][NS - 1];
                 } else if constexpr (kind == 1) {
-                    w0 = *reinterpret_cast<const uint4*>(wlds + (((gi >> 2) * SGK + k) * NS + 0) * 1024 + wlane);
+                    w0 = *reinterpret_cast<const uint4*>(wlds + ((pidx * SGK + k) * NS + 0) * 1024 + wlane);
                     w1 = w0;
                 } else {
                     w0 = w[si % RS][k][0]; w1 = w[si % RS][k][NS - 1];
@@ -953,7 +958,8 @@ __global__ void bilstm_pack_dev_h_kernel(const float* __restrict__ whh_fwd, cons
 template <int HH, int NS, int X_TYPE, int OUT_TYPE>
 int launch_stream(const LstmArgs& a, hipStream_t stream) {
     // h tiles + (bf16 mode) the LDS-resident quarter of W_hh: 8 waves x (groups / 4) x 4 KiB
-    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 && HH == 256 ? (size_t)8 * ((HH / 128) * 4 * (HH / 32 / 4) / 4) * 4096 : 0);
+    // h tiles + (bf16 mode) the LDS-resident groups of W_hh: 8 waves x 4 groups x 4 KiB at either hidden size
+    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 ? (size_t)8 * 4 * 4096 : 0);
     auto kern = bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>;
     AMTX_GRANT_LDS(kern, lds);
     dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
