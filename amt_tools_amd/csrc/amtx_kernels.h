@@ -31,6 +31,10 @@ struct GemmArgs {
     // optional, same kernel: a bf16 copy of the output rows into copy16[m * copy16_ld + copy16_col0 + grp * copy16_gs + n] with copy16_pad zero
     // columns behind column N - 1 (N + copy16_pad <= n_pad); C may be null
     bf16_t* copy16 = nullptr; int64_t copy16_ld = 0; int copy16_col0 = 0, copy16_gs = 0, copy16_pad = 0;
+    // A stored in PLANES of 64 columns (direct-to-LDS kernels only): element (m, k) at A[(k / 64) * a_plane + m * 64 + k % 64] -- the layout the
+    // fused convolution stack writes (one plane per pooled frequency column: a 64-deep k-tile of 256 rows is 32 KiB of CONTIGUOUS memory
+    // instead of 256 pieces of 128 bytes 7296 bytes apart).  0: row-major with lda.
+    int64_t a_plane = 0;
 };
 bool amtx_gemm_has_roll_epilogue(const GemmArgs& g);
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -74,7 +78,7 @@ void amtx_conv3x3_pack_host(const float* w, const float* scale, int c_out, int p
 // shift; out = [groups][B][T][F / 4][64] bf16.  amtx_conv_stack_fused_ok: the batch is large enough for its one-strip-per-CU granularity.
 bool amtx_conv_stack_fused_ok(int B, int T, int F, int groups);
 int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_gs, const float* shift3, void* out, int64_t out_gs,
-                           hipStream_t stream);
+                           int64_t out_plane, hipStream_t stream);
 
 // general channel counts (convg.hip): C_in a multiple of 16, weights staged in LDS per C_out chunk; `a.in` is [B][T][F][c_in]
 int amtx_conv3x3_gen_ntc(int c_in, int c_out);           // 0 = this pair of channel counts is not built

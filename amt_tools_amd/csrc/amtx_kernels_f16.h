@@ -9,7 +9,7 @@ void amtx_conv1_pack_host_f16(const float* w, const float* scale, int c_in, int 
 int amtx_launch_conv3x3_f16(const ConvArgs& c, hipStream_t stream);
 int amtx_launch_conv1_f16(const Conv1Args& c, hipStream_t stream);
 int amtx_launch_conv_stack_f16(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_gs, const float* shift3, void* out, int64_t out_gs,
-                               hipStream_t stream);
+                               int64_t out_plane, hipStream_t stream);
 void amtx_conv3x3_gen_pack_host_f16(const float* w, const float* scale, int c_in, int c_out, int planes, bf16_t* out);
 void amtx_conv1g_pack_host_f16(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out);
 int amtx_launch_conv3x3_gen_f16(const ConvArgs& c, int c_in, hipStream_t stream);

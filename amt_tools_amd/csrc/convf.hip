@@ -109,6 +109,7 @@ struct ConvFArgs {
     const bf16_t* w2frag; int64_t w2_gs; const float* shift2;         // amtx_conv3x3_pack_host(32), [groups][32]
     const bf16_t* w3frag; int64_t w3_gs; const float* shift3;         // amtx_conv3x3_pack_host(64), [groups][64]
     bf16_t* out; int64_t out_gs;                                      // [groups][B][T][F / 4][64]
+    int64_t out_plane;                                                // != 0: [groups][F / 4][B T][64], out_plane = B T 64 (GemmArgs::a_plane)
     int B, T, F;
 };
 
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
                                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
-                                uint4* dst = reinterpret_cast<uint4*>(a.out + (int64_t)grp * a.out_gs + (((int64_t)pc.b * a.T + t) * F4 + m) * 64 + g * 8);
+                                const int64_t orow = (int64_t)pc.b * a.T + t;
+                                uint4* dst = reinterpret_cast<uint4*>(a.out + (int64_t)grp * a.out_gs + (a.out_plane ? m * a.out_plane + orow * 64 : (orow * F4 + m) * 64) + g * 8);
 #pragma unroll
                                 for (int q = 0; q < 2; ++q)
                                     dst[4 * q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
@@ -617,7 +619,7 @@ bool amtx_conv_stack_fused_ok(int B, int T, int F, int groups) {
 }
 
 int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_gs, const float* shift3, void* out, int64_t out_gs,
-                           hipStream_t stream) {
+                           int64_t out_plane, hipStream_t stream) {
     AMTX_REQUIRE(c2.feats && c2.c_in == 1 && c2.w1frag && c2.shift1 && c2.wfrag && c2.shift && w3frag && shift3 && out,
                  "conv_stack: null pointer / not a one-channel input");
     AMTX_REQUIRE(c2.planes == 1 && c2.c_out == 32 && c2.out_type == AMTX_T_BF16, "conv_stack: bf16, 32 -> 32 -> 64 channels only");
@@ -630,7 +632,7 @@ int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_
     a.w1frag = c2.w1frag; a.w1_gs = c2.w1_gs; a.shift1 = c2.shift1;
     a.w2frag = c2.wfrag; a.w2_gs = c2.w_gs; a.shift2 = c2.shift;
     a.w3frag = w3frag; a.w3_gs = w3_gs; a.shift3 = shift3;
-    a.out = (bf16_t*)out; a.out_gs = out_gs;
+    a.out = (bf16_t*)out; a.out_gs = out_gs; a.out_plane = out_plane;
     a.B = c2.B; a.T = c2.T; a.F = c2.F;
     const int ntt = (c2.T + R3 - 1) / R3;
     const int64_t nstrips = (int64_t)c2.B * ntt;

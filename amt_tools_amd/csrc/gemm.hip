@@ -285,6 +285,8 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
     const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
     char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
 
+    // A row-major (row pitch lda, a k-tile 64 columns further) or in planes of 64 columns (GemmArgs::a_plane: row pitch 64, a k-tile one plane further)
+    const int64_t a_pitch = g.a_plane ? GBK : g.lda, a_kstep = g.a_plane ? g.a_plane : GBK;
     // this wave DMAs rows [32*wave, 32*wave+32) of both tiles: 4 instructions x 8 rows each
     const bf16_t* a_src[4];
     const bf16_t* w_src[4];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
             const int cw = (lane & 7) ^ wswz(row);                                                            \
             int64_t mr = tm0 + row;                                                                           \
             if (mr >= g.M) mr = g.M - 1; /* rows past M are never stored; keep the read in bounds */          \
-            a_src[n] = Abase + mr * g.lda + c * 8;                                                            \
+            a_src[n] = Abase + mr * a_pitch + c * 8;                                                          \
             w_src[n] = Wbase + (int64_t)(tn0 + row) * g.k_pad + cw * 8;                                       \
         }                                                                                                     \
     } while (0)
@@ -311,8 +313,9 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
 #define GLDS_ISSUE(k0, buf)                                                                                   \
     do {                                                                                                      \
         const unsigned sb = lds_base + (buf) * 2 * TILE;                                                      \
+        const int64_t a_off = (int64_t)((k0) / GBK) * a_kstep;                                                \
         _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                       \
-            glds16(a_src[n] + (k0), sb + n * 1024);                                                           \
+            glds16(a_src[n] + a_off, sb + n * 1024);                                                          \
             glds16(w_src[n] + (k0), sb + TILE + n * 1024);                                                    \
         }                                                                                                     \
     } while (0)
@@ -827,6 +830,11 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(!g.roll_out || amtx_gemm_has_roll_epilogue(g), "gemm: the piano-roll epilogue exists on the bf16 direct-to-LDS path with fp32 C only");
     AMTX_REQUIRE(!g.roll_out || (g.roll_T > 0 && g.M % g.roll_T == 0 && g.M < (1ll << 31)), "gemm: piano-roll epilogue: M must be clips x frames");
     if (g.a_type == AMTX_T_BF16 && g.planes == 1 && g.K % GBK == 0 && g.k_pad == g.K && (g.lda % 8) == 0) {
+        if (g.a_plane) {      // planar A: the two-buffer direct-to-LDS kernel only
+            if (g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256)
+                return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 256>(g, stream) : launch_glds<AMTX_T_F32, 256>(g, stream);
+            return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 128>(g, stream) : launch_glds<AMTX_T_F32, 128>(g, stream);
+        }
         // A/B switches for tools/bench_gemm.py / tools/check_gemm_pp.py: AMTX_GEMM_PP=1 forces the two-group ring for any K,
         // AMTX_GEMM_NO_PP=1 disables it
         static const bool force_pp = getenv("AMTX_GEMM_PP") != nullptr, no_pp = getenv("AMTX_GEMM_NO_PP") != nullptr;
@@ -839,6 +847,7 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
             return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 256>(g, stream) : launch_glds<AMTX_T_F32, 256>(g, stream);
         return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 128>(g, stream) : launch_glds<AMTX_T_F32, 128>(g, stream);
     }
+    AMTX_REQUIRE(!g.a_plane, "gemm: planar A exists on the bf16 direct-to-LDS path only");
     const int key = (g.a_type << 2) | (g.c_type << 1) | (g.planes - 1);
     switch (key) {
         case 0: return launch<AMTX_T_BF16, AMTX_T_BF16, 1>(g, stream);

@@ -630,10 +630,14 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         c2.f_clip_max = clip_max; c2.f_ref = ref;
     }
     const bool fused_stack = m->fuse_stack && amtx_conv_stack_fused_ok(B, T, F, m->n_heads);
+    // the fused stack writes its output in planes of 64 channels per pooled frequency column ([F / 4][B T][64]): a k-tile of the two GEMMs
+    // that read it (fc1, the folded pitch head) is then contiguous memory.  A/B switch: AMTX_OF_ROWMAJOR_A3=1
+    static const bool rowmajor_a3 = getenv("AMTX_OF_ROWMAJOR_A3") != nullptr;
+    const int64_t a3_plane = (fused_stack && !rowmajor_a3 && m->nf3 == 64 && m->kfc_pad == m->kfc) ? BT * 64 : 0;
     if (fused_stack) {
         // layer1 -> layer2 -> layer3 in one kernel: neither intermediate map reaches HBM (stage timer: all of it under conv2_pool)
         if ((rc = (f16 ? amtx_launch_conv_stack_f16 : amtx_launch_conv_stack)(c2, (const bf16_t*)m->conv3_w.p, (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl), (const float*)m->conv3_s.p,
-                                         w.a3, BT * m->kfc_pad, s)) != AMTX_OK) return rc;
+                                         w.a3, BT * m->kfc_pad, a3_plane, s)) != AMTX_OK) return rc;
     } else if ((rc = m->gen_conv2 ? launch_convg(c2, m->nf1, s) : launch_conv(c2, s)) != AMTX_OK) return rc;
     mark();
 
@@ -656,6 +660,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
 
     // fc1 of the recurrent heads (heads 0..n_rec-1 of a3); the pitch head's fc1 is folded into its output layer below
     GemmArgs g = gemm_args(w.a3, m->kfc_pad, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_rec, BT * m->kfc_pad, BT * m->dim_am);
+    g.a_plane = a3_plane;
     if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
@@ -682,6 +687,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     const int kp = (m->dim_aj + 63) / 64 * 64;
     GemmArgs gp = gemm_args(w.a3 + (size_t)(m->n_heads - 1) * BT * m->kfc_pad * amtx_tsize(at), m->kfc_pad, at, m->pitch_out, pl,
                             w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
+    gp.a_plane = a3_plane;
     const bool copy_on = pl == 1 && !no_roll_epi && amtx_gemm_has_roll_epilogue(g) && amtx_gemm_has_roll_epilogue(gp) && m->n_out % 4 == 0 &&
                          (kp - m->dim_aj) % 4 == 0 && gp.N + (kp - m->dim_aj) <= gp.n_pad;
     if (copy_on) {
