@@ -414,7 +414,8 @@ def test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path(dim_in, monkey
 def test_whole_tracks_of_several_thousand_frames(monkeypatch):
     """The reference transcribes WHOLE tracks in one forward pass (transcribe.py / evaluate.py feed run_on_batch a track's full feature
     matrix: thousands of frames, batch 1 - 2).  2 tracks x 4001 frames (65 strips per track, the last one 33 frames long; 4001 dependent
-    recurrence steps): the fused stack (2 heads x 2 x 65 = 260 strips) returns the bits of the two-kernel path, and the x3 engine stays
+    recurrence steps): the fused stack (2 heads x 2 x 65 = 260 strips; its output in planes per frequency column or, AMTX_OF_ROWMAJOR_A3=1,
+    row-major) returns the bits of the two-kernel path, and the x3 engine stays
     within 3e-4 of the CPU oracle at the start, in the middle and at the end of the track."""
     from oracle import model_ref
     import amt_tools_amd.models as M
@@ -433,6 +434,20 @@ def test_whole_tracks_of_several_thousand_frames(monkeypatch):
         del model
     for k in got['fused']:
         assert torch.equal(got['fused'][k], got['two-kernel'][k]), k
+    # (the A/B switch is read once per process: the row-major layout of the fused stack's output is compared in a fresh interpreter)
+    import subprocess, sys, os
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, 'tests'); import test_gpu_model as t; "
+            "f = torch.from_numpy(np.random.default_rng(8).random((2, 1, 229, 4001)).astype(np.float32)).cuda(); "
+            "m = t._of1_bf16(32, 229); assert m._get_engine(torch.device('cuda:0')).conv_stack_fused(2, 4001); "
+            "torch.save({k: v.cpu() for k, v in m.engine_logits(f).items()}, sys.argv[1])")
+    out_path = os.path.join(os.environ.get('TMPDIR', '/tmp'), f'amtx_rowmajor_a3_{os.getpid()}.pt')
+    env = dict(os.environ, AMTX_OF_ROWMAJOR_A3='1')
+    env.pop('AMTX_NO_CONV_FUSE', None)
+    subprocess.run([sys.executable, '-c', code, out_path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    rowmajor = torch.load(out_path)
+    os.remove(out_path)
+    for k in got['fused']:
+        assert torch.equal(got['fused'][k].cpu(), rowmajor[k]), k
     monkeypatch.delenv('AMTX_NO_CONV_FUSE', raising=False)
     sd = synth_state_dict(32, dim_in=dim_in, in_channels=1, model_complexity=2)
     sdt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
