@@ -201,6 +201,25 @@ static __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_add
                  : "memory");
 }
 
+// Four pieces with ONE m0 set-up: piece n reads gsrc[n] and lands at lds_addr + n * 1024.  The instruction offset is added to both
+// addresses, so the global pointers are passed n KiB low.
+static __device__ __forceinline__ void glds16x4(const void* g0, const void* g1, const void* g2, const void* g3, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    const char* p1 = static_cast<const char*>(g1) - 1024;
+    const char* p2 = static_cast<const char*>(g2) - 2048;
+    const char* p3 = static_cast<const char*>(g3) - 3072;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "global_load_lds_dwordx4 %3, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %4, off offset:3072\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g0), "v"(p1), "v"(p2), "v"(p3), "s"(lds_addr)
+                 : "memory");
+}
+
 template <int N>
 static __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

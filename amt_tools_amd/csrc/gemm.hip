@@ -314,10 +314,8 @@ __global__ __launch_bounds__(TB * 2, (TB == 128 ? 2 : 1)) void gemm_glds_kernel(
     do {                                                                                                      \
         const unsigned sb = lds_base + (buf) * 2 * TILE;                                                      \
         const int64_t a_off = (int64_t)((k0) / GBK) * a_kstep;                                                \
-        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                       \
-            glds16(a_src[n] + a_off, sb + n * 1024);                                                          \
-            glds16(w_src[n] + (k0), sb + TILE + n * 1024);                                                    \
-        }                                                                                                     \
+        glds16x4(a_src[0] + a_off, a_src[1] + a_off, a_src[2] + a_off, a_src[3] + a_off, sb);                 \
+        glds16x4(w_src[0] + (k0), w_src[1] + (k0), w_src[2] + (k0), w_src[3] + (k0), sb + TILE);              \
     } while (0)
 #define GLDS_COMPUTE(buf)                                                                                     \
     do {                                                                                                      \
