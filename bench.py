@@ -89,7 +89,7 @@ def parse(argv=None):
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'])
     ap.add_argument('--clips', type=int, default=None, help='clips per GPU per step (default 1024 for infer -- sweep on MI355X, round 3: 512: 37.7, '
                                                             '768: 38.6, 1024: 40.2, 1536: 39.5, 2048: 40.4 M frames/s -- and 8 for train, the reference batch)')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'x3'])
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f16', 'x3'])
     ap.add_argument('--of2', action='store_true', help='train mode: OnsetsFrames2 as shipped (model_complexity 3, offset head)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-train-probe', action='store_true', help='skip the one-GPU training-step time (BASELINE metric ii) appended to the default line')
@@ -546,7 +546,7 @@ def run_infer(args, rank, world, device):
         'metric': 'audio frames/sec (OnsetsFrames+Mel-229 inference)', 'value': fps, 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if args.precision == 'bf16' else 'bf16x3', 'data': 'synthetic',
+        'dtype': {'bf16': 'bf16', 'f16': 'f16', 'x3': 'bf16x3'}[args.precision], 'data': 'synthetic',
         'config': config, 'roofline': roof,
     }
     oracle_rolls = None
