@@ -10,7 +10,7 @@
 // run layer3, so that each SIMD hosts one wave of either kind and their (equal) matrix work shares the SIMD's matrix pipe; every wave
 // keeps ITS layer's folded weights stationary in registers (producer 72 + layer1's 32, consumer 144 VGPRs), which is why the split is
 // by layer: one wave cannot hold both sets.
-// A block owns "strips" = (head, clip, 62 consecutive frames) and STREAMS each strip along the frequency axis in steps of 8
+// A block owns "strips" = (head, clip, 62 or 60 consecutive frames: HALO below) and STREAMS each strip along the frequency axis in steps of 8
 // layer2 columns (= 4 pooled columns = 2 output columns), ONE barrier per step:
 //     step k:   producers   layer2 of step k (a1 ring, 66 rows x 18 columns x 32 ch) -> a2 ring (64 rows x 10 pooled columns),
 //                           then the feature staging of step k + 2 and their layer1 unit(s) of step k + 1
@@ -44,9 +44,17 @@ namespace {
 
 constexpr int RT = 4;                 // 16-row tiles per strip
 constexpr int R2 = 16 * RT;           // layer2 rows per strip (64): strip row i2 <-> frame r0 - 1 + i2
-constexpr int R3 = R2 - 2;            // layer3 (output) rows per strip (62): o <-> frame r0 + o
-constexpr int R1 = R2 + 2;            // layer1 rows (66): i1 <-> frame r0 - 2 + i1
-constexpr int RF = R1 + 2;            // feature rows (68): fi <-> frame r0 - 3 + fi
+// HALO = true: 66 layer1 rows (a ninth layer1 unit for rows 64, 65) -> all 64 layer2 rows valid -> 62 output rows per strip.
+// HALO = false: 64 layer1 rows in eight units -> layer2 rows 62, 63 are garbage (they read the two never-written, zeroed ring rows) and are
+// never used -> 60 output rows per strip.  The ninth unit is two rows of work but a whole unit's latency chain (~1000 cycles) on ONE wave
+// of every step, and the step's barrier waits for that wave: every wave stood ~700 cycles at the barrier.  Without it a 625-frame clip is
+// still 11 strips (11 x 60 = 660), i.e. the same matrix work.
+// Both variants are compiled (template parameter of the kernel); the launcher takes HALO = true only where the two extra rows save
+// a strip per clip (ceil(T / 62) < ceil(T / 60)).  The LDS layout is the one of HALO = true for both.
+constexpr int r3_of(bool halo) { return halo ? R2 - 2 : R2 - 4; }   // layer3 (output) rows per strip: o <-> frame r0 + o
+constexpr int r1_of(bool halo) { return halo ? R2 + 2 : R2; }       // layer1 rows computed: i1 <-> frame r0 - 2 + i1
+constexpr int R1A = R2 + 2;                  // layer1 rows the ring holds (layer2's fragment reads reach row 65)
+constexpr int RFA = R1A + 2;                 // feature rows a slab holds (68): fi <-> frame r0 - 3 + fi
 constexpr int CS = 8;                 // layer2 columns per step
 constexpr int CP = CS / 2;            // pooled columns per step (one per producer wave)
 constexpr int RC1 = 2 * CS + 2;       // a1 ring columns: this step's 8 + 2 carried + the next step's 8 (layer1 runs a step ahead)
@@ -54,23 +62,21 @@ constexpr int RC2 = 2 * CP + 2;       // a2 ring columns: the step being consume
 constexpr int PITCH1 = RC1 + 1;       // 19 slots per a1 ring row (odd)
 constexpr int PITCH2 = RC2 + 1;       // 11 (odd)
 constexpr int ROWB1 = PITCH1 * 16, ROWB2 = PITCH2 * 16;
-constexpr int PLANE1 = (R1 * ROWB1 + 255) / 256 * 256;
+constexpr int PLANE1 = (R1A * ROWB1 + 255) / 256 * 256;
 constexpr int PLANE2 = (R2 * ROWB2 + 255) / 256 * 256;
 constexpr int A1_OFF = 0;
 constexpr int A2_OFF = 4 * PLANE1;
 constexpr int SLAB_COLS = CS + 4;     // 12: feature columns 8 j - 2 .. 8 j + 9 of step j (the last two only ever meet zero weights)
 constexpr int SLAB_LOAD = CS + 2;     // 10 of them are loaded
 constexpr int SLABP = SLAB_COLS * 2;  // 24 bytes per slab row = 8 x odd: the 17 rows of a ds_read_b64 lane group on distinct banks
-constexpr int SLAB_BYTES = (RF * SLABP + 15) / 16 * 16;
+constexpr int SLAB_BYTES = (RFA * SLABP + 15) / 16 * 16;
 constexpr int SLAB_OFF = A2_OFF + 4 * PLANE2;
 constexpr int SH3_OFF = SLAB_OFF + 3 * SLAB_BYTES + 128 + 1024;   // + slack: the halo unit's discarded lanes read past their slab; staging's scratch slots
 constexpr int W1_OFF = SH3_OFF + 64 * 4;                   // layer1's Toeplitz fragments (8 x 1 KiB) + shift for the waves that have no registers for them
 constexpr int SH1_OFF = W1_OFF + 8 * 1024;
 constexpr int LDS_BYTES = SH1_OFF + 32 * 4;
-constexpr int FITEMS = RF * SLAB_LOAD;                     // feature values per step (680)
-constexpr int FPRE = (FITEMS + 255) / 256;                 // per producer thread (3)
+constexpr int FPRE = (RFA * SLAB_LOAD + 255) / 256;         // feature values per producer thread and step (3: 660 or 680 values)
 constexpr int XB = CS / 4;                                 // 4-column blocks per step (2)
-constexpr int NUNITS = RT * XB + 1;                        // layer1 units per step: 16 rows x 4 columns each + one unit for rows 64, 65
 static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 static_assert(CP == 4 && XB == 2, "wave roles below are written for 8 layer2 columns per step");
 
@@ -115,21 +121,29 @@ struct ConvFArgs {
 
 // position of one of the block's streams (feature loads, layer1, layer2, layer3) in its sequence of steps: all scalar
 struct Pos { int kk, j, b, r0; };
-__device__ __forceinline__ Pos pos_first(int first, int ntt) {
+template <int R3_>
+__device__ __forceinline__ Pos pos_first_t(int first, int ntt) {
     Pos p;
-    p.kk = 0; p.j = 0; p.b = first / ntt; p.r0 = (first - p.b * ntt) * R3;
+    p.kk = 0; p.j = 0; p.b = first / ntt; p.r0 = (first - p.b * ntt) * R3_;
     return p;
 }
-__device__ __forceinline__ void pos_next(Pos& p, int nstep, int ntt) {
+template <int R3_>
+__device__ __forceinline__ void pos_next_t(Pos& p, int nstep, int ntt) {
     ++p.kk;
     if (++p.j == nstep) {
         p.j = 0;
-        p.r0 += R3;
-        if (p.r0 >= ntt * R3) { p.r0 = 0; ++p.b; }
+        p.r0 += R3_;
+        if (p.r0 >= ntt * R3_) { p.r0 = 0; ++p.b; }
     }
 }
 
+template <bool HALO>
 __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, int ntt, int nstrips, int per_block, int dbg) {
+    constexpr int R3 = r3_of(HALO), R1 = r1_of(HALO), RF = R1 + 2;
+    constexpr int FITEMS = RF * SLAB_LOAD;                     // feature values per step (660 / 680)
+    constexpr int NUNITS = RT * XB + (HALO ? 1 : 0);           // layer1 units per step: 16 rows x 4 columns each (+ one unit for rows 64, 65)
+    auto pos_first = [](int first_, int ntt_) { return pos_first_t<R3>(first_, ntt_); };
+    auto pos_next = [](Pos& p_, int nstep_, int ntt_) { pos_next_t<R3>(p_, nstep_, ntt_); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -156,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         const char* slab = smem + SLAB_OFF + ((P).kk & 1) * SLAB_BYTES;                                     \
         const int base1 = ((P).kk * CS) % RC1;      /* ring slot of the step's first new a1 column (8 j - 1) */ \
         const int u = (U);                                                                                  \
-        const bool mainu = u < NUNITS - 1;                      /* scalar */                                \
+        const bool mainu = !HALO || u < NUNITS - 1;             /* scalar */                                \
         const int row1 = mainu ? 16 * (u >> 1) + n16 : R2 + (n16 & 1);                                      \
         const int xb = mainu ? (u & 1) : (n16 >> 1);                                                        \
         const char* fp = slab + (row1 + gg) * SLABP + 8 * xb;                                               \
@@ -237,9 +251,15 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { settle(sh1[nt][r]); settle(sh2[nt][r]); }
         }
+        // a1 ring rows no unit ever writes (HALO = false: rows 64, 65; layer2's last row tile reads them): zero once, all chunk planes
+        if constexpr (!HALO) {
+            constexpr int per = (R1A - R1) * ROWB1 / 16;
+            for (int i = tid; i < 4 * per; i += 256)
+                reinterpret_cast<uint4*>(smem + A1_OFF + (i / per) * PLANE1 + R1 * ROWB1)[i % per] = make_uint4(0, 0, 0, 0);
+        }
         // the two slab columns no step ever stages (they meet zero weights, but NaN x 0 is NaN): zero once, both slabs
-        for (int i = tid; i < 2 * RF * 2; i += 256) {
-            const int s = i / (RF * 2), r = i % (RF * 2);
+        for (int i = tid; i < 2 * RFA * 2; i += 256) {
+            const int s = i / (RFA * 2), r = i % (RFA * 2);
             *reinterpret_cast<uint16_t*>(smem + SLAB_OFF + s * SLAB_BYTES + (r >> 1) * SLABP + (SLAB_LOAD + (r & 1)) * 2) = 0;
         }
 
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
 #define CONVF_L1_PRODUCER(P)                                                                                \
         do {                                                                                                \
             CONVF_L1_PUNIT(P, wave);                                                                        \
-            if (((P).kk & 3) == wave) CONVF_L1_PUNIT(P, NUNITS - 1);                                        \
+            if (HALO && ((P).kk & 3) == wave) CONVF_L1_PUNIT(P, NUNITS - 1);                                \
         } while (0)
 
         Pos pl = pos_first(first, ntt), p1 = pl, p0 = pl;
@@ -612,10 +632,14 @@ static int convf_steps(int F) {
 
 // One launch handles `groups` heads x B clips x T frames.  The caller decides WHEN (amtx_conv_stack_fused_ok): below ~one strip per
 // CU the two-kernel path's finer tiles fill the chip better.
+// 62 output rows per strip (ninth layer1 unit) only where that saves a strip per clip, else 60
+static bool convf_halo(int T) { return (T + r3_of(true) - 1) / r3_of(true) < (T + r3_of(false) - 1) / r3_of(false); }
+
 bool amtx_conv_stack_fused_ok(int B, int T, int F, int groups) {
     if (F < 4 || B <= 0 || T <= 0 || groups <= 0) return false;
-    const int64_t strips = (int64_t)B * ((T + R3 - 1) / R3) * groups;
-    return strips >= 256 && (int64_t)B * ((T + R3 - 1) / R3) < (1ll << 30);
+    const int r3 = r3_of(convf_halo(T));
+    const int64_t strips = (int64_t)B * ((T + r3 - 1) / r3) * groups;
+    return strips >= 256 && (int64_t)B * ((T + r3 - 1) / r3) < (1ll << 30);
 }
 
 int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_gs, const float* shift3, void* out, int64_t out_gs,
@@ -634,7 +658,9 @@ int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_
     a.w3frag = w3frag; a.w3_gs = w3_gs; a.shift3 = shift3;
     a.out = (bf16_t*)out; a.out_gs = out_gs; a.out_plane = out_plane;
     a.B = c2.B; a.T = c2.T; a.F = c2.F;
-    const int ntt = (c2.T + R3 - 1) / R3;
+    const bool halo = convf_halo(c2.T);
+    const int r3 = r3_of(halo);
+    const int ntt = (c2.T + r3 - 1) / r3;
     const int64_t nstrips = (int64_t)c2.B * ntt;
     AMTX_REQUIRE(nstrips < (1ll << 30), "conv_stack: grid too large");
     const int nstep = convf_steps(c2.F);
@@ -643,8 +669,9 @@ int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_
     if (gx > nstrips) gx = (int)nstrips;
     const int per_block = (int)((nstrips + gx - 1) / gx);
     gx = (int)((nstrips + per_block - 1) / per_block);
-    auto kern = convf_kernel;
-    AMTX_GRANT_LDS(kern, LDS_BYTES);
+    auto kern = halo ? convf_kernel<true> : convf_kernel<false>;
+    AMTX_GRANT_LDS(convf_kernel<true>, LDS_BYTES);
+    AMTX_GRANT_LDS(convf_kernel<false>, LDS_BYTES);
     int dbg = 0;
 #if defined(AMTX_CONVF_TIMING) || defined(AMTX_CONVF_ABLATE)
     if (const char* e = getenv("AMTX_CONVF_DBG")) dbg = atoi(e);

@@ -386,7 +386,9 @@ def test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path(dim_in, monkey
     cases = [('OnsetsFrames', 128, 33), ('OnsetsFrames', 127, 33), ('OnsetsFrames', 43, 140), ('OnsetsFrames', 130, 47),
              ('OnsetsFrames', 260, 1), ('OnsetsFrames', 129, 17), ('OnsetsFrames2', 86, 46), ('OnsetsFrames2', 44, 93),
              # frame counts on both sides of the 62-frame strip boundaries (one strip exactly full, one frame into the next, two strips, ...)
-             ('OnsetsFrames', 130, 62), ('OnsetsFrames', 66, 63), ('OnsetsFrames', 65, 124), ('OnsetsFrames', 44, 125), ('OnsetsFrames', 33, 187)]
+             ('OnsetsFrames', 130, 62), ('OnsetsFrames', 66, 63), ('OnsetsFrames', 65, 124), ('OnsetsFrames', 44, 125), ('OnsetsFrames', 33, 187),
+             # strips of 60 frames without the ninth layer1 unit where 62 would not save a strip (T = 60, 120), 62 where it does (61, 121)
+             ('OnsetsFrames', 130, 60), ('OnsetsFrames', 130, 61), ('OnsetsFrames', 65, 120), ('OnsetsFrames', 65, 121)]
     if dim_in == 229:
         cases.append(('OnsetsFrames', 12, 625))             # the BASELINE clip length: eleven strips, the last one five frames long
     for cls, B, T in cases:
