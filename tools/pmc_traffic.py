@@ -10,6 +10,8 @@ path, tag, clips, passes = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.a
 # kernel name (as pmc_summary.py prints it) -> the bench.py stage(s) it runs; several stages may share a kernel
 STAGES = {
     'convf_kernel': ['conv_stack'],
+    'convf_kernel<false>': ['conv_stack'],       # strips of 60 frames (no ninth first-conv unit): what 625-frame clips run
+    'convf_kernel<true>': ['conv_stack'],
     'conv3x3_kernel<2, 1, 0, 0, true, 1>': ['conv2_pool'],
     'conv3x3_kernel<4, 1, 0, 0, false, 0>': ['conv3_pool'],
     'gemm_glds_kernel<0, 256>': ['fc1_gemm'],
