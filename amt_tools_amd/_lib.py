@@ -159,6 +159,7 @@ def current_stream(device=None):
 # ------------------------------------------------------------------------------------------------------------------------------
 GUARD_BYTES = 0        # > 0 (a multiple of 256): every workspace below gets this many pattern-filled bytes in front of and behind it
 _GUARD_PATTERN = 0xA5
+_GUARDED = {}          # data_ptr of a guarded workspace view -> (weak reference to its full allocation, guard bytes)
 
 
 def alloc_workspace(nbytes, device):
@@ -174,13 +175,21 @@ def alloc_workspace(nbytes, device):
     full = torch.empty(nbytes + 2 * g, dtype=torch.uint8, device=device)
     full[:g] = _GUARD_PATTERN
     full[g + nbytes:] = _GUARD_PATTERN
-    return full[g:g + nbytes]                      # a view: keeps `full` alive, data_ptr() is 256-byte aligned like the allocation
+    ws = full[g:g + nbytes]                        # a view: keeps `full` alive, data_ptr() is 256-byte aligned like the allocation
+    import weakref
+    for k in [k for k, (r, _) in _GUARDED.items() if r() is None]:
+        del _GUARDED[k]
+    _GUARDED[ws.data_ptr()] = (weakref.ref(full), g)
+    return ws
 
 
 def guards_intact(ws):
-    """True when the bands around a workspace from alloc_workspace still hold the pattern (or there are none)."""
+    """True when the bands around a workspace from alloc_workspace still hold the pattern.  Only tensors alloc_workspace itself handed out
+    with guard bands are checked (they are recorded there); anything else -- an unguarded workspace, a plain view of some other buffer --
+    has no bands and answers True."""
+    rec = _GUARDED.get(ws.data_ptr())
     base = getattr(ws, '_base', None)
-    if base is None:
+    if rec is None or base is None or rec[0]() is not base:
         return True
-    g = (base.numel() - ws.numel()) // 2
+    g = rec[1]
     return bool((base[:g] == _GUARD_PATTERN).all().item()) and bool((base[g + ws.numel():] == _GUARD_PATTERN).all().item())

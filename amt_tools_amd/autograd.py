@@ -1,19 +1,27 @@
 """
-Training-mode BiLSTM on the HIP kernels (autograd.Function).
+The training step's layers as autograd.Functions over hand-written HIP forward + backward kernels.
 
-The reference trains through nn.LSTM (amt_tools/models/onsetsframes.py:498-529 inside amt_tools/train.py:126-141).  On
-ROCm that is MIOpen's per-time-step LSTM: thousands of tiny launches per step, 46 of the 61 ms of GPU time of a training
-step at 8 clips x 625 frames, and it keeps the host launch-bound.  Here the T dependent steps of both directions are ONE
-persistent kernel forward (amtx_bilstm_train_fwd, gates and cell states saved) and ONE backward (amtx_bilstm_train_bwd ->
-dL/d(xproj)); the input projection and every parameter gradient are plain GEMMs over B*T (torch.matmul = hipBLASLt:
-plumbing).  Arithmetic: fp32 with split-bf16 (3-MFMA) products for the recurrent mat-vecs -- fp32-class accuracy.
+The reference trains through nn.Conv2d / nn.BatchNorm2d / nn.Linear / nn.LSTM (amt_tools/models/onsetsframes.py:330-575 inside
+amt_tools/train.py:126-141).  On ROCm the LSTM is MIOpen's per-time-step kernel chain (thousands of tiny launches per step, 46 of
+the 61 ms of GPU time of a step at 8 clips x 625 frames).  Here:
+  * BiLSTMFunction: the T dependent steps of both directions are ONE persistent kernel forward (amtx_bilstm_h_train_fwd, gates and
+    cell states saved) and ONE backward (amtx_bilstm_h_train_bwd -> dL/d(xproj)); the input projection and every parameter gradient
+    are GEMMs over B*T on csrc/train.hip (matmul_f32);
+  * Conv3x3Function / LinearFunction: forward, input and weight gradients as split-bf16 implicit GEMMs (csrc/train.hip);
+  * BNReLUPoolFunction (csrc/bn.hip), BCELogitsLossFunction (csrc/head.hip).
+Arithmetic: fp32 in / out with split-bf16 (3-MFMA) products, fp32 accumulation -- fp32-class accuracy.  No vendor BLAS / MIOpen kernel
+runs in a step; a layer whose shape the kernels do not take goes to the stock ATen op AND is recorded (`fallbacks()`,
+`training_backend()`), or raises under `AMTX_STRICT_TRAINING=1`.
 """
+import os
+
 import torch
 
 from . import _lib
 
 __all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction',
-           'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend']
+           'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend', 'note_fallback', 'fallbacks',
+           'reset_fallbacks']
 
 HIDDEN_SIZES = (128, 256, 384)  # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3, 4)
 
@@ -21,13 +29,40 @@ HIDDEN_SIZES = (128, 256, 384)  # hidden sizes per direction the training recurr
 USE_HIP_DENSE = True            # False: nn.Conv2d / nn.Linear / the LSTM's matmuls through ATen (MIOpen / hipBLASLt) -- the A/B switch of the tests
 
 
+_FALLBACKS = {}                 # site -> [reason, count]: layers of a GPU training step that went to a stock ATen op
+
+
+def note_fallback(site, reason):
+    """A layer of the GPU training path is about to run on the stock ATen op (MIOpen / hipBLASLt) instead of the HIP kernels: say so.
+    `AMTX_STRICT_TRAINING=1` turns it into an error -- the inference engine never falls back, training only does so on the record."""
+    if os.environ.get('AMTX_STRICT_TRAINING', '0') not in ('', '0'):
+        raise RuntimeError(f'amt_tools_amd training path: {site} would fall back to ATen ({reason}) and AMTX_STRICT_TRAINING is set')
+    rec = _FALLBACKS.setdefault(site, [reason, 0])
+    rec[0] = reason
+    rec[1] += 1
+
+
+def fallbacks():
+    """{site: (reason, times taken)} since the last reset_fallbacks()."""
+    return {k: (v[0], v[1]) for k, v in _FALLBACKS.items()}
+
+
+def reset_fallbacks():
+    _FALLBACKS.clear()
+
+
 def training_backend():
-    """One line for benchmark records: which kernels a GPU training step runs on."""
+    """One line for benchmark records: which kernels the GPU training steps run so far REALLY ran on (the switches' nominal state plus
+    every recorded ATen fallback)."""
     if USE_HIP_DENSE:
-        return ('HIP: Conv2d fwd/dgrad/wgrad and every Linear / LSTM projection fwd/bwd (split-bf16 implicit GEMMs), BiLSTM fwd/bwd, '
+        line = ('HIP: Conv2d fwd/dgrad/wgrad and every Linear / LSTM projection fwd/bwd (split-bf16 implicit GEMMs), BiLSTM fwd/bwd, '
                 'BatchNorm+ReLU+MaxPool fwd/bwd, BCE loss+grad; ATen: elementwise glue, Dropout, Adam')
-    return ('HIP: BiLSTM fwd/bwd, BatchNorm+ReLU+MaxPool fwd/bwd, BCE loss+grad; ATen (MIOpen / hipBLASLt): conv fwd/dgrad/wgrad, '
-            'Linear fwd/bwd, Adam')
+    else:
+        line = ('HIP: BiLSTM fwd/bwd, BatchNorm+ReLU+MaxPool fwd/bwd, BCE loss+grad; ATen (MIOpen / hipBLASLt): conv fwd/dgrad/wgrad, '
+                'Linear fwd/bwd, Adam')
+    if _FALLBACKS:
+        line += '; ATen FALLBACKS TAKEN: ' + '; '.join(f'{k} ({v[0]}, x{v[1]})' for k, v in sorted(_FALLBACKS.items()))
+    return line
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -137,9 +172,9 @@ def conv3x3_supported(x, conv):
             and conv.bias is not None and conv.padding_mode == 'zeros'):
         return False
     c_in, c_out = conv.in_channels, conv.out_channels
-    if c_in % 4 == 0:
-        return c_out % 4 == 0
-    return c_in == 1 and c_out % 8 == 0 and not x.requires_grad
+    if c_in == 1 and not x.requires_grad:
+        return c_out % 8 == 0                 # direct first-layer kernel forward, K = 9 weight-gradient GEMM
+    return c_out % 4 == 0                     # c_in a multiple of 4, or padded to one with zero channels (conv3x3)
 
 
 class Conv3x3Function(torch.autograd.Function):
@@ -182,8 +217,17 @@ class Conv3x3Function(torch.autograd.Function):
 
 
 def conv3x3(x, conv):
-    """`conv(x)` for an nn.Conv2d(3x3, padding 1) on the HIP kernels, differentiably."""
-    return Conv3x3Function.apply(x, conv.weight, conv.bias)
+    """`conv(x)` for an nn.Conv2d(3x3, padding 1) on the HIP kernels, differentiably.  Input channel counts the implicit GEMMs do not
+    take as they are (3 or 6 = an HCQT / multi-channel first layer, amt_tools/features/hvqt.py:107-133; 1 when the input itself needs a
+    gradient) are padded with zero channels to a multiple of 4 -- in the map and in the weights, so the products are unchanged and the
+    weight gradient of the real channels comes back through the pad's own backward (a slice)."""
+    c_in = x.shape[1]
+    weight = conv.weight
+    if c_in % 4 != 0 and not (c_in == 1 and not x.requires_grad):
+        pad = (-c_in) % 4
+        x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, pad))
+        weight = torch.nn.functional.pad(weight, (0, 0, 0, 0, 0, pad))
+    return Conv3x3Function.apply(x, weight, conv.bias)
 
 
 def _pack(w_hh_f, w_hh_b):
@@ -224,6 +268,8 @@ class BiLSTMFunction(torch.autograd.Function):
             w_ih = torch.cat([w_ih_f, w_ih_b], dim=0)                                  # (8 H, I)
             bias = torch.cat([b_ih_f + b_hh_f, b_ih_b + b_hh_b], dim=0)
             hip_mm = USE_HIP_DENSE and x2.shape[1] % 4 == 0
+            if not hip_mm:
+                note_fallback('BiLSTM input projection', 'USE_HIP_DENSE off' if not USE_HIP_DENSE else f'input size {x2.shape[1]} is not a multiple of 4')
             if hip_mm:
                 if not _ok2d(x2):
                     x2 = x2.contiguous()
@@ -322,12 +368,15 @@ class BCELogitsLossFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(L.amtx_bce_logits_loss(_lib.ptr(x), K, _lib.ptr(y), _lib.ptr(w), B, T, K, _lib.ptr(loss), _lib.ptr(grad),
                                               _lib.ptr(ws), ws.numel(), _lib.current_stream(x.device)), 'amtx_bce_logits_loss')
-        ctx.grad = grad
+        # saved through autograd (not as a plain attribute of ctx): the (B,T,K) gradient is then released with the graph when backward never
+        # runs (a labelled forward under enable_grad whose loss is only read)
+        ctx.save_for_backward(*([grad] if grad is not None else []))
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        return (ctx.grad * g if ctx.grad is not None else None), None, None
+        saved = ctx.saved_tensors
+        return (saved[0] * g if saved else None), None, None
 
 
 def bce_logits_loss(logits, labels, weight=None):

@@ -37,12 +37,19 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_distributed', 'DataParallelOptimizer', 'broadcast_parameters', 'shard_indices', 'rank_log_dir']
+__all__ = ['init_distributed', 'force_collective_default', 'DataParallelOptimizer', 'broadcast_parameters', 'shard_indices', 'rank_log_dir']
 
 
-def init_distributed(backend=None):
+def force_collective_default():
+    """`AMTX_DP_FORCE_COLLECTIVE=1`: run the process group and the flat all-reduce also at world size 1 (a one-rank RCCL communicator
+    on a one-GPU box exercises group creation, RCCL's own stream beside the training kernels and the flatten / unflatten path)."""
+    return os.environ.get('AMTX_DP_FORCE_COLLECTIVE', '0') not in ('', '0')
+
+
+def init_distributed(backend=None, force=None):
     """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_*).  Returns (rank, world_size, device).  Single-process runs return (0, 1, device) untouched."""
+    MASTER_*).  Returns (rank, world_size, device).  Single-process runs return (0, 1, device) untouched unless `force` (default:
+    `AMTX_DP_FORCE_COLLECTIVE`) asks for a one-rank group."""
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -50,10 +57,16 @@ def init_distributed(backend=None):
     device = torch.device(f'cuda:{local_rank}') if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = force_collective_default()
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(backend or ('nccl' if use_gpu else 'gloo'), rank=rank, world_size=world)
+        backend = backend or ('nccl' if use_gpu else 'gloo')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, device
 
 
@@ -79,14 +92,20 @@ def broadcast_parameters(model, src=0):
 class DataParallelOptimizer(torch.optim.Optimizer):
     """Wraps an optimizer class; `step()` averages gradients over all ranks with one flat all-reduce first."""
 
-    def __init__(self, params, optimizer_cls=torch.optim.Adam, process_group=None, buffers=None, **optimizer_kwargs):
+    def __init__(self, params, optimizer_cls=torch.optim.Adam, process_group=None, buffers=None, force_collective=None,
+                 **optimizer_kwargs):
         """`buffers`: optional iterable of tensors (e.g. `model.buffers()`) whose floating-point members -- BatchNorm running
-        statistics -- are averaged over ranks in the same all-reduce as the gradients."""
+        statistics -- are averaged over ranks in the same all-reduce as the gradients.
+        `force_collective` (default: the `AMTX_DP_FORCE_COLLECTIVE` environment switch): run the flatten -> all-reduce -> unflatten
+        path also in a one-rank group.  A sum over one rank divided by one returns the gradients' own bits, so a forced run must
+        leave the same weights as an unforced one (tests/test_gpu_rccl.py) -- it exists to put RCCL under test on a one-GPU box."""
         params = list(params)
         inner = optimizer_cls(params, **optimizer_kwargs)
         self.__dict__['_inner'] = inner
         self.__dict__['_group'] = process_group
         self.__dict__['_flat'] = None
+        self.__dict__['_force'] = force_collective_default() if force_collective is None else bool(force_collective)
+        self.__dict__['collectives_run'] = 0
         self.__dict__['_buffers'] = [b for b in (buffers or []) if torch.is_tensor(b) and b.dtype.is_floating_point]
         super().__init__(params, dict(inner.defaults))
 
@@ -104,7 +123,8 @@ class DataParallelOptimizer(torch.optim.Optimizer):
     @torch.no_grad()
     def allreduce_gradients(self):
         world = self._world()
-        if world == 1:
+        forced = self.__dict__.get('_force', False) and dist.is_available() and dist.is_initialized()
+        if world == 1 and not forced:
             return
         params = [p for g in self.param_groups for p in g['params'] if p.requires_grad]
         if not params:
@@ -136,7 +156,9 @@ class DataParallelOptimizer(torch.optim.Optimizer):
         if bufs:
             torch._foreach_copy_(bviews, [b.detach() for b in bufs])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._group)
-        flat.div_(world)
+        self.__dict__['collectives_run'] = self.__dict__.get('collectives_run', 0) + 1
+        if world > 1:                 # x / 1 is exact anyway; skipping it keeps the one-rank run's kernel list short
+            flat.div_(world)
         if have:
             torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])
         if bufs:

@@ -60,8 +60,8 @@ class TranscriptionModel(nn.Module):
         self.device = device
         self.to(self.device)
         if torch.device(self.device).type == 'cuda':
-            # the autograd (training) path runs its convolutions / BatchNorms through MIOpen: channels-last weights and
-            # activations pick its faster kernels (train step 18.9 -> 15.5 ms); values, shapes and state_dict are unchanged
+            # the training path's HIP convolutions / BatchNorm passes (amt_tools_amd/autograd.py) work on channels-last maps; keeping the
+            # parameters in that memory format too means no layout copies around them.  Values, shapes and state_dict are unchanged
             self.to(memory_format=torch.channels_last)
         # an on-device front-end follows the model (its plans / tables are created per device on first use)
         for m in self.frontend:
@@ -124,9 +124,10 @@ class LogisticBank(OutputLayer):
 
     def forward(self, feats):
         if feats.is_cuda and torch.is_grad_enabled():
-            from .autograd import linear, linear_supported      # training on a GPU: the HIP GEMMs, forward and backward
+            from .autograd import linear, linear_supported, note_fallback     # training on a GPU: the HIP GEMMs, forward and backward
             if linear_supported(feats, self.output_layer.weight):
                 return linear(feats, self.output_layer.weight, self.output_layer.bias)
+            note_fallback('LogisticBank.output_layer', f'Linear {self.dim_in} -> {self.dim_out}, {feats.dtype}')
         return self.output_layer(feats)
 
     def get_loss(self, estimated, reference):
@@ -136,6 +137,9 @@ class LogisticBank(OutputLayer):
                 and reference.shape == (estimated.shape[0], estimated.shape[2], estimated.shape[1])):
             from .autograd import bce_logits_loss     # one HIP pass: loss + d loss / d logits
             return bce_logits_loss(estimated, reference, self.weights)
+        if estimated.is_cuda:
+            from .autograd import note_fallback
+            note_fallback('LogisticBank.get_loss', f'logits {tuple(estimated.shape)} {estimated.dtype} vs labels {tuple(reference.shape)}')
         est = estimated.transpose(-2, -1)
         weight = self.weights.unsqueeze(-1) if self.weights is not None else None
         loss = F.binary_cross_entropy_with_logits(est.float(), reference.float(), weight=weight, reduction='none')
@@ -172,17 +176,25 @@ class AcousticModel(nn.Module):
         amt_tools_amd/autograd.py (bn_relu_pool); the Dropout behind them is the module's own."""
         mods = list(layer)
         if self.training and self.use_hip_bn and x.is_cuda and not isinstance(mods[1], nn.SyncBatchNorm):
-            from .autograd import bn_relu_pool, bn_relu_pool_supported, conv3x3, conv3x3_supported
-            y = conv3x3(x, mods[0]) if conv3x3_supported(x, mods[0]) else mods[0](x)
+            from .autograd import bn_relu_pool, bn_relu_pool_supported, conv3x3, conv3x3_supported, note_fallback
+            if conv3x3_supported(x, mods[0]):
+                y = conv3x3(x, mods[0])
+            else:
+                note_fallback('AcousticModel conv', f'Conv2d {mods[0].in_channels} -> {mods[0].out_channels} on {x.dtype}')
+                y = mods[0](x)
             if bn_relu_pool_supported(y, mods[1]):
                 pool = len(mods) > 3 and isinstance(mods[3], nn.MaxPool2d)
                 y = bn_relu_pool(y, mods[1], pool)
                 for m in mods[(4 if pool else 3):]:
                     y = m(y)
                 return y
+            note_fallback('AcousticModel BatchNorm+ReLU+MaxPool', f'{y.shape[1]} channels, {y.dtype}, channels_last={y.is_contiguous(memory_format=torch.channels_last)}')
             for m in mods[1:]:
                 y = m(y)
             return y
+        if self.training and x.is_cuda:
+            from .autograd import note_fallback
+            note_fallback('AcousticModel stage', 'use_hip_bn off' if not self.use_hip_bn else 'SyncBatchNorm (stock modules by design: its statistics are a collective)')
         return layer(x)
 
     def forward(self, in_feats):
@@ -195,12 +207,19 @@ class AcousticModel(nn.Module):
             lin = self.fc1[0]
             B, C, T, F = x.shape
             w = lin.weight.view(lin.out_features, C, F).transpose(1, 2).reshape(lin.out_features, F * C)
-            from .autograd import linear, linear_supported
+            from .autograd import linear, linear_supported, note_fallback
             xin = x.permute(0, 2, 3, 1).reshape(B, T, F * C)
-            y = linear(xin, w, lin.bias) if linear_supported(xin, w) else torch.nn.functional.linear(xin, w, lin.bias)
+            if linear_supported(xin, w):
+                y = linear(xin, w, lin.bias)
+            else:
+                note_fallback('AcousticModel.fc1', f'Linear {w.shape[1]} -> {w.shape[0]}, {xin.dtype}')
+                y = torch.nn.functional.linear(xin, w, lin.bias)
             for m in list(self.fc1)[1:]:
                 y = m(y)
             return y
+        if self.training and x.is_cuda:
+            from .autograd import note_fallback
+            note_fallback('AcousticModel.fc1', 'conv map not in channels-last layout')
         x = x.transpose(-3, -2).flatten(-2)
         return self.fc1(x)
 
@@ -228,6 +247,10 @@ class LanguageModel(nn.Module):
                 and self.mlm.num_layers == 1 and self.use_hip_autograd):
             from .autograd import bilstm
             return bilstm(in_feats, self.mlm)
+        if in_feats.is_cuda and torch.is_grad_enabled():
+            from .autograd import note_fallback
+            note_fallback('LanguageModel', f'nn.LSTM hidden {self.hidden_size} x {self.num_directions} directions, {in_feats.dtype}, '
+                                           f'use_hip_autograd={self.use_hip_autograd}')
         return self.mlm(in_feats)[0]
 
 

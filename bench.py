@@ -97,6 +97,9 @@ def parse(argv=None):
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only for the "
                                                       "single-GPU smoke test of the multi-process path)")
     ap.add_argument('--share-device', action='store_true', help='test only: every rank uses cuda:0')
+    ap.add_argument('--force-dist', action='store_true', help='create the process group (default backend nccl = RCCL) and run every collective of the '
+                                                              'N > 1 path -- timing barrier, MAX / gather of the elapsed times and, in train mode, the '
+                                                              'flat gradient all-reduce inside optimizer.step() -- also at --gpus 1: RCCL under test on a one-GPU box')
     ap.add_argument('--fail-rank', type=int, default=-1, help='test only (with --dry-run): this rank exits with an error before the rendezvous')
     ap.add_argument('--dry-run', action='store_true', help='test only (CPU): ranks rendezvous over gloo and rank 0 prints a line '
                                                            'without touching a GPU -- exercises the launcher and the relay')
@@ -183,7 +186,9 @@ def init_ranks(args):
         raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as {args.gpus} GPUs')
     import torch.distributed as dist
     if args.dry_run:
-        if world > 1:
+        if world > 1 or args.force_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(_free_port()))
             dist.init_process_group('gloo', rank=rank, world_size=world)
         return rank, world, 'cpu'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
@@ -191,9 +196,11 @@ def init_ranks(args):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f'cuda:{local_rank}'
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()) if world == 1 else '29500')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(device))
         else:
@@ -202,8 +209,13 @@ def init_ranks(args):
     return rank, world, device
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def max_over_ranks(elapsed, world, device, backend):
-    if world == 1:
+    if not _dist_on():
         return elapsed
     import torch.distributed as dist
     t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
@@ -213,7 +225,7 @@ def max_over_ranks(elapsed, world, device, backend):
 
 def gather_over_ranks(elapsed, world, device, backend):
     """Every rank's own elapsed time (list, rank order): the first SCALE record is then diagnosable without a second run."""
-    if world == 1:
+    if not _dist_on():
         return [elapsed]
     import torch.distributed as dist
     t = torch.zeros(world, dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
@@ -225,9 +237,11 @@ def gather_over_ranks(elapsed, world, device, backend):
 def barrier(world):
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
 
 def build_model(device, precision):
@@ -531,7 +545,7 @@ def run_infer(args, rank, world, device):
     config = {'workload': 'OnsetsFrames(mc=2)+MelSpec(229 bins, n_fft 2048, hop 512) inference, synthetic 22.05 kHz clips of 319999 '
                           'samples (625 frames; 8 distinct clips per rank tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
               'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
-              'rccl_ranks': world, 'per_rank_frames_per_s': [B * CLIP_FRAMES * args.steps / t for t in per_rank],
+              'rccl_ranks': world, 'process_group': (args.backend if _dist_on() else None), 'per_rank_frames_per_s': [B * CLIP_FRAMES * args.steps / t for t in per_rank],
               'whole_path_frac_of_mfma_roof': fps / world * MODEL_FLOPS_PER_FRAME / 2.5e15,
               'whole_path_frac_of_mfma_roof_executed_flops': fps / world * EXECUTED_FLOPS_PER_FRAME / 2.5e15,
               'flops_per_frame': {'reference_algorithmic': MODEL_FLOPS_PER_FRAME, 'executed': EXECUTED_FLOPS_PER_FRAME,
@@ -585,7 +599,8 @@ def _train_setup(device, rank, B, of2):
     model.change_device()
     broadcast_parameters(model)
     model.train()
-    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4, buffers=model.buffers())   # BatchNorm policy: amt_tools_amd/dp.py
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4, buffers=model.buffers(),   # BatchNorm policy: amt_tools_amd/dp.py
+                                force_collective=True if _dist_on() else None)
     audio = torch.from_numpy(np.stack([synth_clip(rank * B + i) for i in range(B)])).to(device)
     lab = [synth_labels(rank * B + i) for i in range(B)]
     batch = {tools.KEY_AUDIO: audio,
@@ -637,7 +652,7 @@ def run_train(args, rank, world, device):
     # the gradient all-reduce on its own (flatten + RCCL all-reduce + unflatten, what DataParallelOptimizer.step() adds to an optimizer step),
     # timed after the run on this rank's last gradients
     allreduce_ms = None
-    if world > 1:
+    if _dist_on():
         barrier(world)
         t1 = time.perf_counter()
         for _ in range(5):
@@ -660,6 +675,8 @@ def run_train(args, rank, world, device):
                                f'(synth_labels), audio resident in HBM', 'clips_per_gpu_per_step': B, 'global_batch': world * B,
                    'frames_per_s': fps, 'parallelism': f'dp{world}: one flat fp32 gradient all-reduce per step', 'rccl_ranks': world,
                    'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank], 'allreduce_ms_per_step': allreduce_ms,
+                   'collectives_per_step': opt.collectives_run / max(1, args.steps + args.warmup + (5 if allreduce_ms is not None else 0)),
+                   'process_group': (args.backend if _dist_on() else None),
                    'loss': float(loss), 'backward': training_backend()},
         'roofline': {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None,
@@ -682,18 +699,19 @@ def main(argv=None):
     if args.dry_run:
         import torch.distributed as dist
         elapsed = max_over_ranks(1e-3 * (rank + 1), world, 'cpu', 'gloo')
-        if world > 1:
+        if _dist_on():
             dist.barrier()
         if rank == 0:
             print(json.dumps({'metric': 'dry run (launcher / rendezvous / relay only)', 'value': 0.0, 'unit': 'none', 'n_gpus': world,
-                              'steps': 0, 'warmup': 0, 'ms_per_step': elapsed * 1e3, 'dry_run': True}), flush=True)
-        if world > 1:
+                              'steps': 0, 'warmup': 0, 'ms_per_step': elapsed * 1e3, 'dry_run': True,
+                              'process_group': 'gloo' if _dist_on() else None}), flush=True)
+        if _dist_on():
             dist.destroy_process_group()
         return
     res = run_infer(args, rank, world, device) if args.mode == 'infer' else run_train(args, rank, world, device)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if _dist_on():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

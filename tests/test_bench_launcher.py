@@ -55,3 +55,14 @@ def test_train_mode_shim_passes_through_the_same_launcher():
                        capture_output=True, text=True, timeout=180)
     assert p.returncode == 0, p.stderr
     assert json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])['n_gpus'] == 2
+
+
+def test_force_dist_creates_a_one_rank_group():
+    """`--force-dist` at --gpus 1: the process group exists and the line's collectives run through it (on the GPU box the same switch
+    puts a one-rank RCCL communicator under test: tests/test_gpu_rccl.py)."""
+    p = _run(['--gpus', '1', '--dry-run', '--force-dist'])
+    assert p.returncode == 0, p.stderr
+    rec = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert rec['n_gpus'] == 1 and rec['process_group'] == 'gloo' and rec['ms_per_step'] == 1.0
+    p = _run(['--gpus', '1', '--dry-run'])
+    assert json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])['process_group'] is None

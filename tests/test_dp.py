@@ -211,3 +211,35 @@ def test_shard_helpers():
     assert shard_indices(10, 1, 4) == [1, 5, 9]
     assert sorted(sum((shard_indices(10, r, 4) for r in range(4)), [])) == list(range(10))
     assert rank_log_dir('/x', 0) == '/x' and rank_log_dir('/x', 3) == '/x/.rank3'
+
+
+def _forced_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    states = []
+    for forced in (False, True):
+        if forced:
+            dist.init_process_group('gloo', rank=0, world_size=1)
+        model = _make_model(seed=0, freeze_bn=False)
+        model.train()
+        opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=1e-2, buffers=model.buffers(), force_collective=forced)
+        torch.manual_seed(5)
+        for it in range(3):
+            opt.zero_grad()
+            model.run_on_batch(_cat([_batch(2 * it), _batch(2 * it + 1)]))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+            opt.step()
+        states.append(({k: v.clone() for k, v in model.state_dict().items()}, opt.collectives_run))
+    dist.destroy_process_group()
+    torch.save(states, out)
+
+
+@pytest.mark.timeout(300)
+def test_forced_one_rank_collective_returns_the_same_bits(tmp_path):
+    """`force_collective=True` in a one-rank group (what tests/test_gpu_rccl.py runs over RCCL on the GPU box): the flatten ->
+    all-reduce -> unflatten path runs once per step and leaves bit-identical weights and running statistics."""
+    out = str(tmp_path / 'forced.pt')
+    mp.spawn(_forced_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    (plain, n0), (forced, n1) = torch.load(out)
+    assert n0 == 0 and n1 == 3
+    for k, v in plain.items():
+        assert torch.equal(v, forced[k]), k

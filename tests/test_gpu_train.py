@@ -361,3 +361,64 @@ def test_training_step_runs_without_vendor_gemm_or_conv_kernels():
     vendor = [n for n in names if any(t in n.lower() for t in ('miopen', 'cijk_', 'rocblas', 'hipblas', 'igemm', 'gemv'))]
     assert not vendor, vendor
     assert any('xgemm_kernel' in n for n in names), names[:20]
+
+
+@pytest.mark.parametrize('c_in,dim_in', [(6, 72), (3, 48)])
+def test_multi_channel_first_conv_trains_on_the_hip_kernels(c_in, dim_in):
+    """An HCQT-shaped model (6 harmonics x 72 bins, amt_tools/features/hvqt.py:107-133; also 3 channels) trains its FIRST convolution on
+    the HIP implicit GEMMs too (zero-padded to a multiple of 4 channels) -- VERDICT r03: it went to MIOpen without a word.  Checked three
+    ways: no vendor kernel in the step's trace, no recorded fallback, gradients equal to the stock ATen path's."""
+    from amt_tools_amd import autograd as ag
+    from amt_tools_amd.models import OnsetsFrames
+    from amt_tools_amd.synth import synth_labels
+    B, T = 2, 48
+    lab = [synth_labels(i, num_frames=T) for i in range(B)]
+    torch.manual_seed(1)
+    batch = {tools.KEY_FEATS: torch.rand(B, c_in, dim_in, T), tools.KEY_MULTIPITCH: torch.from_numpy(np.stack([l[0] for l in lab])),
+             tools.KEY_ONSETS: torch.from_numpy(np.stack([l[1] for l in lab]))}
+
+    def make():
+        torch.manual_seed(0)
+        m = OnsetsFrames(dim_in, tools.PianoProfile(), c_in, 2, device='cuda:0')
+        m.change_device()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        m.train()
+        return m
+
+    ag.reset_fallbacks()
+    model = make()
+    model.run_on_batch(batch)[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+        model.zero_grad()
+        loss = model.run_on_batch(batch)[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]
+        loss.backward()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    vendor = [n for n in names if any(t in n.lower() for t in ('miopen', 'cijk_', 'rocblas', 'hipblas', 'igemm', 'gemv'))]
+    assert not vendor, vendor
+    assert ag.fallbacks() == {}, ag.fallbacks()
+    assert 'FALLBACKS' not in ag.training_backend()
+
+    ref = make()
+    ag.USE_HIP_DENSE = False
+    try:
+        for m in ref.modules():
+            if hasattr(m, 'use_hip_bn'):
+                m.use_hip_bn = False
+        loss_ref = ref.run_on_batch(batch)[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]
+        loss_ref.backward()
+    finally:
+        ag.USE_HIP_DENSE = True
+    assert 'AcousticModel stage' in ag.fallbacks()            # the stock path is on the record ...
+    assert 'FALLBACKS TAKEN' in ag.training_backend()         # ... and in the line bench.py prints
+    ag.reset_fallbacks()
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item())
+    rel = []
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        rel.append(float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-12)))
+    w1 = dict(model.named_parameters())['onset_head.0.layer1.0.weight'].grad
+    w1r = dict(ref.named_parameters())['onset_head.0.layer1.0.weight'].grad
+    assert float((w1 - w1r).norm() / w1r.norm()) < 3e-2
+    assert np.median(rel) < 1e-3 and max(rel) < 3e-2, (np.median(rel), max(rel))

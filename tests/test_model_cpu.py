@@ -230,3 +230,15 @@ def test_frame_times_come_from_the_front_end_module_and_safe_globals_cover_a_pic
     tools.register_safe_globals()
     loaded = torch.load(path)                       # weights_only default of the installed torch
     assert isinstance(loaded, OnsetsFrames) and loaded.frontend[0].module.hop_length == 256
+
+
+def test_strict_training_switch_turns_a_fallback_into_an_error(monkeypatch):
+    from amt_tools_amd import autograd as ag
+    monkeypatch.setenv('AMTX_STRICT_TRAINING', '1')
+    with pytest.raises(RuntimeError, match='AMTX_STRICT_TRAINING'):
+        ag.note_fallback('somewhere', 'some shape')
+    monkeypatch.delenv('AMTX_STRICT_TRAINING')
+    ag.reset_fallbacks()
+    ag.note_fallback('somewhere', 'some shape')
+    assert ag.fallbacks() == {'somewhere': ('some shape', 1)}
+    ag.reset_fallbacks()

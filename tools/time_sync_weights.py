@@ -1,5 +1,5 @@
-import sys, time, torch, numpy as np
-sys.path.insert(0, '/root/repo')
+import os, sys, time, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from amt_tools_amd import tools
 from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
 for cls, mc in ((OnsetsFrames, 2), (OnsetsFrames2, 3)):
