@@ -65,6 +65,7 @@ struct amtx_of_model {
     std::map<std::string, std::pair<const float*, int64_t>> dev_tensors;   // amtx_of_model_set_tensor_device: borrowed device pointers
     DevBuf pack_scratch;                       // device re-sync: BatchNorm scale / shift, the folded pitch head, the unused backward LSTM fragments
     bool finalized = false;
+    bool packed_once = false;                  // the packed buffers hold a weight version that forwards may still be reading
     // packed device weights (group-major)
     DevBuf conv1_w, conv1_s, conv1_frag, conv2_w, conv2_s, conv3_w, conv3_s;
     bool fuse_conv1 = false;                   // first conv computed inside the conv2 kernel (9*C_in <= 64)
@@ -255,8 +256,20 @@ extern "C" int amtx_of_model_set_tensor(amtx_of_model* m, const char* name, cons
     return AMTX_OK;
 }
 
+// A RE-sync overwrites the packed buffers in place (DevBuf::upload keeps its allocation; the device packers write on the caller's
+// stream).  A forward pass of the previous weight version may still be in flight on ANOTHER stream (PyTorch side streams do not
+// synchronise with the null stream), so both re-sync entry points first wait for everything the device has been given.
+static int quiesce_before_resync(const amtx_of_model* m) {
+    if (m->packed_once) AMTX_CHECK_HIP(hipDeviceSynchronize());
+    return AMTX_OK;
+}
+
 extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     AMTX_REQUIRE(m, "amtx_of_model_finalize: null model");
+    {
+        int qrc = quiesce_before_resync(m);
+        if (qrc != AMTX_OK) return qrc;
+    }
     const int nh = m->n_heads;
     // ---- acoustic heads
     std::vector<float> c1w((size_t)nh * m->nf1 * m->in_channels * 9), c1s((size_t)nh * m->nf1);
@@ -398,6 +411,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     }
     m->tensors.clear();
     m->finalized = true;
+    m->packed_once = true;
     return AMTX_OK;
 }
 
@@ -440,14 +454,44 @@ int need_dev(const amtx_of_model* m, const std::string& name, size_t numel, cons
     } while (0)
 }  // namespace
 
+// `dry`: look up and size-check every tensor, launch nothing -- amtx_of_model_finalize_device runs this pass first, so a missing or
+// mis-sized tensor is reported before a single packed buffer has been touched (the buffers never end up half new, half old).
+static int finalize_device_pass(amtx_of_model* m, hipStream_t s, const bool dry);
+
 extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
     AMTX_REQUIRE(m, "amtx_of_model_finalize_device: null model");
+    struct Clear {                             // the borrowed device pointers are dropped on EVERY exit: the caller may free them afterwards
+        amtx_of_model* m;
+        ~Clear() { m->dev_tensors.clear(); }
+    } clear{m};
     AMTX_REQUIRE(m->finalized, "amtx_of_model_finalize_device: the first sync goes through amtx_of_model_finalize (it allocates the packed buffers)");
     if (!m->gen_conv2 && m->in_channels != 1) {
         amtx_set_error("amtx_of_model_finalize_device: no device packer for conv.hip's multi-channel first conv; use amtx_of_model_finalize");
         return AMTX_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream_;
+    int rc = finalize_device_pass(m, s, true);
+    if (rc != AMTX_OK) return rc;
+    if ((rc = quiesce_before_resync(m)) != AMTX_OK) return rc;
+    rc = finalize_device_pass(m, s, false);
+    if (rc != AMTX_OK) m->finalized = false;   // a launch failed half-way: the packed weights are no version at all, refuse to run on them
+    return rc;
+}
+
+#undef PACK_TRY
+#define PACK_TRY(expr)                                                 \
+    do {                                                               \
+        if (!dry) {                                                    \
+            int _rc = (expr);                                          \
+            if (_rc != AMTX_OK) return _rc;                            \
+        }                                                              \
+    } while (0)
+#define PACK_COPY(dst, src, bytes)                                                                         \
+    do {                                                                                                   \
+        if (!dry) AMTX_CHECK_HIP(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToDevice, s));       \
+    } while (0)
+
+static int finalize_device_pass(amtx_of_model* m, hipStream_t s, const bool dry) {
     const int nh = m->n_heads, pl = m->planes, H = m->hid, G = 4 * H;
     const bool f16 = m->f16;
     auto pack_conv = [f16](const float* w, const float* sc, int c_out, int planes, bf16_t* out, hipStream_t st) {
@@ -511,7 +555,7 @@ extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
             NEED_DEV(am + ".fc1.0.weight", (size_t)m->dim_am * m->kfc, w);
             NEED_DEV(am + ".fc1.0.bias", (size_t)m->dim_am, fb);
             PACK_TRY(pack_lin(w, m->kfc, m->dim_am, m->kfc, pl, m->fc1.n_pad, m->fc1.k_pad, 0, m->fc1.n_pad, m->nf3, m->fq, (bf16_t*)m->fc1.w.p + fc_per * h, s));
-            AMTX_CHECK_HIP(hipMemcpyAsync((float*)m->fc1.b.p + (size_t)h * m->dim_am, fb, sizeof(float) * m->dim_am, hipMemcpyDeviceToDevice, s));
+            PACK_COPY((float*)m->fc1.b.p + (size_t)h * m->dim_am, fb, sizeof(float) * m->dim_am);
         }
     }
     // LSTM + LogisticBank of a recurrent stage: input projection rows [fwd | reverse], merged biases, W_hh fragments, output layer
@@ -533,11 +577,17 @@ extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
         NEED_DEV(bank + ".output_layer.bias", (size_t)m->n_out, bo);
         PACK_TRY(pack_lin(wo, m->dim_lm, m->n_out, m->dim_lm, pl, outp.n_pad, outp.k_pad, 0, outp.n_pad, 0, 0,
                           (bf16_t*)outp.w.p + (size_t)outp.n_pad * outp.k_pad * pl * grp, s));
-        AMTX_CHECK_HIP(hipMemcpyAsync((float*)outp.b.p + (size_t)outp.N * grp, bo, sizeof(float) * m->n_out, hipMemcpyDeviceToDevice, s));
+        PACK_COPY((float*)outp.b.p + (size_t)outp.N * grp, bo, sizeof(float) * m->n_out);
         return AMTX_OK;
     };
-    for (int r = 0; r < m->n_rec; ++r) PACK_TRY(pack_rec(m->head_names[r] + ".1", m->head_names[r] + ".2", m->dim_am, m->rec_ih, m->rec_hh, m->rec_out, r));
-    PACK_TRY(pack_rec("adjoin.0", "adjoin.1", m->dim_aj, m->adj_ih, m->adj_hh, m->adj_out, 0));
+    for (int r = 0; r < m->n_rec; ++r) {
+        const int prc = pack_rec(m->head_names[r] + ".1", m->head_names[r] + ".2", m->dim_am, m->rec_ih, m->rec_hh, m->rec_out, r);
+        if (prc != AMTX_OK) return prc;
+    }
+    {
+        const int prc = pack_rec("adjoin.0", "adjoin.1", m->dim_aj, m->adj_ih, m->adj_hh, m->adj_out, 0);
+        if (prc != AMTX_OK) return prc;
+    }
     // pitch head: LogisticBank folded into fc1 in double precision, then packed like any Linear layer
     {
         const float *wo, *bo, *w1, *b1;
@@ -548,9 +598,8 @@ extern "C" int amtx_of_model_finalize_device(amtx_of_model* m, void* stream_) {
         PACK_TRY(amtx_pack_head_fold_dev(wo, w1, b1, bo, m->n_out, m->dim_am, m->kfc, m->kfc_pad, m->nf3, m->fq, wfold, bfold, s));
         PACK_TRY(pack_lin(wfold, m->kfc_pad, m->n_out, m->kfc_pad, pl, m->pitch_out.n_pad, m->pitch_out.k_pad, 0, m->pitch_out.n_pad, 0, 0,
                           (bf16_t*)m->pitch_out.w.p, s));
-        AMTX_CHECK_HIP(hipMemcpyAsync(m->pitch_out.b.p, bfold, sizeof(float) * m->n_out, hipMemcpyDeviceToDevice, s));
+        PACK_COPY(m->pitch_out.b.p, bfold, sizeof(float) * m->n_out);
     }
-    m->dev_tensors.clear();
     return AMTX_OK;
 }
 

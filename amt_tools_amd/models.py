@@ -316,7 +316,7 @@ class _OFEngine(object):
         items = [(k, v) for k, v in sd.items() if v.dtype.is_floating_point and not k.startswith('frontend.') and v.numel() > 0]
         # A RE-sync (validate() inside train() pays one at every checkpoint) stays on the GPU where the library can pack there: the
         # tensors are handed over as device pointers and folded / packed by kernels -- the same bits as the host path.
-        if self.version is not None and self.device_sync and all(v.is_cuda and v.dtype == torch.float32 for _, v in items):
+        if self.version is not None and self.device_sync and all(v.is_cuda and v.device == torch.device(self.device) and v.dtype == torch.float32 for _, v in items):
             keep = []                                   # channels-last convolution weights (the GPU training layout) go through a dense device copy
             for k, v in items:
                 t = v.detach()
@@ -433,6 +433,7 @@ class OnsetsFrames(TranscriptionModel):
         state.pop('_engine', None)
         state.pop('_engine_out', None)
         state.pop('_engine_offsets', None)
+        state.pop('_side_stream', None)
         return state
 
     def _get_engine(self, device):
@@ -518,23 +519,31 @@ class OnsetsFrames(TranscriptionModel):
         self.__dict__.pop('_engine_out', None)
         self.__dict__.pop('_engine_offsets', None)
         output = dict()
-        # (A side-stream overlap of the two detector heads lived here in round 1: with two streams the training loop hung
-        # intermittently on MI355X / ROCm 7.2 -- HIP BiLSTM autograd kernels + a second stream, never root-caused, DESIGN.md section 5.
-        # One stream + the HIP BatchNorm passes is faster than the overlap was, so the switch is gone rather than shipped.)
-        multi_pitch = self.pitch_head(feats)
-        onsets = None if self._grouped_recurrences(feats) else self.onset_head(feats)
-        offsets = None
-        if self.has_offsets and feats.is_cuda and self.training and onsets is None:
-            # the onset and offset heads are independent: their two recurrences run as ONE grouped launch each way
-            from .autograd import bilstm_multi
-            (am_on, lm_on, lb_on), (am_off, lm_off, lb_off) = self.onset_head, self.offset_head
-            l_on, l_off = bilstm_multi([am_on(feats), am_off(feats)], [lm_on.mlm, lm_off.mlm])
-            onsets, offsets = lb_on(l_on), lb_off(l_off)
+        if self._overlap_heads(feats):
+            # The detector heads only meet at the refinement stage (onsetsframes.py:118-134): the pitch head runs on a side stream beside the
+            # recurrent heads -- acoustic model + a 625-step BiLSTM that keeps 4 of the 256 CUs busy at 8 clips; autograd replays
+            # every op's backward on the stream of its forward, so the backward passes overlap the same way (11.0 -> 9.85 ms per step).
+            # Tensors that cross streams are handed to the allocator with record_stream.  History: round 1 saw intermittent hangs with two
+            # streams while the convolutions / Linear layers still ran on MIOpen / hipBLASLt; with the all-HIP step tools/two_stream_repro.py
+            # and tests/test_gpu_rccl.py run thousands of steps clean.  AMTX_TRAIN_OVERLAP=0 keeps one stream.
+            main = torch.cuda.current_stream(feats.device)
+            side = self.__dict__.get('_side_stream')
+            if side is None or side.device != feats.device:
+                side = torch.cuda.Stream(device=feats.device)
+                self.__dict__['_side_stream'] = side
+            side.wait_stream(main)
+            feats.record_stream(side)
+            with torch.cuda.stream(side):          # issued first, as in the reference (onsetsframes.py:121-124): same Dropout RNG order
+                multi_pitch = self.pitch_head(feats)
+            onsets, offsets = self._recurrent_heads(feats)
+            main.wait_stream(side)
+            multi_pitch.record_stream(main)
+        else:
+            multi_pitch = self.pitch_head(feats)
+            onsets, offsets = self._recurrent_heads(feats)
         output[tools.KEY_ONSETS] = onsets
         heads = [onsets]
         if self.has_offsets:
-            if offsets is None:
-                offsets = self.offset_head(feats)
             output[tools.KEY_OFFSETS] = offsets
             heads.append(offsets)
         if self.detach_heads:
@@ -542,6 +551,27 @@ class OnsetsFrames(TranscriptionModel):
         joint = torch.cat(heads + [multi_pitch], -1)
         output[tools.KEY_MULTIPITCH] = self.adjoin(joint)
         return output
+
+    def _overlap_heads(self, feats):
+        """Training on a GPU: recurrent heads on a side stream beside the pitch head, unless AMTX_TRAIN_OVERLAP=0 (or the attribute
+        `overlap_heads = False` on the model)."""
+        if not (feats.is_cuda and self.training and torch.is_grad_enabled()):
+            return False
+        if os.environ.get('AMTX_TRAIN_OVERLAP', '1') == '0':
+            return False
+        return bool(self.__dict__.get('overlap_heads', True))
+
+    def _recurrent_heads(self, feats):
+        """Onset (and offset) detector heads: (onsets, offsets or None)."""
+        if self._grouped_recurrences(feats):
+            # the onset and offset heads are independent: their two recurrences run as ONE grouped launch each way
+            from .autograd import bilstm_multi
+            (am_on, lm_on, lb_on), (am_off, lm_off, lb_off) = self.onset_head, self.offset_head
+            l_on, l_off = bilstm_multi([am_on(feats), am_off(feats)], [lm_on.mlm, lm_off.mlm])
+            return lb_on(l_on), lb_off(l_off)
+        onsets = self.onset_head(feats)
+        offsets = self.offset_head(feats) if self.has_offsets else None
+        return onsets, offsets
 
     def _grouped_recurrences(self, feats):
         """Training on a GPU with an offset head whose LSTM and the onset head's are both on the HIP autograd path."""

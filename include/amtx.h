@@ -117,7 +117,12 @@ int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_
  * weight versions can be handed over as DEVICE pointers (fp32, contiguous, same state_dict names, borrowed until finalize_device returns)
  * and are folded / packed by kernels into the model's existing buffers -- the same bits the host path produces.  Every built
  * configuration and precision; AMTX_ERR_UNSUPPORTED only for a multi-channel first conv forced onto conv.hip's kernel
- * (AMTX_NO_CONVG_MC2): callers then use set_tensor + finalize. */
+ * (AMTX_NO_CONVG_MC2): callers then use set_tensor + finalize.
+ * Both re-sync entry points (finalize after a first finalize, finalize_device) overwrite the packed buffers IN PLACE: they first wait for
+ * every operation the device has been given (hipDeviceSynchronize), so a forward pass of the previous weight version still running on
+ * another stream never reads half-updated weights; forwards enqueued AFTER the call on a stream other than `stream` must be ordered
+ * behind it by the caller.  finalize_device validates every tensor (name, size) before it touches a buffer, drops the borrowed pointers
+ * on every exit, and leaves the model un-finalized (forwards refuse to run) if a pack launch fails half-way. */
 int amtx_of_model_set_tensor_device(amtx_of_model* model, const char* name, const float* device_data, int64_t numel);
 int amtx_of_model_finalize_device(amtx_of_model* model, void* stream);
 

@@ -36,6 +36,7 @@ def test_single_rank_rccl_allreduce_300_steps_leaves_the_same_weights(of2):
     assert rec['collectives'] == steps and rec['collectives_plain'] == 0, rec
     assert rec['deterministic_plain'], f'the training step itself is not run-to-run deterministic: {rec}'
     assert rec['identical'], f'weights differ between the RCCL run and the plain run: {rec}'
+    assert rec['two_streams_identical_to_one_stream'], f'the two-stream step (pitch head on a side stream) differs from the one-stream step: {rec}'
     assert rc == 0, err[-2000:]
 
 

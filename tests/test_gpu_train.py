@@ -417,6 +417,11 @@ def test_multi_channel_first_conv_trains_on_the_hip_kernels(c_in, dim_in):
     assert abs(loss.item() - loss_ref.item()) < 2e-3 * abs(loss_ref.item())
     rel = []
     for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if '.layer' in n and n.endswith('.0.bias'):
+            # a convolution bias in front of a training-mode BatchNorm: its gradient is exactly zero in real arithmetic (the batch mean
+            # removes it), both paths return rounding noise
+            assert float(p.grad.norm()) < 1e-3 and float(q.grad.norm()) < 1e-3, n
+            continue
         rel.append(float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-12)))
     w1 = dict(model.named_parameters())['onset_head.0.layer1.0.weight'].grad
     w1r = dict(ref.named_parameters())['onset_head.0.layer1.0.weight'].grad

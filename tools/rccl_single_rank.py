@@ -6,8 +6,11 @@ A sum over one rank returns the gradients' own bits, so both runs must leave bit
 
     python tools/rccl_single_rank.py [--steps 300] [--of2] [--clips 8] [--frames 625]
 
+The default training path runs the pitch head on a side stream beside the recurrent heads (models.py); a third run keeps everything on
+ONE stream -- same kernels, same order per stream, so again the same bits (a cross-stream race would show as a difference).
+
 Prints ONE JSON line: {"steps", "model", "identical", "max_abs_diff", "collectives", "ms_per_step_plain", "ms_per_step_rccl",
-"deterministic_plain"}.  Meant to be started as a FRESH child process under a wall-clock limit (tests/test_gpu_rccl.py): a hang
+"deterministic_plain", "ms_per_step_one_stream", "two_streams_identical_to_one_stream"}.  Meant to be started as a FRESH child process under a wall-clock limit (tests/test_gpu_rccl.py): a hang
 is then a killed child and a failed test, never a re-exec of a process that has touched the GPU.
 """
 import argparse
@@ -24,7 +27,7 @@ import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
 
-def run(steps, of2, clips, frames, collective, device='cuda:0'):
+def run(steps, of2, clips, frames, collective, overlap=True, device='cuda:0'):
     from amt_tools_amd import tools
     from amt_tools_amd.dp import DataParallelOptimizer
     from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
@@ -37,6 +40,7 @@ def run(steps, of2, clips, frames, collective, device='cuda:0'):
         model = OnsetsFrames(229, tools.PianoProfile(), 1, 2, device=device)
     model.change_device()
     model.train()
+    model.__dict__['overlap_heads'] = bool(overlap)       # pitch head on a side stream beside the recurrent heads (models.py)
     opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4, buffers=model.buffers(), force_collective=collective)
     rng = np.random.default_rng(7)
     feats = torch.from_numpy(rng.random((clips, 1, 229, frames), dtype=np.float32)).to(device)
@@ -81,6 +85,8 @@ def main():
     import torch.distributed as dist
     torch.cuda.set_device(0)
     plain, ms_plain, n0, loss_plain = run(args.steps, args.of2, args.clips, args.frames, collective=False)
+    one, ms_one, _, _ = run(args.steps, args.of2, args.clips, args.frames, collective=False, overlap=False)
+    same_streams, worst_streams = diff(plain, one)
     again, _, _, _ = run(min(args.steps, 20), args.of2, args.clips, args.frames, collective=False)
     first, _, _, _ = run(min(args.steps, 20), args.of2, args.clips, args.frames, collective=False)
     deterministic, _ = diff(again, first)
@@ -100,8 +106,9 @@ def main():
     print(json.dumps({'steps': args.steps, 'model': 'OnsetsFrames2(mc=3)' if args.of2 else 'OnsetsFrames(mc=2)', 'backend': args.backend,
                       'identical': same, 'max_abs_diff': worst, 'collectives': n1, 'collectives_plain': n0,
                       'ms_per_step_plain': ms_plain, 'ms_per_step_rccl': ms_rccl, 'deterministic_plain': deterministic,
+                      'ms_per_step_one_stream': ms_one, 'two_streams_identical_to_one_stream': same_streams, 'max_abs_diff_streams': worst_streams,
                       'loss_plain': loss_plain, 'loss_rccl': loss_rccl}), flush=True)
-    return 0 if (same and n1 == args.steps and n0 == 0) else 1
+    return 0 if (same and same_streams and n1 == args.steps and n0 == 0) else 1
 
 
 if __name__ == '__main__':
