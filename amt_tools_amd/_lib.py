@@ -98,6 +98,7 @@ _SIGNATURES = {
     'amtx_rms_norm_workspace_bytes': (C.c_size_t, [_I, _L]),
     'amtx_rms_norm': (_I, [_P, _L, _L, _I, _P, _L, _P, C.c_size_t, _P]),
     'amtx_notes_decode': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    'amtx_notes_rows': (_I, [_P, _P, _I, _I, _I, _P, _L, _I, _P, _P, _L, _P, _P]),
     'amtx_pianoroll_fwd': (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
     'amtx_matmul_workspace_bytes': (C.c_size_t, [_L, _L, _L]),
     'amtx_matmul_f32': (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _L, _L, _L, _L, _P, C.c_size_t, _P]),

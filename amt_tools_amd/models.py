@@ -434,6 +434,7 @@ class OnsetsFrames(TranscriptionModel):
         state.pop('_engine_out', None)
         state.pop('_engine_offsets', None)
         state.pop('_side_stream', None)
+        state.pop('_overlap_armed', None)
         return state
 
     def _get_engine(self, device):
@@ -553,13 +554,23 @@ class OnsetsFrames(TranscriptionModel):
         return output
 
     def _overlap_heads(self, feats):
-        """Training on a GPU: recurrent heads on a side stream beside the pitch head, unless AMTX_TRAIN_OVERLAP=0 (or the attribute
-        `overlap_heads = False` on the model)."""
+        """Training on a GPU: pitch head on a side stream beside the recurrent heads, unless AMTX_TRAIN_OVERLAP=0 (or the attribute
+        `overlap_heads = False` on the model) -- and only while every dense layer of the step runs on this package's HIP kernels.
+        tools/two_stream_repro.py narrowed the round-1 hang down to the vendor libraries: with BOTH MIOpen convolutions and hipBLASLt
+        GEMMs in the two heads the side stream stops in the first head's fc1 GEMM within 2 - 90 steps (either library alone, or the
+        all-HIP step: thousands of steps clean).  So the first training forward of a model runs on one stream, and the overlap is armed
+        only if that forward -- and every one since -- recorded no ATen fallback (autograd.fallbacks())."""
         if not (feats.is_cuda and self.training and torch.is_grad_enabled()):
             return False
-        if os.environ.get('AMTX_TRAIN_OVERLAP', '1') == '0':
+        if os.environ.get('AMTX_TRAIN_OVERLAP', '1') == '0' or not self.__dict__.get('overlap_heads', True):
             return False
-        return bool(self.__dict__.get('overlap_heads', True))
+        from . import autograd as ag
+        if not ag.USE_HIP_DENSE or ag.fallbacks():
+            return False
+        if not self.__dict__.get('_overlap_armed', False):
+            self.__dict__['_overlap_armed'] = True       # this forward is the probe
+            return False
+        return True
 
     def _recurrent_heads(self, feats):
         """Onset (and offset) detector heads: (onsets, offsets or None)."""

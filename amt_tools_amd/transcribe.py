@@ -120,58 +120,91 @@ def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITC
     return _events_to_notes(pitch_idcs, frame_idcs, after[pitch_idcs, frame_idcs], np.asarray(times), low, min_duration=min_duration)
 
 
-class _PendingNotes(object):
-    """Device half of the decoder already enqueued; `result()` brings the compacted events to the host and assembles the
-    reference-ordered note arrays.  Lets a caller enqueue the next batch's kernels before paying for this batch's host work."""
+def _reference_order(onset_col):
+    """Permutation of one clip's notes (np.nonzero order) into the reference's row order: sort_notes in multi_pitch_to_notes
+    (utils.py:469), notes_to_stacked_notes (:745) and stacked_notes_to_notes (:531) = three successive argsorts of the float64 onset
+    column with NumPy's default (unstable) sort, composed as permutations."""
+    p = onset_col.argsort()
+    o = onset_col.take(p)
+    for _ in range(2):
+        q = o.argsort()
+        p = p.take(q)
+        o = o.take(q)
+    return p
 
-    def __init__(self, ev, counts, B, K, times, low):
-        self._ev, self._counts, self._B, self._K, self._times, self._low = ev, counts, B, K, np.asarray(times), low
+
+class _PendingNotes(object):
+    """Device half of the decoder already enqueued (amtx_notes_decode + amtx_notes_rows: one dense (E,3) float64 array of note rows in
+    np.nonzero order per clip, its onset column and the per-clip offsets); `result()` copies them to the host and applies the
+    reference's row order clip by clip.  Lets a caller enqueue the next batch's kernels before paying for this batch's host work."""
+
+    def __init__(self, rows, onset_col, offsets, B, retry):
+        self._rows, self._onset, self._offsets, self._B, self._retry = rows, onset_col, offsets, B, retry
         import torch
         self._done = torch.cuda.Event()
-        self._done.record(torch.cuda.current_stream(ev.device))
+        self._done.record(torch.cuda.current_stream(rows.device))
 
     def result(self):
         self._done.synchronize()
-        B, K, times, low = self._B, self._K, self._times, self._low
-        ev_h = self._ev.cpu().numpy()
-        counts_h = self._counts.cpu().numpy().reshape(B, K)
-        keys_h = np.repeat(np.tile(np.arange(K), B), counts_h.reshape(-1))             # key of every event
-        bounds = np.concatenate([[0], np.cumsum(counts_h.sum(axis=1))])
-        shared_ext = _extend_times(times) if times.ndim == 1 else None
+        off = self._offsets.cpu().numpy()
+        total = int(off[-1])
+        if total > self._rows.shape[0]:             # more notes than the first buffer held: once more with the exact size
+            again = self._retry(total)
+            again._done.synchronize()
+            self._rows, self._onset, off = again._rows, again._onset, again._offsets.cpu().numpy()
+        rows = self._rows[:total].cpu().numpy()
+        onset = self._onset[:total].cpu().numpy()
+        off = off.tolist()
         out = []
-        for b in range(B):
-            lo, hi = bounds[b], bounds[b + 1]
+        for b in range(self._B):
+            lo, hi = off[b], off[b + 1]
             if hi > lo:
-                t = times if shared_ext is not None else times[b]
-                out.append(_events_to_notes(keys_h[lo:hi], ev_h[lo:hi, 0], ev_h[lo:hi, 1], t, low, shared_ext))
+                out.append(rows[lo:hi].take(_reference_order(onset[lo:hi]), axis=0))
             else:
                 out.append(np.empty([0, 3]))
         return out
 
 
-def decode_notes_batch_async(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH):
-    """Enqueue the device decoder (amtx_notes_decode + compaction) and return a handle; `handle.result()` -> list of B (K,3)
-    float64 arrays.  (B,88,T) fp32 CUDA tensors (onsets may be None); `times` is one (T,) grid or a (B,T) array."""
+def decode_notes_batch_async(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH, rows_capacity=None):
+    """Enqueue the device decoder and return a handle; `handle.result()` -> list of B (K,3) float64 arrays.  (B,88,T) fp32 CUDA tensors
+    (onsets may be None); `times` is one (T,) grid or a (B,T) array.  Two C-ABI calls: amtx_notes_decode (event walk per key) and
+    amtx_notes_rows (compaction into the reference's batched-notes rows, frames -> seconds through the extended grid)."""
     import torch
     assert multi_pitch.is_cuda and multi_pitch.dim() == 3
     B, K, T = multi_pitch.shape
+    dev = multi_pitch.device
     multi_pitch = multi_pitch.contiguous().float()
     if onsets is not None:
         onsets = onsets.contiguous().float()
+    times = np.asarray(times)
+    if times.ndim == 1:
+        ext = _extend_times(times).astype(np.float64)                  # float32 grids (run_offline) convert exactly, as in the reference's float64 rows
+        stride = 0
+    else:
+        ext = np.stack([_extend_times(t) for t in times]).astype(np.float64)
+        stride = ext.shape[1]
+    assert ext.shape[-1] == T + 1
+    ext_d = torch.from_numpy(np.ascontiguousarray(ext)).to(dev)
     cap = T // 2 + 2
-    pairs = torch.empty((B * K, cap, 2), dtype=torch.int32, device=multi_pitch.device)
-    counts = torch.empty((B * K,), dtype=torch.int32, device=multi_pitch.device)
-    with torch.cuda.device(multi_pitch.device):
-        _lib.check(_lib.lib().amtx_notes_decode(_lib.ptr(onsets), _lib.ptr(multi_pitch), B, K, T, cap, _lib.ptr(pairs), _lib.ptr(counts),
-                                                _lib.current_stream(multi_pitch.device)), 'amtx_notes_decode')
-        # compact on the device: only the emitted (onset, offset) pairs cross PCIe (a few MB instead of the padded
-        # B*K*cap*8 bytes), per key in ascending frame order (the kernel emits descending frames) = np.nonzero order
-        counts64 = counts.long()
-        j = torch.arange(cap, device=counts.device)[None, :]
-        valid = j < counts64[:, None]
-        rev = (counts64[:, None] - 1 - j).clamp_(min=0)
-        ev = torch.gather(pairs, 1, rev[..., None].expand(-1, -1, 2))[valid]     # (E, 2), (clip, key)-major
-        return _PendingNotes(ev, counts, B, K, times, low)
+    pairs = torch.empty((B * K, cap, 2), dtype=torch.int32, device=dev)
+    counts = torch.empty((B * K,), dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        _lib.check(L.amtx_notes_decode(_lib.ptr(onsets), _lib.ptr(multi_pitch), B, K, T, cap, _lib.ptr(pairs), _lib.ptr(counts),
+                                       _lib.current_stream(dev)), 'amtx_notes_decode')
+
+    def rows_pass(capacity):
+        rows = torch.empty((capacity, 3), dtype=torch.float64, device=dev)
+        onset_col = torch.empty((capacity,), dtype=torch.float64, device=dev)
+        offsets = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.amtx_notes_rows(_lib.ptr(pairs), _lib.ptr(counts), B, K, cap, _lib.ptr(ext_d), stride, int(low), _lib.ptr(rows),
+                                         _lib.ptr(onset_col), capacity, _lib.ptr(offsets), _lib.current_stream(dev)), 'amtx_notes_rows')
+        return _PendingNotes(rows, onset_col, offsets, B, rows_pass)
+
+    # 1024 notes per clip on average covers any realistic transcription (the synthetic bench clips decode to ~400); a denser batch is
+    # caught in result() through the total the device reports and decoded again into a buffer of the exact size
+    return rows_pass(int(rows_capacity) if rows_capacity else max(B * 1024, 1 << 14))
 
 
 def decode_notes_batch(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH):

@@ -93,6 +93,7 @@ def parse(argv=None):
     ap.add_argument('--of2', action='store_true', help='train mode: OnsetsFrames2 as shipped (model_complexity 3, offset head)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='wall-time budget of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--no-train-probe', action='store_true', help='skip the one-GPU training-step time (BASELINE metric ii) appended to the default line')
+    ap.add_argument('--no-hcqt', action='store_true', help='skip the BASELINE config-3 leg (OnsetsFrames + HCQT 6 x 72) appended to the default line')
     ap.add_argument('--no-parity', action='store_true', help='skip the bf16-vs-x3 / oracle cell-mismatch count and the x3 throughput leg')
     ap.add_argument('--backend', default='nccl', help="torch.distributed backend for N > 1 ('nccl' = RCCL; 'gloo' only for the "
                                                       "single-GPU smoke test of the multi-process path)")
@@ -449,6 +450,47 @@ def parity_leg(model, audio, out_bf16, device, oracle_rolls):
     return res
 
 
+def hcqt_leg(device, clips=512, steps=5):
+    """BASELINE config 3 after the timed region: audio resident in HBM -> HIP HCQT (6 harmonics x 72 bins, amt_tools/features/hvqt.py:107-133)
+    as model.frontend -> OnsetsFrames(dim_in 72, 6 channels, mc 2), bf16, the same synthetic clips.  Returns frames/s + ms per step."""
+    from amt_tools_amd import tools
+    from amt_tools_amd.features import HCQT
+    from amt_tools_amd.models import OnsetsFrames
+    from amt_tools_amd.synth import synth_clip, synth_state_dict
+    mod = HCQT(sample_rate=SR, hop_length=HOP, n_bins=72, bins_per_octave=12, device=device)
+    model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device=device, precision='bf16')
+    sd = synth_state_dict(0, dim_in=72, in_channels=6, model_complexity=2)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.frontend = torch.nn.Sequential(mod.frontend())
+    model.change_device()
+    model.eval()
+    base = np.stack([synth_clip(i) for i in range(8)])
+    audio = torch.from_numpy(base).to(device).repeat((clips + 7) // 8, 1)[:clips].contiguous()
+    with torch.no_grad():
+        for _ in range(2):
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.frontend(audio[:, None, :])
+        torch.cuda.synchronize()
+        fe_ms = (time.perf_counter() - t0) / 3 * 1e3
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    T = out[tools.KEY_ONSETS].shape[-1]
+    fps = clips * T / dt
+    del model, out, audio
+    torch.cuda.empty_cache()
+    # SURVEY 8(d): OF1 + HCQT(6 x 72) = 10.3 MFLOP per frame
+    return {'frames_per_s': fps, 'ms_per_step': dt * 1e3, 'clips_per_step': clips, 'frames_per_clip': int(T), 'frontend_ms_per_step': fe_ms,
+            'frac_of_mfma_roof': fps * 10.3e6 / 2.5e15,
+            'workload': 'BASELINE config 3: OnsetsFrames(mc=2, dim_in 72, 6 channels) + HCQT(6 harmonics x 72 bins, hop 512) inference, bf16, '
+                        'audio resident in HBM -> piano rolls'}
+
+
 def run_infer(args, rank, world, device):
     from amt_tools_amd import _lib, tools
     from amt_tools_amd.synth import synth_clip
@@ -570,6 +612,9 @@ def run_infer(args, rank, world, device):
         config.update(parity_leg(model, audio, out, device, oracle_rolls))
         if config.get('precision_modes'):
             config['precision_modes'][0]['frames_per_s'] = fps
+    if world == 1 and not args.no_hcqt and args.precision == 'bf16':
+        config['hcqt'] = hcqt_leg(device)
+        config['hcqt_frames_per_s'] = config['hcqt']['frames_per_s']
     if world == 1 and not args.no_train_probe:
         # BASELINE metric (ii), train step time, at N = 1 (the DP = 8 figure needs the 8-GPU node: python bench.py --mode train --gpus 8)
         del model, out

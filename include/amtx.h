@@ -288,6 +288,20 @@ int amtx_rms_norm(const float* audio, int64_t num_samples, int64_t audio_stride,
 int amtx_notes_decode(const float* onsets, const float* multi_pitch, int batch, int keys, int num_frames, int capacity,
                       int32_t* pairs, int32_t* counts, void* stream);
 
+/* amtx_notes_decode's event lists -> ONE dense array of note rows [onset_s, offset_s, midi_pitch] (float64; the reference's batched
+ * notes, tools/utils.py:135-165) in np.nonzero order per clip (key ascending, onset frame ascending = the order in which
+ * tools.multi_pitch_to_notes appends, utils.py:445-463), the frames converted to seconds through the clip's time grid:
+ *   times_ext   [num_frames + 1] float64 (times_stride 0: one grid for the batch) or [batch][times_stride] -- the frame times plus one
+ *               more frame (utils.py:441-442); the caller builds it (estimate_hop_length is host arithmetic on a small array)
+ *   rows        [rows_capacity][3], onset_col [rows_capacity] (a contiguous copy of column 0: the key of sort_notes' argsort)
+ *   clip_offsets[batch + 1] int32: clip b's rows are [clip_offsets[b], clip_offsets[b + 1]); clip_offsets[batch] is the total, which may
+ *               EXCEED rows_capacity -- rows past the capacity are not written, the caller retries with a larger buffer.
+ * The reference's final row order (three unstable argsorts by onset, utils.py:2713-2746) is applied by the caller: the order among
+ * equal onsets is whatever NumPy's sort makes of it and is not reproduced on the device. */
+int amtx_notes_rows(const int32_t* pairs, const int32_t* counts, int batch, int keys, int capacity, const double* times_ext,
+                    int64_t times_stride, int low_pitch, double* rows, double* onset_col, int64_t rows_capacity, int32_t* clip_offsets,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,6 @@ def test_bench_train_line_with_a_forced_one_rank_nccl_group():
 def test_bench_infer_line_with_a_forced_one_rank_nccl_group():
     """The inference line's only collectives (timing barrier, MAX / gather of the elapsed times) over a one-rank nccl group."""
     rc, rec, err = _child(['bench.py', '--gpus', '1', '--force-dist', '--steps', '3', '--warmup', '1', '--clips', '64', '--cpu-seconds', '0',
-                           '--no-parity', '--no-train-probe'], 400)
+                           '--no-parity', '--no-train-probe', '--no-hcqt'], 400)
     assert rc == 0, err[-2000:]
     assert rec['n_gpus'] == 1 and rec['config']['process_group'] == 'nccl' and rec['value'] > 0

@@ -99,3 +99,28 @@ def test_device_decoder_full_size_batch_vs_host():
     got2 = decode_notes_batch(None, torch.from_numpy(mp).cuda(), times)
     for b in range(B):
         assert np.array_equal(got2[b], multi_pitch_to_notes(mp[b], times, 21, None))
+
+
+@pytest.mark.gpu
+def test_device_decoder_per_clip_grids_many_clips_and_capacity_retry():
+    """amtx_notes_rows: per-clip time grids ((B,T), float32 as run_offline hands them over), more clips than the scan kernel's 1024-clip
+    chunk, empty clips in between, and a first buffer that is too small (the retry with the exact size must return the same notes)."""
+    torch = pytest.importorskip('torch')
+    from amt_tools_amd.transcribe import decode_notes_batch, decode_notes_batch_async
+    rng = np.random.default_rng(5)
+    B, T = 1500, 96
+    mp = (rng.random((B, 88, T)) < 0.08).astype(np.float32)
+    on = (rng.random((B, 88, T)) < 0.02).astype(np.float32)
+    mp[::7] = 0.0
+    on[::7] = 0.0                                                 # clips without a single note
+    hops = rng.integers(128, 1024, B)
+    times = (np.arange(T)[None, :] * hops[:, None] / 22050.0).astype(np.float32)
+    mpd, ond = torch.from_numpy(mp).cuda(), torch.from_numpy(on).cuda()
+    got = decode_notes_batch(ond, mpd, times)
+    small = decode_notes_batch_async(ond, mpd, times, rows_capacity=100).result()
+    assert len(got) == B
+    for b in range(B):
+        ref = multi_pitch_to_notes(mp[b], times[b], 21, on[b])
+        assert got[b].dtype == np.float64 and got[b].shape == ref.shape and np.array_equal(got[b], ref), b
+        assert np.array_equal(small[b], ref), b
+    assert got[0].shape == (0, 3)
