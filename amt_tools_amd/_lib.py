@@ -97,6 +97,7 @@ _SIGNATURES = {
     'amtx_bce_logits_loss': (_I, [_P, _L, _P, _P, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     'amtx_rms_norm_workspace_bytes': (C.c_size_t, [_I, _L]),
     'amtx_rms_norm': (_I, [_P, _L, _L, _I, _P, _L, _P, C.c_size_t, _P]),
+    'amtx_spec_mel_layout': (_I, [_I, _I, _I, _I, _P, _P, _P]),
     'amtx_notes_decode': (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     'amtx_notes_rows': (_I, [_P, _P, _I, _I, _I, _P, _L, _I, _P, _P, _L, _P, _P]),
     'amtx_pianoroll_fwd': (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),

@@ -20,6 +20,8 @@
 #include "amtx_common.h"
 
 #include <math.h>
+#include <algorithm>
+#include <functional>
 #include <vector>
 
 namespace {
@@ -38,7 +40,9 @@ struct SpecDev {
     const float* window;     // [NFFT]
     const float2* tw_fft;    // [M]   exp(-2 pi i k / M)
     const float2* tw_post;   // [M]   exp(-2 pi i k / NFFT), k < M
-    const int* mel_start;    // [64 * rounds] first bin of the row's support (0 for rows past n_mels)
+    const int* mel_start;    // [64 * rounds] slot (round r, lane l): first bin its taps read (the row's first non-zero bin minus an even number of zero taps)
+    const int* mel_row;      // [64 * rounds] slot -> mel row it computes (-1: none).  Rows are dealt to slots so that the 32 lanes of a half-wave start
+                             // on 32 different LDS banks (plan creation: mel_assign_slots), not in row order
     const float* mel_wt;     // tap-major weights of round r at round_off[r]*64: [tap j][lane] = weight j of row 64r + lane, zero padded
     int round_max[MAX_MEL_ROUNDS];   // taps of round r = max tap count of rows [64r, 64r+64), rounded up to a multiple of MEL_UNROLL
     int round_off[MAX_MEL_ROUNDS];   // first tap slot of round r in mel_wt
@@ -223,8 +227,9 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
     float* pb = reinterpret_cast<float*>(smem + WAVES * XB_ELEMS * sizeof(float2)) + wave * PB_ELEMS;
     float2* twp = reinterpret_cast<float2*>(smem + WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float));
     float2* tw2l = twp + M / 2;                       // W_64^(b*c), [b][c]: 64 entries
-    int* mstart = reinterpret_cast<int*>(tw2l + 64);  // first bin of every mel row, [64 * MAX_MEL_ROUNDS]
-    float* melw = reinterpret_cast<float*>(mstart + 64 * MAX_MEL_ROUNDS);   // MELLDS: [slot][lane] weights
+    int* mstart = reinterpret_cast<int*>(tw2l + 64);  // first bin of every mel slot, [64 * MAX_MEL_ROUNDS]
+    int* mrow = mstart + 64 * MAX_MEL_ROUNDS;         // mel row of every slot (-1: none), [64 * MAX_MEL_ROUNDS]
+    float* melw = reinterpret_cast<float*>(mrow + 64 * MAX_MEL_ROUNDS);     // MELLDS: [slot][lane] weights
 
     constexpr int FPB = FPW * WAVES;
     const unsigned chunks = (unsigned)((num_frames + FPB - 1) / FPB);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
         tw1[n1] = p.tw_fft[(lane * n1) & (M - 1)];
     }
     const int rounds = MEL ? (p.n_mels + 63) / 64 : 0;
-    for (int i = threadIdx.x; i < 64 * rounds; i += 256) mstart[i] = p.mel_start[i];
+    for (int i = threadIdx.x; i < 64 * rounds; i += 256) { mstart[i] = p.mel_start[i]; mrow[i] = p.mel_row[i]; }
     if constexpr (MELLDS) {
         const int nw = 64 * (p.round_off[rounds - 1] + p.round_max[rounds - 1]);
         for (int i = threadIdx.x; i < nw; i += 256) melw[i] = p.mel_wt[i];
@@ -343,8 +348,8 @@ __global__ __launch_bounds__(256, 2) void spec_power_kernel(SpecDev p, const flo
             }
 #pragma unroll
             for (int r = 0; r < MAX_MEL_ROUNDS; ++r) {
-                const int row = r * 64 + lane;
-                if (r < rounds && row < p.n_mels) {
+                const int row = r < rounds ? mrow[r * 64 + lane] : -1;
+                if (row >= 0) {
                     out_row[row] = res[r];
                     run_max = fmaxf(run_max, res[r]);
                 }
@@ -418,6 +423,9 @@ __global__ __launch_bounds__(256, 2) void spec_power_ring_kernel(SpecDev p, cons
     float mw[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) mw[q] = p.mel_wt[q * 64 + lane];
+    int orow[4];                                                           // mel row of this lane's slot in each round (-1: none)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) orow[r] = p.mel_row[r * 64 + lane];
     for (int i = pidx(M + 1) + lane; i < PB_ELEMS; i += 64) pb[i] = 0.0f;
 
     // ---- sample staging.  sb = first sample of the block's first frame; sample s lives at ring[(s - sb) & (RING_ELEMS - 1)].
@@ -497,9 +505,8 @@ __global__ __launch_bounds__(256, 2) void spec_power_ring_kernel(SpecDev p, cons
         float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = r * 64 + lane;
-            if (row < p.n_mels) {
-                out_row[row] = res[r];
+            if (orow[r] >= 0) {
+                out_row[orow[r]] = res[r];
                 run_max = fmaxf(run_max, res[r]);
             }
         }
@@ -566,12 +573,12 @@ __global__ __launch_bounds__(256) void spec_power_pow2_kernel(SpecDev p, int log
         float* out_row = power + ((int64_t)clip_idx * num_frames + t) * p.n_out;
         if (mel) {
             for (int r = 0; r < rounds; ++r) {
-                const int row = r * 64 + lane;
-                const int start = p.mel_start[row];
+                const int row = p.mel_row[r * 64 + lane];
+                const int start = p.mel_start[r * 64 + lane];
                 const float* wt = p.mel_wt + p.round_off[r] * 64 + lane;
                 float acc = 0.0f;
                 for (int j = 0; j < p.round_max[r]; ++j) acc = fmaf(wt[j * 64], pb[min(start + j, pb_elems - 1)], acc);
-                if (row < p.n_mels) {
+                if (row >= 0) {
                     out_row[row] = acc;
                     run_max = fmaxf(run_max, acc);
                 }
@@ -654,6 +661,156 @@ double mel_to_hz(double m, bool htk) {
     return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
 }
 
+// Which lane computes which mel row.  The gather reads pb[start + j] for tap j on every lane at once: two lanes of a half-wave whose
+// first bins are congruent mod 32 hit one LDS bank at EVERY tap (dealt in row order, the 229-row Slaney table cost 304 LDS cycles per
+// frame where a conflict-free gather costs 128: 44 % of the kernel's LDS cycles were conflicts, PMC round 3).  Two degrees of freedom
+// remove them without touching any row's arithmetic: a row may sit in ANY round whose tap count covers it (the padding taps are
+// zero), and its first tap may start an EVEN number of bins early (zero weights in front: the even / odd accumulator split of the
+// gather, and with it every sum's rounding, is unchanged).  A slot = (round r, half-wave h, bank b); a maximum bipartite matching
+// rows -> slots (Kuhn's augmenting paths, options tried nearest-to-natural first) gives every row of the BASELINE tables its own
+// bank: 128 cycles.  Rows the matching leaves over take any free lane (they then share a bank with one other row).
+void mel_assign_slots(const std::vector<int>& start, const std::vector<int>& count, int n_mels, int rounds, const int* round_max, bool natural,
+                      std::vector<int>& slot_row, std::vector<int>& slot_start) {
+    const int G = 2 * rounds;
+    std::fill(slot_row.begin(), slot_row.end(), -1);
+    std::fill(slot_start.begin(), slot_start.end(), 0);
+    auto natural_fill = [&]() {
+        std::fill(slot_row.begin(), slot_row.end(), -1);
+        for (int i = 0; i < n_mels; ++i) { slot_row[i] = i; slot_start[i] = start[i]; }
+    };
+    if (natural || rounds == 0) { natural_fill(); return; }
+    struct Opt { int cell, delta; };
+    std::vector<std::vector<Opt>> opts(n_mels);
+    for (int i = 0; i < n_mels; ++i) {
+        std::vector<int> order;                                   // groups by distance from the row's natural round, halves of a round together
+        const int nat = i / 64;
+        for (int dist = 0; dist < rounds; ++dist)
+            for (int sgn = 0; sgn < 2; ++sgn) {
+                const int r = sgn ? nat - dist : nat + dist;
+                if ((dist == 0 && sgn) || r < 0 || r >= rounds) continue;
+                order.push_back(2 * r + ((i / 32) & 1));
+                order.push_back(2 * r + 1 - ((i / 32) & 1));
+            }
+        for (int g : order) {
+            const int S = round_max[g / 2];
+            for (int d = 0; d + count[i] <= S && start[i] - d >= 0; d += 2) opts[i].push_back({g * 32 + ((start[i] - d) & 31), d});
+        }
+    }
+    std::vector<int> owner((size_t)G * 32, -1), pick(n_mels, -1);
+    std::vector<char> seen;
+    std::function<bool(int)> place = [&](int i) -> bool {
+        for (int k = 0; k < (int)opts[i].size(); ++k) {
+            const int cell = opts[i][k].cell;
+            if (seen[cell]) continue;
+            seen[cell] = 1;
+            if (owner[cell] < 0 || place(owner[cell])) { owner[cell] = i; pick[i] = k; return true; }
+        }
+        return false;
+    };
+    std::vector<int> rows(n_mels);
+    for (int i = 0; i < n_mels; ++i) rows[i] = i;
+    std::stable_sort(rows.begin(), rows.end(), [&](int a, int b) { return opts[a].size() < opts[b].size(); });
+    for (int i : rows) {
+        seen.assign((size_t)G * 32, 0);
+        (void)place(i);
+    }
+    // cells -> lanes (the lanes of a half-wave are interchangeable: dealt in bank order), then the leftovers
+    std::vector<int> used(G, 0);
+    for (int g = 0; g < G; ++g)
+        for (int b = 0; b < 32; ++b) {
+            const int i = owner[(size_t)g * 32 + b];
+            if (i < 0) continue;
+            const int sl = (g / 2) * 64 + (g & 1) * 32 + used[g]++;
+            slot_row[sl] = i;
+            slot_start[sl] = start[i] - opts[i][pick[i]].delta;
+        }
+    for (int i = 0; i < n_mels; ++i) {
+        if (pick[i] >= 0 && owner[opts[i][pick[i]].cell] == i) continue;
+        bool done = false;
+        for (int g = 0; g < G && !done; ++g)
+            if (round_max[g / 2] >= count[i] && used[g] < 32) {
+                const int sl = (g / 2) * 64 + (g & 1) * 32 + used[g]++;
+                slot_row[sl] = i; slot_start[sl] = start[i];
+                done = true;
+            }
+        if (!done) { natural_fill(); return; }                    // cannot happen while every row fits its natural round; keep the plan valid anyway
+    }
+}
+
+// Host tables of the mel stage: librosa.filters.mel (norm='slaney', fmin=0, fmax=sr/2; float32 triangle scaled by the float64 area norm,
+// as librosa does) and the gather's slot layout (mel_assign_slots).  No device involved: amtx_spec_mel_layout exposes it to CPU tests.
+struct MelHost {
+    int rounds = 0;
+    int round_max[MAX_MEL_ROUNDS], round_off[MAX_MEL_ROUNDS];
+    std::vector<float> fb_dense;            // n_mels x (n_fft / 2 + 1)
+    std::vector<int> start, count;          // per row: first non-zero bin, taps
+    std::vector<int> slot_row, slot_start;  // per slot (64 per round)
+    std::vector<float> w;                   // tap-major weights, [slot tap][lane]
+};
+
+int build_mel_tables(int sample_rate, int n_fft, int n_mels, int htk, MelHost& mh) {
+    const int nb = n_fft / 2 + 1;
+    const int mel_rounds = n_mels > 0 ? (n_mels + 63) / 64 : 0;
+    mh.rounds = mel_rounds;
+    memset(mh.round_max, 0, sizeof(mh.round_max));
+    memset(mh.round_off, 0, sizeof(mh.round_off));
+    mh.start.assign(n_mels > 0 ? n_mels : 1, 0);
+    mh.count.assign(n_mels > 0 ? n_mels : 1, 0);
+    mh.slot_row.assign(mel_rounds > 0 ? 64 * mel_rounds : 1, -1);
+    mh.slot_start.assign(mel_rounds > 0 ? 64 * mel_rounds : 1, 0);
+    mh.w.clear();
+    mh.fb_dense.clear();
+    if (n_mels > 0) {
+        std::vector<int>& m_start = mh.start;
+        std::vector<int>& m_count = mh.count;
+        mh.fb_dense.assign((size_t)n_mels * nb, 0.0f);
+        const double fmax = sample_rate / 2.0;
+        std::vector<double> mel_f(n_mels + 2);
+        const double mlo = hz_to_mel(0.0, htk), mhi = hz_to_mel(fmax, htk);
+        for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(mlo + (mhi - mlo) * i / (n_mels + 1), htk);
+        for (int i = 0; i < n_mels; ++i) {
+            const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+            int first = -1, last = -1;
+            const double fstep = fmax / (nb - 1);
+            for (int k = 0; k < nb; ++k) {
+                const double f = k * fstep;
+                const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+                const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+                const double w = lower < upper ? lower : upper;
+                // librosa stores the triangle in float32, then scales in place by the float64 area norm
+                const float w32 = (float)(w > 0 ? w : 0);
+                const float wf = (float)((double)w32 * enorm);
+                mh.fb_dense[(size_t)i * nb + k] = wf;
+                if (wf != 0.0f) { if (first < 0) first = k; last = k; }
+            }
+            if (first >= 0) { m_start[i] = first; m_count[i] = last - first + 1; }
+            const int r = i / 64;
+            if (m_count[i] > mh.round_max[r]) mh.round_max[r] = m_count[i];
+        }
+        // tap-major, zero-padded weight table per round of 64 slots
+        int slots = 0;
+        for (int r = 0; r < mel_rounds; ++r) {
+            mh.round_max[r] = (mh.round_max[r] + MEL_UNROLL - 1) / MEL_UNROLL * MEL_UNROLL;
+            mh.round_off[r] = slots;
+            slots += mh.round_max[r];
+        }
+        mel_assign_slots(m_start, m_count, n_mels, mel_rounds, mh.round_max, getenv("AMTX_SPEC_NATURAL_ROWS") != nullptr, mh.slot_row, mh.slot_start);
+        mh.w.assign((size_t)slots * 64, 0.0f);
+        for (int sl = 0; sl < 64 * mel_rounds; ++sl) {
+            const int i = mh.slot_row[sl];
+            if (i < 0) continue;
+            const int r = sl / 64, l = sl % 64;
+            const int lead = m_start[i] - mh.slot_start[sl];          // zero taps in front of the row's first weight (even, >= 0)
+            if (lead < 0 || lead + m_count[i] > mh.round_max[r] || mh.slot_start[sl] + mh.round_max[r] > nb + 128) {
+                amtx_set_error("amtx_spec_plan_create: mel row %d (%d taps from bin %d) does not fit its slot / the padded power row", i, m_count[i], m_start[i]);
+                return AMTX_ERR_UNSUPPORTED;
+            }
+            for (int j = 0; j < m_count[i]; ++j) mh.w[((size_t)mh.round_off[r] + lead + j) * 64 + l] = mh.fb_dense[(size_t)i * nb + m_start[i] + j];
+        }
+    }
+    return AMTX_OK;
+}
+
 }  // namespace
 
 struct amtx_spec_plan {
@@ -696,68 +853,31 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
         tw_fft[k] = make_float2((float)cos(2.0 * PI * k / M), (float)(-sin(2.0 * PI * k / M)));
         tw_post[k] = make_float2((float)cos(2.0 * PI * k / n_fft), (float)(-sin(2.0 * PI * k / n_fft)));
     }
-    // librosa.filters.mel (norm='slaney', fmin=0, fmax=sr/2), rounded to float32 like librosa does
-    const int mel_rounds = n_mels > 0 ? (n_mels + 63) / 64 : 0;
-    std::vector<int> m_start(mel_rounds > 0 ? 64 * mel_rounds : 1, 0), m_count(n_mels > 0 ? n_mels : 1, 0);
-    std::vector<float> m_w;
-    memset(pl->dev.round_max, 0, sizeof(pl->dev.round_max));
-    memset(pl->dev.round_off, 0, sizeof(pl->dev.round_off));
-    if (n_mels > 0) {
-        const int nb = pl->n_bins_fft;
-        pl->fb_dense.assign((size_t)n_mels * nb, 0.0f);
-        const double fmax = sample_rate / 2.0;
-        std::vector<double> mel_f(n_mels + 2);
-        const double mlo = hz_to_mel(0.0, htk), mhi = hz_to_mel(fmax, htk);
-        for (int i = 0; i < n_mels + 2; ++i) mel_f[i] = mel_to_hz(mlo + (mhi - mlo) * i / (n_mels + 1), htk);
-        for (int i = 0; i < n_mels; ++i) {
-            const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
-            int first = -1, last = -1;
-            const double fstep = fmax / (nb - 1);
-            for (int k = 0; k < nb; ++k) {
-                const double f = k * fstep;
-                const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
-                const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
-                const double w = lower < upper ? lower : upper;
-                // librosa stores the triangle in float32, then scales in place by the float64 area norm
-                const float w32 = (float)(w > 0 ? w : 0);
-                const float wf = (float)((double)w32 * enorm);
-                pl->fb_dense[(size_t)i * nb + k] = wf;
-                if (wf != 0.0f) { if (first < 0) first = k; last = k; }
-            }
-            if (first >= 0) { m_start[i] = first; m_count[i] = last - first + 1; }
-            const int r = i / 64;
-            if (m_count[i] > pl->dev.round_max[r]) pl->dev.round_max[r] = m_count[i];
-        }
-        // tap-major, zero-padded weight table per round of 64 rows
-        int slots = 0;
-        for (int r = 0; r < mel_rounds; ++r) {
-            pl->dev.round_max[r] = (pl->dev.round_max[r] + MEL_UNROLL - 1) / MEL_UNROLL * MEL_UNROLL;
-            pl->dev.round_off[r] = slots;
-            slots += pl->dev.round_max[r];
-        }
-        m_w.assign((size_t)slots * 64, 0.0f);
-        for (int i = 0; i < n_mels; ++i) {
-            const int r = i / 64, l = i % 64;
-            if (m_start[i] + pl->dev.round_max[r] > pl->n_bins_fft + 128) {
-                amtx_set_error("amtx_spec_plan_create: mel row %d (%d taps from bin %d) does not fit the padded power row", i, m_count[i], m_start[i]);
-                delete pl;
-                return AMTX_ERR_UNSUPPORTED;
-            }
-            for (int j = 0; j < m_count[i]; ++j) m_w[((size_t)pl->dev.round_off[r] + j) * 64 + l] = pl->fb_dense[(size_t)i * nb + m_start[i] + j];
-        }
+    // librosa.filters.mel + the slot layout of the gather (build_mel_tables)
+    MelHost mh;
+    {
+        const int mrc = build_mel_tables(sample_rate, n_fft, n_mels, htk, mh);
+        if (mrc != AMTX_OK) { delete pl; return mrc; }
     }
+    pl->fb_dense = mh.fb_dense;
+    memcpy(pl->dev.round_max, mh.round_max, sizeof(pl->dev.round_max));
+    memcpy(pl->dev.round_off, mh.round_off, sizeof(pl->dev.round_off));
+    std::vector<int>& m_slot_row = mh.slot_row;
+    std::vector<int>& m_slot_start = mh.slot_start;
+    std::vector<float>& m_w = mh.w;
     if (m_w.empty()) m_w.push_back(0.0f);
 
     // one device blob for all tables
     auto align16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     size_t o_win = 0, o_twf = align16(o_win + window.size() * 4), o_twp = align16(o_twf + tw_fft.size() * 8);
-    size_t o_ms = align16(o_twp + tw_post.size() * 8), o_mw = align16(o_ms + m_start.size() * 4);
+    size_t o_ms = align16(o_twp + tw_post.size() * 8), o_mr = align16(o_ms + m_slot_start.size() * 4), o_mw = align16(o_mr + m_slot_row.size() * 4);
     size_t total = align16(o_mw + m_w.size() * 4);
     std::vector<char> host(total, 0);
     memcpy(host.data() + o_win, window.data(), window.size() * 4);
     memcpy(host.data() + o_twf, tw_fft.data(), tw_fft.size() * 8);
     memcpy(host.data() + o_twp, tw_post.data(), tw_post.size() * 8);
-    memcpy(host.data() + o_ms, m_start.data(), m_start.size() * 4);
+    memcpy(host.data() + o_ms, m_slot_start.data(), m_slot_start.size() * 4);
+    memcpy(host.data() + o_mr, m_slot_row.data(), m_slot_row.size() * 4);
     memcpy(host.data() + o_mw, m_w.data(), m_w.size() * 4);
     hipError_t e = hipMalloc(&pl->d_blob, total);
     if (e == hipSuccess) e = hipMemcpy(pl->d_blob, host.data(), total, hipMemcpyHostToDevice);
@@ -772,11 +892,25 @@ extern "C" int amtx_spec_plan_create(amtx_spec_plan** out, int sample_rate, int 
     pl->dev.tw_fft = (const float2*)(d + o_twf);
     pl->dev.tw_post = (const float2*)(d + o_twp);
     pl->dev.mel_start = (const int*)(d + o_ms);
+    pl->dev.mel_row = (const int*)(d + o_mr);
     pl->dev.mel_wt = (const float*)(d + o_mw);
     pl->dev.hop = hop_length; pl->dev.n_out = pl->n_out; pl->dev.n_mels = n_mels;
     pl->dev.center = center; pl->dev.pad_mode = pad_mode; pl->dev.n_fft = n_fft;
     *out = pl;
     return AMTX_OK;
+}
+
+// Host-only: the mel stage's slot layout for a (sample_rate, n_fft, n_mels, htk) plan, without creating one (no device needed).
+// slot_row / slot_start: [64 * rounds] (capacity 64 * 8), round_max: [rounds] tap slots per round.  Returns the number of rounds.
+extern "C" int amtx_spec_mel_layout(int sample_rate, int n_fft, int n_mels, int htk, int32_t* slot_row, int32_t* slot_start, int32_t* round_max) {
+    AMTX_REQUIRE(slot_row && slot_start && round_max, "amtx_spec_mel_layout: null pointer");
+    AMTX_REQUIRE(n_mels > 0 && n_mels <= 64 * MAX_MEL_ROUNDS && n_fft >= 128 && sample_rate > 0, "amtx_spec_mel_layout: bad sizes");
+    MelHost mh;
+    const int rc = build_mel_tables(sample_rate, n_fft, n_mels, htk, mh);
+    if (rc != AMTX_OK) return rc;
+    for (int i = 0; i < 64 * mh.rounds; ++i) { slot_row[i] = mh.slot_row[i]; slot_start[i] = mh.slot_start[i]; }
+    for (int r = 0; r < mh.rounds; ++r) round_max[r] = mh.round_max[r];
+    return mh.rounds;
 }
 
 extern "C" int amtx_spec_plan_destroy(amtx_spec_plan* plan) {
@@ -840,7 +974,7 @@ extern "C" int amtx_spec_power(const amtx_spec_plan* plan, const float* audio, i
     const int mel_slots = mel_rounds > 0 ? plan->dev.round_off[mel_rounds - 1] + plan->dev.round_max[mel_rounds - 1] : 0;
     const bool mel_lds = mel_rounds > 0 && mel_slots <= MEL_LDS_MAX_SLOTS;
     const size_t lds = WAVES * XB_ELEMS * sizeof(float2) + WAVES * PB_ELEMS * sizeof(float) + (M / 2 + 64) * sizeof(float2) +
-                       64 * MAX_MEL_ROUNDS * sizeof(int) + (mel_lds ? (size_t)mel_slots * 64 * sizeof(float) : 0);
+                       2 * 64 * MAX_MEL_ROUNDS * sizeof(int) + (mel_lds ? (size_t)mel_slots * 64 * sizeof(float) : 0);
     auto launch = [&](auto kern) -> int {
         AMTX_GRANT_LDS(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds, stream, plan->dev, audio, num_samples, audio_stride, T, power,

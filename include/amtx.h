@@ -51,6 +51,11 @@ typedef struct amtx_spec_plan amtx_spec_plan;
  * Builds the window / twiddle / sparse-filterbank tables on the host in fp64 and uploads them. */
 int amtx_spec_plan_create(amtx_spec_plan** plan, int sample_rate, int n_fft, int hop_length, int win_length,
                           int n_mels, int htk, int center, int pad_mode);
+/* Host-only (no device): how a plan with these parameters deals its mel rows to the lanes of the gather kernel.  slot s = 64 * round +
+ * lane computes mel row slot_row[s] (-1: none) from FFT bin slot_start[s] on (an even number of zero taps may precede the row's first
+ * non-zero weight); round_max[r] = taps per slot of round r.  Rows are placed so that the 32 lanes of every half-wave start on 32
+ * different LDS banks (spec.hip, mel_assign_slots).  Returns the number of rounds (>= 1) or a negative error code. */
+int amtx_spec_mel_layout(int sample_rate, int n_fft, int n_mels, int htk, int32_t* slot_row, int32_t* slot_start, int32_t* round_max);
 int amtx_spec_plan_destroy(amtx_spec_plan* plan);
 int amtx_spec_num_bins(const amtx_spec_plan* plan);                    /* rows of the feature map        */
 int64_t amtx_spec_num_frames(const amtx_spec_plan* plan, int64_t num_samples);   /* features/common.py:41-66 */
