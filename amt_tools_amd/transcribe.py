@@ -120,17 +120,7 @@ def multi_pitch_to_notes(multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITC
     return _events_to_notes(pitch_idcs, frame_idcs, after[pitch_idcs, frame_idcs], np.asarray(times), low, min_duration=min_duration)
 
 
-def _reference_order(onset_col):
-    """Permutation of one clip's notes (np.nonzero order) into the reference's row order: sort_notes in multi_pitch_to_notes
-    (utils.py:469), notes_to_stacked_notes (:745) and stacked_notes_to_notes (:531) = three successive argsorts of the float64 onset
-    column with NumPy's default (unstable) sort, composed as permutations."""
-    p = onset_col.argsort()
-    o = onset_col.take(p)
-    for _ in range(2):
-        q = o.argsort()
-        p = p.take(q)
-        o = o.take(q)
-    return p
+from ._order_pool import order_batch, reference_order as _reference_order     # noqa: E402  (the reference's three unstable argsorts)
 
 
 class _PendingNotes(object):
@@ -154,15 +144,9 @@ class _PendingNotes(object):
             self._rows, self._onset, off = again._rows, again._onset, again._offsets.cpu().numpy()
         rows = self._rows[:total].cpu().numpy()
         onset = self._onset[:total].cpu().numpy()
-        off = off.tolist()
-        out = []
-        for b in range(self._B):
-            lo, hi = off[b], off[b + 1]
-            if hi > lo:
-                out.append(rows[lo:hi].take(_reference_order(onset[lo:hi]), axis=0))
-            else:
-                out.append(np.empty([0, 3]))
-        return out
+        # the reference's row order per clip: NumPy's own argsort, three times (amt_tools_amd/_order_pool.py: a few helper processes for
+        # whole batches, in-process for small ones)
+        return order_batch(rows, onset, off, self._B)
 
 
 def decode_notes_batch_async(onsets, multi_pitch, times, low=tools.DEFAULT_PIANO_LOWEST_PITCH, rows_capacity=None):

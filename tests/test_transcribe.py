@@ -124,3 +124,38 @@ def test_device_decoder_per_clip_grids_many_clips_and_capacity_retry():
         assert got[b].dtype == np.float64 and got[b].shape == ref.shape and np.array_equal(got[b], ref), b
         assert np.array_equal(small[b], ref), b
     assert got[0].shape == (0, 3)
+
+
+def test_order_pool_returns_the_in_process_order(monkeypatch):
+    """amt_tools_amd/_order_pool.py: the worker processes only repeat NumPy's argsorts on their share of the clips -- same rows, same order
+    as the in-process loop, empty clips included; a pool that cannot work falls back to the in-process loop."""
+    from amt_tools_amd import _order_pool as op
+    rng = np.random.default_rng(3)
+    B = 200
+    ns = rng.integers(0, 60, B)
+    ns[::9] = 0
+    off = np.concatenate([[0], np.cumsum(ns)])
+    E = int(off[-1])
+    rows = np.empty((E, 3))
+    rows[:, 0] = rng.integers(0, 12, E) * 0.0232                   # many equal onsets: the order among them is the point
+    rows[:, 1] = rows[:, 0] + rng.random(E)
+    rows[:, 2] = rng.integers(21, 109, E)
+    onset = np.ascontiguousarray(rows[:, 0])
+    monkeypatch.setenv('AMTX_NOTE_WORKERS', '0')
+    ref = op.order_batch(rows, onset, off, B)
+    for b in range(B):
+        lo, hi = off[b], off[b + 1]
+        assert ref[b].shape == (hi - lo, 3)
+        if hi > lo:
+            assert np.array_equal(ref[b], rows[lo:hi][op.reference_order(onset[lo:hi])])
+    monkeypatch.setenv('AMTX_NOTE_WORKERS', '3')
+    got = op.order_batch(rows, onset, off, B)
+    assert op._POOL is not None and not op._POOL.failed and len(op._POOL.procs) == 3
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    # a dead worker: the batch is still ordered (in-process), and the pool stays off
+    op._POOL.procs[1].kill()
+    op._POOL.procs[1].wait()
+    got = op.order_batch(rows, onset, off, B)
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    assert op._POOL.failed
+    op._POOL = None
