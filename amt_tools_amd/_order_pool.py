@@ -13,7 +13,9 @@ overhead, ~25-40 us of single-threaded Python: at 8.5 ms of GPU time per 512 cli
              multiprocessing spawn, which would re-import the caller's __main__) write each clip's permutation, as global row indices
     parent:  ONE rows.take(perm) for the whole batch, then per-clip views
 
-AMTX_NOTE_WORKERS=<n> sets the number of workers (default: min(8, cores // 2); 0 = order in-process).  A worker that dies or times
+AMTX_NOTE_WORKERS=<n> sets the number of workers (default: min(4, cores // 4); 0 = order in-process); batches below 384 clips are ordered
+in-process anyway (measured on the MI355X host: at 256 clips per batch the in-process loop already keeps up with the upload, 25.7 M
+frames/s; at 512 - 1024 clips per batch four workers take the driver from 14.6 to 20.4 M frames/s).  A worker that dies or times
 out turns the pool off for the rest of the process and the batch is ordered in-process -- results never depend on the pool.
 """
 import atexit
@@ -51,7 +53,7 @@ def pool_size():
     env = os.environ.get('AMTX_NOTE_WORKERS')
     if env is not None:
         return max(0, int(env))
-    return max(0, min(8, (os.cpu_count() or 1) // 2))
+    return max(0, min(4, (os.cpu_count() or 1) // 4))
 
 
 class _Pool(object):
@@ -133,7 +135,7 @@ class _Pool(object):
 _POOL = None
 
 
-def order_batch(rows, onset, offsets, B, min_clips=64):
+def order_batch(rows, onset, offsets, B, min_clips=384):
     """rows (E,3) float64 in np.nonzero order per clip, onset (E,) its first column (contiguous), offsets (B+1,) -> list of B (K,3) arrays
     in the reference's row order.  Batches of at least `min_clips` clips go through the worker pool when there is one."""
     global _POOL

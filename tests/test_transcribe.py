@@ -149,13 +149,13 @@ def test_order_pool_returns_the_in_process_order(monkeypatch):
         if hi > lo:
             assert np.array_equal(ref[b], rows[lo:hi][op.reference_order(onset[lo:hi])])
     monkeypatch.setenv('AMTX_NOTE_WORKERS', '3')
-    got = op.order_batch(rows, onset, off, B)
+    got = op.order_batch(rows, onset, off, B, min_clips=1)
     assert op._POOL is not None and not op._POOL.failed and len(op._POOL.procs) == 3
     assert all(np.array_equal(a, b) for a, b in zip(ref, got))
     # a dead worker: the batch is still ordered (in-process), and the pool stays off
     op._POOL.procs[1].kill()
     op._POOL.procs[1].wait()
-    got = op.order_batch(rows, onset, off, B)
+    got = op.order_batch(rows, onset, off, B, min_clips=1)
     assert all(np.array_equal(a, b) for a, b in zip(ref, got))
     assert op._POOL.failed
     op._POOL = None
