@@ -35,6 +35,10 @@ struct GemmArgs {
     // fused convolution stack writes (one plane per pooled frequency column: a 64-deep k-tile of 256 rows is 32 KiB of CONTIGUOUS memory
     // instead of 256 pieces of 128 bytes 7296 bytes apart).  0: row-major with lda.
     int64_t a_plane = 0;
+    // optional (fp32-A kernels): only elements [a_valid_lo, a_valid_hi) of a group's A, counted from its base pointer A + grp * a_gs, exist;
+    // everything else reads as zero and is never dereferenced (strided rows hanging over both ends of a clip: the CQT basis product
+    // straight from the caller's audio, whose centre padding is then implicit).  a_valid_hi == 0: no bounds.
+    int64_t a_valid_lo = 0, a_valid_hi = 0;
 };
 bool amtx_gemm_has_roll_epilogue(const GemmArgs& g);
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);

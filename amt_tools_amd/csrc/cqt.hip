@@ -93,14 +93,16 @@ __device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cq_bf16x8, a), __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, float* __restrict__ out,
-                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag, int zero_pads) {
+__global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, int in_pad, float* __restrict__ out,
+                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag, int zero_pads,
+                                                                float* __restrict__ maxbuf, int n_harm) {
     __shared__ __attribute__((aligned(16))) unsigned short xh[DEC_MXS + 8], xm[DEC_MXS + 8], xl[DEC_MXS + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     if (zero_pads) cqt_zero_pads(out + (int64_t)b * out_stride, n_out, out_stride, pad);
+    if (maxbuf && blockIdx.x == 0 && tid < n_harm) maxbuf[b * n_harm + tid] = 0.f;     // first level straight from the caller's audio: no level-0 kernel resets them
     const int64_t m0 = (int64_t)blockIdx.x * DEC_MCH;
-    const float* src = in + (int64_t)b * in_stride + pad;
+    const float* src = in + (int64_t)b * in_stride + in_pad;
     const int64_t base = 2 * m0 - DEC_HALF;
     // all loads of a thread first (clamped addresses, the zeroing applied afterwards): a load -> test -> store loop pays one memory
     // round trip per iteration
@@ -544,16 +546,26 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
     float* maxbuf = (float*)(ws + d.off_max);
     const int zero_pads = p->lib09 ? 0 : 1;
 
+    // librosa >= 0.10 (zero centre padding): level 0 of the pyramid IS the caller's audio -- the first decimation and the level-0 basis
+    // product read it where it lies (out-of-clip samples read as zero: the decimator clamps, the GEMM's A loader takes a valid range), so
+    // the clip is not copied between two paddings first (0.45 ms and 1.3 GB per 512 clips).  librosa 0.9's reflecting pad keeps the copy.
+    static const bool copy_level0 = getenv("AMTX_CQT_COPY_LEVEL0") != nullptr;        // A/B switch
+    const bool direct0 = zero_pads && !copy_level0;
+    if (direct0 && nl == 1) AMTX_CHECK_HIP(hipMemsetAsync(maxbuf, 0, sizeof(float) * B * p->n_harm, s));
     for (int l = 0; l < nl; ++l) {
         float* pyr = (float*)(ws + d.pyr_off[l]);
         if (l == 0) {
+            if (direct0) continue;
             const unsigned nb = (unsigned)std::min<int64_t>((num_samples + 255) / 256, 4096);
             hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad,
                                zero_pads, maxbuf, p->n_harm);
         } else {
             const unsigned nb = (unsigned)((d.len[l] + DEC_MCH - 1) / DEC_MCH);
-            hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s, (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1],
-                               d.stride[l - 1], pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag, zero_pads);
+            const bool from_audio = direct0 && l == 1;
+            hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s,
+                               from_audio ? audio : (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1], from_audio ? audio_stride : d.stride[l - 1],
+                               from_audio ? 0 : p->pad, pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag, zero_pads,
+                               from_audio ? maxbuf : (float*)nullptr, p->n_harm);
         }
         AMTX_CHECK_LAUNCH();
         if (!zero_pads) {      // librosa 0.9: reflecting centre pad, from the level's own samples
@@ -572,10 +584,14 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
         // and read back by a magnitude / transpose kernel: 0.4 GB per level and 512 clips, a third of the front-end's traffic)
         GemmArgs g;
         g.A = (const float*)(ws + d.pyr_off[l]) + (p->pad - L.nfft / 2); g.lda = L.hop; g.a_type = AMTX_T_F32;
+        if (direct0 && l == 0) {   // rows start n_fft / 2 before the clip and run past its end: bounded reads straight from the audio
+            g.A = audio - L.nfft / 2;
+            g.a_valid_lo = L.nfft / 2; g.a_valid_hi = (int64_t)L.nfft / 2 + num_samples;
+        }
         g.W = L.d_w; g.n_pad = L.n_pad; g.k_pad = L.k_pad; g.planes = 2; g.bias = nullptr;
         g.C = nullptr; g.ldc = L.ncols; g.c_type = AMTX_T_F32;
         g.M = d.frames[l]; g.N = L.ncols; g.K = L.nfft;
-        g.groups = B; g.a_gs = d.stride[l]; g.w_gs = 0; g.bias_gs = 0; g.c_gs = 0;
+        g.groups = B; g.a_gs = (direct0 && l == 0) ? audio_stride : d.stride[l]; g.w_gs = 0; g.bias_gs = 0; g.c_gs = 0;
         g.pair_map = L.d_map; g.pair_out = mag; g.pair_gs = (int64_t)p->n_harm * p->n_bins * d.t_buf; g.pair_pitch = d.t_buf;
         for (int h = 0; h < p->n_harm && h < 16; ++h) g.pair_rows[h] = d.frames_h[h];
         g.pair_max = maxbuf; g.pair_nh = p->n_harm;       // the per-(clip, harmonic) maxima of the dB reference, kept by the epilogue

@@ -38,16 +38,31 @@ template <int A_TYPE, int NS>
 struct AStage {
     // one 8-element K chunk of one A row, converted to bf16 planes
     uint4 hi, lo;
-    __device__ __forceinline__ void load(const char* base, int64_t row_off_elems, bool valid) {
+    // vlo / vhi: bounds of the existing elements (vhi == 0: none), see GemmArgs::a_valid_lo
+    __device__ __forceinline__ void load(const char* base, int64_t row_off_elems, bool valid, int64_t vlo = 0, int64_t vhi = 0) {
         if (A_TYPE == AMTX_T_BF16) {
             hi = valid ? *reinterpret_cast<const uint4*>(base + row_off_elems * 2) : make_uint4(0, 0, 0, 0);
             lo = make_uint4(0, 0, 0, 0);
         } else {
             float4 x0 = make_float4(0, 0, 0, 0), x1 = make_float4(0, 0, 0, 0);
-            if (valid) {
-                const float4* p = reinterpret_cast<const float4*>(base + row_off_elems * 4);
-                x0 = p[0];
-                x1 = p[1];
+            if (valid && vhi > 0 && (row_off_elems < vlo || row_off_elems + 8 > vhi)) {
+                // a chunk that hangs over an end of the data (or lies outside it): element by element, nothing outside is touched
+                float e[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int64_t idx = row_off_elems + i;
+                    e[i] = (idx >= vlo && idx < vhi) ? reinterpret_cast<const float*>(base)[idx] : 0.f;
+                }
+                x0 = make_float4(e[0], e[1], e[2], e[3]);
+                x1 = make_float4(e[4], e[5], e[6], e[7]);
+            } else if (valid) {
+                // rows of a strided-row A (the CQT products straight from a caller's audio) start at any 4-byte boundary: the type says so
+                // (still one global_load_dwordx4 each; the hardware takes dword-aligned wide loads)
+                struct __attribute__((packed, aligned(4))) f32x4_a4 { float x, y, z, w; };
+                const f32x4_a4* p = reinterpret_cast<const f32x4_a4*>(base + row_off_elems * 4);
+                const f32x4_a4 p0 = p[0], p1 = p[1];
+                x0 = make_float4(p0.x, p0.y, p0.z, p0.w);
+                x1 = make_float4(p1.x, p1.y, p1.z, p1.w);
             }
             const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             uint32_t h[4], l[4];
@@ -89,8 +104,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
 #define LOAD_TILE(k0)                                                                              \
     do {                                                                                           \
         const bool kok = ((k0) + schunk * 8) < g.K;                                                \
-        sa0.load(Abase, a_off0 + (k0), arow_ok0 && kok);                                           \
-        sa1.load(Abase, a_off1 + (k0), arow_ok1 && kok);                                           \
+        sa0.load(Abase, a_off0 + (k0), arow_ok0 && kok, g.a_valid_lo, g.a_valid_hi);               \
+        sa1.load(Abase, a_off1 + (k0), arow_ok1 && kok, g.a_valid_lo, g.a_valid_hi);               \
         sw0h = *reinterpret_cast<const uint4*>(Wbase + w_off0 + (k0));                             \
         sw1h = *reinterpret_cast<const uint4*>(Wbase + w_off1 + (k0));                             \
         if (NS == 2) {                                                                             \
@@ -779,7 +794,10 @@ static int check_generic(const GemmArgs& g) {
     AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
     AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
     AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
-    AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
+    // bf16 A: 16-byte fragments straight from memory.  fp32 A goes through registers with dword-aligned wide loads: rows may start at any
+    // 4-byte boundary (clips of an odd length in one buffer, strided rows of the CQT products)
+    AMTX_REQUIRE(g.a_type == AMTX_T_F32 ? ((uintptr_t)g.A % 4) == 0 : ((g.lda * 2) % 16 == 0 && ((uintptr_t)g.A % 16) == 0),
+                 "gemm: A rows must be 16-byte aligned (bf16) / 4-byte aligned (fp32)");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     return AMTX_OK;
@@ -818,7 +836,10 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.groups > 0, "gemm: bad sizes");
     AMTX_REQUIRE(g.K % 8 == 0 && g.N % 4 == 0, "gemm: K must be a multiple of 8 and N of 4 (K=%d N=%d)", g.K, g.N);
     AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
-    AMTX_REQUIRE((g.lda * amtx_tsize(g.a_type)) % 16 == 0 && ((uintptr_t)g.A % 16) == 0, "gemm: A rows must be 16-byte aligned");
+    // bf16 A: 16-byte fragments straight from memory.  fp32 A goes through registers with dword-aligned wide loads: rows may start at any
+    // 4-byte boundary (clips of an odd length in one buffer, strided rows of the CQT products)
+    AMTX_REQUIRE(g.a_type == AMTX_T_F32 ? ((uintptr_t)g.A % 4) == 0 : ((g.lda * 2) % 16 == 0 && ((uintptr_t)g.A % 16) == 0),
+                 "gemm: A rows must be 16-byte aligned (bf16) / 4-byte aligned (fp32)");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     AMTX_REQUIRE(!g.copy16 || (amtx_gemm_has_roll_epilogue(g) && g.copy16_pad % 4 == 0 && g.N + g.copy16_pad <= g.n_pad &&
