@@ -43,6 +43,7 @@ import torch         # noqa: E402   (importing torch does not initialise the GPU
 
 SR, HOP, N_MELS, N_FFT = 22050, 512, 229, 2048
 CLIP_SAMPLES, CLIP_FRAMES = 319999, 625
+DISTINCT_CLIPS = 64                  # distinct synthetic clips per rank (seeds 1234 + 64 rank + i); larger batches tile them
 PEAK_MFMA_BF16_TFLOPS = 2500.0      # dense, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 MODEL_FLOPS_PER_FRAME = 26.70e6     # the reference's layer-by-layer arithmetic
@@ -371,14 +372,14 @@ def parity_leg(model, audio, out_bf16, device, oracle_rolls):
         torch.cuda.synchronize()
         res['x3_frames_per_s'] = 3 * Bx * CLIP_FRAMES / (time.perf_counter() - t0)
         res['x3_clips_per_step'] = Bx
-    nd = min(8, Bx)       # distinct clips (the batch tiles 8)
+    nd = min(8, Bx)       # clips compared with the x3 mode / the CPU oracle (the oracle leg keeps the first 8 of the 64 distinct clips)
     # every clip of the batch against the distinct clip it is a copy of: a block- or tail-dependent indexing error in any kernel of the
     # 1024-clip run would show here (clips 0 .. 7 alone are block 0 of most grids)
     Bfull = out_bf16[tools.KEY_ONSETS].shape[0]
     same = True
     for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
         o = out_bf16[k]
-        idx = torch.arange(Bfull, device=o.device) % 8
+        idx = torch.arange(Bfull, device=o.device) % DISTINCT_CLIPS
         same = same and bool(torch.equal(o, o[idx]))
     res['tiled_clips_equal_their_source_clip'] = same
     res['tiled_clips_compared'] = Bfull
@@ -497,8 +498,8 @@ def run_infer(args, rank, world, device):
 
     model, mel, sd = build_model(device, args.precision)
     B = args.clips
-    base = np.stack([synth_clip(rank * 8 + i) for i in range(8)])
-    audio = torch.from_numpy(base).to(device).repeat((B + 7) // 8, 1)[:B].contiguous()
+    base = np.stack([synth_clip(rank * DISTINCT_CLIPS + i) for i in range(DISTINCT_CLIPS)])
+    audio = torch.from_numpy(base).to(device).repeat((B + DISTINCT_CLIPS - 1) // DISTINCT_CLIPS, 1)[:B].contiguous()
     batch = {tools.KEY_AUDIO: audio}
 
     def step():
@@ -585,7 +586,7 @@ def run_infer(args, rank, world, device):
     fps = total_frames / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     config = {'workload': 'OnsetsFrames(mc=2)+MelSpec(229 bins, n_fft 2048, hop 512) inference, synthetic 22.05 kHz clips of 319999 '
-                          'samples (625 frames; 8 distinct clips per rank tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
+                          'samples (625 frames; 64 distinct clips per rank tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
               'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
               'rccl_ranks': world, 'process_group': (args.backend if _dist_on() else None), 'per_rank_frames_per_s': [B * CLIP_FRAMES * args.steps / t for t in per_rank],
               'whole_path_frac_of_mfma_roof': fps / world * MODEL_FLOPS_PER_FRAME / 2.5e15,
