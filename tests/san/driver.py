@@ -121,6 +121,11 @@ for sr, n_fft, hop, win, n_mels, htk, center, pad in ((22050, 2048, 512, 2048, 2
         assert np.isfinite(fb).all() and fb.max() > 0
     _lib.check(L.amtx_spec_plan_destroy(pl))
     n_calls += 1
+    if n_mels:       # the slot matching of the mel gather (mel_assign_slots), host-only
+        srow, sstart, rmax = np.full(512, -5, np.int32), np.zeros(512, np.int32), np.zeros(8, np.int32)
+        rounds = L.amtx_spec_mel_layout(sr, n_fft, n_mels, htk, P(srow), P(sstart), P(rmax))
+        assert rounds == (n_mels + 63) // 64 and sorted(srow[:64 * rounds][srow[:64 * rounds] >= 0].tolist()) == list(range(n_mels))
+        n_calls += 1
 for fmin, n_bins, bpo, harm in ((82.41, 192, 24, [1.0]), (32.70, 72, 12, [0.5, 1, 2, 3, 4, 5]), (27.5, 88, 12, [1.0])):
     pl = C.c_void_p()
     hv = (C.c_double * len(harm))(*harm)

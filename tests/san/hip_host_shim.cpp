@@ -19,6 +19,7 @@ hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t
 }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { g_last = hipErrorNoDevice; return hipErrorNoDevice; }
 hipError_t hipGetLastError(void) { hipError_t e = g_last; g_last = hipSuccess; return e; }
