@@ -54,6 +54,10 @@ typedef uint16_t bf16_t;   // raw 16-bit operand bits (bf16, or half in an AMTX_
 
 #ifdef AMTX_F16
 static inline __host__ __device__ bf16_t f32_to_bf16_rn(float f) {      // round to nearest even (hardware or compiler conversion)
+    // saturating: a folded weight beyond half's range (a BatchNorm scale over a tiny running variance) becomes +-65504, not +-inf -> NaN
+    // downstream.  This is the packers' conversion (host and pack.hip); the kernels' own pack_bf16x2 of activations stays
+    // a plain conversion: log-mel / HCQT features are in [0, 1] and the BatchNorm'd maps of these models far below 65504.
+    if (f == f) f = f > 65504.0f ? 65504.0f : (f < -65504.0f ? -65504.0f : f);
     const _Float16 h = (_Float16)f;
     bf16_t u;
     __builtin_memcpy(&u, &h, 2);

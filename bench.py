@@ -723,7 +723,7 @@ def run_train(args, rank, world, device):
                    'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank], 'allreduce_ms_per_step': allreduce_ms,
                    'collectives_per_step': opt.collectives_run / max(1, args.steps + args.warmup + (5 if allreduce_ms is not None else 0)),
                    'process_group': (args.backend if _dist_on() else None),
-                   'loss': float(loss), 'backward': training_backend()},
+                   'loss': float(loss.detach()), 'backward': training_backend()},
         'roofline': {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None,
                      'note': f'{flops / 1e6:.1f} MFLOP per clip-frame (SURVEY 8d: ~3x forward) x frames / step time; at 8 clips per GPU the step is '

@@ -22,3 +22,11 @@ def golden_dir():
 def load_golden(name):
     import numpy as np
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
+
+
+def golden_grad_slices(g):
+    """(parameter name, row step, reference rows) of the sliced gradients a training golden may carry (`gslice_*`: every n-th row of a
+    large recurrent matrix's gradient, tools/gen_golden.py MC4_GSLICES)."""
+    if 'gslice_keys' not in g:
+        return []
+    return [(str(k), int(st), g[f'gslice_{i}']) for i, (k, st) in enumerate(zip(g['gslice_keys'], g['gslice_step']))]

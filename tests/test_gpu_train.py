@@ -7,7 +7,7 @@ import pytest
 torch = pytest.importorskip('torch')
 pytestmark = pytest.mark.gpu
 
-from conftest import load_golden                 # noqa: E402
+from conftest import load_golden, golden_grad_slices                 # noqa: E402
 from amt_tools_amd import tools                  # noqa: E402
 
 
@@ -245,6 +245,13 @@ def test_complexity_4_training_step_on_gpu_matches_reference_golden():
         rels.append((got - ref).norm().item() / max(1e-9, ref.norm().item()))
         assert rels[-1] < 3e-2, (k, rels[-1])
     assert float(np.median(rels)) < 2e-3
+    # rows of the recurrent matrices' gradients: the hidden-384 streaming forward (saved h) and backward (W_hh^T fragments) kernels
+    slices = golden_grad_slices(g)
+    assert len(slices) == 4
+    for k, st, ref in slices:
+        got = named[k].grad.cpu().numpy()[::st]
+        rel = np.linalg.norm(got - ref) / max(1e-9, np.linalg.norm(ref))
+        assert rel < 3e-3, (k, rel)
 
 
 @pytest.mark.gpu

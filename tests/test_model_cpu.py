@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, golden_grad_slices
 from amt_tools_amd import tools
 from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
 from amt_tools_amd.synth import synth_state_dict, of_state_dict_shapes
@@ -95,6 +95,8 @@ def test_training_step_matches_reference_losses_and_grads(name):
     for i, k in enumerate(g['grad_keys']):
         ref = g[f'grad_{i}']
         assert np.abs(named[str(k)].grad.numpy() - ref).max() / max(1e-6, np.abs(ref).max()) < 2e-3, k
+    for k, st, ref in golden_grad_slices(g):
+        assert np.abs(named[k].grad.numpy()[::st] - ref).max() / max(1e-6, np.abs(ref).max()) < 2e-3, k
     # onsets derived from the multi-pitch labels when none are given (intended behaviour of onsetsframes.py:176-178)
     out2 = model.run_on_batch({tools.KEY_FEATS: torch.from_numpy(g['feats']), tools.KEY_MULTIPITCH: torch.from_numpy(g['multi_pitch'])})
     assert torch.isfinite(out2[tools.KEY_LOSS][tools.KEY_LOSS_ONSETS])

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import load_golden, golden_grad_slices
 from amt_tools_amd.synth import synth_state_dict
 from oracle import model_ref
 
@@ -67,6 +67,9 @@ def test_train_losses_and_grads_match_reference(name):
         got = sd[str(k)].grad.numpy()
         scale = max(1e-6, np.abs(ref).max())
         assert np.abs(got - ref).max() / scale < 2e-3, k
+    for k, st, ref in golden_grad_slices(g):              # rows of the recurrent matrices' gradients (model_complexity 4)
+        got = sd[k].grad.numpy()[::st]
+        assert got.shape == ref.shape and np.abs(got - ref).max() / max(1e-6, np.abs(ref).max()) < 2e-3, k
 
 
 def test_onsetsframes2_train_losses_and_grads_match_reference():

@@ -137,7 +137,13 @@ MC4_GKEYS = ['onset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'on
              'pitch_head.1.output_layer.bias']
 
 
-def gen_of_train(name, seed, dim_in, mc, B, T, gkeys=None):
+# recurrent matrices of model_complexity 4 (1536 x 384 / 1536 x 176): every 64th row of their gradients -- 24 rows each pin the
+# hidden-384 streaming forward / backward kernels' saved h and W_hh^T fragment order without 2 MB of fixture
+MC4_GSLICES = [('onset_head.1.mlm.weight_hh_l0', 64), ('onset_head.1.mlm.weight_hh_l0_reverse', 64), ('adjoin.0.mlm.weight_ih_l0_reverse', 64),
+               ('adjoin.0.mlm.weight_hh_l0', 64)]
+
+
+def gen_of_train(name, seed, dim_in, mc, B, T, gkeys=None, gslices=None):
     """Training-mode golden: BatchNorm batch statistics, Dropout disabled (p=0) so the result is
     deterministic; labels given -> the reference's losses and a few gradients."""
     profile = rtools.PianoProfile()
@@ -167,6 +173,11 @@ def gen_of_train(name, seed, dim_in, mc, B, T, gkeys=None):
     for i, k in enumerate(gkeys):
         rec[f'grad_{i}'] = named[k].grad.detach().numpy().copy()
     rec['grad_keys'] = np.array(gkeys)
+    if gslices:
+        rec['gslice_keys'] = np.array([k for k, _ in gslices])
+        rec['gslice_step'] = np.array([st for _, st in gslices])
+        for i, (k, st) in enumerate(gslices):
+            rec[f'gslice_{i}'] = named[k].grad.detach().numpy()[::st].copy()
     # NOTE: the labels-without-onsets branch (onsetsframes.py:176-178) cannot be recorded: with tensor
     # labels tools.multi_pitch_to_onsets returns an ndarray and LogisticBank.get_loss then fails on
     # `.clone()` (models/common.py:566) -- the reference only works when onsets labels are supplied.
@@ -368,12 +379,12 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'mc4':
         gen_of_eval('of1_mc4_eval.npz', OnsetsFrames, seed=15, dim_in=229, in_channels=1, mc=4, B=2, T=24, offsets=False)
         gen_of_eval('of2_mc4_hcqt_eval.npz', OnsetsFrames2, seed=16, dim_in=72, in_channels=3, mc=4, B=1, T=20, offsets=True)
-        gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS)
+        gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS, gslices=MC4_GSLICES)
         sys.exit(0)
     gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
     gen_of_eval('of1_mc4_eval.npz', OnsetsFrames, seed=15, dim_in=229, in_channels=1, mc=4, B=2, T=24, offsets=False)
     gen_of_eval('of2_mc4_hcqt_eval.npz', OnsetsFrames2, seed=16, dim_in=72, in_channels=3, mc=4, B=1, T=20, offsets=True)
-    gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS)
+    gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS, gslices=MC4_GSLICES)
     gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
     gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
