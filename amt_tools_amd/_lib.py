@@ -10,7 +10,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libamtx.so')
+LIB_PATH = os.environ.get('AMTX_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libamtx.so')      # AMTX_LIB_PATH: a debug / timing build of the same ABI
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'amtx.h')
 
 _lib = None

@@ -27,6 +27,12 @@
 
 namespace {
 
+#ifndef CONVG_FCL_GP
+#define CONVG_FCL_GP 5
+#endif
+#ifndef CONVG_FCL_MINW
+#define CONVG_FCL_MINW 1            // waves per SIMD the 32-channel tap-major variant is compiled for: 4 = two 512-thread blocks per CU (<= 128 VGPRs)
+#endif
 constexpr int GTT = 16;             // frames per tile
 constexpr int GROWS = GTT + 2;
 
@@ -77,8 +83,11 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // inside this kernel, from the fp32 features, straight into the LDS input tile (the C_in-channel map never exists in HBM):
 // K = 9 c_in taps padded to KS1 32-deep steps, im2col gathered per lane from a small feature tile in LDS, D' = W1 . P^T per
 // 16 tile positions, epilogue shift + ReLU + zero outside the map + bf16 (hi/lo) -> 8-byte LDS stores.
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1>
-__global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
+// FCL (with KS1 = 3, one plane): the tap-major form of the fused first conv (amtx_conv1g_tapk): features staged channels-last in bf16.
+// CMAX (FCL): the most input channels this instantiation stages (sizes the per-thread item slots: 6 -> 9 loads per tile instead of 12).
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 8>
+__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
+    static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
     constexpr int NCH = CIN / 8;                 // 16-byte chunks per position
@@ -102,8 +111,9 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     constexpr int NNT1 = (NPOS + 15) / 16;                    // 16-position groups of the fused first conv
     constexpr int NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool PIPE = FCL && CI16 == 2;      // two-tile software pipeline (below): two input tiles and two feature tiles in LDS
     char* xs = smem;
-    char* ws = smem + NS * XPLANE;
+    char* ws = smem + (PIPE ? 2 : 1) * NS * XPLANE;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -115,8 +125,16 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     constexpr int W1BYTES = FUSE1 ? CI16 * KS1 * NS * 1024 + CIN * 4 : 0;
     char* w1s = ws + (w_all ? nchunks : 1) * WCHUNK;
     float* fs = reinterpret_cast<float*>(w1s + W1BYTES);
+    // FCL: the feature tile as bf16 [FROWS1][FT + 4][8 channel slots]: 16 bytes per position = one k-group of a tap
+    char* fs16 = w1s + W1BYTES;
+    constexpr int FW = FT + 4;
+    char* const fscratch = w1s + W1BYTES + (PIPE ? 2 : 1) * FROWS1 * FW * 16;      // 128 bytes behind the feature tile(s): slots without an item
     const int c_in1 = a.c_in;
     const int nfeat = c_in1 * FROWS1 * (FT + 4);
+    if (FCL) {   // channel slots c_in .. 7 meet zero weights, but NaN x 0 is NaN: zero the tile once (the staging only writes real channels)
+        for (int it = tid; it < FROWS1 * FW; it += NTH) reinterpret_cast<uint4*>(fs16)[it] = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     if (FUSE1) {
         const uint4* w1g = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs);
         for (int it = tid; it < CI16 * KS1 * NS * 64; it += NTH) reinterpret_cast<uint4*>(w1s)[it] = w1g[it];
@@ -201,7 +219,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
     // weight chunk travel HBM/L2 -> registers while the current ones are on the matrix cores, so neither the block start-up nor
     // a memory round trip is paid per tile.  With a single C_out chunk the weights stay in LDS for the whole launch.
     // ---- fused first conv helpers
-    constexpr int NF1 = FUSE1 ? (7 * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7)
+    constexpr int NF1 = FUSE1 ? ((FCL ? CMAX : 7) * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7; tap-major: <= 8)
     // A thread's feature items are the same tile-relative (channel, row, column) for every tile: decoded once (the div / mod chains
     // per item and tile were a sixth of the kernel), bit 31 = item exists.  The zeroing of values outside the map waits for
     // store_f: a select right behind the load would wait for the load here.
@@ -219,36 +237,73 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
         fdesc[k] = (it < nfeat ? 0x80000000u : 0u) | ((unsigned)ci << 16) | ((unsigned)i << 8) | (unsigned)j;
     }
     const int nfk = (nfeat + NTH - 1) / NTH;                   // items per thread that exist for this c_in (uniform)
+    // FCL: element offset of every item inside a tile's feature window, tile-independent (32 bits: a clip's view spans < 2^31 elements, checked
+    // at launch).  Per tile and item that leaves two adds, two unsigned compares and a select in front of the load; the 64-bit clamp /
+    // multiply chains of the other variants are 27 vector instructions per loaded value -- the largest block of the HCQT model's conv2 kernel.
+    // (Only in the tap-major variants: the others sit at 256 registers and ten more spill hundreds.)
+    int foff[FCL ? NF1 : 1];
+    if constexpr (FCL) {
+#pragma unroll
+        for (int k = 0; k < NF1; ++k) {
+            const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
+            foff[k] = ci * (int)a.f_stride_c + i * (int)a.f_stride_t + j * (int)a.f_stride_f;
+        }
+    }
     auto load_f = [&](int tile, float (&fr)[NF1], unsigned& okmask) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
         const float* fb = a.feats + (int64_t)b * a.f_stride_b;
         okmask = 0;
+        if constexpr (FCL) {
+            const int wb = (t0 - 2) * (int)a.f_stride_t + (f0 - 2) * (int)a.f_stride_f;   // window origin; negative at the map's edges: only used when valid
+            // straight-line: every item slot loads (a slot without an item, or a padding cell, re-reads the clip's first value) -- a
+            // guarded load is waited for at the join of its branch, one memory round trip per item (the rolled, branchy form of this loop
+            // was 43 % of a tile)
 #pragma unroll
-        for (int k = 0; k < NF1; ++k) {
-            if (k >= nfk) break;
-            const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
-            const int t = t0 - 2 + i, f = f0 - 2 + j;
-            const bool ok = (fdesc[k] >> 31) && t >= 0 && t < T && f >= 0 && f < F;
-            const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
-            fr[k] = fb[(int64_t)ci * a.f_stride_c + (int64_t)tc * a.f_stride_t + (int64_t)fc * a.f_stride_f];
-            if (ok) okmask |= 1u << k;
+            for (int k = 0; k < NF1; ++k) {
+                const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                const bool ok = (int)fdesc[k] < 0 && (unsigned)(t0 - 2 + i) < (unsigned)T && (unsigned)(f0 - 2 + j) < (unsigned)F;
+                fr[k] = fb[(unsigned)(ok ? wb + foff[k] : 0)];
+                okmask |= ok ? (1u << k) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NF1; ++k) {
+                if (k >= nfk) break;
+                const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
+                const int t = t0 - 2 + i, f = f0 - 2 + j;
+                const bool ok = (fdesc[k] >> 31) && t >= 0 && t < T && f >= 0 && f < F;
+                const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
+                fr[k] = fb[(int64_t)ci * a.f_stride_c + (int64_t)tc * a.f_stride_t + (int64_t)fc * a.f_stride_f];
+                if (ok) okmask |= 1u << k;
+            }
         }
     };
     auto store_f = [&](const float (&fr)[NF1], unsigned okmask) {
+        if constexpr (FCL) {
+            // straight-line as well: a slot without an item writes its (zero) value to a scratch line behind the feature tiles
+#pragma unroll
+            for (int k = 0; k < NF1; ++k) {
+                const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                const float v = ((okmask >> k) & 1) ? fr[k] : 0.f;
+                char* dst = (int)fdesc[k] < 0 ? fs16 + ((i * FW + j) * 8 + ci) * 2 : fscratch + (tid & 63) * 2;
+                *reinterpret_cast<uint16_t*>(dst) = (uint16_t)pack_bf16x2(v, 0.f);
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NF1; ++k) {
             if (k >= nfk) break;
             if (fdesc[k] >> 31) {
-                const int j = fdesc[k] & 0xff, rest = ((fdesc[k] >> 16) & 0xff) * FROWS1 + ((fdesc[k] >> 8) & 0xff);
-                fs[rest * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
+                const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                fs[(ci * FROWS1 + i) * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
             }
         }
     };
     // per-lane im2col offsets (floats) of the K slots this lane feeds: k = 32 ks + 8 g + jj -> (ci, kh, kw) in the weight
     // tensor's own order; slots past 9 c_in read a valid address (their weights are zero)
     int koff[KS1 > 0 ? KS1 : 1][8];
-    if (FUSE1) {
+    if (FUSE1 && !FCL) {
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
@@ -275,7 +330,10 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
         float4 s4[CI16];
 #pragma unroll
         for (int nt = 0; nt < CI16; ++nt) s4[nt] = *reinterpret_cast<const float4*>(sh1 + 16 * nt + 4 * g);
-        constexpr int NIT1 = (NNT1 + NW - 1) / NW, GP = (KS1 * NS > 2) ? 1 : 2;
+        // groups in flight at once: their LDS reads, then their MFMA chains (independent of each other), then their epilogues.  The tap-major
+        // form reads three 16-byte chunks per group instead of sixteen scalars: all of a wave's groups fit the registers at once, and five
+        // serial read -> MFMA -> convert -> store chains (~1000 cycles each) become one pass
+        constexpr int NIT1 = (NNT1 + NW - 1) / NW, GP = FCL ? (CI16 <= 2 ? CONVG_FCL_GP : 2) : ((KS1 * NS > 2) ? 1 : 2);   // (48 / 64 mid channels: two at a time, or the accumulators spill)
         static_for<0, (NIT1 + GP - 1) / GP>([&](auto gc) {
             constexpr int it0 = decltype(gc)::value * GP;
             constexpr int cnt = it0 + GP <= NIT1 ? GP : NIT1 - it0;
@@ -292,6 +350,13 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                 inside[i_] = t >= 0 && t < T && f >= 0 && f < F;
                 static_for<0, KS1>([&](auto kc) {
                     constexpr int ks = decltype(kc)::value;
+                    if constexpr (FCL) {
+                        // k-group g of step ks = tap 4 ks + g (taps 9 .. 11: zero weights, any valid address): the 8 channel slots of the
+                        // position (i + kh, j + kw) of the feature tile, already bf16
+                        const int tap = 4 * ks + g, tp = tap < 9 ? tap : 0;
+                        ph[i_][ks] = *reinterpret_cast<const uint4*>(fs16 + ((i + tp / 3) * FW + j + tp % 3) * 16);
+                        return;
+                    }
                     float v[8];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) v[jj] = fp[koff[ks][jj]];
@@ -342,6 +407,173 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
         });
     };
 
+#ifdef AMTX_CONV_TIMING
+    unsigned long long cg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cg_t = __builtin_readcyclecounter();
+#endif
+    // One C_out chunk of one tile: the MFMA loop over the tile `xs` points to and the chunk's weights, then ReLU + MaxPool + stores.
+    auto mma_chunk = [&](int b, int t0, int f0, int ch) {
+        const char* wsc = ws + (w_all ? ch * WCHUNK : 0);
+        const int t_out = t0 + r16;
+        // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
+        f32x4_t acc[4][NTC];
+        {
+            const float* sh = a.shift + (int64_t)grp * a.shift_gs + ch * 16 * NTC + g * 4 * NTC;
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                const float4 s = *reinterpret_cast<const float4*>(sh + 4 * nt);
+#pragma unroll
+                for (int col = 0; col < 4; ++col) acc[col][nt] = (f32x4_t){s.x, s.y, s.z, s.w};
+            }
+        }
+
+        // One "item" = one weight fragment (16 B per lane) x the wave's four columns = 4 MFMAs (12 in the two-plane mode).
+        // Items run row-major over five "rows" of six input-column fragments: tap rows kh = 0, 1, 2 (full 32-deep steps), then
+        // row 3 = the channel tails of tap rows 0 | 1 side by side, row 4 = the tails of tap row 2 at columns c | c + 1.
+        // Weight fragments are read from LDS WD items ahead of their use (ring of WD + 1 register slots); the six column
+        // fragments of a row are read at the row boundary (double-buffering them as well costs 48 more VGPRs and spills).
+        constexpr int NROWS = 3 + 2 * N16;
+        constexpr int IPM = 3 * NTC * N32;                   // items of a main row: (kw, tile, step)
+        constexpr int NITM = 3 * IPM + (3 * NTC + 2 * NTC) * N16;
+        constexpr int WD = 2;
+        uint4 xa[6][N32 > 0 ? N32 : 1][NS];
+        uint4 wq[WD + 1][NS];
+        // item v -> row, kw (column shift of the X fragment), tile, step, index of its weight fragment in the chunk
+        auto load_xrow = [&](auto rowc) {
+            constexpr int row = decltype(rowc)::value;
+            static_for<0, 6>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                static_for<0, NS>([&](auto pc) {
+                    constexpr int pl = decltype(pc)::value;
+                    if constexpr (row < 3) {
+                        static_for<0, N32>([&](auto sc) {
+                            constexpr int st = decltype(sc)::value;
+                            xa[c][st][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + (row * PC + jb + c) * 16 + x32 + st * 4 * CPLANE);
+                        });
+                    } else if constexpr (row == 3) {           // lane groups 0, 1: tap row 0; 2, 3: tap row 1
+                        xa[c][0][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + ((g >> 1) * PC + jb + c) * 16 + x16);
+                    } else {                                   // tap row 2: lane groups 0, 1: column c; 2, 3: column c + 1
+                        // (columns 4, 5 only meet the lone (2,2) tail, whose upper weights are zero: stay inside the tile)
+                        xa[c][0][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + (2 * PC + jb + c + (c < 4 ? (g >> 1) : 0)) * 16 + x16);
+                    }
+                });
+            });
+        };
+        auto load_witem = [&](auto vc) {
+            constexpr int v = decltype(vc)::value;
+            constexpr int widx = v < 3 * IPM ? v                                      // main: ((kh * 3 + kw) * NTC + nt) * N32 + st == v
+                                             : NMAIN + (v - 3 * IPM);                 // tails: A (kw, nt), B (nt), C (nt) in item order
+            static_for<0, NS>([&](auto pc) {
+                constexpr int pl = decltype(pc)::value;
+                wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wsc + (widx * NS + pl) * 1024 + lane * 16);
+            });
+        };
+        load_xrow(std::integral_constant<int, 0>{});
+        static_for<0, WD>([&](auto vc) { load_witem(vc); });
+        static_for<0, NITM>([&](auto vc) {
+            constexpr int v = decltype(vc)::value;
+            constexpr bool is_main = v < 3 * IPM;
+            constexpr int t = v - 3 * IPM;                                            // tail item index
+            constexpr int row = is_main ? v / IPM : (t < 3 * NTC ? 3 : 4);
+            constexpr int kw = is_main ? (v % IPM) / (NTC * N32) : (t < 3 * NTC ? t / NTC : (t < 4 * NTC ? 0 : 2));
+            constexpr int nt = is_main ? ((v % IPM) / N32) % NTC : t % NTC;
+            constexpr int st = is_main ? v % N32 : 0;
+            constexpr bool row_start = is_main ? (v % IPM == 0) : (t == 0 || t == 3 * NTC);
+            if constexpr (row_start && v > 0) load_xrow(std::integral_constant<int, row>{});
+            if constexpr (v + WD < NITM) load_witem(std::integral_constant<int, v + WD>{});
+            static_for<0, 4>([&](auto colc) {
+                constexpr int col = decltype(colc)::value;
+                acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[col + kw][st][0], acc[col][nt]);
+                if constexpr (NS == 2) {
+                    acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[col + kw][st][NS - 1], acc[col][nt]);
+                    acc[col][nt] = gm32(wq[v % (WD + 1)][NS - 1], xa[col + kw][st][0], acc[col][nt]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+
+        CG_TICK(3);
+        // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
+        if (t_out < T) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int fo = (f0 + jb + 2 * pr) >> 1;
+                if (fo >= F2) continue;
+                const int64_t o = (int64_t)grp * a.out_gs + ((int64_t)b * T + t_out) * out_ts + (int64_t)fo * a.c_out + ch * 16 * NTC + g * 4 * NTC;
+#pragma unroll
+                for (int nt = 0; nt < NTC; ++nt) {
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(acc[2 * pr][nt][r], acc[2 * pr + 1][nt][r]), 0.f);
+                    if (OUT_TYPE == AMTX_T_BF16)
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    else
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4 * nt) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+
+    if constexpr (PIPE) {
+        // ---- The 32-channel tap-major variant (BASELINE config 3: HCQT, 6 x 72 bins) as a two-tile software pipeline, ONE barrier per tile:
+        // between two barriers a wave runs the first conv of tile k + 1 (vector / LDS work: ~40 % of a tile when it was a phase of its own
+        // with the matrix pipe idle) AND the matrix loop of tile k; waves 0-3 take them in one order, waves 4-7 in the other, so that each
+        // SIMD's two waves are in different kinds of work.  Two input tiles and two feature tiles in LDS (126 KB), one C_out chunk whose
+        // weights stay resident.  Requires nchunks == 1 (the launcher checks).
+        char* const fs_base = fs16;
+        auto xs2 = [&](int i) { return smem + i * (NS * XPLANE); };
+        auto fsb = [&](int i) { return fs_base + i * (FROWS1 * FW * 16); };
+        float fraw[NF1];
+        unsigned xok = 0;
+        const int stride = (int)gridDim.x;
+        int tile = blockIdx.x;
+        // prologue: weights, features of tile 0 -> fs[0], first conv of tile 0 -> xs[0], features of tile 1 -> fs[1]
+        for (int it = tid; it < WCHUNK / 16; it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[it];
+        for (int it = tid; it < FROWS1 * FW; it += NTH) reinterpret_cast<uint4*>(fsb(1))[it] = make_uint4(0, 0, 0, 0);
+        load_f(tile, fraw, xok);
+        fs16 = fsb(0);
+        store_f(fraw, xok);
+        if (tile + stride < ntiles) load_f(tile + stride, fraw, xok);
+        __syncthreads();
+        {
+            int b, t0, f0;
+            coord(tile, b, t0, f0);
+            xs = xs2(0);
+            first_conv(t0, f0);
+        }
+        if (tile + stride < ntiles) { fs16 = fsb(1); store_f(fraw, xok); }
+        if (tile + 2 * stride < ntiles) load_f(tile + 2 * stride, fraw, xok);
+        __syncthreads();
+        int cur = 0;
+        for (; tile < ntiles; tile += stride, cur ^= 1) {
+            int b, t0, f0;
+            coord(tile, b, t0, f0);
+            const int next = tile + stride;
+            const bool has_next = next < ntiles;
+            int bn = 0, t0n = 0, f0n = 0;
+            if (has_next) coord(next, bn, t0n, f0n);
+            auto fc_next = [&]() {
+                if (has_next) { xs = xs2(cur ^ 1); fs16 = fsb(cur ^ 1); first_conv(t0n, f0n); }
+            };
+            auto mma_cur = [&]() { xs = xs2(cur); mma_chunk(b, t0, f0, 0); };
+            CG_TICK(7);
+            if (wave < NW / 2) { fc_next(); CG_TICK(1); mma_cur(); } else { mma_cur(); fc_next(); }
+            // features of tile k + 2 (in registers since the last iteration) -> the feature tile the first conv of tile k read an iteration ago
+            if (tile + 2 * stride < ntiles) { fs16 = fsb(cur); store_f(fraw, xok); }
+            if (tile + 3 * stride < ntiles) load_f(tile + 3 * stride, fraw, xok);
+            CG_TICK(0);
+            __syncthreads();
+            CG_TICK(5);
+#ifdef AMTX_CONV_TIMING
+            cg_acc[6] += 1;
+#endif
+        }
+#ifdef AMTX_CONV_TIMING
+        if (tid == 0)
+            for (int i = 0; i < 8; ++i) atomicAdd(&g_convg_prof[i], cg_acc[i]);
+#endif
+        return;
+    }
+
     uint4 xraw[FUSE1 ? 1 : NIT][NRAW], wreg[NWIT];
     float fraw[NF1];
     unsigned xok = 0;
@@ -356,13 +588,9 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
         load_w(0, wreg);
     }
 
-#ifdef AMTX_CONV_TIMING
-    unsigned long long cg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cg_t = __builtin_readcyclecounter();
-#endif
     for (; tile < ntiles; tile += gridDim.x) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
-        const int t_out = t0 + r16;
         CG_TICK(7);
         const int next = tile + (int)gridDim.x;
         const bool has_next = next < ntiles;
@@ -392,104 +620,7 @@ __global__ __launch_bounds__(16 * FT) void conv3x3_gen_kernel(ConvArgs a, int nt
                 }
             }
 
-            const char* wsc = ws + (w_all ? ch * WCHUNK : 0);
-            // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
-            f32x4_t acc[4][NTC];
-            {
-                const float* sh = a.shift + (int64_t)grp * a.shift_gs + ch * 16 * NTC + g * 4 * NTC;
-#pragma unroll
-                for (int nt = 0; nt < NTC; ++nt) {
-                    const float4 s = *reinterpret_cast<const float4*>(sh + 4 * nt);
-#pragma unroll
-                    for (int col = 0; col < 4; ++col) acc[col][nt] = (f32x4_t){s.x, s.y, s.z, s.w};
-                }
-            }
-
-            // One "item" = one weight fragment (16 B per lane) x the wave's four columns = 4 MFMAs (12 in the two-plane mode).
-            // Items run row-major over five "rows" of six input-column fragments: tap rows kh = 0, 1, 2 (full 32-deep steps), then
-            // row 3 = the channel tails of tap rows 0 | 1 side by side, row 4 = the tails of tap row 2 at columns c | c + 1.
-            // Weight fragments are read from LDS WD items ahead of their use (ring of WD + 1 register slots); the six column
-            // fragments of a row are read at the row boundary (double-buffering them as well costs 48 more VGPRs and spills).
-            constexpr int NROWS = 3 + 2 * N16;
-            constexpr int IPM = 3 * NTC * N32;                   // items of a main row: (kw, tile, step)
-            constexpr int NITM = 3 * IPM + (3 * NTC + 2 * NTC) * N16;
-            constexpr int WD = 2;
-            uint4 xa[6][N32 > 0 ? N32 : 1][NS];
-            uint4 wq[WD + 1][NS];
-            // item v -> row, kw (column shift of the X fragment), tile, step, index of its weight fragment in the chunk
-            auto load_xrow = [&](auto rowc) {
-                constexpr int row = decltype(rowc)::value;
-                static_for<0, 6>([&](auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    static_for<0, NS>([&](auto pc) {
-                        constexpr int pl = decltype(pc)::value;
-                        if constexpr (row < 3) {
-                            static_for<0, N32>([&](auto sc) {
-                                constexpr int st = decltype(sc)::value;
-                                xa[c][st][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + (row * PC + jb + c) * 16 + x32 + st * 4 * CPLANE);
-                            });
-                        } else if constexpr (row == 3) {           // lane groups 0, 1: tap row 0; 2, 3: tap row 1
-                            xa[c][0][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + ((g >> 1) * PC + jb + c) * 16 + x16);
-                        } else {                                   // tap row 2: lane groups 0, 1: column c; 2, 3: column c + 1
-                            // (columns 4, 5 only meet the lone (2,2) tail, whose upper weights are zero: stay inside the tile)
-                            xa[c][0][pl] = *reinterpret_cast<const uint4*>(xs + pl * XPLANE + xrow + (2 * PC + jb + c + (c < 4 ? (g >> 1) : 0)) * 16 + x16);
-                        }
-                    });
-                });
-            };
-            auto load_witem = [&](auto vc) {
-                constexpr int v = decltype(vc)::value;
-                constexpr int widx = v < 3 * IPM ? v                                      // main: ((kh * 3 + kw) * NTC + nt) * N32 + st == v
-                                                 : NMAIN + (v - 3 * IPM);                 // tails: A (kw, nt), B (nt), C (nt) in item order
-                static_for<0, NS>([&](auto pc) {
-                    constexpr int pl = decltype(pc)::value;
-                    wq[v % (WD + 1)][pl] = *reinterpret_cast<const uint4*>(wsc + (widx * NS + pl) * 1024 + lane * 16);
-                });
-            };
-            load_xrow(std::integral_constant<int, 0>{});
-            static_for<0, WD>([&](auto vc) { load_witem(vc); });
-            static_for<0, NITM>([&](auto vc) {
-                constexpr int v = decltype(vc)::value;
-                constexpr bool is_main = v < 3 * IPM;
-                constexpr int t = v - 3 * IPM;                                            // tail item index
-                constexpr int row = is_main ? v / IPM : (t < 3 * NTC ? 3 : 4);
-                constexpr int kw = is_main ? (v % IPM) / (NTC * N32) : (t < 3 * NTC ? t / NTC : (t < 4 * NTC ? 0 : 2));
-                constexpr int nt = is_main ? ((v % IPM) / N32) % NTC : t % NTC;
-                constexpr int st = is_main ? v % N32 : 0;
-                constexpr bool row_start = is_main ? (v % IPM == 0) : (t == 0 || t == 3 * NTC);
-                if constexpr (row_start && v > 0) load_xrow(std::integral_constant<int, row>{});
-                if constexpr (v + WD < NITM) load_witem(std::integral_constant<int, v + WD>{});
-                static_for<0, 4>([&](auto colc) {
-                    constexpr int col = decltype(colc)::value;
-                    acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[col + kw][st][0], acc[col][nt]);
-                    if constexpr (NS == 2) {
-                        acc[col][nt] = gm32(wq[v % (WD + 1)][0], xa[col + kw][st][NS - 1], acc[col][nt]);
-                        acc[col][nt] = gm32(wq[v % (WD + 1)][NS - 1], xa[col + kw][st][0], acc[col][nt]);
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-
-            CG_TICK(3);
-            // ---- ReLU + MaxPool(1,2) over the column pair, channels-last store of the lane's 4 NTC channels
-            if (t_out < T) {
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const int fo = (f0 + jb + 2 * pr) >> 1;
-                    if (fo >= F2) continue;
-                    const int64_t o = (int64_t)grp * a.out_gs + ((int64_t)b * T + t_out) * out_ts + (int64_t)fo * a.c_out + ch * 16 * NTC + g * 4 * NTC;
-#pragma unroll
-                    for (int nt = 0; nt < NTC; ++nt) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(acc[2 * pr][nt][r], acc[2 * pr + 1][nt][r]), 0.f);
-                        if (OUT_TYPE == AMTX_T_BF16)
-                            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                        else
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4 * nt) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-            }
+            mma_chunk(b, t0, f0, ch);
             CG_TICK(4);
             if (!w_all || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
             CG_TICK(5);
@@ -515,7 +646,7 @@ extern "C" int amtxdbg_convg_prof(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0>
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 8>
 int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
     const int ntf = (fe + FT - 1) / FT;
@@ -524,11 +655,14 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
     const int nchunks = a.c_out / (16 * NTC);
     const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)NTC * NS * g_wfrags_per_tile(CI16) * 1024;
-    const size_t lds_f = KS1 > 0 ? (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float) + (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
-    const int w_all = nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
-    const size_t lds = lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
+    const size_t lds_f = KS1 > 0 ? (FCL ? (size_t)(GROWS + 2) * (FT + 4) * 16 + 128 : (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float)) +
+                                   (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
+    constexpr bool PIPE = FCL && CI16 == 2;                   // two input tiles + two feature tiles, one resident weight chunk
+    const int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
+    const size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16 : lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
+    if (PIPE) AMTX_REQUIRE(nchunks == 1, "conv3x3 (general): the pipelined 32-channel variant takes one C_out chunk");
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
-    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1>;
+    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX>;
     AMTX_GRANT_LDS(kern, lds);
     // persistent grid: as many blocks as fit the chip at once (LDS allows 160 KiB / lds per CU), a multiple of 8 per group so a
     // block's tiles stay on its XCD
@@ -544,10 +678,14 @@ template <int CI16, int NTC>
 int dispatch_gen(const ConvArgs& a, hipStream_t s) {
     if (a.feats) {                                              // fused first conv
         const int ks1 = (9 * a.c_in + 31) / 32;
-        if (a.planes == 1 && a.out_type == AMTX_T_BF16) {
-            if (ks1 == 1) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1>(a, s);
-            if (ks1 == 2) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 2>(a, s);
+        if (amtx_conv1g_tapk(a.c_in, a.planes) && a.out_type == AMTX_T_BF16) {
+            if constexpr (CI16 == 2) {       // the HCQT shape (6 harmonics, amt_tools/features/hvqt.py:107-133) has its own item count
+                if (a.c_in <= 6) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true, 6>(a, s);
+            }
+            return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true>(a, s);
         }
+        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && ks1 == 1)        // one input channel (2 .. 8 channels: the tap-major variant above)
+            return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1>(a, s);
         if (a.planes == 2 && a.out_type == AMTX_T_F32) {
             if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
             if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);
@@ -613,9 +751,23 @@ void amtx_conv3x3_gen_pack_host(const float* w, const float* scale, int c_in, in
 
 // fused first conv (c_in -> c_mid channels, c_mid = this layer's C_in): fragments [tile of 16 channels][k-step][plane][lane][8],
 // k = 32 ks + 8 (lane >> 4) + j over (ci, kh, kw) in the weight tensor's order, zero past 9 c_in
-size_t amtx_conv1g_wfrag_elems(int c_in, int c_mid, int planes) { return (size_t)(c_mid / 16) * ((9 * c_in + 31) / 32) * planes * 512; }
+// (amtx_conv1g_tapk: k = 8 tap + ci instead, three steps)
+size_t amtx_conv1g_wfrag_elems(int c_in, int c_mid, int planes) {
+    return (size_t)(c_mid / 16) * (amtx_conv1g_tapk(c_in, planes) ? 3 : (9 * c_in + 31) / 32) * planes * 512;
+}
 
 void amtx_conv1g_pack_host(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out) {
+    if (amtx_conv1g_tapk(c_in, planes)) {
+        for (int nt = 0; nt < c_mid / 16; ++nt)
+            for (int ks = 0; ks < 3; ++ks)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = 16 * nt + (l & 15), tap = 4 * ks + (l >> 4);
+                        const float v = (tap < 9 && j < c_in) ? w[((size_t)co * c_in + j) * 9 + tap] * (scale ? scale[co] : 1.0f) : 0.0f;
+                        out[((size_t)(nt * 3 + ks)) * 512 + (size_t)l * 8 + j] = f32_to_bf16_rn(v);
+                    }
+        return;
+    }
     const int kvalid = 9 * c_in, ks1 = (kvalid + 31) / 32;
     for (int nt = 0; nt < c_mid / 16; ++nt)
         for (int ks = 0; ks < ks1; ++ks)
@@ -632,16 +784,24 @@ void amtx_conv1g_pack_host(const float* w, const float* scale, int c_in, int c_m
 
 // does the fused-first-conv variant fit the LDS for this layer?
 bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
-    if (c_in < 1 || c_in > 7 || !amtx_conv3x3_gen_ntc(c_mid, c_out)) return false;
+    const bool tapk = amtx_conv1g_tapk(c_in, planes);
+    if (c_in < 1 || c_in > (tapk ? 8 : 7) || !amtx_conv3x3_gen_ntc(c_mid, c_out)) return false;
     const int ft = planes == 2 ? 16 : 32, ntc = amtx_conv3x3_gen_ntc(c_mid, c_out);
-    const size_t lds = (size_t)planes * (c_mid / 8) * g_cplane(ft) + (size_t)ntc * planes * g_wfrags_per_tile(c_mid / 16) * 1024 +
-                       (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float) + (size_t)(c_mid / 16) * ((9 * c_in + 31) / 32) * planes * 1024 + c_mid * 4;
+    const bool pipe = tapk && c_mid == 32;      // two input tiles and two feature tiles (conv3x3_gen_kernel PIPE)
+    const size_t feat = tapk ? (size_t)(pipe ? 2 : 1) * (GROWS + 2) * (ft + 4) * 16 + 128 : (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
+    const size_t lds = (size_t)(pipe ? 2 : 1) * planes * (c_mid / 8) * g_cplane(ft) + (size_t)ntc * planes * g_wfrags_per_tile(c_mid / 16) * 1024 + feat +
+                       (size_t)(c_mid / 16) * (tapk ? 3 : (9 * c_in + 31) / 32) * planes * 1024 + c_mid * 4;
     return lds <= 160 * 1024;
 }
 
 int amtx_launch_conv3x3_gen(const ConvArgs& a, int c_in, hipStream_t stream) {
     AMTX_REQUIRE((a.in || a.feats) && a.wfrag && a.shift && a.out, "conv3x3 (general): null pointer");
-    if (a.feats) AMTX_REQUIRE(a.w1frag && a.shift1 && a.c_in > 0 && a.c_in <= 7, "conv3x3 (general): fused first conv needs w1frag / shift1 and c_in <= 7");
+    if (a.feats && amtx_conv1g_tapk(a.c_in, a.planes))
+        AMTX_REQUIRE(a.f_stride_c >= 0 && a.f_stride_t >= 0 && a.f_stride_f >= 0 &&
+                         (int64_t)(a.c_in - 1) * a.f_stride_c + (int64_t)(a.T - 1) * a.f_stride_t + (int64_t)(a.F - 1) * a.f_stride_f < (1ll << 31),
+                     "conv3x3 (general): a clip's feature view must span fewer than 2^31 elements with non-negative strides");
+    if (a.feats) AMTX_REQUIRE(a.w1frag && a.shift1 && a.c_in > 0 && a.c_in <= (amtx_conv1g_tapk(a.c_in, a.planes) ? 8 : 7),
+                              "conv3x3 (general): fused first conv needs w1frag / shift1 and c_in <= 7 (8 in the one-plane modes)");
     AMTX_REQUIRE(a.B > 0 && a.T > 0 && a.F >= 2 && a.groups > 0, "conv3x3 (general): bad sizes");
     AMTX_REQUIRE(a.planes == 1 || a.planes == 2, "conv3x3 (general): planes must be 1 or 2");
     if (c_in == 48 && amtx_conv3x3_gen_ntc(c_in, a.c_out) == 3) return dispatch_gen<3, 3>(a, stream);

@@ -141,6 +141,19 @@ __global__ void conv_gen_pack_kernel(const float* w, const float* scale, int c_i
 
 // convg.hip amtx_conv1g_pack_host: [tile of 16 channels][k-step][plane][lane][8], k = 32 ks + 8 (lane >> 4) + j over (ci, kh, kw), zero past 9 c_in
 __global__ void conv1g_pack_kernel(const float* w, const float* scale, int c_in, int c_mid, int planes, bf16_t* out) {
+    if (amtx_conv1g_tapk(c_in, planes)) {          // tap-major, 8 channel slots per tap, three steps (amtx_conv1g_pack_host's other branch)
+        const int total = (c_mid / 16) * 3 * 64 * 8;
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+            int r = idx;
+            const int j = r & 7; r >>= 3;
+            const int l = r & 63; r >>= 6;
+            const int ks = r % 3, nt = r / 3;
+            const int co = 16 * nt + (l & 15), tap = 4 * ks + (l >> 4);
+            const float v = (tap < 9 && j < c_in) ? w[((size_t)co * c_in + j) * 9 + tap] * (scale ? scale[co] : 1.0f) : 0.0f;
+            put16(out, ((size_t)(nt * 3 + ks)) * 512 + (size_t)l * 8 + j, 512, 1, v);
+        }
+        return;
+    }
     const int kvalid = 9 * c_in, ks1 = (kvalid + 31) / 32;
     const int total = (c_mid / 16) * ks1 * 64 * 8;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
