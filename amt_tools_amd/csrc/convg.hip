@@ -84,8 +84,9 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // K = 9 c_in taps padded to KS1 32-deep steps, im2col gathered per lane from a small feature tile in LDS, D' = W1 . P^T per
 // 16 tile positions, epilogue shift + ReLU + zero outside the map + bf16 (hi/lo) -> 8-byte LDS stores.
 // FCL (with KS1 = 3, one plane): the tap-major form of the fused first conv (amtx_conv1g_tapk): features staged channels-last in bf16.
-// CMAX (FCL): the most input channels this instantiation stages (sizes the per-thread item slots: 6 -> 9 loads per tile instead of 12).
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 8>
+// CMAX: the most input channels this instantiation stages (sizes the per-thread item slots: 6 -> 9 loads per tile instead of 12; 1 -> 2
+// instead of a rolled ten-slot loop with an early exit); 0 = the variant's limit (8 tap-major, 7 otherwise).
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0>
 __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
     static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
@@ -219,7 +220,9 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     // weight chunk travel HBM/L2 -> registers while the current ones are on the matrix cores, so neither the block start-up nor
     // a memory round trip is paid per tile.  With a single C_out chunk the weights stay in LDS for the whole launch.
     // ---- fused first conv helpers
-    constexpr int NF1 = FUSE1 ? ((FCL ? CMAX : 7) * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7; tap-major: <= 8)
+    constexpr int CMX = CMAX > 0 ? CMAX : (FCL ? 8 : 7);      // channels the item slots are sized for
+    constexpr bool EXACT = FCL || CMAX == 1;                  // every slot loads unconditionally (no early exit from the item loops)
+    constexpr int NF1 = FUSE1 ? (CMX * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7; tap-major: <= 8)
     // A thread's feature items are the same tile-relative (channel, row, column) for every tile: decoded once (the div / mod chains
     // per item and tile were a sixth of the kernel), bit 31 = item exists.  The zeroing of values outside the map waits for
     // store_f: a select right behind the load would wait for the load here.
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         } else {
 #pragma unroll
             for (int k = 0; k < NF1; ++k) {
-                if (k >= nfk) break;
+                if (!EXACT && k >= nfk) break;
                 const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
                 const int t = t0 - 2 + i, f = f0 - 2 + j;
                 const bool ok = (fdesc[k] >> 31) && t >= 0 && t < T && f >= 0 && f < F;
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         }
 #pragma unroll
         for (int k = 0; k < NF1; ++k) {
-            if (k >= nfk) break;
+            if (!EXACT && k >= nfk) break;
             if (fdesc[k] >> 31) {
                 const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
                 fs[(ci * FROWS1 + i) * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
@@ -646,7 +649,7 @@ extern "C" int amtxdbg_convg_prof(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 8>
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 0>
 int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
     const int ntf = (fe + FT - 1) / FT;
@@ -684,8 +687,8 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
             }
             return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true>(a, s);
         }
-        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && ks1 == 1)        // one input channel (2 .. 8 channels: the tap-major variant above)
-            return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1>(a, s);
+        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && a.c_in == 1)     // one input channel (2 .. 8 channels: the tap-major variant above)
+            return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1>(a, s);
         if (a.planes == 2 && a.out_type == AMTX_T_F32) {
             if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
             if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);
