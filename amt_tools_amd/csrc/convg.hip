@@ -317,6 +317,24 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                 koff[ks][jj] = (ci * FROWS1 + tap / 3) * FP1 + tap % 3;
             }
     }
+    // FCL: what a lane's fragment reads need is the same for every tile -- the byte offset of its k-group's tap inside the feature tile, and per
+    // 16-position group its position's offset and (row, column): decoded once (divisions by 3 and by COLS per group and tile otherwise)
+    constexpr int NGRP1 = (NNT1 + NW - 1) / NW;
+    int tapoff[FCL ? 3 : 1], gsrc[FCL ? NGRP1 : 1], gij[FCL ? NGRP1 : 1];
+    if constexpr (FCL) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int tap = 4 * ks + g, tp = tap < 9 ? tap : 0;
+            tapoff[ks] = ((tp / 3) * FW + tp % 3) * 16;
+        }
+#pragma unroll
+        for (int q = 0; q < NGRP1; ++q) {
+            const int pos = (wave + q * NW) * 16 + r16, posc = pos < NPOS ? pos : NPOS - 1;
+            const int i = posc / COLS, j = posc % COLS;
+            gsrc[q] = (i * FW + j) * 16;
+            gij[q] = i << 8 | j;
+        }
+    }
     auto first_conv = [&](int t0, int f0) {
         const uint4* w1 = reinterpret_cast<const uint4*>(w1s);                                   // [tile][ks][plane][lane]
         const float* sh1 = reinterpret_cast<const float*>(w1s + CI16 * KS1 * NS * 1024);
@@ -346,6 +364,17 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             static_for<0, cnt>([&](auto ic) {
                 constexpr int i_ = decltype(ic)::value;
                 pos[i_] = (wave + (it0 + i_) * NW) * 16 + r16;
+                if constexpr (FCL) {
+                    // k-group g of step ks = tap 4 ks + g (taps 9 .. 11: zero weights, any valid address): the 8 channel slots of the
+                    // position (i + kh, j + kw) of the feature tile, already bf16
+                    const int i = gij[it0 + i_] >> 8, j = gij[it0 + i_] & 0xff;
+                    inside[i_] = (unsigned)(t0 - 1 + i) < (unsigned)T && (unsigned)(f0 - 1 + j) < (unsigned)F;
+                    static_for<0, KS1>([&](auto kc) {
+                        constexpr int ks = decltype(kc)::value;
+                        ph[i_][ks] = *reinterpret_cast<const uint4*>(fs16 + gsrc[it0 + i_] + tapoff[ks]);
+                    });
+                    return;
+                }
                 const int posc = pos[i_] < NPOS ? pos[i_] : NPOS - 1;
                 const int i = posc / COLS, j = posc % COLS;
                 const float* fp = fs + i * FP1 + j;
@@ -353,13 +382,6 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                 inside[i_] = t >= 0 && t < T && f >= 0 && f < F;
                 static_for<0, KS1>([&](auto kc) {
                     constexpr int ks = decltype(kc)::value;
-                    if constexpr (FCL) {
-                        // k-group g of step ks = tap 4 ks + g (taps 9 .. 11: zero weights, any valid address): the 8 channel slots of the
-                        // position (i + kh, j + kw) of the feature tile, already bf16
-                        const int tap = 4 * ks + g, tp = tap < 9 ? tap : 0;
-                        ph[i_][ks] = *reinterpret_cast<const uint4*>(fs16 + ((i + tp / 3) * FW + j + tp % 3) * 16);
-                        return;
-                    }
                     float v[8];
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) v[jj] = fp[koff[ks][jj]];
@@ -547,12 +569,12 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         if (tile + 2 * stride < ntiles) load_f(tile + 2 * stride, fraw, xok);
         __syncthreads();
         int cur = 0;
+        int bn = 0, t0n = 0, f0n = 0;
+        coord(tile, bn, t0n, f0n);
         for (; tile < ntiles; tile += stride, cur ^= 1) {
-            int b, t0, f0;
-            coord(tile, b, t0, f0);
+            const int b = bn, t0 = t0n, f0 = f0n;                  // decoded one iteration ago
             const int next = tile + stride;
             const bool has_next = next < ntiles;
-            int bn = 0, t0n = 0, f0n = 0;
             if (has_next) coord(next, bn, t0n, f0n);
             auto fc_next = [&]() {
                 if (has_next) { xs = xs2(cur ^ 1); fs16 = fsb(cur ^ 1); first_conv(t0n, f0n); }
