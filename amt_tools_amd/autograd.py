@@ -23,7 +23,7 @@ __all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELo
            'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend', 'note_fallback', 'fallbacks',
            'reset_fallbacks']
 
-HIDDEN_SIZES = (128, 256, 384)  # hidden sizes per direction the training recurrences are built for (model_complexity 2, 3, 4)
+HIDDEN_SIZES = (128, 256, 384, 512)  # hidden sizes per direction the training recurrences are built for (model_complexity 2 .. 5)
 
 
 USE_HIP_DENSE = True            # False: nn.Conv2d / nn.Linear / the LSTM's matmuls through ATen (MIOpen / hipBLASLt) -- the A/B switch of the tests

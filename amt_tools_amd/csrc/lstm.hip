@@ -557,8 +557,10 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     // (64 spare VGPRs, 128 KiB of LDS per block), the other two are streamed: half the bytes per step.  HH = 384, bf16: 36 groups per
     // wave, no spare registers; every ninth group (4 per wave, again 128 KiB per block) sits in LDS, 32 are streamed.
     constexpr bool PIN = NS == 1 && HH == 256;    // register + LDS pinning, period 4
-    constexpr bool PINL = NS == 1 && HH == 384;   // LDS pinning only, period 9
-    constexpr int NPIN = PIN ? NG / 4 : (PINL ? NG / 9 : 0);   // groups pinned per kind and wave
+    constexpr bool PINL = NS == 1 && HH == 384;   // LDS pinning only: four groups per wave, period PER = 9 (HH = 512: the 128 KiB of pinned groups
+                                                  // and the two h tiles are 512 bytes more than a CU's LDS: everything streamed)
+    constexpr int PER = NG / 4;
+    constexpr int NPIN = PIN ? NG / 4 : (PINL ? 4 : 0);   // groups pinned per kind and wave
     constexpr int NSG = NG - (PIN ? 2 : (PINL ? 1 : 0)) * NPIN;   // streamed groups per step and wave
     static_assert(NU % 8 == 0 && KSN % SGK == 0 && NG % 4 == 0 && NSG % RS == 0, "hidden size must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][HPG] bf16
@@ -613,8 +615,8 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     if constexpr (PIN || PINL) {
         static_for<0, NG>([&](auto ic) {
             constexpr int gi = decltype(ic)::value;
-            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : (gi % 9 == 0 ? 1 : 2);
-            constexpr int pidx = PIN ? gi >> 2 : gi / 9;
+            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : (gi % PER == 0 ? 1 : 2);
+            constexpr int pidx = PIN ? gi >> 2 : gi / PER;
             if constexpr (kind < 2) {
                 static_for<0, SGK>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
@@ -633,7 +635,7 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
     load_xrow(tidx(0), xn);
     static_for<0, RS - 1>([&](auto sc) {
         constexpr int si = decltype(sc)::value;
-        constexpr int gi = PIN ? (si >> 1) * 4 + 2 + (si & 1) : (PINL ? si + si / 8 + 1 : si);
+        constexpr int gi = PIN ? (si >> 1) * 4 + 2 + (si & 1) : (PINL ? si + si / (PER - 1) + 1 : si);
         static_for<0, SGK>([&](auto kc) {
             static_for<0, NS>([&](auto pc) { w[si % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gi, decltype(kc)::value, decltype(pc)::value); });
         });
@@ -667,13 +669,13 @@ __global__ __launch_bounds__(512) void bilstm_stream_kernel(LstmArgs a) {
         static_for<0, NG>([&](auto ic) {
             constexpr int gi = decltype(ic)::value;
             constexpr int ub = gi / (4 * NSUB), q = (gi / NSUB) & 3, sub = gi % NSUB;
-            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : (PINL ? (gi % 9 == 0 ? 1 : 2) : 2);     // 0 registers, 1 LDS, 2 streamed
-            constexpr int pidx = PIN ? gi >> 2 : gi / 9;                                        // index among the pinned groups of its kind
-            constexpr int si = PIN ? (gi >> 2) * 2 + (gi & 3) - 2 : (PINL ? gi - gi / 9 - 1 : gi);   // index among the streamed groups
+            constexpr int kind = PIN ? ((gi & 3) == 0 ? 0 : ((gi & 3) == 1 ? 1 : 2)) : (PINL ? (gi % PER == 0 ? 1 : 2) : 2);     // 0 registers, 1 LDS, 2 streamed
+            constexpr int pidx = PIN ? gi >> 2 : gi / PER;                                      // index among the pinned groups of its kind
+            constexpr int si = PIN ? (gi >> 2) * 2 + (gi & 3) - 2 : (PINL ? gi - gi / PER - 1 : gi);   // index among the streamed groups
             if constexpr (kind == 2) {
                 // behind the last RS - 1 streamed groups: the first ones of the next step
                 constexpr int sn = (si + RS - 1) % NSG;
-                constexpr int gn = PIN ? (sn >> 1) * 4 + 2 + (sn & 1) : (PINL ? sn + sn / 8 + 1 : sn);
+                constexpr int gn = PIN ? (sn >> 1) * 4 + 2 + (sn & 1) : (PINL ? sn + sn / (PER - 1) + 1 : sn);
                 static_for<0, SGK>([&](auto kc) {
                     static_for<0, NS>([&](auto pc) { w[sn % RS][decltype(kc)::value][decltype(pc)::value] = load_frag(gn, decltype(kc)::value, decltype(pc)::value); });
                 });
@@ -959,7 +961,7 @@ template <int HH, int NS, int X_TYPE, int OUT_TYPE>
 int launch_stream(const LstmArgs& a, hipStream_t stream) {
     // h tiles + (bf16 mode) the LDS-resident quarter of W_hh: 8 waves x (groups / 4) x 4 KiB
     // h tiles + (bf16 mode) the LDS-resident groups of W_hh: 8 waves x 4 groups x 4 KiB at either hidden size
-    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 ? (size_t)8 * 4 * 4096 : 0);
+    const size_t lds = 2 * (size_t)NS * 16 * (HH + 8) * 2 + (NS == 1 && HH <= 384 ? (size_t)8 * 4 * 4096 : 0);
     auto kern = bilstm_stream_kernel<HH, NS, X_TYPE, OUT_TYPE>;
     AMTX_GRANT_LDS(kern, lds);
     dim3 grid((unsigned)((a.B + 15) / 16), 2, (unsigned)a.groups);
@@ -1057,7 +1059,8 @@ int amtx_launch_bilstm(const LstmArgs& a, hipStream_t stream) {
         AMTX_REQUIRE(!a.save || a.planes == 2, "bilstm: the training forward (save) is built for the two-plane precision");
         if (a.hidden == 256) return dispatch_stream<256>(a, stream);
         if (a.hidden == 384) return dispatch_stream<384>(a, stream);
-        amtx_set_error("bilstm: unsupported hidden size %d (128, 256 and 384 are built)", a.hidden);
+        if (a.hidden == 512) return dispatch_stream<512>(a, stream);
+        amtx_set_error("bilstm: unsupported hidden size %d (128, 256, 384 and 512 are built)", a.hidden);
         return AMTX_ERR_UNSUPPORTED;
     }
     if (a.planes == 1 && a.x_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch<1, AMTX_T_BF16, AMTX_T_BF16>(a, stream);
@@ -1094,7 +1097,7 @@ int amtx_launch_bilstm_bwd(const float* dout, const float* save, const bf16_t* w
 int amtx_launch_bilstm_pack_dev_h(const float* whh_fwd, const float* whh_bwd, int hidden, int planes, bf16_t* frag_fwd, bf16_t* frag_bwd, hipStream_t stream) {
     AMTX_REQUIRE(whh_fwd && whh_bwd && frag_fwd && frag_bwd && (planes == 1 || planes == 2), "bilstm pack: bad argument");
     if (hidden == H) return amtx_launch_bilstm_pack_dev(whh_fwd, whh_bwd, planes, frag_fwd, frag_bwd, stream);
-    AMTX_REQUIRE(hidden == 256 || hidden == 384, "bilstm pack: hidden size %d is not built (128, 256, 384)", hidden);
+    AMTX_REQUIRE(hidden == 256 || hidden == 384 || hidden == 512, "bilstm pack: hidden size %d is not built (128, 256, 384, 512)", hidden);
     hipLaunchKernelGGL(bilstm_pack_dev_h_kernel, dim3(256), dim3(256), 0, stream, whh_fwd, whh_bwd, hidden, planes, frag_fwd, frag_bwd);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
@@ -1113,17 +1116,20 @@ int amtx_launch_bilstm_bwd_h(const float* dout, const float* save, const bf16_t*
         return AMTX_OK;
     }
     AMTX_REQUIRE(dout && save && whh_t && dxproj, "bilstm backward: null pointer");
-    AMTX_REQUIRE(B > 0 && T > 0 && planes == 2 && (hidden == 256 || hidden == 384),
-                 "bilstm backward: hidden 256 / 384 are built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
+    AMTX_REQUIRE(B > 0 && T > 0 && planes == 2 && (hidden == 256 || hidden == 384 || hidden == 512),
+                 "bilstm backward: hidden 256 / 384 / 512 are built for the two-plane precision only (got hidden %d, planes %d)", hidden, planes);
     LstmBwdHArgs a{dout, save, whh_t, dxproj, B, T, (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes)};
     dim3 grid((unsigned)((B + 3) / 4), 2, (unsigned)groups);
     const size_t lds = 2 * (size_t)planes * 5 * (4 * hidden + 8) * 2;
     if (hidden == 256) {
         AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<256, 2>), lds);
         hipLaunchKernelGGL((bilstm_stream_bwd_kernel<256, 2>), grid, dim3(512), lds, stream, a);
-    } else {
+    } else if (hidden == 384) {
         AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<384, 2>), lds);
         hipLaunchKernelGGL((bilstm_stream_bwd_kernel<384, 2>), grid, dim3(512), lds, stream, a);
+    } else {
+        AMTX_GRANT_LDS((bilstm_stream_bwd_kernel<512, 2>), lds);
+        hipLaunchKernelGGL((bilstm_stream_bwd_kernel<512, 2>), grid, dim3(512), lds, stream, a);
     }
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;

@@ -202,9 +202,9 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     *out = nullptr;
     AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3 || precision == AMTX_PREC_F16, "amtx_of_model_create: bad precision");
     AMTX_REQUIRE(dim_in >= 4 && in_channels >= 1 && n_out > 0 && n_out % 4 == 0, "amtx_of_model_create: bad dims");
-    if (model_complexity < 2 || model_complexity > 4) {
+    if (model_complexity < 2 || model_complexity > 5) {
         amtx_set_error("amtx_of_model_create: model_complexity 2 (32/32/64-channel convolutions, LSTM hidden 128), 3 (48/48/96, hidden 256) and "
-                       "4 (64/64/128, hidden 384) are implemented, with or without the OnsetsFrames2 offset head (got model_complexity=%d)", model_complexity);
+                       "4 (64/64/128, hidden 384), 5 (80/80/160, hidden 512) are implemented, with or without the OnsetsFrames2 offset head (got model_complexity=%d)", model_complexity);
         return AMTX_ERR_UNSUPPORTED;
     }
     amtx_of_model* m = new amtx_of_model();

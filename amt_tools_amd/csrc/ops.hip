@@ -89,13 +89,13 @@ extern "C" int amtx_bilstm_fwd(const void* xproj, const uint16_t* whh_packed, in
 }
 
 extern "C" int64_t amtx_bilstm_h_packed_elems(int hidden, int planes) {
-    if (hidden != 128 && hidden != 256 && hidden != 384) return 0;
+    if (hidden != 128 && hidden != 256 && hidden != 384 && hidden != 512) return 0;
     return (int64_t)amtx_bilstm_wfrag_elems_h(hidden, planes);
 }
 
 extern "C" int amtx_bilstm_h_pack(const float* host_whh_fwd, const float* host_whh_bwd, int hidden, int planes, uint16_t* host_out) {
     AMTX_REQUIRE(host_whh_fwd && host_whh_bwd && host_out && (planes == 1 || planes == 2), "amtx_bilstm_h_pack: bad argument");
-    AMTX_REQUIRE(hidden == 128 || hidden == 256 || hidden == 384, "amtx_bilstm_h_pack: hidden size %d is not built (128, 256, 384)", hidden);
+    AMTX_REQUIRE(hidden == 128 || hidden == 256 || hidden == 384 || hidden == 512, "amtx_bilstm_h_pack: hidden size %d is not built (128, 256, 384, 512)", hidden);
     amtx_bilstm_pack_host_h(host_whh_fwd, host_whh_bwd, hidden, planes, host_out);
     return AMTX_OK;
 }

@@ -88,7 +88,7 @@ int amtx_spec_scale(const amtx_spec_plan* plan, const float* power, const float*
  * ------------------------------------------------------------------------------------------------ */
 typedef struct amtx_of_model amtx_of_model;
 
-/* model_complexity 2, 3 and 4 are built (conv channels 16 mc / 16 mc / 32 mc, fc 256 mc, LSTM hidden 128 (mc - 1): onsetsframes.py:37-41,
+/* model_complexity 2, 3, 4 and 5 are built (conv channels 16 mc / 16 mc / 32 mc, fc 256 mc, LSTM hidden 128 (mc - 1): onsetsframes.py:37-41,
  * 358-364); anything else answers AMTX_ERR_UNSUPPORTED */
 int amtx_of_model_create(amtx_of_model** model, int dim_in, int in_channels, int model_complexity, int n_out,
                          int has_offsets, int precision /* AMTX_PREC_* */);
@@ -166,7 +166,7 @@ int amtx_conv3x3_pack(const float* host_w /*(c_out,32,3,3)*/, const float* host_
 int amtx_conv3x3_fwd(const void* in, int elem_type, const uint16_t* w_packed, int planes, const float* shift, void* out, int batch,
                      int num_frames, int num_bins, int c_out, void* stream);
 /* The same layer for the channel counts of the other model complexities (models/onsetsframes.py:362-364 nf = 16 mc / 16 mc / 32 mc;
- * built: 48 -> 48 and 48 -> 96 = model_complexity 3, OnsetsFrames2's default; 64 -> 64 and 64 -> 128 = model_complexity 4).
+ * built: 48 -> 48 and 48 -> 96 = model_complexity 3, OnsetsFrames2's default; 64 -> 64 and 64 -> 128 = model_complexity 4; 80 -> 80 and 80 -> 160 = 5).
  * `in` is [B][T][F][c_in] channels-last.
  * amtx_conv3x3g_packed_elems returns 0 for a pair of channel counts that is not built. */
 int64_t amtx_conv3x3g_packed_elems(int c_in, int c_out, int planes);
@@ -183,7 +183,7 @@ int64_t amtx_bilstm_packed_elems(int planes);
 int amtx_bilstm_pack(const float* host_whh_fwd, const float* host_whh_bwd /* (512,128) each */, int planes, uint16_t* host_out);
 int amtx_bilstm_fwd(const void* xproj /*(B,T,2,512)*/, const uint16_t* whh_packed, int planes, int elem_type, void* out /*(B,T,256)*/,
                     int batch, int num_frames, void* stream);
-/* Any built hidden size (128, 256, 384 = dim_lm / 2 at model_complexity 2, 3, 4; models/onsetsframes.py:57-58, 498-507):
+/* Any built hidden size (128, 256, 384, 512 = dim_lm / 2 at model_complexity 2 .. 5; models/onsetsframes.py:57-58, 498-507):
  * W_hh (4 hidden, hidden) per direction, xproj (B,T,2,4 hidden), out (B,T,2 hidden). */
 int64_t amtx_bilstm_h_packed_elems(int hidden, int planes);
 int amtx_bilstm_h_pack(const float* host_whh_fwd, const float* host_whh_bwd, int hidden, int planes, uint16_t* host_out);
@@ -200,7 +200,7 @@ int amtx_bilstm_train_fwd(const float* xproj, const uint16_t* whh_packed, int pl
                           void* stream);
 int amtx_bilstm_train_bwd(const float* dout, const float* save, const uint16_t* whh_t_packed, int planes, float* dxproj, int batch,
                           int num_frames, void* stream);
-/* The same three calls for any built hidden size (128, 256, 384): save is [B][T][2][5][hidden], dxproj [B][T][2][4 hidden], fragments
+/* The same three calls for any built hidden size (128, 256, 384, 512): save is [B][T][2][5][hidden], dxproj [B][T][2][4 hidden], fragments
  * amtx_bilstm_h_packed_elems(hidden, planes) elements each.  Two-plane precision only.  `groups` independent LSTMs of the same
  * (batch, num_frames, hidden) run in one launch (the onset and offset recurrences of OnsetsFrames2): every array gets a leading
  * [groups] axis. */

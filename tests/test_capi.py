@@ -29,7 +29,7 @@ def test_errors_are_reported_not_swallowed():
     import ctypes as C
     L = _lib.lib()
     h = C.c_void_p()
-    rc = L.amtx_of_model_create(C.byref(h), 229, 1, 5, 88, 1, 0)    # model_complexity 5: no kernels for its channel counts
+    rc = L.amtx_of_model_create(C.byref(h), 229, 1, 6, 88, 1, 0)    # model_complexity 6: no kernels for its channel counts
     assert rc < 0 and b'model_complexity' in L.amtx_last_error()
     import pytest
     with pytest.raises(_lib.AmtxError):

@@ -109,18 +109,19 @@ def test_onsetsframes2_default_complexity_3_engine_matches_reference_golden(prec
 
 
 @pytest.mark.parametrize('precision', ['x3', 'bf16', 'f16'])
-@pytest.mark.parametrize('name', ['of1_mc4_eval.npz', 'of2_mc4_hcqt_eval.npz'])
+@pytest.mark.parametrize('name', ['of1_mc4_eval.npz', 'of2_mc4_hcqt_eval.npz', 'of1_mc5_eval.npz', 'of2_mc5_hcqt_eval.npz'])
 def test_complexity_4_engine_matches_reference_golden(name, precision):
-    """model_complexity 4 (onsetsframes.py:358-364, 40-41: 64/64/128-channel convolutions, fc 1024, LSTM hidden 384) through the HIP
-    engine against vectors recorded from the real reference classes: OnsetsFrames on one-channel mel features and OnsetsFrames2
-    (offset head) on a three-channel HCQT shape."""
+    """model_complexity 4 (onsetsframes.py:358-364, 40-41: 64/64/128-channel convolutions, fc 1024, LSTM hidden 384) and 5 (80/80/160, fc
+    1280, hidden 512) through the HIP engine against vectors recorded from the real reference classes: OnsetsFrames on one-channel mel
+    features and OnsetsFrames2 (offset head) on a three-channel HCQT shape."""
     import amt_tools_amd.models as M
     g = load_golden(name)
-    assert int(g['model_complexity']) == 4
+    mc = int(g['model_complexity'])
+    assert mc == (5 if 'mc5' in name else 4)
     offsets = name.startswith('of2')
     cls = M.OnsetsFrames2 if offsets else M.OnsetsFrames
-    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=int(g['in_channels']), model_complexity=4, offsets=offsets)
-    model = cls(int(g['dim_in']), tools.PianoProfile(), int(g['in_channels']), 4, device='cuda:0', precision=precision)
+    sd = synth_state_dict(int(g['seed']), dim_in=int(g['dim_in']), in_channels=int(g['in_channels']), model_complexity=mc, offsets=offsets)
+    model = cls(int(g['dim_in']), tools.PianoProfile(), int(g['in_channels']), mc, device='cuda:0', precision=precision)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model.change_device()
     model.eval()
@@ -138,12 +139,13 @@ def test_complexity_4_engine_matches_reference_golden(name, precision):
         assert np.all((out[key].cpu().numpy() == g['out_' + key]) | near)
 
 
-def test_complexity_4_engine_vs_oracle_on_ragged_batches():
-    """model_complexity 4 against the oracle on fresh inputs whose batch and frame counts do not fill the kernels' tiles (x3)."""
+@pytest.mark.parametrize('mc', [4, 5])
+def test_complexity_4_engine_vs_oracle_on_ragged_batches(mc):
+    """model_complexity 4 and 5 against the oracle on fresh inputs whose batch and frame counts do not fill the kernels' tiles (x3)."""
     from oracle import model_ref
     from amt_tools_amd.models import OnsetsFrames
-    sd = synth_state_dict(12, dim_in=229, in_channels=1, model_complexity=4)
-    model = OnsetsFrames(229, tools.PianoProfile(), 1, 4, device='cuda:0', precision='x3')
+    sd = synth_state_dict(12, dim_in=229, in_channels=1, model_complexity=mc)
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, mc, device='cuda:0', precision='x3')
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model.change_device()
     model.eval()
@@ -303,7 +305,8 @@ def test_f16_precision_vs_oracle_on_both_convolution_paths(dim_in):
 
 @pytest.mark.parametrize('precision', ['bf16', 'x3', 'f16'])
 @pytest.mark.parametrize('cls,mc,dim_in,ic', [('OnsetsFrames', 2, 229, 1), ('OnsetsFrames2', 2, 229, 1), ('OnsetsFrames2', 3, 229, 1), ('OnsetsFrames', 2, 72, 6),
-                                              ('OnsetsFrames', 3, 72, 6), ('OnsetsFrames', 4, 229, 1), ('OnsetsFrames2', 4, 72, 3)])
+                                              ('OnsetsFrames', 3, 72, 6), ('OnsetsFrames', 4, 229, 1), ('OnsetsFrames2', 4, 72, 3), ('OnsetsFrames', 5, 229, 1),
+                                              ('OnsetsFrames2', 5, 72, 3)])
 def test_device_side_weight_sync_equals_the_host_path(cls, mc, dim_in, ic, precision, monkeypatch):
     """A weight RE-sync packs on the GPU (pack.hip, amtx_of_model_finalize_device) with the host packers' arithmetic: after the same
     parameter update, an engine re-synced on the device and one re-synced through the host (AMTX_HOST_WEIGHT_SYNC=1) return identical
@@ -516,7 +519,7 @@ def test_engine_is_deterministic_run_to_run(mc, precision):
 def test_unbuilt_model_complexity_is_rejected_loudly_by_the_engine():
     from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd._lib import AmtxError
-    model = OnsetsFrames(229, tools.PianoProfile(), 1, 5, device='cuda:0')        # 80 / 80 / 160 channels, hidden 512: not built
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, 6, device='cuda:0')        # 96 / 96 / 192 channels, hidden 640: not built
     model.change_device()
     model.eval()
     with pytest.raises(AmtxError), torch.no_grad():

@@ -94,9 +94,10 @@ def test_conv3x3_bn_relu_pool(planes, b, t, f, cout):
 @pytest.mark.parametrize('planes', [1, 2])
 @pytest.mark.parametrize('b,t,f,cin,cout', [(2, 40, 229, 48, 48), (1, 17, 114, 48, 96), (3, 5, 36, 48, 48), (1, 33, 18, 48, 96),
                                             (1, 1, 2, 48, 48), (2, 16, 33, 48, 96),
-                                            (2, 40, 229, 64, 64), (1, 17, 114, 64, 128), (3, 5, 36, 64, 64), (1, 33, 18, 64, 128), (1, 1, 2, 64, 64)])
+                                            (2, 40, 229, 64, 64), (1, 17, 114, 64, 128), (3, 5, 36, 64, 64), (1, 33, 18, 64, 128), (1, 1, 2, 64, 64),
+                                            (2, 40, 229, 80, 80), (1, 17, 114, 80, 160), (3, 5, 36, 80, 80), (1, 1, 2, 80, 160)])
 def test_conv3x3_general_channels(planes, b, t, f, cin, cout):
-    """convg.hip (weights staged in LDS): the 48 -> 48 and 48 -> 96 layers of model_complexity 3, 64 -> 64 and 64 -> 128 of 4."""
+    """convg.hip (weights staged in LDS): the 48 -> 48 and 48 -> 96 layers of model_complexity 3, 64 -> 64 and 64 -> 128 of 4, 80 -> 80 and 80 -> 160 of 5."""
     L = _lib.lib()
     g = torch.Generator().manual_seed(b * 1000 + t * 10 + f + cout)
     x = torch.rand(b, t, f, cin, generator=g)
@@ -164,9 +165,9 @@ def _lstm_ref(xproj, whh_f, whh_b, H=128):
 
 @pytest.mark.parametrize('planes', [1, 2])
 @pytest.mark.parametrize('b,t', [(1, 1), (3, 50), (17, 33), (40, 120)])
-@pytest.mark.parametrize('H', [256, 384])
+@pytest.mark.parametrize('H', [256, 384, 512])
 def test_bilstm_hidden_256_384(planes, b, t, H):
-    """lstm.hip bilstm_stream_kernel (W_hh streamed from L2): the recurrences of model_complexity 3 and 4 (hidden 256 / 384 per direction)."""
+    """lstm.hip bilstm_stream_kernel (W_hh streamed from L2): the recurrences of model_complexity 3, 4 and 5 (hidden 256 / 384 / 512 per direction)."""
     L = _lib.lib()
     g = torch.Generator().manual_seed(b * 100 + t)
     xproj = torch.randn(b, t, 2, 4 * H, generator=g)

@@ -216,15 +216,19 @@ def test_bilstm_multi_equals_separate_launches():
 
 
 @pytest.mark.gpu
-def test_complexity_4_training_step_on_gpu_matches_reference_golden():
-    """The reference's training-mode losses and gradients at model_complexity 4 (tests/golden/of1_mc4_train.npz) with the model on the GPU:
-    64 / 64 / 128-channel convolution kernels, the streaming hidden-384 recurrences forward and backward."""
+@pytest.mark.parametrize('mc', [4, 5])
+def test_complexity_4_training_step_on_gpu_matches_reference_golden(mc):
+    """The reference's training-mode losses and gradients at model_complexity 4 and 5 (tests/golden/of1_mc4_train.npz, of1_mc5_train.npz) with
+    the model on the GPU: 64 / 64 / 128 (80 / 80 / 160)-channel convolution kernels, the streaming hidden-384 (512) recurrences forward and
+    backward."""
     from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd.synth import synth_state_dict
-    g = load_golden('of1_mc4_train.npz')
-    assert int(g['model_complexity']) == 4
-    model = OnsetsFrames(229, tools.PianoProfile(), 1, 4, device='cuda:0')
-    sd = synth_state_dict(int(g['seed']), dim_in=229, in_channels=1, model_complexity=4)
+    import amt_tools_amd.autograd as ag
+    g = load_golden(f'of1_mc{mc}_train.npz')
+    assert int(g['model_complexity']) == mc
+    ag.reset_fallbacks()
+    model = OnsetsFrames(229, tools.PianoProfile(), 1, mc, device='cuda:0')
+    sd = synth_state_dict(int(g['seed']), dim_in=229, in_channels=1, model_complexity=mc)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model.change_device()
     for mod in model.modules():
@@ -247,11 +251,12 @@ def test_complexity_4_training_step_on_gpu_matches_reference_golden():
     assert float(np.median(rels)) < 2e-3
     # rows of the recurrent matrices' gradients: the hidden-384 streaming forward (saved h) and backward (W_hh^T fragments) kernels
     slices = golden_grad_slices(g)
-    assert len(slices) == 4
+    assert len(slices) == (4 if mc == 4 else 5)
     for k, st, ref in slices:
         got = named[k].grad.cpu().numpy()[::st]
         rel = np.linalg.norm(got - ref) / max(1e-9, np.linalg.norm(ref))
         assert rel < 3e-3, (k, rel)
+    assert ag.fallbacks() == {}, ag.fallbacks()          # every layer of the step on the HIP kernels
 
 
 @pytest.mark.gpu

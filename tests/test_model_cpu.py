@@ -37,7 +37,7 @@ def test_eval_run_on_batch_matches_reference_on_cpu():
     assert batch[tools.KEY_FEATS].shape == (2, 1, 229, 40)            # caller's batch untouched
 
 
-@pytest.mark.parametrize('name', ['of2_eval.npz', 'of2_mc2_eval.npz', 'of2_mc4_hcqt_eval.npz'])
+@pytest.mark.parametrize('name', ['of2_eval.npz', 'of2_mc2_eval.npz', 'of2_mc4_hcqt_eval.npz', 'of2_mc5_hcqt_eval.npz'])
 def test_onsetsframes2_matches_reference_on_cpu(name):
     """OnsetsFrames2 (offset head, detach_heads, model_complexity 3 and 2): same state_dict keys as the reference, same logits,
     same outputs (offsets as probabilities, onsetsframes.py:323-325)."""
@@ -75,7 +75,7 @@ def test_onsetsframes2_matches_reference_on_cpu(name):
     assert off.shape == mp.shape and off[..., -1].sum() == mp[..., -1].sum() and set(np.unique(off)) <= {0.0, 1.0}
 
 
-@pytest.mark.parametrize('name', ['of1_train.npz', 'of1_mc4_train.npz'])
+@pytest.mark.parametrize('name', ['of1_train.npz', 'of1_mc4_train.npz', 'of1_mc5_train.npz'])
 def test_training_step_matches_reference_losses_and_grads(name):
     g = load_golden(name)
     model = _model(g)

@@ -17,7 +17,8 @@ def _sd(g):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
 
 
-@pytest.mark.parametrize('name', ['of1_eval.npz', 'of1_hcqt_eval.npz', 'of2_eval.npz', 'of1_mc4_eval.npz', 'of2_mc4_hcqt_eval.npz'])
+@pytest.mark.parametrize('name', ['of1_eval.npz', 'of1_hcqt_eval.npz', 'of2_eval.npz', 'of1_mc4_eval.npz', 'of2_mc4_hcqt_eval.npz', 'of1_mc5_eval.npz',
+                                  'of2_mc5_hcqt_eval.npz'])
 def test_eval_logits_and_outputs_match_reference(name):
     g = load_golden(name)
     sd = _sd(g)
@@ -48,7 +49,7 @@ def test_aten_lstm_option_of_the_oracle_matches_the_golden_too(monkeypatch):
         np.testing.assert_allclose(out['logits'][key].numpy(), g['logits_' + key], atol=2e-5, rtol=0)
 
 
-@pytest.mark.parametrize('name', ['of1_train.npz', 'of1_mc4_train.npz'])
+@pytest.mark.parametrize('name', ['of1_train.npz', 'of1_mc4_train.npz', 'of1_mc5_train.npz'])
 def test_train_losses_and_grads_match_reference(name):
     g = load_golden(name)
     sd = _sd(g)

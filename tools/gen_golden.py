@@ -137,10 +137,15 @@ MC4_GKEYS = ['onset_head.0.layer1.0.weight', 'onset_head.0.layer3.1.weight', 'on
              'pitch_head.1.output_layer.bias']
 
 
-# recurrent matrices of model_complexity 4 (1536 x 384 / 1536 x 176): every 64th row of their gradients -- 24 rows each pin the
+# recurrent matrices of model_complexity 4 (1536 x 384 / 1536 x 176; 5: 2048 x 512 / 2048 x 176): every 64th row of their gradients -- 24 rows each pin the
 # hidden-384 streaming forward / backward kernels' saved h and W_hh^T fragment order without 2 MB of fixture
 MC4_GSLICES = [('onset_head.1.mlm.weight_hh_l0', 64), ('onset_head.1.mlm.weight_hh_l0_reverse', 64), ('adjoin.0.mlm.weight_ih_l0_reverse', 64),
                ('adjoin.0.mlm.weight_hh_l0', 64)]
+
+
+# model_complexity 5: the refinement stage's output layer (88 x 1024) as every 4th row
+MC5_GKEYS = [k for k in MC4_GKEYS if k != 'adjoin.1.output_layer.weight']
+MC5_GSLICES = MC4_GSLICES + [('adjoin.1.output_layer.weight', 4)]
 
 
 def gen_of_train(name, seed, dim_in, mc, B, T, gkeys=None, gslices=None):
@@ -381,10 +386,18 @@ if __name__ == '__main__':
         gen_of_eval('of2_mc4_hcqt_eval.npz', OnsetsFrames2, seed=16, dim_in=72, in_channels=3, mc=4, B=1, T=20, offsets=True)
         gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS, gslices=MC4_GSLICES)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'mc5':
+        gen_of_eval('of1_mc5_eval.npz', OnsetsFrames, seed=17, dim_in=229, in_channels=1, mc=5, B=2, T=24, offsets=False)
+        gen_of_eval('of2_mc5_hcqt_eval.npz', OnsetsFrames2, seed=18, dim_in=72, in_channels=3, mc=5, B=1, T=20, offsets=True)
+        gen_of_train('of1_mc5_train.npz', seed=24, dim_in=229, mc=5, B=2, T=16, gkeys=MC5_GKEYS, gslices=MC5_GSLICES)
+        sys.exit(0)
     gen_of_eval('of1_eval.npz', OnsetsFrames, seed=11, dim_in=229, in_channels=1, mc=2, B=2, T=40, offsets=False)
     gen_of_eval('of1_mc4_eval.npz', OnsetsFrames, seed=15, dim_in=229, in_channels=1, mc=4, B=2, T=24, offsets=False)
     gen_of_eval('of2_mc4_hcqt_eval.npz', OnsetsFrames2, seed=16, dim_in=72, in_channels=3, mc=4, B=1, T=20, offsets=True)
     gen_of_train('of1_mc4_train.npz', seed=23, dim_in=229, mc=4, B=2, T=16, gkeys=MC4_GKEYS, gslices=MC4_GSLICES)
+    gen_of_eval('of1_mc5_eval.npz', OnsetsFrames, seed=17, dim_in=229, in_channels=1, mc=5, B=2, T=24, offsets=False)
+    gen_of_eval('of2_mc5_hcqt_eval.npz', OnsetsFrames2, seed=18, dim_in=72, in_channels=3, mc=5, B=1, T=20, offsets=True)
+    gen_of_train('of1_mc5_train.npz', seed=24, dim_in=229, mc=5, B=2, T=16, gkeys=MC5_GKEYS, gslices=MC5_GSLICES)
     gen_of_eval('of1_hcqt_eval.npz', OnsetsFrames, seed=12, dim_in=72, in_channels=6, mc=2, B=1, T=33, offsets=False)
     gen_of_eval('of2_eval.npz', OnsetsFrames2, seed=13, dim_in=229, in_channels=1, mc=3, B=1, T=24, offsets=True)
     gen_of_eval('of2_mc2_eval.npz', OnsetsFrames2, seed=14, dim_in=229, in_channels=1, mc=2, B=2, T=36, offsets=True)
