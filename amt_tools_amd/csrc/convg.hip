@@ -87,7 +87,7 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // CMAX: the most input channels this instantiation stages (sizes the per-thread item slots: 6 -> 9 loads per tile instead of 12; 1 -> 2
 // instead of a rolled ten-slot loop with an early exit); 0 = the variant's limit (8 tap-major, 7 otherwise).
 template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0>
-__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : ((FT == 16 && NS == 1) ? 2 : 1)) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
+__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
     static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : ((FT
     // FUSE1: first-conv weight fragments [tile][ks][plane][lane] + shift [CIN] (copied once: a global load per tile would put an
     // L2 round trip in front of every tile's first MFMA), then [c_in][FROWS1][FP1] fp32 features
     constexpr int W1BYTES = FUSE1 ? CI16 * KS1 * NS * 1024 + CIN * 4 : 0;
-    char* w1s = ws + (w_all == 1 ? nchunks : 1) * WCHUNK;
+    char* w1s = ws + (w_all ? nchunks : 1) * WCHUNK;
     float* fs = reinterpret_cast<float*>(w1s + W1BYTES);
     // FCL: the feature tile as bf16 [FROWS1][FT + 4][8 channel slots]: 16 bytes per position = one k-group of a tap
     char* fs16 = w1s + W1BYTES;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : ((FT
 #endif
     // One C_out chunk of one tile: the MFMA loop over the tile `xs` points to and the chunk's weights, then ReLU + MaxPool + stores.
     auto mma_chunk = [&](int b, int t0, int f0, int ch) {
-        const char* wsc = ws + (w_all == 1 ? ch * WCHUNK : 0);
+        const char* wsc = ws + (w_all ? ch * WCHUNK : 0);
         const int t_out = t0 + r16;
         // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
         f32x4_t acc[4][NTC];
@@ -602,31 +602,22 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : ((FT
     uint4 xraw[FUSE1 ? 1 : NIT][NRAW], wreg[NWIT];
     float fraw[NF1];
     unsigned xok = 0;
-    // w_all == 2: one C_out chunk per block, resident for the launch; blocks i and i + 8 k (the same XCD) walk the same tiles with
-    // different chunks (the grid is a multiple of 8 nchunks)
-    const bool csplit = w_all == 2;
-    const int bq = (int)blockIdx.x >> 3;
-    const int ch_first = csplit ? bq % nchunks : 0, ch_end = csplit ? ch_first + 1 : nchunks;
-    const int tstride = csplit ? (int)gridDim.x / nchunks : (int)gridDim.x;
-    int tile = csplit ? (bq / nchunks) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
+    int tile = blockIdx.x;
     if (FUSE1) load_f(tile, fraw, xok);
     else load_x(tile, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);
     bool w_resident = false;
-    if (csplit) {
-        for (int it = tid; it < WCHUNK / 16; it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[(int64_t)ch_first * (WCHUNK / 16) + it];
-        w_resident = true;
-    } else if (w_all) {                                               // every C_out chunk fits next to the tile: weights stay in LDS for the launch
+    if (w_all) {                                               // every C_out chunk fits next to the tile: weights stay in LDS for the launch
         for (int it = tid; it < nchunks * (WCHUNK / 16); it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[it];
         w_resident = true;
     } else {
         load_w(0, wreg);
     }
 
-    for (; tile < ntiles; tile += tstride) {
+    for (; tile < ntiles; tile += gridDim.x) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
         CG_TICK(7);
-        const int next = tile + tstride;
+        const int next = tile + (int)gridDim.x;
         const bool has_next = next < ntiles;
         if (FUSE1) {
             store_f(fraw, xok);
@@ -640,9 +631,9 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : ((FT
             CG_TICK(0);
         }
 
-        for (int ch = ch_first; ch < ch_end; ++ch) {
+        for (int ch = 0; ch < nchunks; ++ch) {
             if (!w_resident) store_w(wreg);
-            if (w_all != 1 || ch == 0) __syncthreads();        // tile and weight chunk visible
+            if (!w_all || ch == 0) __syncthreads();            // tile and weight chunk visible
             CG_TICK(2);
             if (!FUSE1 && ch == 0 && has_next) load_x(next, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);  // in flight during the MFMA phase
             if (!w_all) {
@@ -656,7 +647,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : ((FT
 
             mma_chunk(b, t0, f0, ch);
             CG_TICK(4);
-            if (w_all != 1 || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
+            if (!w_all || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
             CG_TICK(5);
 #ifdef AMTX_CONV_TIMING
             cg_acc[6] += 1;
@@ -681,7 +672,7 @@ extern "C" int amtxdbg_convg_prof(unsigned long long* out8, int reset) {
 #endif
 
 template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 0>
-int launch_gen(const ConvArgs& a, hipStream_t stream, bool csplit = false) {
+int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
     const int ntf = (fe + FT - 1) / FT;
     const int ntt = (a.T + GTT - 1) / GTT;
@@ -692,9 +683,8 @@ int launch_gen(const ConvArgs& a, hipStream_t stream, bool csplit = false) {
     const size_t lds_f = KS1 > 0 ? (FCL ? (size_t)(GROWS + 2) * (FT + 4) * 16 + 128 : (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float)) +
                                    (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
     constexpr bool PIPE = FCL && CI16 == 2;                   // two input tiles + two feature tiles, one resident weight chunk
-    csplit = csplit && !PIPE && nchunks > 1;
-    const int w_all = csplit ? 2 : (!PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024);
-    const size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16 : lds_x + (w_all == 1 ? nchunks : 1) * wchunk + lds_f;
+    const int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
+    const size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16 : lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
     if (PIPE) AMTX_REQUIRE(nchunks == 1, "conv3x3 (general): the pipelined 32-channel variant takes one C_out chunk");
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
     auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX>;
@@ -703,12 +693,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream, bool csplit = false) {
     // block's tiles stay on its XCD
     const int per_cu = std::max(1, (int)(160 * 1024 / lds));
     int64_t gx = std::max<int64_t>(8, (256 * per_cu / std::max(1, a.groups)) / 8 * 8);
-    if (csplit) {
-        gx = std::max<int64_t>(8 * nchunks, gx / (8 * nchunks) * (8 * nchunks));
-        // every block of a chunk group needs a first tile: shrink the grid in steps of 8 nchunks, or give the split up
-        while (gx > 8 * nchunks && gx / nchunks > ntiles) gx -= 8 * nchunks;
-        if (gx / nchunks > ntiles) return launch_gen<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX>(a, stream, false);
-    } else if (gx > ntiles) gx = ntiles;
+    if (gx > ntiles) gx = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
@@ -724,11 +709,8 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
             }
             return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true>(a, s);
         }
-        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && a.c_in == 1) {   // one input channel (2 .. 8 channels: the tap-major variant above)
-            static const int ft16 = getenv("AMTX_CONVG_FT16") ? atoi(getenv("AMTX_CONVG_FT16")) : 0;
-            if (ft16) return launch_gen<CI16, NTC, 1, 16, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1>(a, s, ft16 == 2);
+        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && a.c_in == 1)     // one input channel (2 .. 8 channels: the tap-major variant above)
             return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1>(a, s);
-        }
         if (a.planes == 2 && a.out_type == AMTX_T_F32) {
             if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
             if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);
@@ -738,11 +720,7 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
     }
     // (16-column tiles = two 256-thread blocks per CU were measured too: 22.5 vs 15.9 ms for conv2 at mc 3, the kernels need more
     // than 256 VGPRs so only one of the two blocks is resident)
-    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) {
-        static const int ft16 = getenv("AMTX_CONVG_FT16") ? atoi(getenv("AMTX_CONVG_FT16")) : 0;     // 1: 16-column tiles, two blocks per CU; 2: + one chunk per block
-        if (ft16) return launch_gen<CI16, NTC, 1, 16, AMTX_T_BF16, AMTX_T_BF16>(a, s, ft16 == 2);
-        return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
-    }
+    if (a.planes == 1 && a.in_type == AMTX_T_BF16 && a.out_type == AMTX_T_BF16) return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16>(a, s);
     if (a.planes == 2 && a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32>(a, s);
     amtx_set_error("conv3x3 (general): unsupported precision/type combination");
     return AMTX_ERR_UNSUPPORTED;
