@@ -87,7 +87,7 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // CMAX: the most input channels this instantiation stages (sizes the per-thread item slots: 6 -> 9 loads per tile instead of 12; 1 -> 2
 // instead of a rolled ten-slot loop with an early exit); 0 = the variant's limit (8 tap-major, 7 otherwise).
 template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0>
-__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all) {
+__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all, int sh_off) {
     static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
@@ -141,6 +141,10 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         for (int it = tid; it < CI16 * KS1 * NS * 64; it += NTH) reinterpret_cast<uint4*>(w1s)[it] = w1g[it];
         if (tid < CIN) reinterpret_cast<float*>(w1s + CI16 * KS1 * NS * 1024)[tid] = a.shift1[(int64_t)grp * CIN + tid];
     }
+    // the folded BatchNorm shift of this layer, [c_out] fp32, in LDS for the launch: a global load per chunk would queue behind the next
+    // tile's prefetch loads (vmcnt retires in order) and put that round trip in front of every tile's first MFMA
+    const float* shs = reinterpret_cast<const float*>(smem + sh_off);
+    for (int i = tid; i < a.c_out; i += NTH) reinterpret_cast<float*>(smem + sh_off)[i] = a.shift[(int64_t)grp * a.shift_gs + i];
     const char* in_g = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * IES;
     const uint4* wsrc = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a.wfrag) + (int64_t)grp * a.w_gs * 2);
 
@@ -154,6 +158,20 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     };
     // All loads of a thread are issued before the first LDS store (clamped addresses + a select instead of a branch: a branchy
     // loop costs one full memory round trip per item).  Rows t0-1 .. t0+16, columns f0-1 .. f0+FT, zero outside the map.
+    // Item k of a thread = 16-byte chunk c of tile position (i, j), fixed for the launch: (byte offset of the chunk inside a position) |
+    // i << 10 | j << 16, decoded once.  Per tile an item then costs a dozen 32-bit vector instructions (clamp, validity, one offset from the
+    // clip's scalar base: a clip's map is < 4 GiB, the launcher checks) instead of ~30 with 64-bit addresses -- staging runs with the
+    // matrix pipe idle, two waves per SIMD deep.
+    unsigned xmeta[FUSE1 ? 1 : NIT];
+    if (!FUSE1) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            int it = tid + k * NTH;
+            it = it < NITEMS ? it : NITEMS - 1;
+            const int c = it % NCH, pos = it / NCH;
+            xmeta[k] = (unsigned)(c * 8 * IES) | (unsigned)(pos / COLS) << 10 | (unsigned)(pos % COLS) << 16;
+        }
+    }
     auto load_x = [&](int tile, uint4 (&raw)[NIT][NRAW], unsigned& okmask) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
@@ -161,14 +179,12 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         okmask = 0;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
-            int it = tid + k * NTH;
-            it = it < NITEMS ? it : NITEMS - 1;
-            const int c = it % NCH, pos = it / NCH;
-            const int i = pos / COLS, j = pos % COLS;
-            const int t = t0 - 1 + i, f = f0 - 1 + j;
-            if (t >= 0 && t < T && f >= 0 && f < F) okmask |= 1u << k;
+            const unsigned m = xmeta[FUSE1 ? 0 : k];
+            const int t = t0 - 1 + (int)((m >> 10) & 63), f = f0 - 1 + (int)(m >> 16);
             const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
-            const char* p = in + (((int64_t)tc * F + fc) * CIN + c * 8) * IES;
+            if (t == tc && f == fc) okmask |= 1u << k;
+            const unsigned off = (unsigned)(tc * F + fc) * (unsigned)(CIN * IES) + (m & 1023u);
+            const char* p = in + off;
             raw[k][0] = *reinterpret_cast<const uint4*>(p);
             if (NRAW == 2) raw[k][NRAW - 1] = reinterpret_cast<const uint4*>(p)[1];
         }
@@ -437,12 +453,16 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
 #endif
     // One C_out chunk of one tile: the MFMA loop over the tile `xs` points to and the chunk's weights, then ReLU + MaxPool + stores.
     auto mma_chunk = [&](int b, int t0, int f0, int ch) {
+        // a wave whose four columns all lie past the last pooled column has nothing to store: no matrix work either (F = 229: 28 of the
+        // 256 tile columns, 114: 14 of 128, the HCQT shape's 72: 24 of 96; the waves that do work are not faster for it -- each runs at
+        // the pace of its own instruction stream -- so this saves energy, not time)
+        if (f0 + jb >= (F & ~1)) return;
         const char* wsc = ws + (w_all ? ch * WCHUNK : 0);
         const int t_out = t0 + r16;
         // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
         f32x4_t acc[4][NTC];
         {
-            const float* sh = a.shift + (int64_t)grp * a.shift_gs + ch * 16 * NTC + g * 4 * NTC;
+            const float* sh = shs + ch * 16 * NTC + g * 4 * NTC;
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) {
                 const float4 s = *reinterpret_cast<const float4*>(sh + 4 * nt);
@@ -678,14 +698,18 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int ntt = (a.T + GTT - 1) / GTT;
     const int64_t ntiles = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
+    if (KS1 == 0) AMTX_REQUIRE((int64_t)a.T * a.F * 16 * CI16 * (IN_TYPE == AMTX_T_BF16 ? 2 : 4) < (1ll << 32),
+                               "conv3x3 (general): a clip's input map must be smaller than 4 GiB");
     const int nchunks = a.c_out / (16 * NTC);
     const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)NTC * NS * g_wfrags_per_tile(CI16) * 1024;
     const size_t lds_f = KS1 > 0 ? (FCL ? (size_t)(GROWS + 2) * (FT + 4) * 16 + 128 : (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float)) +
                                    (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
     constexpr bool PIPE = FCL && CI16 == 2;                   // two input tiles + two feature tiles, one resident weight chunk
-    const int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f <= 160 * 1024;
-    const size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16 : lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
+    const int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f + 16 + (size_t)a.c_out * sizeof(float) <= 160 * 1024;
+    size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16 : lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
     if (PIPE) AMTX_REQUIRE(nchunks == 1, "conv3x3 (general): the pipelined 32-channel variant takes one C_out chunk");
+    const int sh_off = (int)((lds + 15) / 16 * 16);           // [c_out] fp32 shift behind everything else
+    lds = (size_t)sh_off + (size_t)a.c_out * sizeof(float);
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
     auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX>;
     AMTX_GRANT_LDS(kern, lds);
@@ -694,7 +718,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int per_cu = std::max(1, (int)(160 * 1024 / lds));
     int64_t gx = std::max<int64_t>(8, (256 * per_cu / std::max(1, a.groups)) / 8 * 8);
     if (gx > ntiles) gx = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all, sh_off);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -816,7 +840,7 @@ bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
     const bool pipe = tapk && c_mid == 32;      // two input tiles and two feature tiles (conv3x3_gen_kernel PIPE)
     const size_t feat = tapk ? (size_t)(pipe ? 2 : 1) * (GROWS + 2) * (ft + 4) * 16 + 128 : (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
     const size_t lds = (size_t)(pipe ? 2 : 1) * planes * (c_mid / 8) * g_cplane(ft) + (size_t)ntc * planes * g_wfrags_per_tile(c_mid / 16) * 1024 + feat +
-                       (size_t)(c_mid / 16) * (tapk ? 3 : (9 * c_in + 31) / 32) * planes * 1024 + c_mid * 4;
+                       (size_t)(c_mid / 16) * (tapk ? 3 : (9 * c_in + 31) / 32) * planes * 1024 + c_mid * 4 + 16 + (size_t)c_out * 4;   // + this layer's shift
     return lds <= 160 * 1024;
 }
 

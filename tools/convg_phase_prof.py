@@ -14,7 +14,26 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 L = _lib.lib()
 prof = L.amtxdbg_convg_prof
 prof.restype = C.c_int; prof.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-if 'hcqt' in sys.argv[2:]:
+if 'conv3' in sys.argv[2:]:
+    # the 48 -> 96 layer of model_complexity 3 alone (F = 114), through the operator entry point: no fused first conv in the counters
+    cin, cout, F = 48, 96, 114
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (9.0 * cin) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    n = L.amtx_conv3x3g_packed_elems(cin, cout, 1)
+    packed = np.zeros(n, dtype=np.uint16)
+    _lib.check(L.amtx_conv3x3g_pack(_lib.ptr(w.numpy()), _lib.ptr(scale.numpy()), cin, cout, 1, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    x = torch.rand(B, 625, F, cin, device='cuda:0').to(torch.bfloat16)
+    out = torch.empty(B, 625, F // 2, cout, dtype=torch.bfloat16, device='cuda:0')
+    shift = torch.zeros(cout, device='cuda:0')
+
+    class _Op(object):
+        def engine_logits(self, _):
+            _lib.check(L.amtx_conv3x3g_fwd(_lib.ptr(x), 0, _lib.ptr(wp), 1, _lib.ptr(shift), _lib.ptr(out), B, 625, F, cin, cout,
+                                           _lib.current_stream(x.device)), 'amtx_conv3x3g_fwd')
+    model, feats, sd = _Op(), None, None
+elif 'hcqt' in sys.argv[2:]:
     from amt_tools_amd.models import OnsetsFrames
     model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0', precision='bf16')
     sd = synth_state_dict(0, dim_in=72, in_channels=6, model_complexity=2)
@@ -23,8 +42,9 @@ else:
     model = OnsetsFrames2(229, tools.PianoProfile(), 1, 3, device='cuda:0', precision='bf16')
     sd = synth_state_dict(0, dim_in=229, in_channels=1, model_complexity=3, offsets=True)
     feats = torch.rand(B, 1, 229, 625, device='cuda:0')
-model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-model.change_device(); model.eval()
+if sd is not None:
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device(); model.eval()
 with torch.no_grad():
     model.engine_logits(feats)
 torch.cuda.synchronize()
