@@ -26,6 +26,9 @@ range end points and frame-count identities, and cross-checked against two
 independent implementations present in the image: scipy.signal.ShortTimeFFT (framed
 FFT) and transformers.audio_utils (HF's librosa-compatible mel filterbank and log-mel
 chain): agreement to 1e-9 / float32 rounding / 1e-5 on the scaled features.
+The only librosa OUTPUTS at hand -- the example values its docstrings print for hz_to_mel,
+mel_to_hz, mel_frequencies(n_mels=40) and filters.mel(sr=22050, n_fft=2048) -- are reproduced at
+their printed precision (test_mel_scale_and_filterbank_reproduce_the_values_librosa_documents).
 """
 
 import numpy as np

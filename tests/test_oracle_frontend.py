@@ -142,3 +142,22 @@ def test_mel_front_end_agrees_with_hf_transformers_audio_utils():
     ours = fe.melspec_process_audio(y, 16000)[0]
     assert ours.shape == theirs.shape
     assert np.abs(ours - theirs).max() < 1e-5
+
+
+def test_mel_scale_and_filterbank_reproduce_the_values_librosa_documents():
+    """The only librosa OUTPUTS available offline: the example values printed in librosa's own docstrings (librosa/core/convert.py
+    `hz_to_mel`, `mel_to_hz`, `mel_frequencies`; librosa/filters.py `mel`; 0.9 / 0.10 print the same numbers), typed in from the
+    documentation at the three decimals it prints.  Small, but they are values of the third-party code the reference calls
+    (amt_tools/features/mel.py:64-71), not of an identity: the Slaney break point and log step, the band edges and the area
+    normalisation of the filterbank all have to be right to reproduce them."""
+    assert abs(fe.hz_to_mel(60.0) - 0.9) < 1e-12
+    assert np.allclose(fe.hz_to_mel(np.array([110.0, 220.0, 440.0])), [1.65, 3.3, 6.6], atol=5e-4)
+    assert np.allclose(fe.mel_to_hz(np.array([1.0, 2.0, 3.0, 4.0, 5.0])), [66.667, 133.333, 200.0, 266.667, 333.333], atol=5e-4)
+    doc = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856, 1119.114,
+           1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686, 2945.799, 3216.731,
+           3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009, 7754.107, 8467.272, 9246.028,
+           10096.408, 11025.]
+    assert np.allclose(fe.mel_frequencies(40, 0.0, 11025.0), doc, atol=5e-4)
+    fb = fe.mel_filterbank(22050, 2048)                     # librosa.filters.mel(sr=22050, n_fft=2048): 128 bands
+    assert fb.shape == (128, 1025)
+    assert abs(fb[0, 0]) < 5e-4 and abs(fb[0, 1] - 0.016) < 5e-4 and np.all(np.abs(fb[-1, :2]) < 5e-4) and np.all(np.abs(fb[1, :2]) < 5e-4)
