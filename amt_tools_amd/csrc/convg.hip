@@ -124,7 +124,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     // FUSE1: first-conv weight fragments [tile][ks][plane][lane] + shift [CIN] (copied once: a global load per tile would put an
     // L2 round trip in front of every tile's first MFMA), then [c_in][FROWS1][FP1] fp32 features
     constexpr int W1BYTES = FUSE1 ? CI16 * KS1 * NS * 1024 + CIN * 4 : 0;
-    char* w1s = ws + (w_all ? nchunks : 1) * WCHUNK;
+    char* w1s = ws + (w_all == 1 ? nchunks : (w_all == 2 ? 2 : 1)) * WCHUNK;
     float* fs = reinterpret_cast<float*>(w1s + W1BYTES);
     // FCL: the feature tile as bf16 [FROWS1][FT + 4][8 channel slots]: 16 bytes per position = one k-group of a tap
     char* fs16 = w1s + W1BYTES;
@@ -452,12 +452,11 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     unsigned long long cg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cg_t = __builtin_readcyclecounter();
 #endif
     // One C_out chunk of one tile: the MFMA loop over the tile `xs` points to and the chunk's weights, then ReLU + MaxPool + stores.
-    auto mma_chunk = [&](int b, int t0, int f0, int ch) {
+    auto mma_chunk = [&](int b, int t0, int f0, int ch, const char* wsc) {
         // a wave whose four columns all lie past the last pooled column has nothing to store: no matrix work either (F = 229: 28 of the
         // 256 tile columns, 114: 14 of 128, the HCQT shape's 72: 24 of 96; the waves that do work are not faster for it -- each runs at
         // the pace of its own instruction stream -- so this saves energy, not time)
         if (f0 + jb >= (F & ~1)) return;
-        const char* wsc = ws + (w_all ? ch * WCHUNK : 0);
         const int t_out = t0 + r16;
         // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
         f32x4_t acc[4][NTC];
@@ -476,7 +475,6 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         // row 3 = the channel tails of tap rows 0 | 1 side by side, row 4 = the tails of tap row 2 at columns c | c + 1.
         // Weight fragments are read from LDS WD items ahead of their use (ring of WD + 1 register slots); the six column
         // fragments of a row are read at the row boundary (double-buffering them as well costs 48 more VGPRs and spills).
-        constexpr int NROWS = 3 + 2 * N16;
         constexpr int IPM = 3 * NTC * N32;                   // items of a main row: (kw, tile, step)
         constexpr int NITM = 3 * IPM + (3 * NTC + 2 * NTC) * N16;
         constexpr int WD = 2;
@@ -599,7 +597,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             auto fc_next = [&]() {
                 if (has_next) { xs = xs2(cur ^ 1); fs16 = fsb(cur ^ 1); first_conv(t0n, f0n); }
             };
-            auto mma_cur = [&]() { xs = xs2(cur); mma_chunk(b, t0, f0, 0); };
+            auto mma_cur = [&]() { xs = xs2(cur); mma_chunk(b, t0, f0, 0, ws); };
             CG_TICK(7);
             if (wave < NW / 2) { fc_next(); CG_TICK(1); mma_cur(); } else { mma_cur(); fc_next(); }
             // features of tile k + 2 (in registers since the last iteration) -> the feature tile the first conv of tile k read an iteration ago
@@ -626,7 +624,21 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     if (FUSE1) load_f(tile, fraw, xok);
     else load_x(tile, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);
     bool w_resident = false;
-    if (w_all) {                                               // every C_out chunk fits next to the tile: weights stay in LDS for the launch
+    // w_all == 2: the chunks do not all fit, but two do (64 -> 64 / 128 and 80 -> 80 / 160 channels in the one-plane modes): two weight
+    // buffers filled by LDS-DMA, the next chunk in flight under the current one's matrix loop, one barrier per chunk.  (The register
+    // staging of w_all == 0 -- what the two-plane modes still use -- ends up in scratch memory and needs two barriers per chunk.)
+    const bool wdma = w_all == 2;
+    const unsigned ws_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)ws);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma_w = [&](int ch, int buf) {                        // this wave's 1-KiB fragments of chunk ch -> weight buffer buf
+        const char* src = reinterpret_cast<const char*>(wsrc) + (int64_t)ch * WCHUNK + lane * 16;
+        for (int f = wave_u; f < WCHUNK / 1024; f += NW) glds16(src + f * 1024, ws_lds + buf * WCHUNK + f * 1024);
+    };
+    int wcur = 0;
+    if (wdma) {
+        dma_w(0, 0);
+        w_resident = true;
+    } else if (w_all) {                                        // every C_out chunk fits next to the tile: weights stay in LDS for the launch
         for (int it = tid; it < nchunks * (WCHUNK / 16); it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[it];
         w_resident = true;
     } else {
@@ -652,11 +664,15 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         }
 
         for (int ch = 0; ch < nchunks; ++ch) {
-            if (!w_resident) store_w(wreg);
-            if (!w_all || ch == 0) __syncthreads();            // tile and weight chunk visible
+            if (wdma) wait_vm<0>();                            // this wave's pieces of the chunk have landed (issued a whole chunk ago)
+            else if (!w_resident) store_w(wreg);
+            if (w_all != 1 || ch == 0) __syncthreads();        // tile and weight chunk visible
             CG_TICK(2);
             if (!FUSE1 && ch == 0 && has_next) load_x(next, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);  // in flight during the MFMA phase
-            if (!w_all) {
+            if (wdma) {                                        // the buffer the previous chunk read is free: every wave is past the barrier
+                if (ch + 1 < nchunks) dma_w(ch + 1, wcur ^ 1);
+                else if (has_next) dma_w(0, wcur ^ 1);
+            } else if (!w_all) {
                 if (nchunks > 1) {
                     if (ch + 1 < nchunks) load_w(ch + 1, wreg);
                     else if (has_next) load_w(0, wreg);
@@ -665,8 +681,9 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                 }
             }
 
-            mma_chunk(b, t0, f0, ch);
+            mma_chunk(b, t0, f0, ch, ws + (w_all == 1 ? ch : wcur) * WCHUNK);
             CG_TICK(4);
+            if (wdma) wcur ^= 1;
             if (!w_all || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
             CG_TICK(5);
 #ifdef AMTX_CONV_TIMING
@@ -705,8 +722,12 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const size_t lds_f = KS1 > 0 ? (FCL ? (size_t)(GROWS + 2) * (FT + 4) * 16 + 128 : (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float)) +
                                    (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
     constexpr bool PIPE = FCL && CI16 == 2;                   // two input tiles + two feature tiles, one resident weight chunk
-    const int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f + 16 + (size_t)a.c_out * sizeof(float) <= 160 * 1024;
-    size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16 : lds_x + (w_all ? nchunks : 1) * wchunk + lds_f;
+    const size_t lds_sh = 16 + (size_t)a.c_out * sizeof(float);
+    static const bool no_wdma = getenv("AMTX_CONVG_NO_WDMA") != nullptr;     // A/B switch
+    int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f + lds_sh <= 160 * 1024;
+    if (!w_all && !PIPE && NS == 1 && nchunks > 1 && !no_wdma && lds_x + 2 * wchunk + lds_f + lds_sh <= 160 * 1024) w_all = 2;
+    size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16
+                      : lds_x + (w_all == 1 ? nchunks : (w_all == 2 ? 2 : 1)) * wchunk + lds_f;
     if (PIPE) AMTX_REQUIRE(nchunks == 1, "conv3x3 (general): the pipelined 32-channel variant takes one C_out chunk");
     const int sh_off = (int)((lds + 15) / 16 * 16);           // [c_out] fp32 shift behind everything else
     lds = (size_t)sh_off + (size_t)a.c_out * sizeof(float);
