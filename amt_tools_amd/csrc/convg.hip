@@ -620,7 +620,14 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     uint4 xraw[FUSE1 ? 1 : NIT][NRAW], wreg[NWIT];
     float fraw[NF1];
     unsigned xok = 0;
-    int tile = blockIdx.x;
+    // w_all == 3: ONE C_out chunk per block, resident for the launch: blocks i and i + 8 k (the same XCD) walk the same tiles with different
+    // chunks (the grid is a multiple of 8 nchunks).  Every tile is staged nchunks times, but no weight ever moves again: what the two-plane
+    // modes run when their chunks do not all fit (their matrix phase is three times as long for the same staging).
+    const bool csplit = w_all == 3;
+    const int bq = (int)blockIdx.x >> 3;
+    const int ch_first = csplit ? bq % nchunks : 0, ch_end = csplit ? ch_first + 1 : nchunks;
+    const int tstride = csplit ? (int)gridDim.x / nchunks : (int)gridDim.x;
+    int tile = csplit ? (bq / nchunks) * 8 + ((int)blockIdx.x & 7) : (int)blockIdx.x;
     if (FUSE1) load_f(tile, fraw, xok);
     else load_x(tile, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);
     bool w_resident = false;
@@ -638,6 +645,9 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     if (wdma) {
         dma_w(0, 0);
         w_resident = true;
+    } else if (csplit) {
+        for (int it = tid; it < WCHUNK / 16; it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[(int64_t)ch_first * (WCHUNK / 16) + it];
+        w_resident = true;
     } else if (w_all) {                                        // every C_out chunk fits next to the tile: weights stay in LDS for the launch
         for (int it = tid; it < nchunks * (WCHUNK / 16); it += NTH) reinterpret_cast<uint4*>(ws)[it] = wsrc[it];
         w_resident = true;
@@ -645,11 +655,11 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         load_w(0, wreg);
     }
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < ntiles; tile += tstride) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
         CG_TICK(7);
-        const int next = tile + (int)gridDim.x;
+        const int next = tile + tstride;
         const bool has_next = next < ntiles;
         if (FUSE1) {
             store_f(fraw, xok);
@@ -663,12 +673,12 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             CG_TICK(0);
         }
 
-        for (int ch = 0; ch < nchunks; ++ch) {
+        for (int ch = ch_first; ch < ch_end; ++ch) {
             if (wdma) wait_vm<0>();                            // this wave's pieces of the chunk have landed (issued a whole chunk ago)
             else if (!w_resident) store_w(wreg);
             if (w_all != 1 || ch == 0) __syncthreads();        // tile and weight chunk visible
             CG_TICK(2);
-            if (!FUSE1 && ch == 0 && has_next) load_x(next, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);  // in flight during the MFMA phase
+            if (!FUSE1 && ch == ch_first && has_next) load_x(next, reinterpret_cast<uint4 (&)[NIT][NRAW]>(xraw), xok);  // in flight during the MFMA phase
             if (wdma) {                                        // the buffer the previous chunk read is free: every wave is past the barrier
                 if (ch + 1 < nchunks) dma_w(ch + 1, wcur ^ 1);
                 else if (has_next) dma_w(0, wcur ^ 1);
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             mma_chunk(b, t0, f0, ch, ws + (w_all == 1 ? ch : wcur) * WCHUNK);
             CG_TICK(4);
             if (wdma) wcur ^= 1;
-            if (!w_all || ch + 1 == nchunks) __syncthreads();  // every wave is done reading this chunk's weights / (last chunk) the tile
+            if (!w_all || ch + 1 == ch_end) __syncthreads();   // every wave is done reading this chunk's weights / (last chunk) the tile
             CG_TICK(5);
 #ifdef AMTX_CONV_TIMING
             cg_acc[6] += 1;
@@ -726,6 +736,8 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     static const bool no_wdma = getenv("AMTX_CONVG_NO_WDMA") != nullptr;     // A/B switch
     int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f + lds_sh <= 160 * 1024;
     if (!w_all && !PIPE && NS == 1 && nchunks > 1 && !no_wdma && lds_x + 2 * wchunk + lds_f + lds_sh <= 160 * 1024) w_all = 2;
+    static const bool no_csplit = getenv("AMTX_CONVG_NO_CSPLIT") != nullptr;  // A/B switch
+    if (!w_all && !PIPE && NS == 2 && nchunks > 1 && !no_csplit) w_all = 3;
     size_t lds = PIPE ? 2 * lds_x + wchunk + lds_f + (size_t)(GROWS + 2) * (FT + 4) * 16
                       : lds_x + (w_all == 1 ? nchunks : (w_all == 2 ? 2 : 1)) * wchunk + lds_f;
     if (PIPE) AMTX_REQUIRE(nchunks == 1, "conv3x3 (general): the pipelined 32-channel variant takes one C_out chunk");
@@ -738,7 +750,11 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     // block's tiles stay on its XCD
     const int per_cu = std::max(1, (int)(160 * 1024 / lds));
     int64_t gx = std::max<int64_t>(8, (256 * per_cu / std::max(1, a.groups)) / 8 * 8);
-    if (gx > ntiles) gx = ntiles;
+    if (w_all == 3) {                                         // a multiple of 8 nchunks blocks, every one with a first tile
+        gx = std::max<int64_t>(8 * nchunks, gx / (8 * nchunks) * (8 * nchunks));
+        while (gx > 8 * nchunks && gx / nchunks > ntiles) gx -= 8 * nchunks;
+        if (gx / nchunks > ntiles) { w_all = 0; gx = std::min<int64_t>(std::max<int64_t>(8, (256 * per_cu / std::max(1, a.groups)) / 8 * 8), ntiles); }
+    } else if (gx > ntiles) gx = ntiles;
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all, sh_off);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
