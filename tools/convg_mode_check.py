@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""One JSON line with a SHA-256 of the engine's logits for one (model_complexity, precision): run in child processes with and without
+convg.hip's A/B switches (AMTX_CONVG_NO_WDMA, AMTX_CONVG_NO_CSPLIT -- read once per process) to check that the weight-chunk modes
+of the general convolution kernel return the same bits.  Usage: python tools/convg_mode_check.py <mc> <bf16|f16|x3> [clips=5] [frames=70]"""
+import hashlib, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from amt_tools_amd import tools
+from amt_tools_amd.models import OnsetsFrames2
+from amt_tools_amd.synth import synth_state_dict
+
+mc, prec = int(sys.argv[1]), sys.argv[2]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 70
+model = OnsetsFrames2(229, tools.PianoProfile(), 1, mc, device='cuda:0', precision=prec)
+sd = synth_state_dict(3, dim_in=229, in_channels=1, model_complexity=mc, offsets=True)
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+model.change_device(); model.eval()
+feats = torch.from_numpy(np.random.default_rng(5).random((B, 1, 229, T)).astype(np.float32)).cuda()
+with torch.no_grad():
+    out = model.engine_logits(feats)
+h = hashlib.sha256()
+for k in sorted(out):
+    h.update(out[k].float().cpu().numpy().tobytes())
+print(json.dumps({'mc': mc, 'precision': prec, 'sha256': h.hexdigest(), 'finite': bool(all(torch.isfinite(v).all() for v in out.values())),
+                  'switches': {k: os.environ.get(k) for k in ('AMTX_CONVG_NO_WDMA', 'AMTX_CONVG_NO_CSPLIT')}}))
