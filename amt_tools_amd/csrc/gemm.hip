@@ -36,7 +36,10 @@ __device__ __forceinline__ f32x4_t mfma16(uint4 a, uint4 b, f32x4_t c) {
 
 template <int A_TYPE, int NS>
 struct AStage {
-    // one 8-element K chunk of one A row, converted to bf16 planes
+    // one 8-element K chunk of one A row.  load() only ISSUES the loads (fp32 A: the raw bits of elements 0-3 in `hi`, 4-7 in `lo`);
+    // finish() turns them into the bf16 planes and runs where the tile is stored, BEHIND the k-step's MFMAs (with the conversion inside
+    // load() hipcc waited for a k-step's A loads before its first MFMA: fc1 of the two-plane mode 4.61 -> 4.43 ms per 512 clips).
+    // A second register stage (loads two k-steps ahead) was measured slower: 4.81 ms.
     uint4 hi, lo;
     // vlo / vhi: bounds of the existing elements (vhi == 0: none), see GemmArgs::a_valid_lo
     __device__ __forceinline__ void load(const char* base, int64_t row_off_elems, bool valid, int64_t vlo = 0, int64_t vhi = 0) {
@@ -64,6 +67,13 @@ struct AStage {
                 x0 = make_float4(p0.x, p0.y, p0.z, p0.w);
                 x1 = make_float4(p1.x, p1.y, p1.z, p1.w);
             }
+            hi = __builtin_bit_cast(uint4, x0);
+            lo = __builtin_bit_cast(uint4, x1);
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        if (A_TYPE != AMTX_T_BF16) {
+            const float4 x0 = __builtin_bit_cast(float4, hi), x1 = __builtin_bit_cast(float4, lo);
             const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             uint32_t h[4], l[4];
 #pragma unroll
@@ -116,6 +126,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
 #define STORE_TILE(buf)                                                                            \
     do {                                                                                           \
         char* sb = smem + (buf) * BUF_BYTES;                                                       \
+        sa0.finish();                                                                              \
+        sa1.finish();                                                                              \
         *reinterpret_cast<uint4*>(sb + soff0) = sa0.hi;                                            \
         *reinterpret_cast<uint4*>(sb + soff1) = sa1.hi;                                            \
         if (NS == 2) {                                                                             \
