@@ -20,7 +20,10 @@ def guards(monkeypatch):
 
 @pytest.mark.parametrize('cls,mc,ch,dim_in,precision', [('OnsetsFrames', 2, 1, 229, 'bf16'), ('OnsetsFrames', 2, 1, 229, 'x3'), ('OnsetsFrames', 2, 1, 229, 'f16'),
                                                         ('OnsetsFrames2', 3, 1, 229, 'bf16'), ('OnsetsFrames2', 3, 1, 229, 'f16'), ('OnsetsFrames', 2, 6, 72, 'bf16'), ('OnsetsFrames', 2, 6, 72, 'f16'), ('OnsetsFrames', 2, 1, 54, 'bf16'),
-                                                        ('OnsetsFrames', 2, 1, 8, 'x3')])
+                                                        ('OnsetsFrames', 2, 1, 8, 'x3'),
+                                                        # convg.hip's weight-chunk modes: two DMA buffers (4, 5 in one plane), one chunk per block (two planes)
+                                                        ('OnsetsFrames', 4, 1, 229, 'bf16'), ('OnsetsFrames', 5, 1, 229, 'bf16'), ('OnsetsFrames2', 3, 1, 229, 'x3'),
+                                                        ('OnsetsFrames', 4, 3, 72, 'x3')])
 def test_engine_workspace_guard_bands_survive_ragged_forwards(guards, cls, mc, ch, dim_in, precision):
     import amt_tools_amd.models as M
     sd = synth_state_dict(7, dim_in=dim_in, in_channels=ch, model_complexity=mc, offsets=cls == 'OnsetsFrames2')
