@@ -336,18 +336,20 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     // FCL: what a lane's fragment reads need is the same for every tile -- the byte offset of its k-group's tap inside the feature tile, and per
     // 16-position group its position's offset and (row, column): decoded once (divisions by 3 and by COLS per group and tile otherwise)
     constexpr int NGRP1 = (NNT1 + NW - 1) / NW;
-    int tapoff[FCL ? 3 : 1], gsrc[FCL ? NGRP1 : 1], gij[FCL ? NGRP1 : 1];
+    int tapoff[FCL ? 3 : 1], gsrc[NGRP1], gij[NGRP1];
     if constexpr (FCL) {
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const int tap = 4 * ks + g, tp = tap < 9 ? tap : 0;
             tapoff[ks] = ((tp / 3) * FW + tp % 3) * 16;
         }
+    }
+    if constexpr (FUSE1) {
 #pragma unroll
         for (int q = 0; q < NGRP1; ++q) {
             const int pos = (wave + q * NW) * 16 + r16, posc = pos < NPOS ? pos : NPOS - 1;
             const int i = posc / COLS, j = posc % COLS;
-            gsrc[q] = (i * FW + j) * 16;
+            gsrc[q] = FCL ? (i * FW + j) * 16 : i * FP1 + j;     // feature tile offset of the position: bytes (bf16 channels-last) / floats
             gij[q] = i << 8 | j;
         }
     }
@@ -391,11 +393,9 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                     });
                     return;
                 }
-                const int posc = pos[i_] < NPOS ? pos[i_] : NPOS - 1;
-                const int i = posc / COLS, j = posc % COLS;
-                const float* fp = fs + i * FP1 + j;
-                const int t = t0 - 1 + i, f = f0 - 1 + j;
-                inside[i_] = t >= 0 && t < T && f >= 0 && f < F;
+                const int i = gij[it0 + i_] >> 8, j = gij[it0 + i_] & 0xff;
+                const float* fp = fs + gsrc[it0 + i_];
+                inside[i_] = (unsigned)(t0 - 1 + i) < (unsigned)T && (unsigned)(f0 - 1 + j) < (unsigned)F;
                 static_for<0, KS1>([&](auto kc) {
                     constexpr int ks = decltype(kc)::value;
                     float v[8];
