@@ -256,16 +256,19 @@ __device__ __forceinline__ void lstm4_step(char* smem, int cur, const uint4 (&wf
 #pragma unroll
         for (int j = 0; j < NC; ++j) acc[q][RSTEP * j] = unpack_xs(xcur[j][q], lane & 1);
     }
+    // (two planes: the three products of a k-step one gate after the other, not one accumulator three times in a row -- the same sums in
+    // the same order per accumulator, without back-to-back dependent MFMAs)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[q] = mfma16(hf[ks][0], wf[q][ks][0], acc[q]);
-            if (NS == 2) {
-                acc[q] = mfma16(hf[ks][1], wf[q][ks][0], acc[q]);
-                acc[q] = mfma16(hf[ks][0], wf[q][ks][1], acc[q]);
-            }
+        for (int q = 0; q < 4; ++q) acc[q] = mfma16(hf[ks][0], wf[q][ks][0], acc[q]);
+        if (NS == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = mfma16(hf[ks][NS - 1], wf[q][ks][0], acc[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = mfma16(hf[ks][0], wf[q][ks][NS - 1], acc[q]);
         }
+    }
 
     char* hn = smem + (cur ^ 1) * NS * HBUF_BYTES;
     // The cells of a lane are independent chains of ~12 dependent operations (five of them exp / rcp pairs): all arithmetic first, the
@@ -462,21 +465,30 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
             if (NS == 2) *reinterpret_cast<unsigned short*>(gt + GBUF_BYTES + gwoff + q * H * 2) = (unsigned short)low;
         }
         lds_barrier();
-        // dh_{prev} = dgates . W_hh: 16 k-steps over the 512 gate rows
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // dh_{prev} = dgates . W_hh: 16 k-steps over the 512 gate rows, in FOUR accumulators (k-step ks -> accumulator ks & 3, summed at
+        // the end): one accumulator is a chain of 48 dependent MFMAs (two-plane mode), each waiting for the one before it -- most of
+        // a backward step
+        f32x4_t acc4[4];
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            uint4 gf[NS];
+        for (int i = 0; i < 4; ++i) acc4[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < NS; ++p)
-                gf[p] = *reinterpret_cast<const uint4*>(gt + p * GBUF_BYTES + ((lane & 15) * GP + 32 * ks + 8 * (lane >> 4)) * 2);
-            acc = mfma16(gf[0], wt[ks][0], acc);
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+            uint4 gf[4][NS];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    gf[i][p] = *reinterpret_cast<const uint4*>(gt + p * GBUF_BYTES + ((lane & 15) * GP + 32 * (k4 + i) + 8 * (lane >> 4)) * 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc4[i] = mfma16(gf[i][0], wt[k4 + i][0], acc4[i]);
             if (NS == 2) {
-                acc = mfma16(gf[1], wt[ks][0], acc);
-                acc = mfma16(gf[0], wt[ks][1], acc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc4[i] = mfma16(gf[i][NS - 1], wt[k4 + i][0], acc4[i]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc4[i] = mfma16(gf[i][0], wt[k4 + i][NS - 1], acc4[i]);
             }
         }
-        dh_rec = acc[0];
+        dh_rec = (acc4[0][0] + acc4[1][0]) + (acc4[2][0] + acc4[3][0]);
     }
 }
 
