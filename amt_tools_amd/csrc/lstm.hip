@@ -395,6 +395,14 @@ struct LstmBwdArgs {
     int B, T;
 };
 
+#ifdef AMTX_LSTM_TIMING
+// Debug build only: cycles wave 0 of block 0 spends per phase of a backward step: [0] saved-value wait + elementwise + LDS writes,
+// [1] barrier, [2] fragment reads + MFMAs, [3] steps.  Read with amtxdbg_lstm_prof().
+__device__ unsigned long long g_lstm_prof[4];
+#define LT_TICK(SLOT) do { const unsigned long long n_ = __builtin_readcyclecounter(); lt_acc[SLOT] += n_ - lt_t; lt_t = n_; } while (0)
+#else
+#define LT_TICK(SLOT) do {} while (0)
+#endif
 template <int NS>
 __global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 bufs][NS planes][16][GP] bf16, rows 0/4/8/12 used
@@ -434,6 +442,9 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
         n_i = sv[0]; n_f = sv[H]; n_g = sv[2 * H]; n_o = sv[3 * H]; n_c = sv[4 * H];
         n_do = do0[(int64_t)frame(0) * 256];
     }
+#ifdef AMTX_LSTM_TIMING
+    unsigned long long lt_acc[4] = {0, 0, 0, 0}, lt_t = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = frame(s);
         const float ig = n_i, fg = n_f, gg = n_g, og = n_o, ct = n_c, dout_t = n_do;
@@ -464,7 +475,9 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
             *reinterpret_cast<unsigned short*>(gt + gwoff + q * H * 2) = (unsigned short)hiw;
             if (NS == 2) *reinterpret_cast<unsigned short*>(gt + GBUF_BYTES + gwoff + q * H * 2) = (unsigned short)low;
         }
+        LT_TICK(0);
         lds_barrier();
+        LT_TICK(1);
         // dh_{prev} = dgates . W_hh: 16 k-steps over the 512 gate rows, in FOUR accumulators (k-step ks -> accumulator ks & 3, summed at
         // the end): one accumulator is a chain of 48 dependent MFMAs (two-plane mode), each waiting for the one before it -- most of
         // a backward step
@@ -489,8 +502,27 @@ __global__ __launch_bounds__(LTHREADS) void bilstm4_bwd_kernel(LstmBwdArgs a) {
             }
         }
         dh_rec = (acc4[0][0] + acc4[1][0]) + (acc4[2][0] + acc4[3][0]);
+#ifdef AMTX_LSTM_TIMING
+        asm volatile("" ::"v"(dh_rec));
+        LT_TICK(2);
+        lt_acc[3] += 1;
+#endif
     }
+#ifdef AMTX_LSTM_TIMING
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_lstm_prof[i], lt_acc[i]);
+#endif
 }
+#ifdef AMTX_LSTM_TIMING
+extern "C" int amtxdbg_lstm_prof(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_lstm_prof), 4 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 // fp32 W_hh (512 x 128, both directions) on the DEVICE -> forward fragments (amtx_bilstm_pack_host's layout) and transposed
 // fragments for the backward kernel, hi/lo planes: training repacks after every optimizer step without a host round trip.
