@@ -1,8 +1,9 @@
 """GPU parity: HIP spectral front-end (through the C ABI) vs the fp64 oracle restatement.
 
 Tolerance: the scaled features live in [0, 1]; the fp32 on-device FFT differs from the fp64 oracle by
-rounding noise that is largest (in dB) in bins near the -80 dB floor.  Bound: 1e-4 absolute in the
-scaled domain (SURVEY 8(c) suggests 1e-5..1e-4), 2e-6 relative on linear power."""
+rounding noise that is largest (in dB) in bins near the -80 dB floor.  Bound: 2e-5 absolute in the
+scaled domain (SURVEY 8(c) asks for <= 1e-5 .. 1e-4; measured on MI355X: 9e-6 on the log-mel shape -- the bound is 2 x that, so a
+regression of the FFT's accuracy shows), 2e-6 relative on linear power."""
 import os
 
 import numpy as np
@@ -14,7 +15,7 @@ pytestmark = pytest.mark.gpu
 from oracle import frontend_np as fe          # noqa: E402
 from amt_tools_amd.synth import synth_clip    # noqa: E402
 
-TOL_SCALED = 1e-4
+TOL_SCALED = 2e-5
 
 
 def _mods():
@@ -145,16 +146,29 @@ def test_full_size_clip_properties():
     assert torch.equal(cmax, power.amax(dim=(1, 2)))
 
 
-def test_rms_norm_batch_matches_reference_formula():
+def test_rms_norm_batch_matches_reference_fixture():
+    """amtx_rms_norm against outputs of the REFERENCE's own `tools.rms_norm` (amt_tools/tools/utils.py:2789-2814), recorded by
+    tools/gen_golden.py in tests/golden/rms_norm.npz (a seed per clip + every 97th output sample + the output's sum of squares):
+    float32 clips of three scales, a 7-sample and a 1-sample clip and a silent clip (returned as is)."""
     from amt_tools_amd import tools
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'rms_norm.npz'))
+    stride = int(g['stride'])
+    for i, (n, sc) in enumerate(zip(g['lengths'], g['scales'])):
+        x = (np.random.default_rng(700 + i).standard_normal(int(n)) * sc).astype(np.float32)
+        got = tools.rms_norm_batch(torch.from_numpy(x[None]).cuda()).cpu().numpy()[0]
+        ref = g[f'out_{i}_float32']
+        assert got.dtype == np.float32 and str(g[f'dtype_{i}_float32']) == 'float32'
+        assert np.abs(got[::stride] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), i
+        assert abs(float(np.sum(got.astype(np.float64) ** 2)) - float(g[f'sumsq_{i}_float32'])) <= 1e-5 * max(1.0, float(g[f'sumsq_{i}_float32'])), i
+        if sc == 0:
+            assert np.all(got == 0)
+    # a batch of clips of one length: every row normalised on its own
     rng = np.random.default_rng(3)
     clips = (rng.standard_normal((4, 100001)) * np.array([[0.01], [1.0], [30.0], [0.0]])).astype(np.float32)
     got = tools.rms_norm_batch(torch.from_numpy(clips).cuda()).cpu().numpy()
-    for b in range(4):
-        ref = tools.rms_norm(clips[b].astype(np.float64)).astype(np.float32)     # tools/utils.py:2789-2814
-        assert np.abs(got[b] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
     assert np.all(got[3] == 0)
-    assert abs(np.sqrt(np.mean(got[1].astype(np.float64) ** 2)) - 1.0) < 1e-5
+    for b in range(3):
+        assert abs(np.sqrt(np.mean(got[b].astype(np.float64) ** 2)) - 1.0) < 1e-5
 
 
 @pytest.mark.parametrize('n_fft', [128, 512, 1024, 4096])

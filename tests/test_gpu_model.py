@@ -158,7 +158,7 @@ def test_complexity_4_engine_vs_oracle_on_ragged_batches(mc):
             got = model.engine_logits(feats.cuda())
         for key in ('onsets', 'multi_pitch'):
             assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
-            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 1.5e-4
 
 
 @pytest.mark.parametrize('dim_in,in_channels', [(229, 1), (72, 6)])
@@ -181,7 +181,7 @@ def test_complexity_3_engine_vs_oracle_on_ragged_batches(dim_in, in_channels):
             got = model.engine_logits(feats.cuda())
         for key in ('onsets', 'multi_pitch'):
             assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
-            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 1.5e-4
 
 
 @pytest.mark.parametrize('dim_in', [229, 40, 88, 54, 192, 8])
@@ -189,7 +189,7 @@ def test_complexity_2_engine_vs_oracle_feature_sizes_and_ragged_batches(dim_in):
     """OnsetsFrames at model_complexity 2 (the headline engine: Toeplitz first conv fused into conv2) against the oracle on fresh
     inputs: feature sizes whose tile width is / is not a multiple of the first conv's 4-column units and that need 1 .. 5
     frequency tiles, frame counts that do not fill the 16-frame tiles (halo-row units, padded rows), batches that do not fill
-    the persistent grid.  x3 (the parity gate): logits within 3e-4 / activations within 1e-4; bf16: a loose 1e-1 screen for gross errors."""
+    the persistent grid.  x3 (the parity gate): logits within 1.5e-4 / activations within 1e-4; bf16: a loose 1e-1 screen for gross errors."""
     from oracle import model_ref
     from amt_tools_amd.models import OnsetsFrames
     sd = synth_state_dict(17, dim_in=dim_in, in_channels=1, model_complexity=2)
@@ -199,7 +199,7 @@ def test_complexity_2_engine_vs_oracle_feature_sizes_and_ragged_batches(dim_in):
     feats = [torch.from_numpy(rng.random((B, 1, dim_in, T)).astype(np.float32)) for B, T in cases]
     with torch.no_grad():
         refs = [model_ref.run_on_batch(f, sdt) for f in feats]
-    for precision, tol in (('x3', 3e-4), ('bf16', 1e-1)):
+    for precision, tol in (('x3', 1.5e-4), ('bf16', 1e-1)):
         model = OnsetsFrames(dim_in, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
         model.load_state_dict(sdt)
         model.change_device()
@@ -221,7 +221,7 @@ def test_engine_at_batch_sizes_that_take_the_eight_clip_recurrence(cls, B, T, pr
     block (bilstm4_kernel<.., NC = 2>) once four-clip blocks would outnumber the 256 CUs: more than 512 clips with one recurrent head,
     more than 256 with the two grouped recurrences of OnsetsFrames2 -- the mapping the headline bench (1024 clips) runs.  Whole engine
     against the CPU oracle for clips of the first block, blocks in the middle and the ragged last block (523 = 65 x 8 + 3, 261 = 32 x 8
-    + 5), every clip distinct; x3: logits within 3e-4 and activations within 1e-4 (the parity gate), bf16: the 6e-2 logit bound."""
+    + 5), every clip distinct; x3: logits within 1.5e-4 and activations within 1e-4 (the parity gate), bf16: the 6e-2 logit bound."""
     from oracle import model_ref
     import amt_tools_amd.models as M
     offsets = cls == 'OnsetsFrames2'
@@ -237,7 +237,7 @@ def test_engine_at_batch_sizes_that_take_the_eight_clip_recurrence(cls, B, T, pr
     with torch.no_grad():
         got = model.engine_logits(feats.cuda())
         ref = model_ref.run_on_batch(feats[pick], sdt)
-    tol = 3e-4 if precision == 'x3' else TOL['bf16']
+    tol = 1.5e-4 if precision == 'x3' else TOL['bf16']
     keys = ('onsets', 'multi_pitch', 'pitch_head') + (('offsets',) if offsets else ())
     for key in keys:
         g = got[key].cpu()[pick]
@@ -421,7 +421,7 @@ def test_whole_tracks_of_several_thousand_frames(monkeypatch):
     matrix: thousands of frames, batch 1 - 2).  2 tracks x 4001 frames (65 strips per track, the last one 33 frames long; 4001 dependent
     recurrence steps): the fused stack (2 heads x 2 x 65 = 260 strips; its output in planes per frequency column or, AMTX_OF_ROWMAJOR_A3=1,
     row-major) returns the bits of the two-kernel path, and the x3 engine stays
-    within 3e-4 of the CPU oracle at the start, in the middle and at the end of the track."""
+    within 1.5e-4 of the CPU oracle at the start, in the middle and at the end of the track."""
     from oracle import model_ref
     import amt_tools_amd.models as M
     B, T, dim_in = 2, 4001, 229
@@ -467,7 +467,7 @@ def test_whole_tracks_of_several_thousand_frames(monkeypatch):
     for key in ('onsets', 'multi_pitch', 'pitch_head'):
         for lo, hi in ((0, 64), (1970, 2034), (T - 64, T)):
             err = (x3[key][0, lo:hi].cpu() - ref['logits'][key][0, lo:hi]).abs().max().item()
-            assert err < 3e-4, (key, lo, err)
+            assert err < 1.5e-4, (key, lo, err)
         assert (got['fused'][key][0].cpu() - ref['logits'][key][0]).abs().max().item() < 6e-2, key
 
 
@@ -565,9 +565,9 @@ def test_engine_ragged_batch_and_single_frame():
             ref = model_ref.run_on_batch(feats, sd)
             got = model.engine_logits(feats.cuda())
         for key in ('onsets', 'multi_pitch'):
-            # pre-threshold piano-roll activations (sigmoid) within 1e-4; raw logits (|x| up to ~5) within 3e-4
+            # pre-threshold piano-roll activations (sigmoid) within 1e-4; raw logits (|x| up to ~5) within 1.5e-4
             assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
-            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+            assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 1.5e-4
 
 
 def test_weights_are_resynced_after_an_update_and_model_pickles():
@@ -803,7 +803,7 @@ def test_engine_long_single_clip():
         got = model.engine_logits(feats.cuda())
     for key in ('onsets', 'multi_pitch'):
         assert (torch.sigmoid(got[key].cpu()) - torch.sigmoid(ref['logits'][key])).abs().max().item() < 1e-4
-        assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 3e-4
+        assert (got[key].cpu() - ref['logits'][key]).abs().max().item() < 1.5e-4
 
 
 def test_bench_workload_parity_of_both_precisions_against_the_cpu_oracle(capsys):
@@ -812,7 +812,9 @@ def test_bench_workload_parity_of_both_precisions_against_the_cpu_oracle(capsys)
     model restatement).  SURVEY F8: on thresholded outputs the parity metric is the count of differing cells.
       x3  : logits within 2e-4 and activations (sigmoid) within 1e-4 of the oracle -- the mode that meets north_star's 1e-4 --
             and fewer than 1e-4 of the piano-roll cells differ (cells whose logit is ~0);
-      bf16: the headline throughput mode; the fraction of differing cells is measured, printed and bounded (< 5e-3)."""
+      bf16: the throughput mode; the fraction of differing cells is measured, printed and bounded at 2 x what MI355X measures
+            (1.4e-3 of the cells, max |dlogit| 2.8e-2) -- and it is asserted to be OUTSIDE north_star's 1e-4, so that the log says which
+            mode carries the parity claim (x3) and which one does not (bf16)."""
     from oracle import frontend_np as fe, model_ref
     from amt_tools_amd.features import MelSpec
     from amt_tools_amd.models import OnsetsFrames
@@ -855,7 +857,11 @@ def test_bench_workload_parity_of_both_precisions_against_the_cpu_oracle(capsys)
     rate, el, ea = report['x3']
     assert el < 2e-4 and ea < 1e-4 and rate < 1e-4, report['x3']
     rate, el, ea = report['bf16']
-    assert rate < 5e-3 and el < 0.12, report['bf16']
+    assert rate < 3e-3 and el < 0.06, report['bf16']
+    # status, made visible: bf16 operands do NOT meet the 1e-4 activation tolerance (measured 6.8e-3); only x3 does
+    assert ea > 1e-4, ('bf16 is inside 1e-4 now: promote it to the parity mode and tighten its bounds', report['bf16'])
+    with capsys.disabled():
+        print(f'[parity] precision x3 is INSIDE the 1e-4 activation tolerance ({report["x3"][2]:.2e}); bf16 is OUTSIDE it ({ea:.2e})')
 
 
 _EPILOGUE_AB = r'''

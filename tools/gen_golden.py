@@ -367,7 +367,27 @@ def gen_notes(name, seed, T, p_on, p_mp, with_onsets=True, hop=512, sr=22050, ti
     print(name, 'notes', rec['notes'].shape)
 
 
+def gen_rms_norm(name):
+    """amt_tools.tools.rms_norm (tools/utils.py:2789-2814) on float32 and float64 clips of several scales, a silent clip and a one-sample
+    clip: inputs (a seed per clip, not the samples) + the reference's outputs, downsampled to every 97th sample plus the exact RMS."""
+    rec = {'seeds': np.arange(5), 'lengths': np.array([100001, 40000, 7, 1, 5000]), 'scales': np.array([0.01, 1.0, 30.0, 2.5, 0.0]), 'stride': 97}
+    for i, (n, sc) in enumerate(zip(rec['lengths'], rec['scales'])):
+        x64 = np.random.default_rng(700 + i).standard_normal(int(n)) * sc
+        for dt in (np.float32, np.float64):
+            x = x64.astype(dt)
+            y = rtools.rms_norm(x)
+            tag = f'{i}_{np.dtype(dt).name}'
+            rec[f'out_{tag}'] = np.asarray(y)[::97].copy()
+            rec[f'dtype_{tag}'] = str(np.asarray(y).dtype)
+            rec[f'sumsq_{tag}'] = np.float64(np.sum(np.asarray(y, dtype=np.float64) ** 2))
+    np.savez_compressed(os.path.join(OUT, name), **rec)
+    print(name, 'rms_norm', len(rec))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'rms_norm':
+        gen_rms_norm('rms_norm.npz')
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'labels_edges':
         gen_labels_edges('labels_edges.npz')
         sys.exit(0)
@@ -406,6 +426,7 @@ if __name__ == '__main__':
     gen_tabcnn('tabcnn_eval.npz', seed=41, dim_in=192, B=2, T=30)
     gen_labels_and_cache('labels.npz', 'feature_cache_ref.npz', seed=51, T=200, n_notes=60)
     gen_labels_edges('labels_edges.npz')
+    gen_rms_norm('rms_norm.npz')
     gen_feature_bookkeeping('feature_bookkeeping.npz')
     gen_notes('notes_dense.npz', 31, 300, 0.02, 0.08, True)
     gen_notes('notes_sparse.npz', 32, 625, 0.002, 0.01, True)
