@@ -65,6 +65,8 @@ _SIGNATURES = {
     'amtx_linear_packed_elems': (_L, [_I, _I, _I]),
     'amtx_linear_pack': (_I, [_P, _I, _I, _I, _P]),
     'amtx_linear_fwd': (_I, [_P, _L, _I, _P, _I, _P, _P, _L, _I, _L, _I, _I, _P]),
+    'amtx_split_planes': (_I, [_P, _L, _I, _P, _I, _L, _L, _P]),
+    'amtx_linear_fwd_split': (_I, [_P, _L, _L, _P, _P, _P, _L, _I, _L, _L, _I, _I, _P]),
     'amtx_conv3x3_packed_elems': (_L, [_I, _I]),
     'amtx_conv3x3_pack': (_I, [_P, _P, _I, _I, _P]),
     'amtx_conv3x3_fwd': (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P]),

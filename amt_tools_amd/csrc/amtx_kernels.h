@@ -2,8 +2,11 @@
 #pragma once
 #include "amtx_common.h"
 
-// element types of activations held in HBM
-enum { AMTX_T_BF16 = 0, AMTX_T_F32 = 1 };
+// element types of activations held in HBM.  AMTX_T_SPLIT (round 5, the x3 precision's own activation format): TWO 16-bit planes,
+// hi = 16-bit(x) at the tensor's base pointer and lo = 16-bit(x - hi) `*_split` elements behind it -- the operand planes of the
+// three-MFMA product, written once by the producing kernel instead of being re-derived from fp32 by every consumer (and therefore
+// loadable HBM -> LDS by DMA).  Four bytes per element like fp32.
+enum { AMTX_T_BF16 = 0, AMTX_T_F32 = 1, AMTX_T_SPLIT = 2 };
 
 static inline size_t amtx_tsize(int t) { return t == AMTX_T_BF16 ? 2 : 4; }
 
@@ -39,6 +42,8 @@ struct GemmArgs {
     // everything else reads as zero and is never dereferenced (strided rows hanging over both ends of a clip: the CQT basis product
     // straight from the caller's audio, whose centre padding is then implicit).  a_valid_hi == 0: no bounds.
     int64_t a_valid_lo = 0, a_valid_hi = 0;
+    // AMTX_T_SPLIT operands: elements between the hi and the lo plane of A / of C
+    int64_t a_split = 0, c_split = 0;
 };
 bool amtx_gemm_has_roll_epilogue(const GemmArgs& g);
 int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream);
@@ -68,8 +73,11 @@ struct ConvArgs {
     // them: f_clip_max[b] = the clip's own maximum, f_ref[b] = the reference power (null: the own maximum).  Null f_clip_max: features as is.
     const float* f_clip_max = nullptr; const float* f_ref = nullptr;
     int64_t out_ts = 0;                                  // convg.hip only: elements between consecutive (b, t) rows of `out`; 0 = (F/2) * c_out
+    int64_t in_split = 0, out_split = 0;                 // AMTX_T_SPLIT maps (conv.hip, two-plane mode): elements between the hi and the lo plane
 };
 int amtx_launch_conv3x3(const ConvArgs& c, hipStream_t stream);
+// convx.hip: the same layer (no fused first conv) on AMTX_T_SPLIT maps, two-plane weights: tiles DMA'd into a second LDS buffer under the matrix work
+int amtx_launch_convx3(const ConvArgs& c, hipStream_t stream);
 size_t amtx_conv1_wfrag_elems(int c_in, int planes);
 // host packing of the fused first conv: weight (32, c_in, 3, 3) fp32 * scale[32] -> fragment order
 void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int planes, bf16_t* out);
@@ -143,6 +151,8 @@ int amtx_launch_pianoroll(const float* logits, int64_t ld, int col0, int B, int 
 
 int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t rows, hipStream_t stream,
                              bool f16 = false /* IEEE half instead of bf16 (AMTX_PREC_F16) */);
+// fp32 rows -> AMTX_T_SPLIT rows (hi / lo planes `split` elements apart), columns n_src .. ld_dst zero
+int amtx_launch_cvt_split(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t split, int64_t rows, hipStream_t stream);
 int amtx_launch_zero_cols(void* base, int64_t pitch_bytes, int width_bytes, int64_t rows, hipStream_t stream);
 
 // ---------------------------------------------------------------- device-side weight packing (pack.hip): the host packers' layouts and

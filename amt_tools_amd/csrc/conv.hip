@@ -190,7 +190,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
     const int npos = ROWS * cols;
     const int Fo = a.F >> 1;
     const int c = tid & 3;                              // staging chunk handled by this thread (256 % 4 == 0)
-    const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
+    const char* in_grp = reinterpret_cast<const char*>(a.in) + (int64_t)grp * a.in_gs * (IN_TYPE == AMTX_T_F32 ? 4 : 2);
 
     // ---- constants of the fused first conv
     float* ftile = reinterpret_cast<float*>(smem + NS * PB);
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
         } else {
             // ---- stage the (TT+2) x (ft+2) x 32 tile in two batches (all loads of a batch issued before the first
             // LDS store)
-            const char* in = in_grp + (int64_t)tc.b * a.T * a.F * CIN * (IN_TYPE == AMTX_T_BF16 ? 2 : 4);
+            const char* in = in_grp + (int64_t)tc.b * a.T * a.F * CIN * (IN_TYPE == AMTX_T_F32 ? 4 : 2);
             constexpr int BATCH = ITEMS / 2;
             // opaque copy of the thread index: keeps the compiler from hoisting the 14 tile-invariant (row, column, LDS offset)
             // triples out of the persistent loop, where they would sit in registers next to the stationary weights and spill
@@ -667,6 +667,10 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
                         const int64_t e = ((int64_t)t * a.F + f) * CIN + c * 8;
                         if (IN_TYPE == AMTX_T_BF16) {
                             v0[n] = *reinterpret_cast<const uint4*>(in + e * 2);
+                        } else if (IN_TYPE == AMTX_T_SPLIT) {
+                            // the two planes as the previous layer's epilogue wrote them: nothing to convert
+                            v0[n] = *reinterpret_cast<const uint4*>(in + e * 2);
+                            v1[n] = *reinterpret_cast<const uint4*>(in + (a.in_split + e) * 2);
                         } else {
                             v0[n] = *reinterpret_cast<const uint4*>(in + e * 4);
                             v1[n] = *reinterpret_cast<const uint4*>(in + e * 4 + 16);
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
 #pragma unroll
                 for (int n = 0; n < BATCH; ++n) {
                     if (off[n] < 0) continue;
-                    uint4 hi = v0[n], lo = make_uint4(0, 0, 0, 0);
+                    uint4 hi = v0[n], lo = IN_TYPE == AMTX_T_SPLIT ? v1[n] : make_uint4(0, 0, 0, 0);
                     if (IN_TYPE == AMTX_T_F32) {
                         const float fv[8] = {__uint_as_float(v0[n].x), __uint_as_float(v0[n].y), __uint_as_float(v0[n].z), __uint_as_float(v0[n].w),
                                              __uint_as_float(v1[n].x), __uint_as_float(v1[n].y), __uint_as_float(v1[n].z), __uint_as_float(v1[n].w)};
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
         }
 
         const int t = t0 + trow;
-        char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)tc.b * a.T + t) * Fo * COUT) * (OUT_TYPE == AMTX_T_BF16 ? 2 : 4);
+        char* out = reinterpret_cast<char*>(a.out) + ((int64_t)grp * a.out_gs + ((int64_t)tc.b * a.T + t) * Fo * COUT) * (OUT_TYPE == AMTX_T_F32 ? 4 : 2);
         // Fragment reads are software-pipelined by tap row: while the MFMAs of row kh run, the ds_reads of the same
         // row of this wave's NEXT column pair are already in flight (x[kh] is refilled right after its last use), so the
         // LDS latency never sits between two MFMA groups and the epilogue overlaps the next pair's reads.
@@ -764,6 +768,18 @@ __global__ __launch_bounds__(conv_threads(FUSE1, KS, NS), (NS == 1 ? conv_thread
                     for (int q = 0; q < NT / 2; ++q)
                         dst[WIDE_ST ? 4 * q : q] = make_uint4(pack_bf16x2(v[8 * q], v[8 * q + 1]), pack_bf16x2(v[8 * q + 2], v[8 * q + 3]),
                                             pack_bf16x2(v[8 * q + 4], v[8 * q + 5]), pack_bf16x2(v[8 * q + 6], v[8 * q + 7]));
+                } else if (OUT_TYPE == AMTX_T_SPLIT) {
+                    // the next layer's operand planes, split here once (split_bf16x2: what that layer's staging would have computed)
+                    uint4* dh = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 2);
+                    uint4* dl = reinterpret_cast<uint4*>(out + ((int64_t)fo * COUT + g * 4 * NT + a.out_split) * 2);
+#pragma unroll
+                    for (int q = 0; q < NT / 2; ++q) {
+                        const float y[8] = {v[8 * q], v[8 * q + 1], v[8 * q + 2], v[8 * q + 3], v[8 * q + 4], v[8 * q + 5], v[8 * q + 6], v[8 * q + 7]};
+                        uint4 hi, lo;
+                        cvt8(y, true, hi, lo);
+                        dh[q] = hi;
+                        dl[q] = lo;
+                    }
                 } else {
                     float4* dst = reinterpret_cast<float4*>(out + ((int64_t)fo * COUT + g * 4 * NT) * 4);
 #pragma unroll
@@ -831,6 +847,14 @@ int dispatch_types(const ConvArgs& a, hipStream_t s) {
         }
         if (a.c_in * 9 <= 16) {
             if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true, 1>(a, s);
+            if (a.out_type == AMTX_T_SPLIT) {
+                if constexpr (NS == 2) {
+                    AMTX_REQUIRE(a.out_split > 0 && a.out_split % 8 == 0, "conv3x3: two-plane output needs a plane stride");
+                    return launch_conv<2, NS, AMTX_T_F32, AMTX_T_SPLIT, true, 1>(a, s);
+                }
+                amtx_set_error("conv3x3: two-plane maps exist in the two-plane mode only");
+                return AMTX_ERR_UNSUPPORTED;
+            }
             return launch_conv<2, NS, AMTX_T_F32, AMTX_T_F32, true, 1>(a, s);
         }
         if (a.out_type == AMTX_T_BF16) return launch_conv<2, NS, AMTX_T_BF16, AMTX_T_BF16, true, 4>(a, s);
@@ -842,6 +866,15 @@ int dispatch_types(const ConvArgs& a, hipStream_t s) {
         return launch_conv<NT, NS, AMTX_T_BF16, AMTX_T_BF16, false>(a, s);
     }
     if (a.in_type == AMTX_T_F32 && a.out_type == AMTX_T_F32) return launch_conv<NT, NS, AMTX_T_F32, AMTX_T_F32, false>(a, s);
+    if (a.in_type == AMTX_T_SPLIT && a.out_type == AMTX_T_SPLIT) {
+        if constexpr (NS == 2) {
+            AMTX_REQUIRE(a.in_split > 0 && a.in_split % 8 == 0 && a.out_split > 0 && a.out_split % 8 == 0, "conv3x3: two-plane maps need plane strides");
+            // A/B switch: AMTX_NO_CONVX=1 keeps this file's register-staged kernel on the two-plane maps
+            static const bool no_convx = getenv("AMTX_NO_CONVX") != nullptr;
+            if (!no_convx) return amtx_launch_convx3(a, s);
+            return launch_conv<NT, NS, AMTX_T_SPLIT, AMTX_T_SPLIT, false>(a, s);
+        }
+    }
     amtx_set_error("conv3x3: in/out element types must match (bf16/bf16 or f32/f32)");
     return AMTX_ERR_UNSUPPORTED;
 }

@@ -42,8 +42,12 @@ struct AStage {
     // A second register stage (loads two k-steps ahead) was measured slower: 4.81 ms.
     uint4 hi, lo;
     // vlo / vhi: bounds of the existing elements (vhi == 0: none), see GemmArgs::a_valid_lo
-    __device__ __forceinline__ void load(const char* base, int64_t row_off_elems, bool valid, int64_t vlo = 0, int64_t vhi = 0) {
-        if (A_TYPE == AMTX_T_BF16) {
+    __device__ __forceinline__ void load(const char* base, int64_t row_off_elems, bool valid, int64_t vlo = 0, int64_t vhi = 0, int64_t split = 0) {
+        if (A_TYPE == AMTX_T_SPLIT) {
+            // the planes as the producer wrote them: nothing to convert
+            hi = valid ? *reinterpret_cast<const uint4*>(base + row_off_elems * 2) : make_uint4(0, 0, 0, 0);
+            lo = valid ? *reinterpret_cast<const uint4*>(base + (split + row_off_elems) * 2) : make_uint4(0, 0, 0, 0);
+        } else if (A_TYPE == AMTX_T_BF16) {
             hi = valid ? *reinterpret_cast<const uint4*>(base + row_off_elems * 2) : make_uint4(0, 0, 0, 0);
             lo = make_uint4(0, 0, 0, 0);
         } else {
@@ -72,7 +76,7 @@ struct AStage {
         }
     }
     __device__ __forceinline__ void finish() {
-        if (A_TYPE != AMTX_T_BF16) {
+        if (A_TYPE == AMTX_T_F32) {
             const float4 x0 = __builtin_bit_cast(float4, hi), x1 = __builtin_bit_cast(float4, lo);
             const float f[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
             uint32_t h[4], l[4];
@@ -98,7 +102,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
     const int64_t m0 = (int64_t)bx * BM;
     const int n0 = by * BN;
 
-    const char* Abase = reinterpret_cast<const char*>(g.A) + (int64_t)grp * g.a_gs * (A_TYPE == AMTX_T_BF16 ? 2 : 4);
+    const char* Abase = reinterpret_cast<const char*>(g.A) + (int64_t)grp * g.a_gs * (A_TYPE == AMTX_T_F32 ? 4 : 2);
     const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
     const int64_t plane_elems = (int64_t)g.n_pad * g.k_pad;
 
@@ -114,8 +118,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
 #define LOAD_TILE(k0)                                                                              \
     do {                                                                                           \
         const bool kok = ((k0) + schunk * 8) < g.K;                                                \
-        sa0.load(Abase, a_off0 + (k0), arow_ok0 && kok, g.a_valid_lo, g.a_valid_hi);               \
-        sa1.load(Abase, a_off1 + (k0), arow_ok1 && kok, g.a_valid_lo, g.a_valid_hi);               \
+        sa0.load(Abase, a_off0 + (k0), arow_ok0 && kok, g.a_valid_lo, g.a_valid_hi, g.a_split);    \
+        sa1.load(Abase, a_off1 + (k0), arow_ok1 && kok, g.a_valid_lo, g.a_valid_hi, g.a_split);    \
         sw0h = *reinterpret_cast<const uint4*>(Wbase + w_off0 + (k0));                             \
         sw1h = *reinterpret_cast<const uint4*>(Wbase + w_off1 + (k0));                             \
         if (NS == 2) {                                                                             \
@@ -187,7 +191,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
 #undef STORE_TILE
     // epilogue: lane holds D'[n = 4*(lane>>4) + r][m = lane&15] of every 16x16 tile
     const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
-    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_BF16 ? 2 : 4);
+    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * (C_TYPE == AMTX_T_F32 ? 4 : 2);
     // magnitude epilogue with a running maximum per (group, harmonic): block-local maxima in LDS (the tile buffers are free after
     // the loop's last barrier), then one global atomic per harmonic and block.  Magnitudes are >= 0: uint order == float order.
     unsigned* lmax = reinterpret_cast<unsigned*>(smem);
@@ -240,6 +244,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
             const float o0 = v[0] + bv[0], o1 = v[1] + bv[1], o2 = v[2] + bv[2], o3 = v[3] + bv[3];
             if (C_TYPE == AMTX_T_F32) {
                 *reinterpret_cast<float4*>(Cbase + (m * g.ldc + n) * 4) = make_float4(o0, o1, o2, o3);
+            } else if (C_TYPE == AMTX_T_SPLIT) {
+                uint32_t h0, h1, l0, l1;
+                split_bf16x2(o0, o1, h0, l0);
+                split_bf16x2(o2, o3, h1, l1);
+                *reinterpret_cast<uint2*>(Cbase + (m * g.ldc + n) * 2) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2*>(Cbase + (g.c_split + m * g.ldc + n) * 2) = make_uint2(l0, l1);
             } else {
                 *reinterpret_cast<uint2*>(Cbase + (m * g.ldc + n) * 2) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
             }
@@ -729,6 +739,195 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmArgs g, int ntiles) {
 #undef PP_BARRIER
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-plane ("x3") problems whose A operand already IS two 16-bit planes (AMTX_T_SPLIT: the producing kernel's epilogue wrote
+// hi = 16-bit(x), lo = 16-bit(x - hi)): all four operand planes travel HBM / L2 -> LDS by DMA, nothing is converted here.  The fp32-A
+// path above (gemm_tile) spends ~60 conversion + 16 LDS-store instructions per thread and 32-deep step next to its 48 MFMAs and holds
+// a 64 x 64 wave tile; this one is the direct-to-LDS kernel's structure (256 x 256 tile, eight waves of 128 x 64, two buffers, one barrier
+// per stage) with 32-deep stages of 64 KiB = [A hi | A lo | W hi | W lo] x 256 rows x 64 bytes, the ring kernel's row swizzles, and
+// three MFMAs per fragment pair: 96 MFMAs per wave and stage against 24 fragment reads and 8 DMA instructions -- three times the matrix
+// work per staged byte of the one-plane kernels.  Same product order (hi.hi, hi.lo, lo.hi per 32-deep step, k ascending) as gemm_tile:
+// the two kernels return the same bits for the same planes.
+// C_TYPE: AMTX_T_F32 or AMTX_T_SPLIT (the next GEMM's A).
+constexpr int SPL = 256 * RBK * 2;          // bytes per operand plane and stage (16 KiB)
+constexpr int SSTAGE = 4 * SPL;
+
+static __device__ __forceinline__ void glds16x2(const void* g0, const void* g1, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    const char* p1 = static_cast<const char*>(g1) - 1024;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %2, off offset:1024\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g0), "v"(p1), "s"(lds_addr)
+                 : "memory");
+}
+
+template <int C_TYPE>
+__global__ __launch_bounds__(512) void gemm_split_kernel(GemmArgs g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A hi | A lo | W hi | W lo]
+    constexpr int MT = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int grp = blockIdx.z;
+    const unsigned nbn = g.n_pad / RTB;
+    const int nk = g.k_pad / RBK;
+
+    const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)grp * g.a_gs;
+    const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
+    const int64_t w_plane = (int64_t)g.n_pad * g.k_pad;
+    const float* bias = g.bias ? g.bias + (int64_t)grp * g.bias_gs : nullptr;
+
+    // this wave DMAs rows [32 wave, 32 wave + 32) of every plane: two 1-KiB pieces (16 rows x 4 chunks) each
+    const bf16_t* a_src[2];
+    const bf16_t* w_src[2];
+#define SP_SET_TILE(TILE_ID)                                                                                  \
+    do {                                                                                                      \
+        const unsigned lg = xcd_remap((unsigned)(TILE_ID), (unsigned)ntiles);                                 \
+        const int tn0 = (lg % nbn) * RTB;                                                                     \
+        const int64_t tm0 = (int64_t)(lg / nbn) * RTB;                                                        \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                       \
+            const int row = wave * 32 + n * 16 + (lane >> 2);                                                 \
+            int64_t mr = tm0 + row;                                                                           \
+            if (mr >= g.M) mr = g.M - 1;                                                                      \
+            a_src[n] = Abase + mr * g.lda + ((lane & 3) ^ rswz((row >> 2) & 3)) * 8;                          \
+            w_src[n] = Wbase + (int64_t)(tn0 + row) * g.k_pad + ((lane & 3) ^ rswz((row >> 4) & 3)) * 8;      \
+        }                                                                                                     \
+    } while (0)
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem) + wave * 2048;
+#define SP_ISSUE(k0, buf)                                                                                     \
+    do {                                                                                                      \
+        const unsigned sb = lds_base + (buf) * SSTAGE;                                                        \
+        glds16x2(a_src[0] + (k0), a_src[1] + (k0), sb);                                                       \
+        glds16x2(a_src[0] + g.a_split + (k0), a_src[1] + g.a_split + (k0), sb + SPL);                         \
+        glds16x2(w_src[0] + (k0), w_src[1] + (k0), sb + 2 * SPL);                                             \
+        glds16x2(w_src[0] + w_plane + (k0), w_src[1] + w_plane + (k0), sb + 3 * SPL);                         \
+    } while (0)
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int a_off = (wm * 128 + frow) * 64 + ((fchunk ^ rswz((frow >> 2) & 3)) << 4);
+    const int w_off = 2 * SPL + (wn * 64 + 16 * (frow >> 2) + (frow & 3)) * 64 + ((fchunk ^ rswz(frow >> 2)) << 4);
+    // Per half (four 16-row tiles of A): the three products as three passes over the 16 accumulators, so that consecutive MFMAs never
+    // share an accumulator; per accumulator the order stays hi.hi, hi.lo, lo.hi.
+#define SP_COMPUTE(buf)                                                                                       \
+    do {                                                                                                      \
+        const char* b = smem + (buf) * SSTAGE;                                                                \
+        uint4 wh[4], wl[4];                                                                                   \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                       \
+            wh[t] = *reinterpret_cast<const uint4*>(b + w_off + t * 256);                                     \
+            wl[t] = *reinterpret_cast<const uint4*>(b + w_off + SPL + t * 256);                               \
+        }                                                                                                     \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                       \
+            uint4 ah[4], al[4];                                                                               \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                   \
+                ah[t] = *reinterpret_cast<const uint4*>(b + a_off + (4 * h + t) * 1024);                      \
+                al[t] = *reinterpret_cast<const uint4*>(b + a_off + SPL + (4 * h + t) * 1024);                \
+            }                                                                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                  \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[nt][4 * h + mt] = mfma16(wh[nt], ah[mt], acc[nt][4 * h + mt]); \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                  \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[nt][4 * h + mt] = mfma16(wh[nt], al[mt], acc[nt][4 * h + mt]); \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                  \
+                _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[nt][4 * h + mt] = mfma16(wl[nt], ah[mt], acc[nt][4 * h + mt]); \
+        }                                                                                                     \
+    } while (0)
+#define SP_SYNC()                                                                                             \
+    do {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        __syncthreads();                                                                                      \
+    } while (0)
+
+    int tile = blockIdx.x;
+    SP_SET_TILE(tile);
+    SP_ISSUE(0, 0);
+    SP_SYNC();
+    int cur = 0;
+    for (;;) {
+        const unsigned lg = xcd_remap((unsigned)tile, (unsigned)ntiles);
+        const int n0 = (lg % nbn) * RTB;
+        const int64_t m0 = (int64_t)(lg / nbn) * RTB;
+        const int next = tile + (int)gridDim.x;
+        const bool has_next = next < ntiles;
+
+        f32x4_t acc[4][MT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            SP_ISSUE((kt + 1) * RBK, cur ^ 1);
+            SP_COMPUTE(cur);
+            SP_SYNC();
+            cur ^= 1;
+        }
+        if (has_next) {
+            SP_SET_TILE(next);
+            SP_ISSUE(0, cur ^ 1);
+        }
+        SP_COMPUTE(cur);
+
+        // ---- epilogue (the next tile's first stage is in flight underneath): lane (g, m) holds columns nb .. nb + 15 of row m
+        {
+            const int nb = n0 + wn * 64 + 16 * (lane >> 4);
+            float bv[4][4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv[nt][r] = (bias && nb + 4 * nt < g.N) ? bias[nb + 4 * nt + r] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int64_t m = m0 + wm * 128 + mt * 16 + (lane & 15);
+                if (m >= g.M || nb + 16 > g.N) continue;
+                float o[16];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[4 * nt + r] = acc[nt][mt][r] + bv[nt][r];
+                if (C_TYPE == AMTX_T_F32) {
+                    float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + (int64_t)grp * g.c_gs + m * g.ldc + nb);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) dst[nt] = make_float4(o[4 * nt], o[4 * nt + 1], o[4 * nt + 2], o[4 * nt + 3]);
+                } else {
+                    bf16_t* dh = reinterpret_cast<bf16_t*>(g.C) + (int64_t)grp * g.c_gs + m * g.ldc + nb;
+                    uint32_t hh[8], ll[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) split_bf16x2(o[2 * i], o[2 * i + 1], hh[i], ll[i]);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        reinterpret_cast<uint4*>(dh)[q] = make_uint4(hh[4 * q], hh[4 * q + 1], hh[4 * q + 2], hh[4 * q + 3]);
+                        reinterpret_cast<uint4*>(dh + g.c_split)[q] = make_uint4(ll[4 * q], ll[4 * q + 1], ll[4 * q + 2], ll[4 * q + 3]);
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        SP_SYNC();
+        cur ^= 1;
+        tile = next;
+    }
+#undef SP_SET_TILE
+#undef SP_ISSUE
+#undef SP_COMPUTE
+#undef SP_SYNC
+}
+
+template <int C_TYPE>
+int launch_split(const GemmArgs& g, hipStream_t stream) {
+    const int64_t ntiles = ((g.M + RTB - 1) / RTB) * (g.n_pad / RTB);
+    AMTX_REQUIRE(ntiles < (1ll << 31), "gemm: too many output tiles");
+    const size_t lds = 2 * (size_t)SSTAGE;
+    auto kern = gemm_split_kernel<C_TYPE>;
+    AMTX_GRANT_LDS(kern, lds);
+    int64_t gx = 256 / std::max(1, g.groups);
+    gx = std::max<int64_t>(8, gx / 8 * 8);
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(512), lds, stream, g, (int)ntiles);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
 template <int C_TYPE>
 int launch_pp(const GemmArgs& g, hipStream_t stream) {
     const int64_t ntiles = ((g.M + RTB - 1) / RTB) * (g.n_pad / RTB);
@@ -854,6 +1053,7 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
                  "gemm: A rows must be 16-byte aligned (bf16) / 4-byte aligned (fp32)");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
+    AMTX_REQUIRE(g.a_type == AMTX_T_BF16 || g.a_type == AMTX_T_F32 || g.a_type == AMTX_T_SPLIT, "gemm: bad A type");
     AMTX_REQUIRE(!g.copy16 || (amtx_gemm_has_roll_epilogue(g) && g.copy16_pad % 4 == 0 && g.N + g.copy16_pad <= g.n_pad &&
                                (g.copy16_ld % 4) == 0 && ((g.copy16_col0 | g.copy16_gs) % 4) == 0 && ((uintptr_t)g.copy16 % 8) == 0),
                  "gemm: bad bf16-copy epilogue arguments");
@@ -879,6 +1079,19 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
         return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 128>(g, stream) : launch_glds<AMTX_T_F32, 128>(g, stream);
     }
     AMTX_REQUIRE(!g.a_plane, "gemm: planar A exists on the bf16 direct-to-LDS path only");
+    if (g.a_type == AMTX_T_SPLIT) {
+        AMTX_REQUIRE(g.planes == 2 && g.a_split > 0 && (g.a_split % 8) == 0, "gemm: two-plane A needs two-plane weights and a plane stride that keeps 16-byte alignment");
+        AMTX_REQUIRE(g.c_type != AMTX_T_SPLIT || (g.c_split > 0 && (g.c_split % 8) == 0), "gemm: two-plane C needs a plane stride");
+        AMTX_REQUIRE(!g.pair_map && !g.roll_out && !g.copy16 && g.C, "gemm: two-plane A has the plain epilogues only");
+        // the direct-to-LDS two-plane kernel: whole 256-column tiles, whole 32-deep stages of real A columns
+        static const bool no_split_dma = getenv("AMTX_GEMM_NO_SPLIT_DMA") != nullptr;   // A/B switch: the generic kernel on the same planes
+        if (!no_split_dma && g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.K == g.k_pad && (g.lda % 8) == 0 && g.c_type != AMTX_T_BF16 &&
+            (g.ldc * 4) % 16 == 0)
+            return g.c_type == AMTX_T_SPLIT ? launch_split<AMTX_T_SPLIT>(g, stream) : launch_split<AMTX_T_F32>(g, stream);
+        AMTX_REQUIRE(g.c_type != AMTX_T_BF16, "gemm: two-plane A writes fp32 or two-plane C");
+        return g.c_type == AMTX_T_SPLIT ? launch<AMTX_T_SPLIT, AMTX_T_SPLIT, 2>(g, stream) : launch<AMTX_T_SPLIT, AMTX_T_F32, 2>(g, stream);
+    }
+    AMTX_REQUIRE(g.c_type != AMTX_T_SPLIT, "gemm: two-plane C needs two-plane A");
     const int key = (g.a_type << 2) | (g.c_type << 1) | (g.planes - 1);
     switch (key) {
         case 0: return launch<AMTX_T_BF16, AMTX_T_BF16, 1>(g, stream);

@@ -57,6 +57,26 @@ __global__ __launch_bounds__(256) void cvt_pad_bf16_kernel(const float* __restri
     }
 }
 
+// fp32 rows -> the two 16-bit planes of AMTX_T_SPLIT (hi = 16-bit(x), lo = 16-bit(x - hi): split_bf16x2, the conversion every two-plane
+// kernel applies to its fp32 operands), columns n_src .. ld_dst zero: the refinement stage's input projection reads the joint logits
+// through the direct-to-LDS two-plane GEMM, whose stages are 32 columns deep
+__global__ __launch_bounds__(256) void cvt_split_kernel(const float* __restrict__ src, int64_t ld_src, int n_src, bf16_t* __restrict__ dst,
+                                                        int ld_dst, int64_t split, int64_t rows) {
+    const int groups = ld_dst >> 2;                                   // 4 columns per thread
+    const int64_t total = rows * groups;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / groups;
+        const int c = (int)(i - r * groups) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 3 < n_src) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        uint32_t h0, h1, l0, l1;
+        split_bf16x2(v.x, v.y, h0, l0);
+        split_bf16x2(v.z, v.w, h1, l1);
+        *reinterpret_cast<uint2*>(dst + r * ld_dst + c) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + split + r * ld_dst + c) = make_uint2(l0, l1);
+    }
+}
+
 }  // namespace
 
 // zero `width` bytes (a multiple of 16) at the start of each of `rows` rows that are `pitch` bytes apart
@@ -82,6 +102,16 @@ int amtx_launch_cvt_pad_bf16(const float* src, int64_t ld_src, int n_src, bf16_t
     if (nb > 8192) nb = 8192;
     if (f16) hipLaunchKernelGGL(cvt_pad_bf16_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, rows);
     else hipLaunchKernelGGL(cvt_pad_bf16_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, rows);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}
+
+int amtx_launch_cvt_split(const float* src, int64_t ld_src, int n_src, bf16_t* dst, int ld_dst, int64_t split, int64_t rows, hipStream_t stream) {
+    AMTX_REQUIRE(src && dst && rows > 0 && n_src % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0 && ld_dst >= n_src && split % 4 == 0 &&
+                     split >= rows * ld_dst, "cvt_split: bad argument");
+    int64_t nb = (rows * (ld_dst >> 2) + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(cvt_split_kernel, dim3((unsigned)nb), dim3(256), 0, stream, src, ld_src, n_src, dst, ld_dst, split, rows);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }

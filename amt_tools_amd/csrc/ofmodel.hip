@@ -70,6 +70,8 @@ struct amtx_of_model {
     DevBuf conv1_w, conv1_s, conv1_frag, conv2_w, conv2_s, conv3_w, conv3_s;
     bool fuse_conv1 = false;                   // first conv computed inside the conv2 kernel (9*C_in <= 64)
     bool fuse_stack = false;                   // layer1 -> layer2 -> layer3 in one kernel (convf.hip) for batches that fill the chip with strips
+    bool split_acts = false;                   // x3 (round 5): the dense layers' activations live in HBM as two 16-bit planes (AMTX_T_SPLIT), written by
+                                               // the producing kernel's epilogue; the GEMMs DMA them straight into LDS (gemm_split_kernel)
     LinearPack fc1;                            // groups = n_heads
     LinearPack rec_ih;                         // groups = n_rec, N = 1024
     DevBuf rec_hh;                             // groups = n_rec
@@ -186,7 +188,7 @@ Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
     w.xp = take(BT * m->xw * es * m->n_rec);
     w.l1 = take(BT * m->dim_lm * es * m->n_rec);
     w.joint = take(BT * m->dim_aj * sizeof(float));
-    w.joint16 = take(BT * (size_t)((m->dim_aj + 63) / 64 * 64) * 2);   // bf16 copy, K padded to the GEMM's 64-deep k-tile
+    w.joint16 = take(BT * (size_t)((m->dim_aj + 63) / 64 * 64) * 2 * (m->split_acts ? 2 : 1));   // bf16 copy (two planes with split_acts), K padded to the GEMM's 64-deep k-tile
     w.xp2 = take(BT * m->xw * es);
     w.l2 = take(BT * m->dim_lm * es);
     w.mp = take(BT * m->n_out * sizeof(float));
@@ -234,6 +236,8 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     m->fuse_conv1 = m->gen_conv2 ? amtx_conv3x3_gen_can_fuse1(in_channels, m->nf1, m->nf2, m->planes) : (9 * in_channels <= 64);
     // A/B switch: AMTX_NO_CONV_FUSE=1 keeps conv.hip's two kernels (conv1+conv2, conv3) at every batch size
     m->fuse_stack = !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && m->planes == 1 && getenv("AMTX_NO_CONV_FUSE") == nullptr;
+    // A/B switch: AMTX_X3_NO_SPLIT=1 keeps fp32 activations between the two-plane kernels (round 4's data path)
+    m->split_acts = m->planes == 2 && !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && getenv("AMTX_X3_NO_SPLIT") == nullptr;
     *out = m;
     return AMTX_OK;
 }
@@ -671,6 +675,10 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     c2.groups = m->n_heads; c2.in_gs = BT * F * m->nf1; c2.shift_gs = m->nf2;
     c2.w_gs = (int64_t)(m->gen_conv2 ? amtx_conv3x3_gen_wfrag_elems(m->nf1, m->nf2, pl) : amtx_conv3x3_wfrag_elems(m->nf2, pl));
     c2.out_gs = BT * F2 * m->nf2;
+    const bool sp = m->split_acts;
+    // two-plane maps: plane stride = all groups of one plane
+    const int64_t a2_split = BT * F2 * m->nf2 * m->n_heads, a3_split = BT * m->kfc_pad * m->n_heads, e_split = BT * m->dim_am * m->n_heads;
+    if (sp) { c2.out_type = AMTX_T_SPLIT; c2.out_split = a2_split; }
     if (m->fuse_conv1) {   // Conv(c_in->32)+BN+ReLU computed inside the conv2 kernel; a1 is never materialised
         c2.in = nullptr;
         c2.feats = feats; c2.f_stride_b = stride_b; c2.f_stride_c = stride_c; c2.f_stride_t = stride_t; c2.f_stride_f = stride_f;
@@ -696,6 +704,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2;
     c3.w_gs = (int64_t)(m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, pl) : amtx_conv3x3_wfrag_elems(m->nf3, pl));
     c3.shift_gs = m->nf3; c3.out_gs = BT * m->kfc_pad;
+    if (sp) { c3.in_type = AMTX_T_SPLIT; c3.in_split = a2_split; c3.out_type = AMTX_T_SPLIT; c3.out_split = a3_split; }
     if (m->kfc_pad != m->kfc) {
         // rows of a3 are padded to the DMA GEMM's k-tile: the pad columns meet zero weights, they only have to be finite
         AMTX_REQUIRE(m->gen_conv, "amtx_of_forward: internal: padded fc1 rows need the general conv kernel");
@@ -708,13 +717,15 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     mark();
 
     // fc1 of the recurrent heads (heads 0..n_rec-1 of a3); the pitch head's fc1 is folded into its output layer below
-    GemmArgs g = gemm_args(w.a3, m->kfc_pad, at, m->fc1, pl, w.e, m->dim_am, at, BT, m->n_rec, BT * m->kfc_pad, BT * m->dim_am);
-    g.a_plane = a3_plane;
+    const int at_d = sp ? AMTX_T_SPLIT : at;   // element type of the dense layers' activations
+    GemmArgs g = gemm_args(w.a3, m->kfc_pad, at_d, m->fc1, pl, w.e, m->dim_am, at_d, BT, m->n_rec, BT * m->kfc_pad, BT * m->dim_am);
+    g.a_plane = a3_plane; g.a_split = a3_split; g.c_split = e_split;
     if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
 
     // recurrent heads: heads 0..n_rec-1 of `e`
-    g = gemm_args(w.e, m->dim_am, at, m->rec_ih, pl, w.xp, m->xw, at, BT, m->n_rec, BT * m->dim_am, BT * m->xw);
+    g = gemm_args(w.e, m->dim_am, at_d, m->rec_ih, pl, w.xp, m->xw, at, BT, m->n_rec, BT * m->dim_am, BT * m->xw);
+    g.a_split = e_split;
     if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
     LstmArgs l;
@@ -734,9 +745,9 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     // written by the same two epilogues instead of a conversion pass over the fp32 joint buffer; the fp32 joint logits themselves are
     // only written when something reads them (logit outputs, the offset head's probabilities, the modes without these epilogues)
     const int kp = (m->dim_aj + 63) / 64 * 64;
-    GemmArgs gp = gemm_args(w.a3 + (size_t)(m->n_heads - 1) * BT * m->kfc_pad * amtx_tsize(at), m->kfc_pad, at, m->pitch_out, pl,
+    GemmArgs gp = gemm_args(w.a3 + (size_t)(m->n_heads - 1) * BT * m->kfc_pad * (sp ? 2 : amtx_tsize(at)), m->kfc_pad, at_d, m->pitch_out, pl,
                             w.joint + (size_t)m->n_rec * m->n_out * sizeof(float), m->dim_aj, AMTX_T_F32, BT, 1, 0, 0);
-    gp.a_plane = a3_plane;
+    gp.a_plane = a3_plane; gp.a_split = a3_split;
     const bool copy_on = pl == 1 && !no_roll_epi && amtx_gemm_has_roll_epilogue(g) && amtx_gemm_has_roll_epilogue(gp) && m->n_out % 4 == 0 &&
                          (kp - m->dim_aj) % 4 == 0 && gp.N + (kp - m->dim_aj) <= gp.n_pad;
     if (copy_on) {
@@ -756,6 +767,11 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         if (!copy_on && (rc = amtx_launch_cvt_pad_bf16((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT, s, f16)) != AMTX_OK) return rc;
         g = gemm_args(w.joint16, kp, AMTX_T_BF16, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
         g.K = kp;
+    } else if (sp) {
+        // two-plane mode: the joint logits as two 16-bit planes, K zero-padded to whole 32-deep stages, feed the direct-to-LDS two-plane GEMM
+        if ((rc = amtx_launch_cvt_split((const float*)w.joint, m->dim_aj, m->dim_aj, (bf16_t*)w.joint16, kp, BT * kp, BT, s)) != AMTX_OK) return rc;
+        g = gemm_args(w.joint16, kp, AMTX_T_SPLIT, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
+        g.K = kp; g.a_split = BT * kp;
     } else {
         g = gemm_args(w.joint, m->dim_aj, AMTX_T_F32, m->adj_ih, pl, w.xp2, m->xw, at, BT, 1, 0, 0);
     }

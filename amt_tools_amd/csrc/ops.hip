@@ -23,6 +23,20 @@ extern "C" int amtx_linear_fwd(const void* a, int64_t lda, int a_type, const uin
     return amtx_launch_gemm(g, (hipStream_t)stream);
 }
 
+extern "C" int amtx_split_planes(const float* src, int64_t ld_src, int n, uint16_t* dst, int ld_dst, int64_t split, int64_t rows, void* stream) {
+    return amtx_launch_cvt_split(src, ld_src, n, dst, ld_dst, split, rows, (hipStream_t)stream);
+}
+
+extern "C" int amtx_linear_fwd_split(const void* a, int64_t lda, int64_t a_split, const uint16_t* w_packed, const float* bias, void* c, int64_t ldc,
+                                     int c_type, int64_t c_split, int64_t m, int n, int k, void* stream) {
+    GemmArgs g;
+    g.A = a; g.lda = lda; g.a_type = AMTX_T_SPLIT; g.a_split = a_split; g.W = w_packed; g.planes = 2;
+    amtx_gemm_pack_dims(n, k, &g.n_pad, &g.k_pad);
+    g.bias = bias; g.C = c; g.ldc = ldc; g.c_type = c_type; g.c_split = c_split; g.M = m; g.N = n; g.K = k;
+    g.groups = 1; g.a_gs = g.w_gs = g.bias_gs = g.c_gs = 0;
+    return amtx_launch_gemm(g, (hipStream_t)stream);
+}
+
 extern "C" int64_t amtx_conv3x3_packed_elems(int c_out, int planes) { return (int64_t)amtx_conv3x3_wfrag_elems(c_out, planes); }
 
 extern "C" int amtx_conv3x3_pack(const float* host_w, const float* host_scale, int c_out, int planes, uint16_t* host_out) {

@@ -256,7 +256,8 @@ def rms_norm_batch(audio):
     ws = torch.empty(int(L.amtx_rms_norm_workspace_bytes(B, N)), dtype=torch.uint8, device=audio.device)
     out = torch.empty_like(audio)
     with torch.cuda.device(audio.device):
-        _lib.check(L.amtx_rms_norm(_lib.ptr(audio), N, audio.stride(0), B, _lib.ptr(out), out.stride(0), _lib.ptr(ws), ws.numel(),
+        # a one-clip batch may carry any stride in its size-1 dimension (numpy's x[None] has 0): the rows are N apart by definition then
+        _lib.check(L.amtx_rms_norm(_lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, _lib.ptr(out), out.stride(0) if B > 1 else N, _lib.ptr(ws), ws.numel(),
                                    _lib.current_stream(audio.device)), 'amtx_rms_norm')
     return out
 

@@ -152,13 +152,20 @@ int amtx_of_profile_read(amtx_of_model* model, double* stage_ms /*[amtx_of_num_s
 
 /* ------------------------------------------------------------------------------------------------
  * Op-level entry points (the kernels the engine is built from; used by the parity tests).
- * Element types: 0 = bf16, 1 = fp32.  `planes` = 1 (bf16) or 2 (x3 split).  *_pack_* run on the host.
+ * Element types: 0 = bf16, 1 = fp32 (2 = split planes where stated).  `planes` = 1 (bf16) or 2 (x3 split).  *_pack_* run on the host.
  * ------------------------------------------------------------------------------------------------ */
 /* nn.Linear: C[M,N] = A[M,K] W[N,K]^T + bias  (models/onsetsframes.py:422-427, models/common.py:539) */
 int64_t amtx_linear_packed_elems(int n, int k, int planes);
 int amtx_linear_pack(const float* host_w, int n, int k, int planes, uint16_t* host_out);
 int amtx_linear_fwd(const void* a, int64_t lda, int a_type, const uint16_t* w_packed, int planes, const float* bias, void* c,
                     int64_t ldc, int c_type, int64_t m, int n, int k, void* stream);
+/* Element type 2 = "split" (the x3 precision's activation format since round 5): TWO 16-bit planes, hi = bf16(x) at the base pointer and
+ * lo = bf16(x - hi) `split` elements behind it; four bytes per element like fp32.  amtx_split_planes writes them from fp32 rows (columns
+ * n .. ld_dst zero); amtx_linear_fwd_split is amtx_linear_fwd with a split A (planes = 2 weights) and an fp32 (1) or split (2) C:
+ * whole 256-column tiles with k == its packed width run on the direct-to-LDS two-plane kernel, everything else on the generic one. */
+int amtx_split_planes(const float* src, int64_t ld_src, int n, uint16_t* dst, int ld_dst, int64_t split, int64_t rows, void* stream);
+int amtx_linear_fwd_split(const void* a, int64_t lda, int64_t a_split, const uint16_t* w_packed, const float* bias, void* c, int64_t ldc,
+                          int c_type, int64_t c_split, int64_t m, int n, int k, void* stream);
 /* Conv2d(32 -> c_out, 3x3, pad 1) + folded BatchNorm + ReLU + MaxPool(1,2), channels-last (models/onsetsframes.py:387-416) */
 int64_t amtx_conv3x3_packed_elems(int c_out, int planes);
 int amtx_conv3x3_pack(const float* host_w /*(c_out,32,3,3)*/, const float* host_scale /*[c_out] or null*/, int c_out, int planes,

@@ -912,3 +912,53 @@ def test_head_gemm_epilogues_return_the_bits_of_the_separate_kernels(tmp_path):
     for k in a.files:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     assert set(np.unique(a['of1_roll_' + tools.KEY_ONSETS])) <= {0.0, 1.0}
+
+
+_X3_SPLIT_AB = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd import tools
+from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
+from amt_tools_amd.synth import synth_state_dict
+outs = {}
+for name, cls, B, T in (('of1', OnsetsFrames, 3, 70), ('of1_big', OnsetsFrames, 9, 333), ('of2', OnsetsFrames2, 2, 45)):
+    sd = synth_state_dict(11, dim_in=229, in_channels=1, model_complexity=2, offsets=(cls is OnsetsFrames2))
+    model = cls(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision='x3')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    rng = np.random.default_rng(3)
+    feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32))
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_FEATS: feats})
+        lg = model.engine_logits(feats.cuda())
+    for k, v in out.items():
+        if torch.is_tensor(v):
+            outs[f'{name}_roll_{k}'] = v.cpu().numpy()
+    for k, v in lg.items():
+        outs[f'{name}_logit_{k}'] = v.cpu().numpy()
+np.savez(sys.argv[1], **outs)
+'''
+
+
+def test_x3_split_plane_activations_return_the_bits_of_the_fp32_activation_path(tmp_path):
+    """Round 5: in the x3 precision the dense layers' activations travel as two 16-bit planes written by the producing kernel's epilogue
+    (conv2 -> conv3 -> fc1 -> input projection; AMTX_T_SPLIT) and the GEMMs DMA them into LDS; AMTX_X3_NO_SPLIT=1 keeps round 4's fp32
+    activations, split by every consumer.  The planes are what the consumers computed themselves and the product order is the same, so
+    logits, rolls and offset probabilities must be IDENTICAL -- for batches whose GEMM rows are below and above one 256-row tile, with and
+    without the offset head."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('split', {}), ('fp32', {'AMTX_X3_NO_SPLIT': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _X3_SPLIT_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['split']), np.load(files['fp32'])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 12
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)

@@ -61,6 +61,52 @@ def test_linear(planes, m, n, k):
         assert (c.cpu() - ref2).abs().max().item() < 1e-3 * ref2.abs().max().item()
 
 
+SPLIT = 2
+
+
+@pytest.mark.parametrize('m,n,k', [(300, 512, 3648), (1000, 1024, 512), (777, 1024, 192), (256, 256, 64), (257, 88, 256), (64, 1024, 192), (5, 88, 512)])
+def test_linear_split_planes(m, n, k):
+    """The x3 precision's own activation format (round 5): A as two 16-bit planes (amtx_split_planes), two-plane weights.  Whole 256-column
+    tiles with M >= 256 run on the direct-to-LDS two-plane kernel (gemm_split_kernel), the rest on the generic kernel's split-A loader.
+    Checked against (1) a float64 product of the fp32 values -- fp32-class tolerance -- and (2) the fp32-A two-plane path
+    (amtx_linear_fwd, planes = 2) on the same values: the SAME BITS (same planes, same product order hi.hi, hi.lo, lo.hi per 32-deep step);
+    (3) the split C epilogue returns hi + lo == the fp32 C rounded the way split_bf16x2 does."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    bias = torch.randn(n, generator=g)
+    packed = np.zeros(L.amtx_linear_packed_elems(n, k, 2), dtype=np.uint16)
+    _lib.check(L.amtx_linear_pack(_lib.ptr(w.numpy()), n, k, 2, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    a_d, bias_d = a.cuda(), bias.cuda()
+    lda = k + 8
+    planes = torch.full((2, m, lda), 0x7fc0, dtype=torch.int16, device='cuda')          # NaN canaries in the pad columns: never read
+    _lib.check(L.amtx_split_planes(_lib.ptr(a_d), k, k, _lib.ptr(planes), lda, m * lda, m, _stream()), 'amtx_split_planes')
+    hi = (planes[0, :, :k].to(torch.int32) << 16).view(torch.float32)
+    lo = (planes[1, :, :k].to(torch.int32) << 16).view(torch.float32)
+    assert (hi + lo - a_d).abs().max().item() <= 2.0 ** -16 * a_d.abs().max().item()
+    ref = F.linear(a.double(), w.double(), bias.double()).float()
+    c32 = torch.zeros(m, n, device='cuda')
+    _lib.check(L.amtx_linear_fwd(_lib.ptr(a_d), k, F32, _lib.ptr(wp), 2, _lib.ptr(bias_d), _lib.ptr(c32), n, F32, m, n, k, _stream()))
+    ldc = n + 8
+    c = torch.zeros(m, ldc, device='cuda')
+    _lib.check(L.amtx_linear_fwd_split(_lib.ptr(planes), lda, m * lda, _lib.ptr(wp), _lib.ptr(bias_d), _lib.ptr(c), ldc, F32, 0, m, n, k, _stream()),
+               'amtx_linear_fwd_split')
+    assert (c[:, :n].cpu() - ref).abs().max().item() < _tol(2, ref.abs().max().item())
+    assert torch.equal(c[:, :n], c32), (c[:, :n] - c32).abs().max().item()
+    assert torch.all(c[:, n:] == 0)
+    if n % 4 == 0:                                                                     # both kernels have the two-plane C epilogue
+        cs = torch.zeros(2, m, ldc, dtype=torch.int16, device='cuda')
+        _lib.check(L.amtx_linear_fwd_split(_lib.ptr(planes), lda, m * lda, _lib.ptr(wp), _lib.ptr(bias_d), _lib.ptr(cs), ldc, SPLIT, m * ldc, m, n, k,
+                                           _stream()), 'amtx_linear_fwd_split (split C)')
+        chi = (cs[0, :, :n].to(torch.int32) << 16).view(torch.float32)
+        clo = (cs[1, :, :n].to(torch.int32) << 16).view(torch.float32)
+        assert torch.equal(chi, c32.bfloat16().float())                               # hi plane = round-to-nearest-even bf16 of the fp32 result
+        assert torch.equal(clo, (c32 - chi).bfloat16().float())
+        assert torch.all(cs[:, :, n:] == 0)
+
+
 def _conv_ref(x_btfc, w, scale, shift):
     """x (B,T,F,C) channels-last -> conv3x3 pad1 (no bias) * scale + shift -> ReLU -> MaxPool(1,2) -> (B,T,F/2,Co)."""
     x = x_btfc.permute(0, 3, 1, 2).double()

@@ -10,7 +10,8 @@ import bench
 from amt_tools_amd import tools, _lib
 from amt_tools_amd.synth import synth_clip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-model, mel, sd = bench.build_model('cuda:0', 'bf16')
+PREC = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+model, mel, sd = bench.build_model("cuda:0", PREC)
 base = np.stack([synth_clip(i) for i in range(4)])
 audio = torch.from_numpy(base).cuda().repeat((B + 3) // 4, 1)[:B].contiguous()
 L = C.CDLL(_lib.LIB_PATH)
