@@ -78,6 +78,8 @@ struct ConvArgs {
 int amtx_launch_conv3x3(const ConvArgs& c, hipStream_t stream);
 // convx.hip: the same layer (no fused first conv) on AMTX_T_SPLIT maps, two-plane weights: tiles DMA'd into a second LDS buffer under the matrix work
 int amtx_launch_convx3(const ConvArgs& c, hipStream_t stream);
+// convx.hip: conv.hip's fused first conv + 32 -> 32 layer (c_in = 1, two-plane weights) with a2 written as AMTX_T_SPLIT planes, two a1 tiles in LDS
+int amtx_launch_convx12(const ConvArgs& c, hipStream_t stream);
 size_t amtx_conv1_wfrag_elems(int c_in, int planes);
 // host packing of the fused first conv: weight (32, c_in, 3, 3) fp32 * scale[32] -> fragment order
 void amtx_conv1_pack_host(const float* w, const float* scale, int c_in, int planes, bf16_t* out);

@@ -850,6 +850,8 @@ int dispatch_types(const ConvArgs& a, hipStream_t s) {
             if (a.out_type == AMTX_T_SPLIT) {
                 if constexpr (NS == 2) {
                     AMTX_REQUIRE(a.out_split > 0 && a.out_split % 8 == 0, "conv3x3: two-plane output needs a plane stride");
+                    static const bool no_convx = getenv("AMTX_NO_CONVX") != nullptr;      // A/B switch, as below
+                    if (!no_convx && a.c_in == 1) return amtx_launch_convx12(a, s);
                     return launch_conv<2, NS, AMTX_T_F32, AMTX_T_SPLIT, true, 1>(a, s);
                 }
                 amtx_set_error("conv3x3: two-plane maps exist in the two-plane mode only");

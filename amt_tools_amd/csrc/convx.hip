@@ -153,20 +153,19 @@ __global__ __launch_bounds__(512) void convx3_kernel(ConvArgs a, int ft, int ntf
             x[BUF][cc][0] = *reinterpret_cast<const uint4*>(tb + off);                                     \
             x[BUF][cc][1] = *reinterpret_cast<const uint4*>(tb + XPLANE + off);                            \
         }
+        // per accumulator the order is conv.hip's (taps kw = 0, 1, 2, each hi.hi, hi.lo, lo.hi); the four accumulators (2 columns x NW
+        // tiles) take turns and the order is pinned, so that an MFMA never waits for the one or two issued right before it
 #define XROW(BUF, KH)                                                                                      \
-        _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                                   \
-            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                \
-                const int kw = cc - e;                                                                     \
-                if (kw < 0 || kw > 2) continue;                                                            \
-                _Pragma("unroll") for (int k = 0; k < NW; ++k) {                                           \
-                    acc[e][k] = mfma16(wf[(KH) * 3 + kw][k][0], x[BUF][cc][0], acc[e][k]);                 \
-                    acc[e][k] = mfma16(wf[(KH) * 3 + kw][k][0], x[BUF][cc][1], acc[e][k]);                 \
-                    acc[e][k] = mfma16(wf[(KH) * 3 + kw][k][1], x[BUF][cc][0], acc[e][k]);                 \
-                }                                                                                          \
+        _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                   \
+            _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) {                                             \
+                _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
+                    _Pragma("unroll") for (int k = 0; k < NW; ++k)                                         \
+                        acc[e][k] = mfma16(wf[(KH) * 3 + kw][k][pr == 2 ? 1 : 0], x[BUF][kw + e][pr == 1 ? 1 : 0], acc[e][k]); \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
             }
         // one pair whose first row is in ring slot B0: + shift (the accumulators' initial value), ReLU, MaxPool(1,2) over the (f, f + 1)
         // pair, the two planes of the result
-#define XPAIR(B0, JP, JNEXT)                                                                               \
+#define XPAIR(B0, JP, JNEXT, LAST)                                                                         \
         {                                                                                                  \
             f32x4_t acc[2][NW];                                                                            \
             _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                  \
@@ -182,6 +181,7 @@ __global__ __launch_bounds__(512) void convx3_kernel(ConvArgs a, int ft, int ntf
             XLOAD((B0) ^ 1, 0, JNEXT)                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             XROW(B0, 2)                                                                                    \
+            if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* see the end of the tile loop */  \
             const int fo = (tc.f0 >> 1) + (JP);                                                            \
             if (t < a.T && fo < Fo) {                                                                      \
                 uint32_t h[2 * NW], l[2 * NW];                                                             \
@@ -206,20 +206,333 @@ __global__ __launch_bounds__(512) void convx3_kernel(ConvArgs a, int ft, int ntf
             for (int pi = 0; pi < np; pi += 2) {
                 const int ja = pg + 4 * pi;
                 const int jb = min(ja + 4, npairs - 1), jc = min(ja + 8, npairs - 1);   // past the end: re-read a valid pair, never used
-                XPAIR(0, ja, jb)
+                XPAIR(0, ja, jb, pi + 1 >= np)
                 if (pi + 1 < np) {
-                    XPAIR(1, jb, jc)
+                    XPAIR(1, jb, jc, pi + 2 >= np)
                 }
             }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
 #undef XPAIR
 #undef XROW
 #undef XLOAD
-        // the next tile has landed (this wave's pieces: vmcnt; everybody's: the barrier) and everybody is done reading this one
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // The next tile has landed: every wave waited for its own pieces (vmcnt(0) in front of its LAST pair's stores -- the pieces were
+        // issued a whole tile of matrix work ago) and the barrier covers everybody's; everybody is done reading this tile.  The barrier
+        // waits for LDS traffic only: the last pair's global stores stay in flight across it (a __syncthreads() here waited for their
+        // acknowledgement, ~a quarter of the kernel's wave cycles at s_waitcnt / barrier in the PMC pass).
+        lds_only_barrier();
         cur ^= 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// layer1 + layer2 of a one-channel model in the two-plane mode: Conv(1 -> 32) + BN + ReLU computed into the LDS input tile of
+// Conv(32 -> 32) + BN + ReLU + MaxPool(1,2) (conv.hip's fused kernel, KS == 1), a2 written as AMTX_T_SPLIT planes.
+//
+// conv.hip's version is one wave per SIMD (208 weight registers) and three phases per tile separated by barriers: with 1 wave per
+// SIMD the first conv -- 3 % of the flops, but ~200 vector instructions per 64 positions (hi / lo splits of its operands and of its
+// 2048 results) around a dependent read -> convert -> MFMA -> convert -> write chain -- is 40 % of a tile and the matrix pipe idles
+// through it (tools/conv_phase_prof.py: 10 850 of 27 100 cycles).  Here:
+//   * EIGHT waves, wave = (pair group pg = wave >> 1, channel half ch = wave & 1): a wave holds its 16 output channels' weights of
+//     both layers (72 + 32 registers) -> two waves per SIMD;
+//   * TWO a1 tiles in LDS (16 x 24 outputs: 18 x 26 positions x 32 channels x 2 planes = 33 KB per plane, position-major, pitch 29):
+//     per iteration a wave runs layer2 of tile k out of one buffer and layer1 of tile k + 1 into the other, ONE barrier per tile;
+//   * the two waves of a SIMD run the two kinds of work in OPPOSITE order (waves 0 - 3: layer1 then layer2, waves 4 - 7: layer2
+//     then layer1), so one wave's conversions sit beside the other's matrix work;
+//   * features of tile k + 2 are loaded at the top of an iteration and dB-scaled + stored to LDS at its end.
+// Same arithmetic as conv.hip's kernel (Toeplitz first conv, the same fragments, tap order and product order): identical bits.
+constexpr int YFT = 24;                         // output columns per tile
+constexpr int YP = 29;                          // a1 tile pitch in positions (>= YFT + 2, = 1 mod 4)
+constexpr int YPLANE = XROWS * YP * 64;         // 33 408 bytes
+constexpr int YBUF = 2 * YPLANE;
+constexpr int YFROWS = XROWS + 2;               // feature rows of a tile
+constexpr int YFW = 40;                         // feature row pitch in 16-bit values: 80 bytes -> 16 consecutive rows on 16 distinct 8-byte slots of a bank row
+constexpr int YFPLANE = (YFROWS * YFW + 16) * 2;   // one 16-bit plane of a feature tile (+ slack for the 8-value reads of the last unit)
+constexpr int YFEAT = 2 * YFPLANE;              // hi | lo: the features are split ONCE, when they are staged (layer1's two channel halves
+                                                // and its overlapping 8-value windows would otherwise each convert them again)
+constexpr int YFPRE = 2;                        // feature values per thread and tile (20 x 28 = 560 <= 1024)
+constexpr int YLDS = 2 * YBUF + 2 * YFEAT + 2 * 512 * 8;   // + one 8-byte scratch slot per thread and plane for masked stores
+
+// Chunk swizzle of the a1 tile: layer1's lanes run along ROWS (16 rows of one column and chunk per ds_write_b64 lane group; LDS stores bank
+// mod 128 bytes), layer2's fragment reads take rows r .. r + 15 of one column (ds_read_b128, mod 256 bytes).  (i >> 1) & 3 keeps the reads
+// conflict-free for every tap row and makes the stores 2-way (xswz: 4-way, 36 % of this kernel's LDS cycles; tools/lds_swizzle_check_convx.py).
+__device__ __forceinline__ int yswz(int i) { return (i >> 1) & 3; }
+
+__global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int ntf, int ntt, int ntiles, int inv_fcols) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][a1 hi | a1 lo] | [2] feature tiles | scratch
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ch = wave & 1, pg = wave >> 1;
+    const bool early = wave < 4;                                  // waves w and w + 4 share a SIMD
+    const int grp = blockIdx.y;
+    const int g = lane >> 4, trow = lane & 15, n16 = lane & 15;
+    const int Fo = a.F >> 1;
+    const int cols = ft + 2, fcols = ft + 4;
+
+    // ---- stationary weights of this wave's 16 channels: layer2 (9 taps x 2 planes), layer1's Toeplitz fragments (4 columns x 2 planes)
+    uint4 wf[9][2], w1t[4][2];
+    {
+        const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) wf[tap][p] = w[((tap * 2 + ch) * 2 + p) * 64];
+        const uint4* wp = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) w1t[q][p] = wp[((q * 2 + ch) * 2 + p) * 64];
+    }
+    const int c0 = g * 8 + 4 * ch;                                // this lane's first channel (of both layers)
+    f32x4_t shr, sh1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        shr[r] = a.shift[(int64_t)grp * a.shift_gs + c0 + r];
+        sh1[r] = a.shift1[(int64_t)grp * 32 + c0 + r];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) xsettle(wf[tap][p]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) xsettle(w1t[q][p]);
+
+    char* feat0 = smem + 2 * YBUF;
+    char* scratch = smem + 2 * YBUF + 2 * YFEAT + tid * 8;
+    // feature columns past the staged ones are only ever multiplied by zero weights but must hold finite values (NaN x 0 is NaN): zero
+    // both tiles once (the staged cells are rewritten per tile)
+    for (int i = tid; i < 2 * YFEAT / 4; i += 512) reinterpret_cast<float*>(feat0)[i] = 0.f;
+    __syncthreads();
+
+    // ---- feature staging: cells it = tid + 512 n of the 20 x fcols tile; issue -> registers, (dB scaling +) store later
+    float fpre[YFPRE];
+    float fown = 0.f, fref = 0.f;
+    auto feat_issue = [&](const XTile& tc) {
+        const float* fb = a.feats + (int64_t)tc.b * a.f_stride_b;
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+#pragma unroll
+        for (int n = 0; n < YFPRE; ++n) {
+            const int it = tid_l + 512 * n;
+            const int fi = (it * inv_fcols) >> 16, fj = it - fi * fcols;      // it / fcols, exact for it < 1024 (checked at launch)
+            const int t = tc.t0 - 2 + fi, f = tc.f0 - 2 + fj;
+            fpre[n] = a.f_clip_max ? -1.f : 0.f;                  // power is never negative: -1 marks the zero padding
+            if (it < YFROWS * fcols && (unsigned)t < (unsigned)a.T && (unsigned)f < (unsigned)a.F) fpre[n] = fb[(int64_t)t * a.f_stride_t + f * a.f_stride_f];
+        }
+        if (a.f_clip_max) {
+            fown = a.f_clip_max[tc.b];
+            fref = a.f_ref ? a.f_ref[tc.b] : fown;
+        }
+    };
+    auto feat_store = [&](int buf) {
+        bf16_t* ftile = reinterpret_cast<bf16_t*>(feat0 + buf * YFEAT);
+        DbScale dbs = {0.f, 0.f};
+        if (a.f_clip_max) dbs = db_scale_make(fown, fref);
+        int tid_l = tid;
+        asm volatile("" : "+v"(tid_l));
+#pragma unroll
+        for (int n = 0; n < YFPRE; ++n) {
+            const int it = tid_l + 512 * n;
+            const int fi = (it * inv_fcols) >> 16, fj = it - fi * fcols;
+            float v = fpre[n];
+            if (a.f_clip_max) {
+                const float sv = db_scale_apply(v, dbs);
+                v = v < 0.f ? 0.f : sv;
+            }
+            uint32_t h, l;
+            split_bf16x2(v, 0.f, h, l);               // the conversion layer1 applied to its B operand
+            if (it < YFROWS * fcols) {
+                ftile[fi * YFW + fj] = (bf16_t)h;
+                ftile[YFPLANE / 2 + fi * YFW + fj] = (bf16_t)l;
+            }
+        }
+    };
+
+    // ---- layer1 of one tile: units u = pg, pg + 4 of the 7 main units (16 rows x 4 columns) + the halo unit (rows 16 - 17 x 8 column
+    // blocks); this wave's 16 channels.  See conv.hip (KS == 1) for the Toeplitz form.
+    const int nmain = (cols + 3) >> 2;
+    const int nunits = nmain + 1;
+    const int gg = min(g, 2);                                     // k-group 3 has zero weights: re-read group 2's row
+    const int fa_main = (n16 + gg) * YFW * 2;
+    const int fa_halo = ((XT + (n16 & 1) + gg) * YFW + 4 * (n16 >> 1)) * 2;
+    const int oa_main = (n16 * YP * 4 + (g ^ yswz(n16))) * 16 + ch * 8;
+    const int hrow = XT + (n16 & 1);
+    const int oa_halo = ((hrow * YP + 4 * (n16 >> 1)) * 4 + (g ^ yswz(hrow))) * 16 + ch * 8;
+    auto layer1 = [&](const XTile& tc, int buf) {
+        const char* fbytes = feat0 + buf * YFEAT;
+        char* ob = smem + buf * YBUF;
+        const bool interior = tc.t0 >= 1 && tc.t0 + XT < a.T && tc.f0 >= 1 && tc.f0 + ft < a.F;   // no position of the tile is padding
+        for (int u = pg; u < nunits; u += 4) {
+            const bool mainu = u < nmain;                                                              // scalar
+            // B operand of lane (row n, k-group g): 8 consecutive staged values of feature row n + g from column 4 u, both planes (8-byte aligned)
+            const int fa = mainu ? fa_main + u * 8 : fa_halo;
+            const uint2 h0 = *reinterpret_cast<const uint2*>(fbytes + fa), h1 = *reinterpret_cast<const uint2*>(fbytes + fa + 8);
+            const uint2 l0 = *reinterpret_cast<const uint2*>(fbytes + YFPLANE + fa), l1 = *reinterpret_cast<const uint2*>(fbytes + YFPLANE + fa + 8);
+            const uint4 bh = make_uint4(h0.x, h0.y, h1.x, h1.y), bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            f32x4_t acc1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc1[q] = mfma16(w1t[q][0], bh, sh1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc1[q] = mfma16(w1t[q][0], bl, acc1[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc1[q] = mfma16(w1t[q][1], bh, acc1[q]);
+            const int oa = mainu ? oa_main + u * 256 : oa_halo;
+            const bool fast = __builtin_amdgcn_readfirstlane((int)(interior && mainu)) != 0;
+            if (fast) {
+                // no position of this unit is padding (columns past the tile's last one land in the row's pad cells, which nobody reads)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t h0, h1, l0, l1;
+                    split_bf16x2(fmaxf(acc1[q][0], 0.f), fmaxf(acc1[q][1], 0.f), h0, l0);
+                    split_bf16x2(fmaxf(acc1[q][2], 0.f), fmaxf(acc1[q][3], 0.f), h1, l1);
+                    *reinterpret_cast<uint2*>(ob + oa + q * 64) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(ob + YPLANE + oa + q * 64) = make_uint2(l0, l1);
+                }
+            } else {
+                // border tiles and the halo-row unit: branch-free per-lane padding (ReLU and the zero padding of the map in one v_med3
+                // against inf / 0); positions past the tile's last column go to a scratch slot
+                const int jl = mainu ? 4 * u : 4 * (n16 >> 1);
+                const int tl = tc.t0 - 1 + (mainu ? n16 : hrow);
+                const bool row_ok = (unsigned)tl < (unsigned)a.T;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = row_ok && (unsigned)(tc.f0 - 1 + jl + q) < (unsigned)a.F;
+                    const float lim = ok ? __builtin_inff() : 0.f;
+                    uint32_t h0, h1, l0, l1;
+                    split_bf16x2(__builtin_amdgcn_fmed3f(acc1[q][0], 0.f, lim), __builtin_amdgcn_fmed3f(acc1[q][1], 0.f, lim), h0, l0);
+                    split_bf16x2(__builtin_amdgcn_fmed3f(acc1[q][2], 0.f, lim), __builtin_amdgcn_fmed3f(acc1[q][3], 0.f, lim), h1, l1);
+                    const bool in_tile = jl + q < YP - 1;
+                    *reinterpret_cast<uint2*>(in_tile ? ob + oa + q * 64 : scratch) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(in_tile ? ob + YPLANE + oa + q * 64 : scratch + 4096) = make_uint2(l0, l1);
+                }
+            }
+        }
+    };
+
+    // ---- layer2 of one tile: pairs jp = pg, pg + 4, ... of this tile, this wave's 16 channels, fragment rows through a two-row ring
+    int rbase[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) rbase[kh] = ((trow + kh) * YP * 4 + (g ^ yswz(trow + kh))) * 16;
+    auto layer2 = [&](const XTile& tc, int buf) {
+        const char* tb = smem + buf * YBUF;
+        const int t = tc.t0 + trow;
+        // clip base (wave-uniform) + a 32-bit element offset per lane: one clip's map is T x F / 2 x 32 < 2^31 elements
+        bf16_t* out = reinterpret_cast<bf16_t*>(a.out) + (int64_t)grp * a.out_gs + (int64_t)tc.b * a.T * Fo * 32;
+        bf16_t* out_lo = out + a.out_split;
+        const unsigned orow = (unsigned)((t * Fo + (tc.f0 >> 1)) * 32 + c0);
+        const int npairs = min(ft, ((a.F + 1) & ~1) - tc.f0) >> 1;
+        const int np = pg < npairs ? (npairs - pg + 3) >> 2 : 0;
+        uint4 x[2][4][2];
+#define YLOAD(BUF, KH, JP)                                                                                 \
+        _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) {                                                 \
+            const int off = rbase[KH] + (2 * (JP) + cc) * 64;                                              \
+            x[BUF][cc][0] = *reinterpret_cast<const uint4*>(tb + off);                                     \
+            x[BUF][cc][1] = *reinterpret_cast<const uint4*>(tb + YPLANE + off);                            \
+        }
+        // per accumulator (e = 0 / 1: the two columns of the pair) the order is conv.hip's -- taps kw = 0, 1, 2, each hi.hi, hi.lo, lo.hi -- but
+        // the two accumulators' chains are interleaved, so that an MFMA never waits for the one issued right before it
+#define YROW(BUF, KH)                                                                                      \
+        _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                   \
+            _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                               \
+                _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
+                    acc[e] = mfma16(wf[(KH) * 3 + kw][pr == 2 ? 1 : 0], x[BUF][kw + e][pr == 1 ? 1 : 0], acc[e]);
+#define YPAIR(B0, JP, JNEXT)                                                                               \
+        {                                                                                                  \
+            f32x4_t acc[2] = {shr, shr};                                                                   \
+            YLOAD((B0) ^ 1, 1, JP)                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            YROW(B0, 0)                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            YLOAD(B0, 2, JP)                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            YROW((B0) ^ 1, 1)                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            YLOAD((B0) ^ 1, 0, JNEXT)                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            YROW(B0, 2)                                                                                    \
+            const int fo = (tc.f0 >> 1) + (JP);                                                            \
+            if (t < a.T && fo < Fo) {                                                                      \
+                uint32_t h0, h1, l0, l1;                                                                   \
+                split_bf16x2(fmaxf(fmaxf(acc[0][0], acc[1][0]), 0.f), fmaxf(fmaxf(acc[0][1], acc[1][1]), 0.f), h0, l0); \
+                split_bf16x2(fmaxf(fmaxf(acc[0][2], acc[1][2]), 0.f), fmaxf(fmaxf(acc[0][3], acc[1][3]), 0.f), h1, l1); \
+                const unsigned eo = orow + (unsigned)(JP) * 32u;                                           \
+                *reinterpret_cast<uint2*>(out + eo) = make_uint2(h0, h1);                                  \
+                *reinterpret_cast<uint2*>(out_lo + eo) = make_uint2(l0, l1);                               \
+            }                                                                                              \
+        }
+        if (np > 0) {
+            YLOAD(0, 0, pg)
+            for (int pi = 0; pi < np; pi += 2) {
+                const int ja = pg + 4 * pi;
+                const int jb = min(ja + 4, npairs - 1), jc = min(ja + 8, npairs - 1);
+                YPAIR(0, ja, jb)
+                if (pi + 1 < np) {
+                    YPAIR(1, jb, jc)
+                }
+            }
+        }
+#undef YPAIR
+#undef YROW
+#undef YLOAD
+    };
+
+    // ---- prologue: features of the first two tiles, layer1 of the first
+    const int G = (int)gridDim.x;
+    int tile = blockIdx.x;
+    if (tile < ntiles) {
+        feat_issue(xtile(tile, ntf, ntt, ft, ntiles));
+        feat_store(0);
+    }
+    if (tile + G < ntiles) {
+        feat_issue(xtile(tile + G, ntf, ntt, ft, ntiles));
+        feat_store(1);
+    }
+    __syncthreads();
+    if (tile < ntiles) layer1(xtile(tile, ntf, ntt, ft, ntiles), 0);
+    __syncthreads();
+
+    int cur = 0;
+    for (; tile < ntiles; tile += G) {
+        const XTile tc = xtile(tile, ntf, ntt, ft, ntiles);
+        const bool has1 = tile + G < ntiles, has2 = tile + 2 * G < ntiles;
+        const XTile t1 = xtile(has1 ? tile + G : tile, ntf, ntt, ft, ntiles);
+        if (has2) feat_issue(xtile(tile + 2 * G, ntf, ntt, ft, ntiles));
+        if (early) {
+            if (has1) layer1(t1, cur ^ 1);
+            layer2(tc, cur);
+        } else {
+            layer2(tc, cur);
+            if (has1) layer1(t1, cur ^ 1);
+        }
+        if (has2) feat_store(cur);                    // tile k's features were consumed an iteration ago
+        lds_only_barrier();                           // LDS traffic only: the a2 stores stay in flight across it
+        cur ^= 1;
+    }
+}
+
+int launch_x12(const ConvArgs& a, hipStream_t stream) {
+    const int fe = (a.F + 1) & ~1;
+    const int ntf = (fe + YFT - 1) / YFT;
+    const int ft = 2 * (((fe >> 1) + ntf - 1) / ntf);
+    const int ntt = (a.T + XT - 1) / XT;
+    const int64_t nblocks = (int64_t)ntf * ntt * a.B;
+    AMTX_REQUIRE(nblocks < (1ll << 31), "convx12: grid too large");
+    auto kern = convx12_kernel;
+    AMTX_GRANT_LDS(kern, YLDS);
+    int64_t gx = std::max<int64_t>(8, 256 / std::max(1, a.groups) / 8 * 8);
+    if (gx > nblocks) gx = nblocks;
+    const int fcols = ft + 4, inv_fcols = 65536 / fcols + 1;
+    for (int it = 0; it < YFPRE * 512; ++it)
+        if (((it * inv_fcols) >> 16) != it / fcols) {
+            amtx_set_error("convx12: internal: reciprocal division inexact for fcols=%d", fcols);
+            return AMTX_ERR_ARG;
+        }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(512), YLDS, stream, a, ft, ntf, ntt, (int)nblocks, inv_fcols);
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
 }
 
 template <int NT>
@@ -243,6 +556,14 @@ int launch_x3(const ConvArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// fused layer1 + layer2 of a one-channel model, two-plane weights, a2 as AMTX_T_SPLIT planes (ConvArgs as for conv.hip's fused kernel)
+int amtx_launch_convx12(const ConvArgs& a, hipStream_t stream) {
+    AMTX_REQUIRE(a.feats && a.w1frag && a.shift1 && a.wfrag && a.shift && a.out && a.c_in == 1 && a.c_out == 32 && a.planes == 2 && a.out_type == AMTX_T_SPLIT,
+                 "convx12: one input channel, 32 -> 32 channels, two-plane weights and maps only");
+    AMTX_REQUIRE(a.out_split > 0 && a.out_split % 8 == 0 && ((uintptr_t)a.out % 16) == 0, "convx12: planes must be 16-byte aligned");
+    return launch_x12(a, stream);
+}
 
 // 32 -> c_out channels on AMTX_T_SPLIT maps; the caller (amtx_launch_conv3x3) has checked pointers, sizes and plane strides
 int amtx_launch_convx3(const ConvArgs& a, hipStream_t stream) {

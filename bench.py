@@ -360,18 +360,43 @@ def parity_leg(model, audio, out_bf16, device, oracle_rolls):
     (computed by the cpu_baseline leg).  SURVEY F8: on thresholded outputs the mismatch count IS the parity metric."""
     from amt_tools_amd import tools
     res = {}
-    Bx = min(512, audio.shape[0])      # the x3 mode's rate is flat from 512 clips per step (128: 9.7, 512: 11.6, 1024: 11.7 M frames/s)
+    # the mode that is INSIDE north_star's 1e-4 runs the headline batch itself (round 5: two-plane activations, DMA GEMMs, convx.hip) with
+    # its own stage timers and roofline block: three bf16 MFMAs per fp32-class product -> its matrix roof is 2.5 PFLOP/s / 3
+    Bx = audio.shape[0]
     mx, _, _ = build_model(device, 'x3')
     bx = {tools.KEY_AUDIO: audio[:Bx]}
+    from amt_tools_amd import _lib
+    L = _lib.lib()
     with torch.no_grad():
         ox = mx.run_on_batch(bx)
+        ox = mx.run_on_batch(bx)
         torch.cuda.synchronize()
+        engx = mx._get_engine(torch.device(device))
+        _lib.check(L.amtx_of_profile_enable(engx.handle, 1))
+        nx = 5
         t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(nx):
             ox = mx.run_on_batch(bx)
         torch.cuda.synchronize()
-        res['x3_frames_per_s'] = 3 * Bx * CLIP_FRAMES / (time.perf_counter() - t0)
-        res['x3_clips_per_step'] = Bx
+        dtx = (time.perf_counter() - t0) / nx
+        stage_ms = (C.c_double * L.amtx_of_num_stages())()
+        nfw = C.c_int(0)
+        _lib.check(L.amtx_of_profile_read(engx.handle, stage_ms, C.byref(nfw)))
+        _lib.check(L.amtx_of_profile_enable(engx.handle, 0))
+    res['x3_frames_per_s'] = Bx * CLIP_FRAMES / dtx
+    res['x3_clips_per_step'] = Bx
+    plx = {L.amtx_of_stage_name(i).decode(): stage_ms[i] / max(1, nfw.value) for i in range(L.amtx_of_num_stages())}
+    domx = max((k for k in plx if k in STAGE_FLOPS), key=plx.get)
+    peak3 = PEAK_MFMA_BF16_TFLOPS / 3.0
+    achx = STAGE_FLOPS[domx] * Bx * CLIP_FRAMES / (plx[domx] * 1e-3) / 1e12
+    res['x3'] = {
+        'frames_per_s': res['x3_frames_per_s'], 'ms_per_step': dtx * 1e3, 'clips_per_step': Bx, 'dtype': 'bf16x3',
+        'whole_path_frac_of_its_mfma_roof': res['x3_frames_per_s'] * MODEL_FLOPS_PER_FRAME / (2.5e15 / 3.0),
+        'roofline': {'kernel': domx, 'bound': 'mfma', 'achieved': achx, 'peak': peak3, 'unit': 'TFLOP/s', 'frac': achx / peak3, 'traffic': None,
+                     'avg_launch_ms': plx[domx], 'kernel_ms_per_step': {k: round(v, 4) for k, v in sorted(plx.items(), key=lambda kv: -kv[1])},
+                     'note': 'achieved = fp32-class algorithmic flops of the stage (SURVEY 8d) / its HIP-event time (front-end kernels not in this '
+                             'table); peak = dense bf16 MFMA peak / 3: every product is hi.hi + hi.lo + lo.hi'},
+    }
     nd = min(8, Bx)       # clips compared with the x3 mode / the CPU oracle (the oracle leg keeps the first 8 of the 64 distinct clips)
     # every clip of the batch against the distinct clip it is a copy of: a block- or tail-dependent indexing error in any kernel of the
     # 1024-clip run would show here (clips 0 .. 7 alone are block 0 of most grids)
@@ -445,7 +470,7 @@ def parity_leg(model, audio, out_bf16, device, oracle_rolls):
              'max_abs_logit_err_vs_cpu_oracle': errs['bf16']},
             {'mode': 'f16', 'frames_per_s': res['f16_frames_per_s'], 'cell_mismatch_rate_vs_cpu_oracle': res['f16_cell_mismatch_rate_vs_cpu_oracle'],
              'max_abs_logit_err_vs_cpu_oracle': errs['f16']},
-            {'mode': 'x3 (meets 1e-4)', 'frames_per_s': res['x3_frames_per_s'], 'cell_mismatch_rate_vs_cpu_oracle': res.get('x3_cell_mismatch_rate_vs_cpu_oracle'),
+            {'mode': 'x3 (meets 1e-4)', 'clips_per_step': res['x3_clips_per_step'], 'frames_per_s': res['x3_frames_per_s'], 'cell_mismatch_rate_vs_cpu_oracle': res.get('x3_cell_mismatch_rate_vs_cpu_oracle'),
              'max_abs_logit_err_vs_cpu_oracle': res.get('x3_max_abs_logit_err_vs_cpu_oracle')}]
     del mf
     return res
