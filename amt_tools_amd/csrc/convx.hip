@@ -50,6 +50,15 @@ __device__ __forceinline__ XTile xtile(int tile, int ntf, int ntt, int ft, int n
     return c;
 }
 
+// 8 floats -> the two 16-bit planes (split_bf16x2 pairwise: conv.hip's cvt8)
+__device__ __forceinline__ void xcvt8(const float (&f)[8], uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_bf16x2(f[2 * i], f[2 * i + 1], h[i], l[i]);
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 __device__ __forceinline__ void xsettle(const uint4& v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 
 // C_in = 32 -> C_out = 16 NT; in [2 planes][B][T][F][32], out [2 planes][B][T][F / 2][C_out] (channels-last, planes in_split / out_split apart).
@@ -230,17 +239,19 @@ __global__ __launch_bounds__(512) void convx3_kernel(ConvArgs a, int ft, int ntf
 // layer1 + layer2 of a one-channel model in the two-plane mode: Conv(1 -> 32) + BN + ReLU computed into the LDS input tile of
 // Conv(32 -> 32) + BN + ReLU + MaxPool(1,2) (conv.hip's fused kernel, KS == 1), a2 written as AMTX_T_SPLIT planes.
 //
-// conv.hip's version is one wave per SIMD (208 weight registers) and three phases per tile separated by barriers: with 1 wave per
-// SIMD the first conv -- 3 % of the flops, but ~200 vector instructions per 64 positions (hi / lo splits of its operands and of its
-// 2048 results) around a dependent read -> convert -> MFMA -> convert -> write chain -- is 40 % of a tile and the matrix pipe idles
-// through it (tools/conv_phase_prof.py: 10 850 of 27 100 cycles).  Here:
-//   * EIGHT waves, wave = (pair group pg = wave >> 1, channel half ch = wave & 1): a wave holds its 16 output channels' weights of
-//     both layers (72 + 32 registers) -> two waves per SIMD;
-//   * TWO a1 tiles in LDS (16 x 24 outputs: 18 x 26 positions x 32 channels x 2 planes = 33 KB per plane, position-major, pitch 29):
-//     per iteration a wave runs layer2 of tile k out of one buffer and layer1 of tile k + 1 into the other, ONE barrier per tile;
-//   * the two waves of a SIMD run the two kinds of work in OPPOSITE order (waves 0 - 3: layer1 then layer2, waves 4 - 7: layer2
-//     then layer1), so one wave's conversions sit beside the other's matrix work;
-//   * features of tile k + 2 are loaded at the top of an iteration and dB-scaled + stored to LDS at its end.
+// conv.hip's version is one wave per SIMD (208 weight registers) and three phases per tile separated by barriers: the first conv --
+// 3 % of the flops, but ~200 vector instructions per 64 positions (hi / lo splits of its operands and of its 2048 results) around a
+// dependent read -> convert -> MFMA -> convert -> write chain -- is 40 % of a tile and the matrix pipe idles through it
+// (tools/conv_phase_prof.py: 10 850 of 27 100 cycles).  Here the block is WAVE-SPECIALISED BY LAYER, as convf.hip is for the one-plane modes:
+//   * waves 0 - 3 ("layer2 waves", one per SIMD) hold layer2's 144 weight registers and do nothing but its matrix loop: pairs w, w + 4, ..
+//     of tile k out of one of TWO a1 tiles in LDS (16 x 24 outputs: 18 x 26 positions x 32 channels, 33 KB per plane, position-major, pitch 29);
+//   * waves 4 - 7 ("layer1 waves", the other wave of every SIMD) stage the features of tile k + 2 (split into the two 16-bit planes ONCE, at
+//     the store), run layer1 of tile k + 1 into the OTHER a1 tile (Toeplitz product, conv.hip) and convert its results -- vector work that
+//     issues beside the layer2 wave's MFMAs instead of in front of them;
+//   * ONE barrier per tile.  A first version that gave every wave both layers' work for half the channels ran at conv.hip's speed (8.5 - 8.9
+//     against 9.1 ms per 512 clips): matrix time and vector time of a wave ADD, whatever the partner does (measured by switching parts off:
+//     layer2 alone 6.6 ms -- 5.65 without its reads and epilogue --, layer1 2.0, staging 0.7).
+// Both roles index ONE weight-register array (a kernel's waves share one register allocation: two arrays would not fit 256).
 // Same arithmetic as conv.hip's kernel (Toeplitz first conv, the same fragments, tap order and product order): identical bits.
 constexpr int YFT = 24;                         // output columns per tile
 constexpr int YP = 29;                          // a1 tile pitch in positions (>= YFT + 2, = 1 mod 4)
@@ -249,74 +260,61 @@ constexpr int YBUF = 2 * YPLANE;
 constexpr int YFROWS = XROWS + 2;               // feature rows of a tile
 constexpr int YFW = 40;                         // feature row pitch in 16-bit values: 80 bytes -> 16 consecutive rows on 16 distinct 8-byte slots of a bank row
 constexpr int YFPLANE = (YFROWS * YFW + 16) * 2;   // one 16-bit plane of a feature tile (+ slack for the 8-value reads of the last unit)
-constexpr int YFEAT = 2 * YFPLANE;              // hi | lo: the features are split ONCE, when they are staged (layer1's two channel halves
-                                                // and its overlapping 8-value windows would otherwise each convert them again)
-constexpr int YFPRE = 2;                        // feature values per thread and tile (20 x 28 = 560 <= 1024)
-constexpr int YLDS = 2 * YBUF + 2 * YFEAT + 2 * 512 * 8;   // + one 8-byte scratch slot per thread and plane for masked stores
+constexpr int YFEAT = 2 * YFPLANE;              // hi | lo: the features are split ONCE, when they are staged (layer1's overlapping 8-value
+                                                // windows would otherwise each convert them again)
+constexpr int YFPRE = 3;                        // feature values per layer1-wave thread and tile (20 x 28 = 560 <= 768)
+constexpr int YLDS = 2 * YBUF + 2 * YFEAT + 2 * 256 * 16 + 256;   // + one 16-byte scratch slot per layer1 thread and plane for masked stores + the shift tables
 
-// Chunk swizzle of the a1 tile: layer1's lanes run along ROWS (16 rows of one column and chunk per ds_write_b64 lane group; LDS stores bank
+// Chunk swizzle of the a1 tile: layer1's lanes run along ROWS (8 rows of one column and chunk per ds_write_b128 lane group; LDS stores bank
 // mod 128 bytes), layer2's fragment reads take rows r .. r + 15 of one column (ds_read_b128, mod 256 bytes).  (i >> 1) & 3 keeps the reads
-// conflict-free for every tap row and makes the stores 2-way (xswz: 4-way, 36 % of this kernel's LDS cycles; tools/lds_swizzle_check_convx.py).
+// conflict-free for every tap row and the stores conflict-free too (xswz: 4-way stores; tools/lds_swizzle_check_convx.py).
 __device__ __forceinline__ int yswz(int i) { return (i >> 1) & 3; }
 
 __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int ntf, int ntt, int ntiles, int inv_fcols) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][a1 hi | a1 lo] | [2] feature tiles | scratch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ch = wave & 1, pg = wave >> 1;
-    const bool early = wave < 4;                                  // waves w and w + 4 share a SIMD
+    const bool l2role = wave < 4;                                 // waves w and w + 4 share a SIMD: one of each role
+    const int wq = wave & 3;                                      // index inside the role
     const int grp = blockIdx.y;
-    const int g = lane >> 4, trow = lane & 15, n16 = lane & 15;
+    const int g = lane >> 4, trow = lane & 15;
     const int Fo = a.F >> 1;
     const int cols = ft + 2, fcols = ft + 4;
 
-    // ---- stationary weights of this wave's 16 channels: layer2 (9 taps x 2 planes), layer1's Toeplitz fragments (4 columns x 2 planes)
-    uint4 wf[9][2], w1t[4][2];
+    // ---- stationary weights, ONE array for both roles: layer2's 9 taps x 2 tiles x 2 planes (36 fragments), or layer1's Toeplitz fragments
+    // (4 columns x 2 tiles x 2 planes = the first 16)
+    uint4 wreg[36];
     {
-        const uint4* w = reinterpret_cast<const uint4*>(a.wfrag + (int64_t)grp * a.w_gs) + lane;
+        const uint4* w = reinterpret_cast<const uint4*>(l2role ? a.wfrag + (int64_t)grp * a.w_gs : a.w1frag + (int64_t)grp * a.w1_gs) + lane;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) wf[tap][p] = w[((tap * 2 + ch) * 2 + p) * 64];
-        const uint4* wp = reinterpret_cast<const uint4*>(a.w1frag + (int64_t)grp * a.w1_gs) + lane;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) w1t[q][p] = wp[((q * 2 + ch) * 2 + p) * 64];
+        for (int i = 0; i < 36; ++i) wreg[i] = w[(l2role || i < 16 ? i : 0) * 64];
     }
-    const int c0 = g * 8 + 4 * ch;                                // this lane's first channel (of both layers)
-    f32x4_t shr, sh1;
+    const int c0 = g * 8;                                         // this lane's first channel (of both layers)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        shr[r] = a.shift[(int64_t)grp * a.shift_gs + c0 + r];
-        sh1[r] = a.shift1[(int64_t)grp * 32 + c0 + r];
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) xsettle(wf[tap][p]);
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) xsettle(w1t[q][p]);
+    for (int i = 0; i < 36; ++i) xsettle(wreg[i]);
+    // the folded BatchNorm shifts (the accumulators' initial values) live in LDS: 8 registers per lane are what this kernel does not have
+    float* shtab = reinterpret_cast<float*>(smem + YLDS - 256);                 // [layer2's 32 | layer1's 32]
+    if (tid < 64) shtab[tid] = tid < 32 ? a.shift[(int64_t)grp * a.shift_gs + tid] : a.shift1[(int64_t)grp * 32 + tid - 32];
+    const f32x4_t* sh = reinterpret_cast<const f32x4_t*>(shtab + (l2role ? 0 : 32) + c0);   // sh[k]: channels c0 + 4 k ..
 
     char* feat0 = smem + 2 * YBUF;
-    char* scratch = smem + 2 * YBUF + 2 * YFEAT + tid * 8;
+    const int ltid = tid & 255;                                   // thread index inside the layer1 half
+    char* scratch = smem + 2 * YBUF + 2 * YFEAT + ltid * 16;
     // feature columns past the staged ones are only ever multiplied by zero weights but must hold finite values (NaN x 0 is NaN): zero
     // both tiles once (the staged cells are rewritten per tile)
     for (int i = tid; i < 2 * YFEAT / 4; i += 512) reinterpret_cast<float*>(feat0)[i] = 0.f;
     __syncthreads();
 
-    // ---- feature staging: cells it = tid + 512 n of the 20 x fcols tile; issue -> registers, (dB scaling +) store later
+    // ---- feature staging (layer1 waves): cells it = ltid + 256 n of the 20 x fcols tile; issue -> registers, (dB scaling +) split + store later
     float fpre[YFPRE];
     float fown = 0.f, fref = 0.f;
     auto feat_issue = [&](const XTile& tc) {
         const float* fb = a.feats + (int64_t)tc.b * a.f_stride_b;
-        int tid_l = tid;
+        int tid_l = ltid;
         asm volatile("" : "+v"(tid_l));
 #pragma unroll
         for (int n = 0; n < YFPRE; ++n) {
-            const int it = tid_l + 512 * n;
+            const int it = tid_l + 256 * n;
             const int fi = (it * inv_fcols) >> 16, fj = it - fi * fcols;      // it / fcols, exact for it < 1024 (checked at launch)
             const int t = tc.t0 - 2 + fi, f = tc.f0 - 2 + fj;
             fpre[n] = a.f_clip_max ? -1.f : 0.f;                  // power is never negative: -1 marks the zero padding
@@ -331,11 +329,11 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         bf16_t* ftile = reinterpret_cast<bf16_t*>(feat0 + buf * YFEAT);
         DbScale dbs = {0.f, 0.f};
         if (a.f_clip_max) dbs = db_scale_make(fown, fref);
-        int tid_l = tid;
+        int tid_l = ltid;
         asm volatile("" : "+v"(tid_l));
 #pragma unroll
         for (int n = 0; n < YFPRE; ++n) {
-            const int it = tid_l + 512 * n;
+            const int it = tid_l + 256 * n;
             const int fi = (it * inv_fcols) >> 16, fj = it - fi * fcols;
             float v = fpre[n];
             if (a.f_clip_max) {
@@ -351,49 +349,64 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         }
     };
 
-    // ---- layer1 of one tile: units u = pg, pg + 4 of the 7 main units (16 rows x 4 columns) + the halo unit (rows 16 - 17 x 8 column
-    // blocks); this wave's 16 channels.  See conv.hip (KS == 1) for the Toeplitz form.
+    // ---- layer1 of one tile (layer1 waves): units u = wq, wq + 4 of the 7 main units (16 rows x 4 columns) + the halo unit (rows 16 - 17 x 8
+    // column blocks), all 32 channels.  See conv.hip (KS == 1) for the Toeplitz form.
     const int nmain = (cols + 3) >> 2;
     const int nunits = nmain + 1;
-    const int gg = min(g, 2);                                     // k-group 3 has zero weights: re-read group 2's row
-    const int fa_main = (n16 + gg) * YFW * 2;
-    const int fa_halo = ((XT + (n16 & 1) + gg) * YFW + 4 * (n16 >> 1)) * 2;
-    const int oa_main = (n16 * YP * 4 + (g ^ yswz(n16))) * 16 + ch * 8;
-    const int hrow = XT + (n16 & 1);
-    const int oa_halo = ((hrow * YP + 4 * (n16 >> 1)) * 4 + (g ^ yswz(hrow))) * 16 + ch * 8;
     auto layer1 = [&](const XTile& tc, int buf) {
+        // per-lane offsets, recomputed per tile from an opaque copy of the lane id rather than held in registers across the tile loop
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int n16 = lane_o & 15, g = lane_o >> 4;
+        const int gg = min(g, 2);                                     // k-group 3 has zero weights: re-read group 2's row
+        const int fa_main = (n16 + gg) * YFW * 2;
+        const int fa_halo = ((XT + (n16 & 1) + gg) * YFW + 4 * (n16 >> 1)) * 2;
+        const int oa_main = (n16 * YP * 4 + (g ^ yswz(n16))) * 16;
+        const int hrow = XT + (n16 & 1);
+        const int oa_halo = ((hrow * YP + 4 * (n16 >> 1)) * 4 + (g ^ yswz(hrow))) * 16;
         const char* fbytes = feat0 + buf * YFEAT;
         char* ob = smem + buf * YBUF;
         const bool interior = tc.t0 >= 1 && tc.t0 + XT < a.T && tc.f0 >= 1 && tc.f0 + ft < a.F;   // no position of the tile is padding
-        for (int u = pg; u < nunits; u += 4) {
+        for (int u = wq; u < nunits; u += 4) {
             const bool mainu = u < nmain;                                                              // scalar
             // B operand of lane (row n, k-group g): 8 consecutive staged values of feature row n + g from column 4 u, both planes (8-byte aligned)
             const int fa = mainu ? fa_main + u * 8 : fa_halo;
             const uint2 h0 = *reinterpret_cast<const uint2*>(fbytes + fa), h1 = *reinterpret_cast<const uint2*>(fbytes + fa + 8);
             const uint2 l0 = *reinterpret_cast<const uint2*>(fbytes + YFPLANE + fa), l1 = *reinterpret_cast<const uint2*>(fbytes + YFPLANE + fa + 8);
             const uint4 bh = make_uint4(h0.x, h0.y, h1.x, h1.y), bl = make_uint4(l0.x, l0.y, l1.x, l1.y);
-            f32x4_t acc1[4];
+            f32x4_t acc1[4][2];
+            // fragment (q, nt, plane) = wreg[(q * 2 + nt) * 2 + plane]; per accumulator hi.hi, hi.lo, lo.hi as in conv.hip
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc1[q] = mfma16(w1t[q][0], bh, sh1);
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc1[q] = mfma16(w1t[q][0], bl, acc1[q]);
+                for (int nt = 0; nt < 2; ++nt) acc1[q][nt] = mfma16(wreg[(q * 2 + nt) * 2], bh, sh[nt]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc1[q] = mfma16(w1t[q][1], bh, acc1[q]);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc1[q][nt] = mfma16(wreg[(q * 2 + nt) * 2], bl, acc1[q][nt]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc1[q][nt] = mfma16(wreg[(q * 2 + nt) * 2 + 1], bh, acc1[q][nt]);
             const int oa = mainu ? oa_main + u * 256 : oa_halo;
             const bool fast = __builtin_amdgcn_readfirstlane((int)(interior && mainu)) != 0;
             if (fast) {
                 // no position of this unit is padding (columns past the tile's last one land in the row's pad cells, which nobody reads)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint32_t h0, h1, l0, l1;
-                    split_bf16x2(fmaxf(acc1[q][0], 0.f), fmaxf(acc1[q][1], 0.f), h0, l0);
-                    split_bf16x2(fmaxf(acc1[q][2], 0.f), fmaxf(acc1[q][3], 0.f), h1, l1);
-                    *reinterpret_cast<uint2*>(ob + oa + q * 64) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(ob + YPLANE + oa + q * 64) = make_uint2(l0, l1);
+                    float y[8];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[nt * 4 + r] = fmaxf(acc1[q][nt][r], 0.f);
+                    uint4 hi, lo;
+                    xcvt8(y, hi, lo);
+                    *reinterpret_cast<uint4*>(ob + oa + q * 64) = hi;
+                    *reinterpret_cast<uint4*>(ob + YPLANE + oa + q * 64) = lo;
                 }
             } else {
                 // border tiles and the halo-row unit: branch-free per-lane padding (ReLU and the zero padding of the map in one v_med3
-                // against inf / 0); positions past the tile's last column go to a scratch slot
+                // against inf / 0); positions past the tile's pitch go to a scratch slot
                 const int jl = mainu ? 4 * u : 4 * (n16 >> 1);
                 const int tl = tc.t0 - 1 + (mainu ? n16 : hrow);
                 const bool row_ok = (unsigned)tl < (unsigned)a.T;
@@ -401,22 +414,30 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
                 for (int q = 0; q < 4; ++q) {
                     const bool ok = row_ok && (unsigned)(tc.f0 - 1 + jl + q) < (unsigned)a.F;
                     const float lim = ok ? __builtin_inff() : 0.f;
-                    uint32_t h0, h1, l0, l1;
-                    split_bf16x2(__builtin_amdgcn_fmed3f(acc1[q][0], 0.f, lim), __builtin_amdgcn_fmed3f(acc1[q][1], 0.f, lim), h0, l0);
-                    split_bf16x2(__builtin_amdgcn_fmed3f(acc1[q][2], 0.f, lim), __builtin_amdgcn_fmed3f(acc1[q][3], 0.f, lim), h1, l1);
+                    float y[8];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[nt * 4 + r] = __builtin_amdgcn_fmed3f(acc1[q][nt][r], 0.f, lim);
+                    uint4 hi, lo;
+                    xcvt8(y, hi, lo);
                     const bool in_tile = jl + q < YP - 1;
-                    *reinterpret_cast<uint2*>(in_tile ? ob + oa + q * 64 : scratch) = make_uint2(h0, h1);
-                    *reinterpret_cast<uint2*>(in_tile ? ob + YPLANE + oa + q * 64 : scratch + 4096) = make_uint2(l0, l1);
+                    *reinterpret_cast<uint4*>(in_tile ? ob + oa + q * 64 : scratch) = hi;
+                    *reinterpret_cast<uint4*>(in_tile ? ob + YPLANE + oa + q * 64 : scratch + 4096) = lo;
                 }
             }
         }
     };
 
-    // ---- layer2 of one tile: pairs jp = pg, pg + 4, ... of this tile, this wave's 16 channels, fragment rows through a two-row ring
-    int rbase[3];
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) rbase[kh] = ((trow + kh) * YP * 4 + (g ^ yswz(trow + kh))) * 16;
+    // ---- layer2 of one tile (layer2 waves): pairs jp = wq, wq + 4, ... of this tile, all 32 channels, fragment rows through a two-row ring
     auto layer2 = [&](const XTile& tc, int buf) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int trow = lane_o & 15, g = lane_o >> 4;
+        const int c0 = g * 8;
+        int rbase[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) rbase[kh] = ((trow + kh) * YP * 4 + (g ^ yswz(trow + kh))) * 16;
         const char* tb = smem + buf * YBUF;
         const int t = tc.t0 + trow;
         // clip base (wave-uniform) + a 32-bit element offset per lane: one clip's map is T x F / 2 x 32 < 2^31 elements
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         bf16_t* out_lo = out + a.out_split;
         const unsigned orow = (unsigned)((t * Fo + (tc.f0 >> 1)) * 32 + c0);
         const int npairs = min(ft, ((a.F + 1) & ~1) - tc.f0) >> 1;
-        const int np = pg < npairs ? (npairs - pg + 3) >> 2 : 0;
+        const int np = wq < npairs ? (npairs - wq + 3) >> 2 : 0;
         uint4 x[2][4][2];
 #define YLOAD(BUF, KH, JP)                                                                                 \
         _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) {                                                 \
@@ -432,41 +453,45 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
             x[BUF][cc][0] = *reinterpret_cast<const uint4*>(tb + off);                                     \
             x[BUF][cc][1] = *reinterpret_cast<const uint4*>(tb + YPLANE + off);                            \
         }
-        // per accumulator (e = 0 / 1: the two columns of the pair) the order is conv.hip's -- taps kw = 0, 1, 2, each hi.hi, hi.lo, lo.hi -- but
-        // the two accumulators' chains are interleaved, so that an MFMA never waits for the one issued right before it
+        // fragment (tap, k, plane) = wreg[(tap * 2 + k) * 2 + plane].  Per accumulator the order is conv.hip's (taps kw = 0, 1, 2, each hi.hi,
+        // hi.lo, lo.hi); the four accumulators (2 columns x 2 tiles) take turns and the order is pinned.
 #define YROW(BUF, KH)                                                                                      \
         _Pragma("unroll") for (int kw = 0; kw < 3; ++kw)                                                   \
-            _Pragma("unroll") for (int pr = 0; pr < 3; ++pr)                                               \
+            _Pragma("unroll") for (int pr = 0; pr < 3; ++pr) {                                             \
                 _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
-                    acc[e] = mfma16(wf[(KH) * 3 + kw][pr == 2 ? 1 : 0], x[BUF][kw + e][pr == 1 ? 1 : 0], acc[e]);
+                    _Pragma("unroll") for (int k = 0; k < 2; ++k)                                          \
+                        acc[e][k] = mfma16(wreg[(((KH) * 3 + kw) * 2 + k) * 2 + (pr == 2 ? 1 : 0)], x[BUF][kw + e][pr == 1 ? 1 : 0], acc[e][k]); \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }
 #define YPAIR(B0, JP, JNEXT)                                                                               \
         {                                                                                                  \
-            f32x4_t acc[2] = {shr, shr};                                                                   \
+            const f32x4_t s0_ = sh[0], s1_ = sh[1];                                                        \
+            f32x4_t acc[2][2] = {{s0_, s1_}, {s0_, s1_}};                                                  \
             YLOAD((B0) ^ 1, 1, JP)                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             YROW(B0, 0)                                                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
             YLOAD(B0, 2, JP)                                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             YROW((B0) ^ 1, 1)                                                                              \
-            __builtin_amdgcn_sched_barrier(0);                                                             \
             YLOAD((B0) ^ 1, 0, JNEXT)                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             YROW(B0, 2)                                                                                    \
             const int fo = (tc.f0 >> 1) + (JP);                                                            \
             if (t < a.T && fo < Fo) {                                                                      \
-                uint32_t h0, h1, l0, l1;                                                                   \
-                split_bf16x2(fmaxf(fmaxf(acc[0][0], acc[1][0]), 0.f), fmaxf(fmaxf(acc[0][1], acc[1][1]), 0.f), h0, l0); \
-                split_bf16x2(fmaxf(fmaxf(acc[0][2], acc[1][2]), 0.f), fmaxf(fmaxf(acc[0][3], acc[1][3]), 0.f), h1, l1); \
+                float y[8];                                                                                \
+                _Pragma("unroll") for (int k = 0; k < 2; ++k)                                              \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) y[4 * k + r] = fmaxf(fmaxf(acc[0][k][r], acc[1][k][r]), 0.f); \
+                uint4 hi, lo;                                                                              \
+                xcvt8(y, hi, lo);                                                                          \
                 const unsigned eo = orow + (unsigned)(JP) * 32u;                                           \
-                *reinterpret_cast<uint2*>(out + eo) = make_uint2(h0, h1);                                  \
-                *reinterpret_cast<uint2*>(out_lo + eo) = make_uint2(l0, l1);                               \
+                *reinterpret_cast<uint4*>(out + eo) = hi;                                                  \
+                *reinterpret_cast<uint4*>(out_lo + eo) = lo;                                               \
             }                                                                                              \
         }
         if (np > 0) {
-            YLOAD(0, 0, pg)
+            YLOAD(0, 0, wq)
             for (int pi = 0; pi < np; pi += 2) {
-                const int ja = pg + 4 * pi;
+                const int ja = wq + 4 * pi;
                 const int jb = min(ja + 4, npairs - 1), jc = min(ja + 8, npairs - 1);
                 YPAIR(0, ja, jb)
                 if (pi + 1 < np) {
@@ -482,32 +507,30 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
     // ---- prologue: features of the first two tiles, layer1 of the first
     const int G = (int)gridDim.x;
     int tile = blockIdx.x;
-    if (tile < ntiles) {
-        feat_issue(xtile(tile, ntf, ntt, ft, ntiles));
-        feat_store(0);
-    }
-    if (tile + G < ntiles) {
-        feat_issue(xtile(tile + G, ntf, ntt, ft, ntiles));
-        feat_store(1);
+    if (!l2role) {
+        if (tile < ntiles) {
+            feat_issue(xtile(tile, ntf, ntt, ft, ntiles));
+            feat_store(0);
+        }
+        if (tile + G < ntiles) {
+            feat_issue(xtile(tile + G, ntf, ntt, ft, ntiles));
+            feat_store(1);
+        }
     }
     __syncthreads();
-    if (tile < ntiles) layer1(xtile(tile, ntf, ntt, ft, ntiles), 0);
+    if (!l2role && tile < ntiles) layer1(xtile(tile, ntf, ntt, ft, ntiles), 0);
     __syncthreads();
 
     int cur = 0;
     for (; tile < ntiles; tile += G) {
-        const XTile tc = xtile(tile, ntf, ntt, ft, ntiles);
-        const bool has1 = tile + G < ntiles, has2 = tile + 2 * G < ntiles;
-        const XTile t1 = xtile(has1 ? tile + G : tile, ntf, ntt, ft, ntiles);
-        if (has2) feat_issue(xtile(tile + 2 * G, ntf, ntt, ft, ntiles));
-        if (early) {
-            if (has1) layer1(t1, cur ^ 1);
-            layer2(tc, cur);
+        if (l2role) {
+            layer2(xtile(tile, ntf, ntt, ft, ntiles), cur);
         } else {
-            layer2(tc, cur);
-            if (has1) layer1(t1, cur ^ 1);
+            const bool has1 = tile + G < ntiles, has2 = tile + 2 * G < ntiles;
+            if (has2) feat_issue(xtile(tile + 2 * G, ntf, ntt, ft, ntiles));
+            if (has1) layer1(xtile(tile + G, ntf, ntt, ft, ntiles), cur ^ 1);
+            if (has2) feat_store(cur);                // tile k's features were consumed an iteration ago
         }
-        if (has2) feat_store(cur);                    // tile k's features were consumed an iteration ago
         lds_only_barrier();                           // LDS traffic only: the a2 stores stay in flight across it
         cur ^= 1;
     }
@@ -525,7 +548,7 @@ int launch_x12(const ConvArgs& a, hipStream_t stream) {
     int64_t gx = std::max<int64_t>(8, 256 / std::max(1, a.groups) / 8 * 8);
     if (gx > nblocks) gx = nblocks;
     const int fcols = ft + 4, inv_fcols = 65536 / fcols + 1;
-    for (int it = 0; it < YFPRE * 512; ++it)
+    for (int it = 0; it < YFPRE * 256; ++it)
         if (((it * inv_fcols) >> 16) != it / fcols) {
             amtx_set_error("convx12: internal: reciprocal division inexact for fcols=%d", fcols);
             return AMTX_ERR_ARG;

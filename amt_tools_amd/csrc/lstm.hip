@@ -1033,7 +1033,9 @@ int launch(const LstmArgs& a, hipStream_t stream) {
     // 512 clips); the eight-clip block does the same 16 MFMAs per wave and step for twice the clips, one block per CU.
     static const bool no8 = getenv("AMTX_LSTM_NO8") != nullptr;       // A/B switch
     const int64_t blocks4 = (int64_t)((a.B + 3) / 4) * 2 * a.groups;
-    if (!a.save && !no8 && blocks4 > 256 && use_four_clip_blocks(a)) {
+    // (one plane only: in the two-plane mode a step is 48 MFMAs per wave and the eight-clip block's doubled gate arithmetic sits on top of
+    // them -- 1.64 ms per 625 steps at 1024 clips against 1.25 for two co-resident four-clip blocks, round 5)
+    if (!a.save && !no8 && NS == 1 && blocks4 > 256 && use_four_clip_blocks(a)) {
         dim3 grid((unsigned)((a.B + 7) / 8), 2, (unsigned)a.groups);
         hipLaunchKernelGGL((bilstm4_kernel<NS, X_TYPE, OUT_TYPE, 2>), grid, dim3(LTHREADS), lds, stream, a);
     } else if (use_four_clip_blocks(a) || a.save) {     // the training forward (save != null) exists for the 4-clip mapping only
