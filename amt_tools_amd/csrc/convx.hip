@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
     const bool l2role = wave < 4;                                 // waves w and w + 4 share a SIMD: one of each role
     const int wq = wave & 3;                                      // index inside the role
     const int grp = blockIdx.y;
-    const int g = lane >> 4, trow = lane & 15;
+    const int g = lane >> 4;
     const int Fo = a.F >> 1;
     const int cols = ft + 2, fcols = ft + 4;
 
