@@ -15,12 +15,15 @@ overhead, ~25-40 us of single-threaded Python: at 8.5 ms of GPU time per 512 cli
 
 AMTX_NOTE_WORKERS=<n> sets the number of workers (default: min(4, cores // 4); 0 = order in-process); batches below 384 clips are ordered
 in-process anyway (measured on the MI355X host: at 256 clips per batch the in-process loop already keeps up with the upload, 25.7 M
-frames/s; at 512 - 1024 clips per batch four workers take the driver from 14.6 to 20.4 M frames/s).  A worker that dies or times
-out turns the pool off for the rest of the process and the batch is ordered in-process -- results never depend on the pool.
+frames/s; at 512 - 1024 clips per batch four workers take the driver from 14.6 to 20.4 M frames/s).  A worker that dies, answers
+anything but "ok" or does not answer within AMTX_NOTE_TIMEOUT seconds (default 30; replies are read with a deadline, never a bare
+readline) gets the whole pool killed and turned off for the rest of the process, and the batch is ordered in-process -- results never
+depend on the pool.  The shared file is unlinked as soon as every worker has mapped it: a crash of the parent leaves nothing in /dev/shm.
 """
 import atexit
 import json
 import os
+import select
 import subprocess
 import sys
 import tempfile
@@ -70,16 +73,36 @@ class _Pool(object):
                                                env=env, text=True, bufsize=1))
         atexit.register(self.close)
 
+    def _reply(self, p):
+        """One reply line of worker `p`, read with a deadline (a stopped / swapped-out worker must not hang the transcription driver)."""
+        deadline = float(os.environ.get('AMTX_NOTE_TIMEOUT', '30'))
+        ready, _, _ = select.select([p.stdout], [], [], deadline)
+        if not ready:
+            raise RuntimeError(f'note-order worker {p.pid} did not answer within {deadline:.0f} s')
+        line = p.stdout.readline()
+        if line.strip() != 'ok':
+            raise RuntimeError(f'note-order worker answered {line!r}')
+
     def _buffer(self, E, B):
         need = 16 * E + 8 * (B + 1) + 64
         if self.path is None or need > self.capacity:
             self._drop_file()
             d = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
             fd, self.path = tempfile.mkstemp(prefix=f'amtx_notes_{os.getpid()}_', dir=d)
-            self.capacity = max(need, 1 << 22)
-            os.ftruncate(fd, self.capacity)
-            os.close(fd)
-        self._mm = np.memmap(self.path, dtype=np.uint8, mode='r+', shape=(self.capacity,))
+            try:
+                self.capacity = max(need, 1 << 22)
+                os.ftruncate(fd, self.capacity)
+                self._mm = np.memmap(self.path, dtype=np.uint8, mode='r+', shape=(self.capacity,))
+                # every worker maps the new file now (an empty task), then the name goes away: the mappings keep the pages, and nothing
+                # is left behind in /dev/shm if this process dies
+                for p in self.procs:
+                    p.stdin.write(json.dumps({'path': self.path, 'size': self.capacity, 'E': 0, 'B': 0, 'b0': 0, 'b1': 0}) + '\n')
+                    p.stdin.flush()
+                for p in self.procs:
+                    self._reply(p)
+            finally:
+                os.close(fd)
+                self._unlink()
         return np.asarray(self._mm)                  # plain ndarray view: slicing an np.memmap builds a subclass instance per slice (slow)
 
     def order(self, onset, offsets, B):
@@ -100,24 +123,26 @@ class _Pool(object):
         for w, p in enumerate(self.procs):
             b0, b1 = cuts[w], max(cuts[w], cuts[w + 1])
             if b1 > b0:
-                p.stdin.write(json.dumps({'path': self.path, 'E': E, 'B': B, 'b0': b0, 'b1': b1}) + '\n')
+                p.stdin.write(json.dumps({'path': self.path, 'size': self.capacity, 'E': E, 'B': B, 'b0': b0, 'b1': b1}) + '\n')
                 p.stdin.flush()
                 active.append(p)
         for p in active:
-            line = p.stdout.readline()
-            if line.strip() != 'ok':
-                raise RuntimeError(f'note-order worker answered {line!r}')
+            self._reply(p)
         return np.array(pm, copy=True)
 
-    def _drop_file(self):
-        if self.path is not None:
+    def _unlink(self):
+        if self.path is not None and os.path.exists(self.path):
             try:
                 os.unlink(self.path)
             except OSError:
                 pass
-            self.path = None
 
-    def close(self):
+    def _drop_file(self):
+        self._unlink()
+        self.path = None
+        self._mm = None
+
+    def close(self, kill=False):
         for p in self.procs:
             try:
                 p.stdin.close()
@@ -125,6 +150,8 @@ class _Pool(object):
                 pass
         for p in self.procs:
             try:
+                if kill:
+                    p.kill()
                 p.wait(timeout=2)
             except Exception:       # noqa: BLE001
                 p.kill()
@@ -146,12 +173,14 @@ def order_batch(rows, onset, offsets, B, min_clips=384):
     if n > 0 and B >= min_clips and E > 0 and not (_POOL is not None and _POOL.failed):
         try:
             if _POOL is None or _POOL.n != n or not _POOL.procs:
+                if _POOL is not None:
+                    _POOL.close()   # AMTX_NOTE_WORKERS changed: the old workers and their mapping go first
                 _POOL = _Pool(n)
             perm = _POOL.order(onset, offsets, B)
-        except Exception:           # noqa: BLE001  (a dead worker, a full /dev/shm ...): order in-process, and stay there
+        except Exception:           # noqa: BLE001  (a dead / wedged worker, a full /dev/shm ...): order in-process, and stay there
             if _POOL is not None:
                 _POOL.failed = True
-                _POOL.close()
+                _POOL.close(kill=True)
             perm = None
     if perm is None:
         perm = np.empty(E, dtype=np.int64)
@@ -167,11 +196,10 @@ def _worker_main():
         try:
             t = json.loads(line)
             key = t['path']
-            size = os.path.getsize(key)
             mm = maps.get(key)
-            if mm is None or mm.shape[0] != size:
+            if mm is None:          # a new file: map it now (the parent unlinks the name as soon as every worker has answered)
                 maps.clear()
-                maps[key + '#mm'] = np.memmap(key, dtype=np.uint8, mode='r+', shape=(size,))
+                maps[key + '#mm'] = np.memmap(key, dtype=np.uint8, mode='r+', shape=(int(t['size']),))
                 mm = maps[key] = np.asarray(maps[key + '#mm'])      # plain ndarray view of the mapping
             E, B = t['E'], t['B']
             on = mm[:8 * E].view(np.float64)

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 
 __all__ = ['bilstm', 'bilstm_multi', 'BiLSTMFunction', 'bce_logits_loss', 'BCELogitsLossFunction', 'bn_relu_pool', 'BNReLUPoolFunction',
-           'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend', 'note_fallback', 'fallbacks',
+           'matmul_f32', 'linear', 'LinearFunction', 'conv3x3', 'Conv3x3Function', 'training_backend', 'note_fallback', 'fallbacks', 'fallback_total',
            'reset_fallbacks']
 
 HIDDEN_SIZES = (128, 256, 384, 512)  # hidden sizes per direction the training recurrences are built for (model_complexity 2 .. 5)
@@ -30,6 +30,7 @@ USE_HIP_DENSE = True            # False: nn.Conv2d / nn.Linear / the LSTM's matm
 
 
 _FALLBACKS = {}                 # site -> [reason, count]: layers of a GPU training step that went to a stock ATen op
+_FALLBACK_TOTAL = 0             # every fallback ever recorded (never reset): a model brackets its own forward with it
 
 
 def note_fallback(site, reason):
@@ -37,14 +38,22 @@ def note_fallback(site, reason):
     `AMTX_STRICT_TRAINING=1` turns it into an error -- the inference engine never falls back, training only does so on the record."""
     if os.environ.get('AMTX_STRICT_TRAINING', '0') not in ('', '0'):
         raise RuntimeError(f'amt_tools_amd training path: {site} would fall back to ATen ({reason}) and AMTX_STRICT_TRAINING is set')
+    global _FALLBACK_TOTAL
     rec = _FALLBACKS.setdefault(site, [reason, 0])
     rec[0] = reason
     rec[1] += 1
+    _FALLBACK_TOTAL += 1
 
 
 def fallbacks():
     """{site: (reason, times taken)} since the last reset_fallbacks()."""
     return {k: (v[0], v[1]) for k, v in _FALLBACKS.items()}
+
+
+def fallback_total():
+    """Monotonic count of recorded fallbacks (reset_fallbacks() does not touch it): the difference across a model's own training forward
+    says whether THAT forward took one, whatever other models or earlier validation passes of the process recorded."""
+    return _FALLBACK_TOTAL
 
 
 def reset_fallbacks():

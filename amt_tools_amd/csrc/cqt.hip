@@ -585,8 +585,11 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
         GemmArgs g;
         g.A = (const float*)(ws + d.pyr_off[l]) + (p->pad - L.nfft / 2); g.lda = L.hop; g.a_type = AMTX_T_F32;
         if (direct0 && l == 0) {   // rows start n_fft / 2 before the clip and run past its end: bounded reads straight from the audio
+            // a pointer n_fft / 2 elements BEFORE the caller's allocation: nothing below a_valid_lo is ever dereferenced (AStage::load), and
+            // the range starts exactly where the clip does
             g.A = audio - L.nfft / 2;
             g.a_valid_lo = L.nfft / 2; g.a_valid_hi = (int64_t)L.nfft / 2 + num_samples;
+            AMTX_REQUIRE(g.a_valid_lo >= L.nfft / 2, "amtx_cqt_forward: internal: level-0 rows would reach below the clip");
         }
         g.W = L.d_w; g.n_pad = L.n_pad; g.k_pad = L.k_pad; g.planes = 2; g.bias = nullptr;
         g.C = nullptr; g.ldc = L.ncols; g.c_type = AMTX_T_F32;

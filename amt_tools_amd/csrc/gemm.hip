@@ -1007,8 +1007,13 @@ static int check_generic(const GemmArgs& g) {
     AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
     // bf16 A: 16-byte fragments straight from memory.  fp32 A goes through registers with dword-aligned wide loads: rows may start at any
     // 4-byte boundary (clips of an odd length in one buffer, strided rows of the CQT products)
-    AMTX_REQUIRE(g.a_type == AMTX_T_F32 ? ((uintptr_t)g.A % 4) == 0 : ((g.lda * 2) % 16 == 0 && ((uintptr_t)g.A % 16) == 0),
-                 "gemm: A rows must be 16-byte aligned (bf16) / 4-byte aligned (fp32)");
+    // bf16 / two-plane A: 16-byte fragments straight from memory.  fp32 A goes through registers; rows that start at ANY 4-byte boundary
+    // (dword-aligned wide loads) are for the bounded strided-row problems only (a_valid_hi > 0: the CQT products straight from a caller's
+    // audio) -- a plain fp32 A keeps 16-byte aligned rows (the relaxation had reached every caller)
+    AMTX_REQUIRE(g.a_type == AMTX_T_F32 ? (g.a_valid_hi > 0 ? ((uintptr_t)g.A % 4) == 0 : (g.lda % 4 == 0 && ((uintptr_t)g.A % 16) == 0))
+                                        : ((g.lda * 2) % 16 == 0 && ((uintptr_t)g.A % 16) == 0),
+                 "gemm: A rows must be 16-byte aligned (4-byte aligned for a bounded fp32 A)");
+    AMTX_REQUIRE(g.a_valid_hi == 0 || (g.a_type == AMTX_T_F32 && g.a_valid_lo >= 0 && g.a_valid_hi > g.a_valid_lo), "gemm: bad valid range of A");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     return AMTX_OK;
@@ -1049,8 +1054,13 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
     AMTX_REQUIRE(g.n_pad % BN == 0 && g.k_pad % BK == 0 && g.n_pad >= g.N && g.k_pad >= g.K, "gemm: bad packed dims");
     // bf16 A: 16-byte fragments straight from memory.  fp32 A goes through registers with dword-aligned wide loads: rows may start at any
     // 4-byte boundary (clips of an odd length in one buffer, strided rows of the CQT products)
-    AMTX_REQUIRE(g.a_type == AMTX_T_F32 ? ((uintptr_t)g.A % 4) == 0 : ((g.lda * 2) % 16 == 0 && ((uintptr_t)g.A % 16) == 0),
-                 "gemm: A rows must be 16-byte aligned (bf16) / 4-byte aligned (fp32)");
+    // bf16 / two-plane A: 16-byte fragments straight from memory.  fp32 A goes through registers; rows that start at ANY 4-byte boundary
+    // (dword-aligned wide loads) are for the bounded strided-row problems only (a_valid_hi > 0: the CQT products straight from a caller's
+    // audio) -- a plain fp32 A keeps 16-byte aligned rows (the relaxation had reached every caller)
+    AMTX_REQUIRE(g.a_type == AMTX_T_F32 ? (g.a_valid_hi > 0 ? ((uintptr_t)g.A % 4) == 0 : (g.lda % 4 == 0 && ((uintptr_t)g.A % 16) == 0))
+                                        : ((g.lda * 2) % 16 == 0 && ((uintptr_t)g.A % 16) == 0),
+                 "gemm: A rows must be 16-byte aligned (4-byte aligned for a bounded fp32 A)");
+    AMTX_REQUIRE(g.a_valid_hi == 0 || (g.a_type == AMTX_T_F32 && g.a_valid_lo >= 0 && g.a_valid_hi > g.a_valid_lo), "gemm: bad valid range of A");
     AMTX_REQUIRE(g.ldc % 4 == 0 && ((uintptr_t)g.C % 16) == 0, "gemm: C rows must be 16-byte aligned");
     AMTX_REQUIRE(g.planes == 1 || g.planes == 2, "gemm: planes must be 1 or 2");
     AMTX_REQUIRE(g.a_type == AMTX_T_BF16 || g.a_type == AMTX_T_F32 || g.a_type == AMTX_T_SPLIT, "gemm: bad A type");

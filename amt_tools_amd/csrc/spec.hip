@@ -423,7 +423,10 @@ __global__ __launch_bounds__(256, 2) void spec_power_ring_kernel(SpecDev p, cons
     float mw[NSLOT];
 #pragma unroll
     for (int q = 0; q < NSLOT; ++q) mw[q] = p.mel_wt[q * 64 + lane];
-    int orow[4];                                                           // mel row of this lane's slot in each round (-1: none)
+    // mel row of this lane's slot in each round (-1: none).  FOUR rounds exactly: the dispatcher (amtx_spec_power) sends only plans with
+    // mel_rounds == 4 here -- with fewer, entries r >= rounds of mel_row would be weight bits, not row indices
+    static_assert(NSLOT == 4 + 8 + 20 + 32, "spec_power_ring_kernel is built for the four mel rounds of the BASELINE table");
+    int orow[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) orow[r] = p.mel_row[r * 64 + lane];
     for (int i = pidx(M + 1) + lane; i < PB_ELEMS; i += 64) pb[i] = 0.0f;
@@ -794,18 +797,28 @@ int build_mel_tables(int sample_rate, int n_fft, int n_mels, int htk, MelHost& m
             mh.round_off[r] = slots;
             slots += mh.round_max[r];
         }
-        mel_assign_slots(m_start, m_count, n_mels, mel_rounds, mh.round_max, getenv("AMTX_SPEC_NATURAL_ROWS") != nullptr, mh.slot_row, mh.slot_start);
-        mh.w.assign((size_t)slots * 64, 0.0f);
-        for (int sl = 0; sl < 64 * mel_rounds; ++sl) {
-            const int i = mh.slot_row[sl];
-            if (i < 0) continue;
-            const int r = sl / 64, l = sl % 64;
-            const int lead = m_start[i] - mh.slot_start[sl];          // zero taps in front of the row's first weight (even, >= 0)
-            if (lead < 0 || lead + m_count[i] > mh.round_max[r] || mh.slot_start[sl] + mh.round_max[r] > nb + 128) {
-                amtx_set_error("amtx_spec_plan_create: mel row %d (%d taps from bin %d) does not fit its slot / the padded power row", i, m_count[i], m_start[i]);
+        // The bank-conflict-free matching may move a row into a round with more tap slots or start it early behind zero weights; should that
+        // ever push a slot past the padded power row, the natural row-order layout (which fits whenever the rows do) is used instead of
+        // failing the plan.
+        bool natural = getenv("AMTX_SPEC_NATURAL_ROWS") != nullptr;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            mel_assign_slots(m_start, m_count, n_mels, mel_rounds, mh.round_max, natural, mh.slot_row, mh.slot_start);
+            mh.w.assign((size_t)slots * 64, 0.0f);
+            int bad = -1;
+            for (int sl = 0; sl < 64 * mel_rounds && bad < 0; ++sl) {
+                const int i = mh.slot_row[sl];
+                if (i < 0) continue;
+                const int r = sl / 64, l = sl % 64;
+                const int lead = m_start[i] - mh.slot_start[sl];          // zero taps in front of the row's first weight (even, >= 0)
+                if (lead < 0 || lead + m_count[i] > mh.round_max[r] || mh.slot_start[sl] + mh.round_max[r] > nb + 128) { bad = i; break; }
+                for (int j = 0; j < m_count[i]; ++j) mh.w[((size_t)mh.round_off[r] + lead + j) * 64 + l] = mh.fb_dense[(size_t)i * nb + m_start[i] + j];
+            }
+            if (bad < 0) break;
+            if (natural) {
+                amtx_set_error("amtx_spec_plan_create: mel row %d (%d taps from bin %d) does not fit its slot / the padded power row", bad, m_count[bad], m_start[bad]);
                 return AMTX_ERR_UNSUPPORTED;
             }
-            for (int j = 0; j < m_count[i]; ++j) mh.w[((size_t)mh.round_off[r] + lead + j) * 64 + l] = mh.fb_dense[(size_t)i * nb + m_start[i] + j];
+            natural = true;                                              // second attempt: rows in order
         }
     }
     return AMTX_OK;

@@ -137,7 +137,8 @@ class LogisticBank(OutputLayer):
                 and reference.shape == (estimated.shape[0], estimated.shape[2], estimated.shape[1])):
             from .autograd import bce_logits_loss     # one HIP pass: loss + d loss / d logits
             return bce_logits_loss(estimated, reference, self.weights)
-        if estimated.is_cuda:
+        if estimated.is_cuda and torch.is_grad_enabled() and estimated.requires_grad:
+            # (a validation pass that computes a loss on logits of another dtype / layout is not a training step: nothing to record)
             from .autograd import note_fallback
             note_fallback('LogisticBank.get_loss', f'logits {tuple(estimated.shape)} {estimated.dtype} vs labels {tuple(reference.shape)}')
         est = estimated.transpose(-2, -1)
@@ -435,6 +436,7 @@ class OnsetsFrames(TranscriptionModel):
         state.pop('_engine_offsets', None)
         state.pop('_side_stream', None)
         state.pop('_overlap_armed', None)
+        state.pop('_fb_last_forward', None)
         return state
 
     def _get_engine(self, device):
@@ -520,6 +522,10 @@ class OnsetsFrames(TranscriptionModel):
         self.__dict__.pop('_engine_out', None)
         self.__dict__.pop('_engine_offsets', None)
         output = dict()
+        fb0 = None
+        if feats.is_cuda and self.training and torch.is_grad_enabled():
+            from . import autograd as _ag
+            fb0 = _ag.fallback_total()
         if self._overlap_heads(feats):
             # The detector heads only meet at the refinement stage (onsetsframes.py:118-134): the pitch head runs on a side stream beside the
             # recurrent heads -- acoustic model + a 625-step BiLSTM that keeps 4 of the 256 CUs busy at 8 clips; autograd replays
@@ -551,6 +557,8 @@ class OnsetsFrames(TranscriptionModel):
             heads = [h.clone().detach() for h in heads]
         joint = torch.cat(heads + [multi_pitch], -1)
         output[tools.KEY_MULTIPITCH] = self.adjoin(joint)
+        if fb0 is not None:
+            self.__dict__['_fb_last_forward'] = _ag.fallback_total() - fb0     # 0: the next training forward may overlap its heads
         return output
 
     def _overlap_heads(self, feats):
@@ -559,16 +567,23 @@ class OnsetsFrames(TranscriptionModel):
         tools/two_stream_repro.py narrowed the round-1 hang down to the vendor libraries: with BOTH MIOpen convolutions and hipBLASLt
         GEMMs in the two heads the side stream stops in the first head's fc1 GEMM within 2 - 90 steps (either library alone, or the
         all-HIP step: thousands of steps clean).  So the first training forward of a model runs on one stream, and the overlap is armed
-        only if that forward -- and every one since -- recorded no ATen fallback (autograd.fallbacks())."""
+        only if THIS model's previous training forward recorded no ATen fallback (bracketed with autograd.fallback_total() in forward():
+        fallbacks of other models or of a validation pass do not count); with more than one rank it stays off unless AMTX_TRAIN_OVERLAP=1."""
         if not (feats.is_cuda and self.training and torch.is_grad_enabled()):
             return False
         if os.environ.get('AMTX_TRAIN_OVERLAP', '1') == '0' or not self.__dict__.get('overlap_heads', True):
             return False
         from . import autograd as ag
-        if not ag.USE_HIP_DENSE or ag.fallbacks():
+        if not ag.USE_HIP_DENSE:
             return False
-        if not self.__dict__.get('_overlap_armed', False):
-            self.__dict__['_overlap_armed'] = True       # this forward is the probe
+        # several ranks: the overlap has only ever been soaked on one GPU (with a one-rank RCCL group); with a real process group it stays
+        # off unless asked for explicitly (AMTX_TRAIN_OVERLAP=1) until an 8-GPU soak has run (ADVICE r04)
+        if 'AMTX_TRAIN_OVERLAP' not in os.environ and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            return False
+        # THIS model's previous training forward must have run without an ATen fallback (the count is bracketed per forward in forward():
+        # other models, or a validation pass, do not switch the overlap off for the rest of the process)
+        if self.__dict__.get('_fb_last_forward', None) != 0:
             return False
         return True
 

@@ -65,7 +65,9 @@ def _events_to_notes(pitch_idcs, on_frames, off_frames, times, low, times_ext=No
     # successive argsorts by onset with NumPy's default (unstable) sort.  The same three argsorts run here on the 1-D onset
     # column only and their permutations are composed; the (K,3) rows are gathered once (same result as re-indexing the whole
     # array three times, 40 % less host time per clip -- the host assembly bounds the batched transcription driver).
-    onset_t = times_ext[on_frames]
+    # float64 keys whatever the grid's dtype: the reference's sort runs on the (K, 3) array np.concatenate built from the float32 / float64
+    # intervals and the int64 pitches, i.e. on float64 (utils.py:135-164) -- and NumPy's unstable sort orders ties differently per key width
+    onset_t = times_ext[on_frames].astype(np.float64)
     perm = np.argsort(onset_t)
     if min_duration is not None:
         dur = times_ext[np.asarray(off_frames)[perm]] - onset_t[perm]
@@ -132,13 +134,18 @@ def _grid_on_device(ext, dev):
     current stream: it returns only when every kernel enqueued before it has finished, so one upload per batch made the batched driver wait
     for its own model forward before it could go on to the previous batch's host work (4 x 8 ms per 2048 clips; config 5's host-to-host
     rate went from 14 to 25 M frames/s with the grid cached)."""
-    key = (str(dev), ext.shape, ext.tobytes())
+    import hashlib
+    import torch
+    # keyed on a digest, not on the bytes themselves (a (B, T) grid is megabytes per batch)
+    key = (str(dev), ext.shape, ext.dtype.str, hashlib.blake2b(np.ascontiguousarray(ext).view(np.uint8).reshape(-1), digest_size=16).digest())
     t = _GRIDS.get(key)
     if t is None:
-        import torch
         if len(_GRIDS) >= 16:
-            _GRIDS.clear()
+            _GRIDS.pop(next(iter(_GRIDS)))         # the oldest ONE; its memory is only reused behind the streams recorded below
         t = _GRIDS[key] = torch.from_numpy(ext).to(dev)
+    # the decoder's kernels read the grid on the caller's current stream, which need not be the stream it was allocated on: tell the
+    # caching allocator, so that an evicted grid is not handed out again while those kernels are still queued
+    t.record_stream(torch.cuda.current_stream(t.device))
     return t
 
 

@@ -60,6 +60,26 @@ def test_host_decoder_random_maps_vs_oracle():
             assert np.array_equal(got, ref)
 
 
+def test_host_decoder_float32_grid_with_many_chords_orders_like_the_reference():
+    """`run_offline` hands over float32 time grids; the reference sorts the (K, 3) array np.concatenate built from them, i.e.
+    float64 keys, and NumPy's unstable sort orders ties differently for 32- and 64-bit keys once a clip has more than 16 notes.  Chord-heavy
+    maps (every onset lands on one of a few frames, so most notes tie), float32 grids: the host decoder against the oracle restatement of
+    the reference (pinned to reference-generated fixtures in tests/test_oracle_notes.py), row order included."""
+    rng = np.random.default_rng(77)
+    for T, sr in ((120, 22050), (625, 16000), (300, 44100)):
+        times = (np.arange(T) * 512 / sr).astype(np.float32)
+        on = np.zeros((88, T), dtype=np.float32)
+        for f in rng.choice(T - 8, 6, replace=False):
+            on[rng.choice(88, 25, replace=False), f] = 1               # 25-note chords on six frames
+        mp = on.copy()
+        for k, f in zip(*np.nonzero(on)):
+            mp[k, f:f + rng.integers(1, 8)] = 1
+        ref = notes_np.note_transcriber(mp, on, times)
+        got = multi_pitch_to_notes(mp, times, 21, on)
+        assert ref.shape[0] > 100 and got.dtype == np.float64
+        assert np.array_equal(got, ref), (T, sr)
+
+
 def test_pitch_list_wrapper():
     mp = np.zeros((88, 4), dtype=np.float32)
     mp[[3, 10], 1] = 1
