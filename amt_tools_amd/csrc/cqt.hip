@@ -207,6 +207,222 @@ __global__ __launch_bounds__(256) void cqt_scale_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The basis products of every pyramid level, one launch (round 5; until then amtx_launch_gemm_multi ran them on the generic fp32-A
+// two-plane GEMM).  A row of a level's product is a WINDOW of its signal: row t = y[t hop - K / 2 .. t hop + K / 2), K = n_fft = 128 / 256,
+// hop = 512 .. 4 -- consecutive rows overlap by K - hop samples, up to 63 / 64 of a row.  The generic GEMM loaded and converted (fp32 ->
+// hi / lo planes, ~3 vector instructions per value) every row on its own: each sample of a deep level up to 64 times.  Here a block
+// stages the signal of FT consecutive frames of one clip ONCE (coalesced fp32 loads, one split per sample, two 16-bit planes in LDS) and
+// every row's MFMA operand is a 16-byte window of that copy; the level's basis (<= 256 columns x K, two planes) sits in the waves'
+// registers for the whole launch.  Frames run down the lanes (lane & 15), so a frame's window starts hop samples after its neighbour's:
+// the copy is stored with 8 pad samples behind every hop samples (hop >= 16) -- a frame stride of (hop + 8) x 2 bytes = an odd number
+// of 16-byte slots -- which makes every ds_read_b128 lane group conflict-free; hop = 8 needs none, hop = 4 reads two 8-byte halves.
+// Same planes, same product order (hi.hi, hi.lo, lo.hi per 32-deep step, k ascending) and the same epilogue (|re + i im| transposed into
+// mag[b][harmonic][bin][t], per-(clip, harmonic) maxima) as gemm_tile: the same bits.
+constexpr int BAS_MAXLEV = 10;
+constexpr int BAS_MAXWIN = 16384;         // samples of a tile's window at most (66 KB of LDS with the pads: two blocks per CU)
+struct BasisLevel {
+    const float* sig; int64_t sig_gs;      // level signal of clip 0 (sample 0 = first sample of the clip at this level), elements per clip
+    int64_t len;                           // samples that exist: indices [0, len) of `sig`; everything else reads as zero
+    int off;                               // index of the level's sample 0 in `sig` (librosa 0.9: the reflecting pad in front of it exists)
+    const bf16_t* w; const int2* map;      // packed basis [2][n_pad][k_pad], pair map
+    int n_pad, k_pad, ncols, hop, frames, ft, tiles_per_clip;
+    int tile0;                             // first tile id of this level in the launch
+};
+struct BasisArgs {
+    BasisLevel lev[BAS_MAXLEV];
+    int nlev, ntiles, B;
+    float* mag; int64_t mag_gs, mag_pitch; // mag[b * mag_gs + row * mag_pitch + t]
+    float* maxbuf; int n_harm;
+    int rows[16];                          // frames of harmonic h
+};
+
+struct BasisLevs { int n; int lev[BAS_MAXLEV]; };
+
+// grid: (blocks per level, levels of this K, column slices of 128): all levels of a call run side by side, the small deep ones under the large
+// shallow ones.  256-thread blocks, two per CU: a wave keeps the basis of ITS two column tiles in registers and walks the tile's frames on
+// its own (a dependent read -> MFMA chain per 16 frames), so what fills the matrix pipe is the other waves of the CU; a level with more than
+// 128 columns (HCQT's middle levels stack 144) runs a second slice of blocks for the rest, which stages the same signal again (an L2 hit).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLevs ls) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [hi plane | lo plane] of the padded window, then 16 maxima
+    constexpr int K = 32 * KS;
+    const BasisLevel& L = a.lev[ls.lev[blockIdx.y]];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // `hop` below is the frame stride of the STAGED copy: the level's hop, or K where the hop is larger (level 0, hop 512 > K = 256: rows do
+    // not overlap and only the K samples of every frame are staged, back to back)
+    const int ghop = L.hop, ft = L.ft;
+    const int hop = min(ghop, K), lh = __builtin_ctz(hop);        // powers of two
+    const int padded = hop >= 16;                                  // 8 pad samples behind every `hop`
+    const int ws = (ft - 1) * hop + K;                             // samples of a tile's window
+    const int wsp = padded ? ws + 8 * ((ws + hop - 1) / hop) : ws; // ... in LDS
+    const int plane = ((wsp + 7) & ~7) * 2;                        // bytes per plane
+    unsigned* lmax = reinterpret_cast<unsigned*>(smem + 2 * plane);
+
+    // ---- this wave's columns: two 16-column tiles per wave, four waves = one slice of 128 columns; waves beyond the slice's columns share
+    // the frame tiles of a column group
+    const int col0 = 128 * blockIdx.z;                             // first column of this slice
+    if (col0 >= L.ncols) return;
+    const int nct = (min(L.ncols - col0, 128) + 15) >> 4;          // 16-column tiles with real columns in the slice (<= 8)
+    const int ncg = (nct + 1) >> 1;                                // column groups of two tiles (1 .. 4)
+    const int wpg = 4 / ncg;                                       // waves per group (4, 2, 1, 1)
+    const bool idle = wave >= ncg * wpg;
+    const int cg = (idle ? 0 : wave % ncg) + 4 * blockIdx.z, sub = wave / ncg;
+    const int g = lane >> 4, fl = lane & 15;
+    uint4 wh[2][KS], wl[2][KS];
+    {
+        const int64_t wplane = (int64_t)L.n_pad * L.k_pad;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = min((2 * cg + c) * 16 + fl, L.n_pad - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                wh[c][ks] = *reinterpret_cast<const uint4*>(L.w + (int64_t)n * L.k_pad + ks * 32 + 8 * g);
+                wl[c][ks] = *reinterpret_cast<const uint4*>(L.w + wplane + (int64_t)n * L.k_pad + ks * 32 + 8 * g);
+            }
+        }
+    }
+    // pair maps of this lane's four columns per tile: columns n0 + 4 g + {0, 1} = (re, im) of one filter, + {2, 3} of the next
+    int2 pm[2][2];
+    bool pv[2][2];
+    int rl[2][2], ro[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int n = (2 * cg + c) * 16 + 4 * g + 2 * h;
+            pv[c][h] = !idle && n < L.ncols;
+            pm[c][h] = L.map[min(n, L.ncols - 2) >> 1];
+            // frames of this filter's harmonic (0: the lane's columns do not exist): read ONCE -- indexed per lane inside the frame loop it was
+            // a memory round trip per filter and 16 frames
+            rl[c][h] = pv[c][h] ? a.rows[pm[c][h].y & 15] : 0;
+            ro[c][h] = pm[c][h].x * (int)a.mag_pitch;            // row offset inside the clip's map
+        }
+    // byte offset of this lane's operand inside a frame's window: sample 8 g of k-step 0 (+ 32 samples per k-step), pads included
+    auto soff = [&](int s) { return (padded ? s + 8 * (s >> lh) : s) * 2; };
+
+    // ---- tile loop.  Staging: four samples per thread and step (a 16-byte load at any 4-byte boundary: clips of odd length in one buffer), in
+    // ROUNDS of six steps whose loads are issued back to back from clamped addresses (a load -> test -> store loop pays one memory round
+    // trip per step); what lies outside the signal is zeroed at the split.  Staged indices are multiples of 4 and so are the window origins,
+    // so a group hangs over the signal's END only (by 1 - 3 samples when the length is not a multiple of 4): its values are picked out of
+    // the clamped load by the distance it was moved.  The block's barriers wait for LDS traffic only (the stores of a tile's magnitudes
+    // and the maxima's atomics stay in flight), and the other block of the CU covers a tile's load round trips.
+    struct __attribute__((packed, aligned(4))) f32x4_a4 { float x, y, z, w; };
+    constexpr int NST = 6;
+    const int ntile = L.tiles_per_clip * a.B;
+    if (tid < 16) lmax[tid] = 0u;
+    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const int b = tile / L.tiles_per_clip, tt = tile - b * L.tiles_per_clip;
+        const int f0 = tt * ft;                                    // first frame of the tile
+        const float* sig = L.sig + (int64_t)b * L.sig_gs;
+        const int64_t s0 = (int64_t)f0 * ghop - K / 2 + L.off;     // first sample of the window (index into sig)
+        // staged index i -> signal index: identity while the windows overlap, frame-wise (hop > K) otherwise
+        auto sidx = [&](int i) { return s0 + (ghop > K ? (int64_t)(i >> lh) * ghop + (i & (hop - 1)) : (int64_t)i); };
+        for (int base = 0; base < ws; base += 1024 * NST) {
+            f32x4_a4 rr[NST];
+#pragma unroll
+            for (int n = 0; n < NST; ++n) {
+                const int64_t q = sidx(min(base + 4 * tid + 1024 * n, ws - 4));
+                rr[n] = *reinterpret_cast<const f32x4_a4*>(sig + min(max(q, (int64_t)0), L.len - 4));
+            }
+#pragma unroll
+            for (int n = 0; n < NST; ++n) {
+                const int i = base + 4 * tid + 1024 * n;
+                const int64_t q = sidx(min(i, ws - 4));
+                // 0: as loaded; 1 - 3: the load was moved back by that much; 4: nothing of the group exists
+                const int d = (q < 0 || q >= L.len) ? 4 : (int)(q - min(q, L.len - 4));
+                const float r[4] = {rr[n].x, rr[n].y, rr[n].z, rr[n].w};
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // element e of the group is element e + d of the load, if that exists
+                    float x = r[e];
+                    if (e + 1 < 4) x = d == 1 ? r[e + 1] : x;
+                    if (e + 2 < 4) x = d == 2 ? r[e + 2] : x;
+                    if (e + 3 < 4) x = d == 3 ? r[e + 3] : x;
+                    v[e] = e + d < 4 ? x : 0.f;
+                }
+                uint32_t h0, h1, l0, l1;
+                split_bf16x2(v[0], v[1], h0, l0);
+                split_bf16x2(v[2], v[3], h1, l1);
+                if (i < ws) {
+                    const int o = soff(i);                         // four samples never straddle a pad (blocks are multiples of 4)
+                    *reinterpret_cast<uint2*>(smem + o) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(smem + plane + o) = make_uint2(l0, l1);
+                }
+            }
+        }
+        lds_only_barrier();
+        float mx[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+        const int nft = idle ? 0 : min(ft, L.frames - f0 + 15) >> 4;   // 16-frame tiles with real frames (a wave without columns has none)
+        float* magb = a.mag + (int64_t)b * a.mag_gs;               // wave-uniform base, 32-bit offsets per lane (a clip's map is < 2^31 elements)
+        // TWO 16-frame tiles per step: four independent accumulator chains and twice the reads in flight (one tile at a time, a wave waited for
+        // every k-step's reads in front of its six dependent MFMAs)
+        for (int q = sub; q < nft; q += 2 * wpg) {
+            const int q2 = q + wpg < nft ? q + wpg : q;            // the second tile of the step (the first again when there is none: not stored)
+            const int fr[2] = {q * 16 + fl, q2 * 16 + fl};         // this lane's frames inside the tile
+            f32x4_t acc[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[u][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                uint4 ah[2], al[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int o = soff(fr[u] * hop + ks * 32 + 8 * g);
+                    if (hop >= 8) {
+                        ah[u] = *reinterpret_cast<const uint4*>(smem + o);
+                        al[u] = *reinterpret_cast<const uint4*>(smem + plane + o);
+                    } else {                                       // hop 4: windows start at 8-byte boundaries
+                        const uint2 h0 = *reinterpret_cast<const uint2*>(smem + o), h1 = *reinterpret_cast<const uint2*>(smem + o + 8);
+                        const uint2 l0 = *reinterpret_cast<const uint2*>(smem + plane + o), l1 = *reinterpret_cast<const uint2*>(smem + plane + o + 8);
+                        ah[u] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                        al[u] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    }
+                }
+                // per accumulator hi.hi, hi.lo, lo.hi (gemm_tile's order), the four accumulators taking turns
+#pragma unroll
+                for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) acc[u][c] = cq_mfma(pr == 2 ? wl[c][ks] : wh[c][ks], pr == 1 ? al[u] : ah[u], acc[u][c]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && q2 == q) break;                      // wave-uniform
+                const int m = f0 + fr[u];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (m < rl[c][h]) {
+                            const float re = acc[u][c][2 * h], im = acc[u][c][2 * h + 1];
+                            const float v = sqrtf(re * re + im * im);
+                            magb[(unsigned)(ro[c][h] + m)] = v;
+                            mx[c][h] = fmaxf(mx[c][h], v);
+                        }
+                    }
+            }
+        }
+        // per-(clip, harmonic) maxima: magnitudes are >= 0, so uint order == float order
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (mx[c][h] > 0.f) atomicMax(lmax + (pm[c][h].y & 15), __float_as_uint(mx[c][h]));
+        lds_only_barrier();                                        // everybody is done with the staged copy, the maxima are in
+        if (tid < 16) {
+            const unsigned v = lmax[tid];
+            lmax[tid] = 0u;                                        // for the next tile (ordered behind its barrier)
+            if (v != 0u) atomicMax(reinterpret_cast<unsigned*>(a.maxbuf) + (int64_t)b * a.n_harm + tid, v);
+        }
+    }
+}
+
 struct Level {
     int nfft = 0, ncols = 0, hop = 0;
     std::vector<BankDev> banks;
@@ -573,6 +789,70 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
             AMTX_CHECK_LAUNCH();
         }
     }
+    // the basis products of all levels: the windowed kernel (cqt_basis_kernel), one launch per level on the same stream; AMTX_CQT_GEMM_BASIS=1
+    // keeps round 4's path (all levels in ONE launch of the generic fp32-A two-plane GEMM) for the A/B
+    static const bool gemm_basis = getenv("AMTX_CQT_GEMM_BASIS") != nullptr;
+    bool windowed = !gemm_basis && nl <= BAS_MAXLEV && p->n_harm <= 16 && (int64_t)p->n_harm * p->n_bins * d.t_buf < (1ll << 31);
+    for (int l = 0; l < nl && windowed; ++l) {
+        const Level& L = p->levels[l];
+        if (L.banks.empty()) continue;
+        windowed = (L.nfft == 128 || L.nfft == 256) && L.k_pad >= L.nfft && L.ncols <= 256 && L.ncols % 2 == 0 && L.hop >= 4 && (L.hop & (L.hop - 1)) == 0 &&
+                   (L.hop <= 512) && d.len[l] >= 4;
+    }
+    if (windowed) {
+        BasisArgs ba;
+        ba.nlev = nl; ba.B = B; ba.ntiles = 0;
+        ba.mag = mag; ba.mag_gs = (int64_t)p->n_harm * p->n_bins * d.t_buf; ba.mag_pitch = d.t_buf;
+        ba.maxbuf = maxbuf; ba.n_harm = p->n_harm;
+        for (int h = 0; h < 16; ++h) ba.rows[h] = h < p->n_harm ? d.frames_h[h] : 0;
+        for (int l = 0; l < nl; ++l) {
+            const Level& L = p->levels[l];
+            BasisLevel& bl = ba.lev[l];
+            bl = BasisLevel();
+            if (L.banks.empty()) { bl.frames = 0; continue; }
+            if (direct0 && l == 0) { bl.sig = audio; bl.sig_gs = audio_stride; }
+            else { bl.sig = (const float*)(ws + d.pyr_off[l]) + p->pad; bl.sig_gs = d.stride[l]; }
+            bl.len = d.len[l];
+            // librosa 0.9's reflecting pads live in the pyramid buffer on both sides of the signal: there every sample the windows touch exists
+            bl.off = 0;
+            if (!zero_pads) { bl.sig -= p->pad; bl.off = p->pad; bl.len = d.stride[l]; }
+            bl.w = L.d_w; bl.map = L.d_map; bl.n_pad = L.n_pad; bl.k_pad = L.k_pad; bl.ncols = L.ncols; bl.hop = L.hop;
+            bl.frames = (int)d.frames[l];
+            const int hs0 = std::min(L.hop, L.nfft);
+            int ftl = std::max(16, std::min(128, ((BAS_MAXWIN - L.nfft) / hs0 + 1) / 16 * 16));
+            ftl = std::min(ftl, (bl.frames + 15) / 16 * 16);
+            bl.ft = ftl;
+            bl.tiles_per_clip = (bl.frames + ftl - 1) / ftl;
+        }
+        for (int kk = 128; kk <= 256; kk *= 2) {
+            BasisLevs ls;
+            ls.n = 0;
+            size_t lds = 0;
+            for (int l = 0; l < nl; ++l) {
+                const BasisLevel& bl = ba.lev[l];
+                if (bl.frames <= 0 || p->levels[l].nfft != kk) continue;
+                const int hs = std::min(bl.hop, kk);               // frame stride of the staged copy (cqt_basis_kernel)
+                const int ws_s = (bl.ft - 1) * hs + kk;
+                const int wsp = hs >= 16 ? ws_s + 8 * ((ws_s + hs - 1) / hs) : ws_s;
+                lds = std::max(lds, (size_t)((wsp + 7) & ~7) * 2 * 2 + 64);
+                ls.lev[ls.n++] = l;
+            }
+            if (!ls.n) continue;
+            // two 256-thread blocks per CU; the levels (and the second column slice of the wide ones) share the chip
+            int slices = 1;
+            for (int i = 0; i < ls.n; ++i) slices = std::max(slices, (ba.lev[ls.lev[i]].ncols + 127) / 128);
+            // (every level gets the same number of blocks; its tiles are sized so that the levels' block times are of one order)
+            const unsigned gx = (unsigned)std::max(1, 512 / ls.n);
+            if (kk == 256) {
+                AMTX_GRANT_LDS(cqt_basis_kernel<8>, lds);
+                hipLaunchKernelGGL(cqt_basis_kernel<8>, dim3(gx, ls.n, slices), dim3(256), lds, s, ba, ls);
+            } else {
+                AMTX_GRANT_LDS(cqt_basis_kernel<4>, lds);
+                hipLaunchKernelGGL(cqt_basis_kernel<4>, dim3(gx, ls.n, slices), dim3(256), lds, s, ba, ls);
+            }
+            AMTX_CHECK_LAUNCH();
+        }
+    } else {
     // the basis products of ALL levels in one launch (same kernel, per-level A / W / sizes; 8 launches before)
     GemmArgs gs[AMTX_GEMM_MULTI_MAX];
     int ng = 0;
@@ -608,6 +888,7 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
     if (ng) {
         int rc = amtx_launch_gemm_multi(gs, ng, s);
         if (rc != AMTX_OK) return rc;
+    }
     }
     hipLaunchKernelGGL(cqt_scale_kernel, dim3(8, B * p->n_harm), dim3(256), 0, s, (const float*)mag, (const float*)maxbuf, p->n_bins, d.t_buf,
                        d.t_out, decibels, out);

@@ -109,3 +109,45 @@ def test_config1_cqt_into_tabcnn_end_to_end():
     top2 = np.sort(logits[1].reshape(1, -1, 6, 21), axis=-1)[..., -2:]
     decided = np.swapaxes(top2[..., 1] - top2[..., 0], -1, -2) > 0.1               # (1, 6, T): argmax not a near-tie
     assert np.all((outs[0] == outs[1]) | ~decided) and decided.mean() > 0.5
+
+
+_BASIS_AB = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd.features import CQT, HCQT, VQT
+from amt_tools_amd.synth import synth_clip
+outs = {}
+y = np.stack([synth_clip(i, num_samples=70001) for i in range(3)])
+y[1] *= 1e-3
+for name, mod in (('cqt1', CQT(sample_rate=22050, hop_length=512, n_bins=192, bins_per_octave=24)),
+                  ('cqt1_09', CQT(sample_rate=22050, hop_length=512, n_bins=192, bins_per_octave=24, librosa_version='0.9')),
+                  ('hcqt3', HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)),
+                  ('vqt', VQT(sample_rate=22050, hop_length=256, n_bins=60, bins_per_octave=12, gamma=5.0)),
+                  ('hcqt_lin', HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, decibels=False))):
+    outs[name] = mod.process_batch(torch.from_numpy(y).cuda()).cpu().numpy()
+    outs[name + '_one'] = mod.process_audio(y[2][:33333])
+np.savez(sys.argv[1], **outs)
+'''
+
+
+def test_windowed_basis_kernel_returns_the_bits_of_the_gemm_path(tmp_path):
+    """Round 5: the per-level basis products run on cqt_basis_kernel (a tile's signal staged and split into its two 16-bit planes ONCE in
+    LDS, rows = overlapping 16-byte windows of it, the basis in registers); AMTX_CQT_GEMM_BASIS=1 keeps the generic fp32-A two-plane GEMM.
+    Same planes, same product order, same epilogue: CQT (8 levels, hops 512 .. 4, 48 columns per level), HCQT (banks of several
+    harmonics per level), a VQT, both librosa padding conventions, dB and linear output must be IDENTICAL."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('windowed', {}), ('gemm', {'AMTX_CQT_GEMM_BASIS': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _BASIS_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['windowed']), np.load(files['gemm'])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 10
+    for k in a.files:
+        assert a[k].shape == b[k].shape and a[k].size > 0
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
