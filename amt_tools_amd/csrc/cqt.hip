@@ -237,9 +237,9 @@ struct BasisArgs {
     int rows[16];                          // frames of harmonic h
 };
 
-struct BasisLevs { int n; int lev[BAS_MAXLEV]; };
+struct BasisLevs { int n; int lev[BAS_MAXLEV]; int b0[BAS_MAXLEV + 1]; };   // levels of a launch; blocks [b0[i], b0[i + 1]) work on level lev[i]
 
-// grid: (blocks per level, levels of this K, column slices of 128): all levels of a call run side by side, the small deep ones under the large
+// grid: (blocks of all levels of this K, column slices of 128): all levels of a call run side by side, the small deep ones under the large
 // shallow ones.  256-thread blocks, two per CU: a wave keeps the basis of ITS two column tiles in registers and walks the tile's frames on
 // its own (a dependent read -> MFMA chain per 16 frames), so what fills the matrix pipe is the other waves of the CU; a level with more than
 // 128 columns (HCQT's middle levels stack 144) runs a second slice of blocks for the rest, which stages the same signal again (an L2 hit).
@@ -247,7 +247,11 @@ template <int KS>
 __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLevs ls) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [hi plane | lo plane] of the padded window, then 16 maxima
     constexpr int K = 32 * KS;
-    const BasisLevel& L = a.lev[ls.lev[blockIdx.y]];
+    // this block's level: the launch deals its blocks to the levels by their work (staged samples + a per-tile charge)
+    int li = 0;
+    while (li + 1 < ls.n && (int)blockIdx.x >= ls.b0[li + 1]) ++li;
+    const BasisLevel& L = a.lev[ls.lev[li]];
+    const int bid = (int)blockIdx.x - ls.b0[li], nblk = ls.b0[li + 1] - ls.b0[li];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // `hop` below is the frame stride of the STAGED copy: the level's hop, or K where the hop is larger (level 0, hop 512 > K = 256: rows do
@@ -262,13 +266,13 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
 
     // ---- this wave's columns: two 16-column tiles per wave, four waves = one slice of 128 columns; waves beyond the slice's columns share
     // the frame tiles of a column group
-    const int col0 = 128 * blockIdx.z;                             // first column of this slice
+    const int col0 = 128 * blockIdx.y;                             // first column of this slice
     if (col0 >= L.ncols) return;
     const int nct = (min(L.ncols - col0, 128) + 15) >> 4;          // 16-column tiles with real columns in the slice (<= 8)
     const int ncg = (nct + 1) >> 1;                                // column groups of two tiles (1 .. 4)
     const int wpg = 4 / ncg;                                       // waves per group (4, 2, 1, 1)
     const bool idle = wave >= ncg * wpg;
-    const int cg = (idle ? 0 : wave % ncg) + 4 * blockIdx.z, sub = wave / ncg;
+    const int cg = (idle ? 0 : wave % ncg) + 4 * blockIdx.y, sub = wave / ncg;
     const int g = lane >> 4, fl = lane & 15;
     uint4 wh[2][KS], wl[2][KS];
     {
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
     constexpr int NST = 6;
     const int ntile = L.tiles_per_clip * a.B;
     if (tid < 16) lmax[tid] = 0u;
-    for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    for (int tile = bid; tile < ntile; tile += nblk) {
         const int b = tile / L.tiles_per_clip, tt = tile - b * L.tiles_per_clip;
         const int f0 = tt * ft;                                    // first frame of the tile
         const float* sig = L.sig + (int64_t)b * L.sig_gs;
@@ -838,17 +842,24 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
                 ls.lev[ls.n++] = l;
             }
             if (!ls.n) continue;
-            // two 256-thread blocks per CU; the levels (and the second column slice of the wide ones) share the chip
+            // two 256-thread blocks per CU; the levels (and the second column slice of the wide ones) share the chip: 512 blocks dealt EVENLY to the
+            // levels (dealing them by staged samples, by matrix work or by a mix was measured slower, 2.2 - 2.6 against 1.97 ms for the
+            // front-end: the deep levels' tiles are as many as the shallow ones' and a tile's fixed costs -- barriers, a load round trip, the
+            // maxima's atomics -- weigh as much as its size)
             int slices = 1;
             for (int i = 0; i < ls.n; ++i) slices = std::max(slices, (ba.lev[ls.lev[i]].ncols + 127) / 128);
-            // (every level gets the same number of blocks; its tiles are sized so that the levels' block times are of one order)
-            const unsigned gx = (unsigned)std::max(1, 512 / ls.n);
+            ls.b0[0] = 0;
+            for (int i = 0; i < ls.n; ++i) {
+                const int64_t tiles = (int64_t)ba.lev[ls.lev[i]].tiles_per_clip * B;
+                ls.b0[i + 1] = ls.b0[i] + (int)std::min<int64_t>(std::max(8, 512 / ls.n), tiles);
+            }
+            const unsigned gx = (unsigned)ls.b0[ls.n];
             if (kk == 256) {
                 AMTX_GRANT_LDS(cqt_basis_kernel<8>, lds);
-                hipLaunchKernelGGL(cqt_basis_kernel<8>, dim3(gx, ls.n, slices), dim3(256), lds, s, ba, ls);
+                hipLaunchKernelGGL(cqt_basis_kernel<8>, dim3(gx, slices), dim3(256), lds, s, ba, ls);
             } else {
                 AMTX_GRANT_LDS(cqt_basis_kernel<4>, lds);
-                hipLaunchKernelGGL(cqt_basis_kernel<4>, dim3(gx, ls.n, slices), dim3(256), lds, s, ba, ls);
+                hipLaunchKernelGGL(cqt_basis_kernel<4>, dim3(gx, slices), dim3(256), lds, s, ba, ls);
             }
             AMTX_CHECK_LAUNCH();
         }
