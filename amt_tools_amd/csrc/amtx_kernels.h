@@ -171,3 +171,14 @@ int amtx_pack_linear_dev(const float* W, int64_t ldw, int N, int K, int planes, 
 int amtx_pack_head_fold_dev(const float* w_out, const float* w_fc1, const float* b_fc1, const float* b_out, int n_out, int dim_am, int kfc, int kfc_pad,
                             int nf3, int fq, float* wfold, float* bfold, hipStream_t s);
 int amtx_pack_vec_add_dev(const float* a, const float* b, int n, float* out, hipStream_t s);
+
+// ---- cqt_dec.hip: the half-band decimator of the CQT pyramid (cqt.hip builds its Toeplitz fragments and calls it per level)
+constexpr int DEC_HALF = 150;                     // 301-tap Kaiser half-band filter
+constexpr int DEC_TAPS = 2 * DEC_HALF + 1;
+constexpr int DEC_KW = 352;                       // >= 30 + DEC_TAPS, a multiple of 32: columns of the 16-row Toeplitz matrix
+constexpr int DEC_NKS = DEC_KW / 32;
+// out[b][pad + m] = sqrt(2) sum_k h[k] in[b][in_pad + 2 m + k - DEC_HALF] (zero outside [0, n_in)), m < n_out; tfrag = DEC_NKS x 3 planes x 64 lanes
+// x 16 bytes (cqt.hip, plan creation); zero_pads: the [0, pad) and [pad + n_out, out_stride) ranges of every output row are zeroed as well;
+// maxbuf (or null): batch x n_harm floats reset to zero
+int amtx_launch_cqt_decimate(const float* in, int64_t n_in, int64_t in_stride, int in_pad, float* out, int64_t n_out, int64_t out_stride, int pad,
+                             const void* tfrag, int zero_pads, float* maxbuf, int n_harm, int batch, hipStream_t stream);

@@ -25,8 +25,6 @@
 
 namespace {
 
-constexpr int DEC_HALF = 150;
-constexpr int DEC_TAPS = 2 * DEC_HALF + 1;
 constexpr double DEC_CUTOFF = 0.239;
 constexpr double DEC_BETA = 10.0;
 constexpr int MAX_BANKS = 16;          // banks per pyramid level
@@ -48,6 +46,11 @@ double bessel_i0(double x) {
 }
 
 // ---------------------------------------------------------------- kernels
+typedef __attribute__((ext_vector_type(8))) __bf16 cq_bf16x8;
+__device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cq_bf16x8, a), __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
+}
+
 // level 0 of the pyramid: the clip copied between its centre paddings.  `zero_pads`: the paddings are written here too (zeros, librosa
 // >= 0.10; the reflecting pad of 0.9 keeps its own kernel); the per-(clip, harmonic) maxima the basis products accumulate are reset.
 __global__ __launch_bounds__(256) void cqt_level0_kernel(const float* __restrict__ audio, int64_t n, int64_t astride, float* __restrict__ pyr,
@@ -61,107 +64,6 @@ __global__ __launch_bounds__(256) void cqt_level0_kernel(const float* __restrict
             row[i] = (i >= pad && i < pad + n) ? src[i - pad] : 0.f;
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) row[pad + i] = src[i];
-    }
-}
-
-// zero centre paddings of a decimated level, written by the first / last block of the kernel that produces the level
-__device__ __forceinline__ void cqt_zero_pads(float* __restrict__ row, int64_t n_out, int64_t out_stride, int pad) {
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < pad; i += 256) row[i] = 0.f;
-    if (blockIdx.x == gridDim.x - 1)
-        for (int64_t i = pad + n_out + threadIdx.x; i < out_stride; i += 256) row[i] = 0.f;
-}
-
-// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in): the half-band decimation of the pyramid.  (A register-blocked
-// vector-ALU FIR did this until round 2, 1.62 ms per HCQT call; the matrix-core kernel below replaced it and its A/B switch is gone.)
-
-// The same decimation on the matrix cores.  For a block of 16 consecutive outputs y[16 q + i] = sum_k h[k] in[32 q + 2 i + k - HALF]
-// is a 16 x KW Toeplitz matrix T[i][j] = h[j - 2 i] (constant: fragments built once per plan) times the window
-// in[32 q - HALF .. + KW); 16 such blocks q are the 16 columns of one MFMA, so 256 outputs cost NKS x 6 MFMAs and 3 NKS 16-byte
-// LDS reads per lane instead of ~1200 vector FMAs per lane.  Operands are split into THREE bf16 planes (hi + mid + lo = all 24
-// mantissa bits) and the six products down to 2^-24 are kept: the decimator feeds up to seven further stages and the -80 dB floor
-// of the log-magnitude map, and with the two-plane split of the other kernels (2^-17 per operand) the 8-octave CQT of config 1
-// missed its 1e-3 tolerance (1.07e-3).  The input tile is split once at staging; windows of neighbouring columns overlap in LDS,
-// lanes read 16 contiguous bytes at 64 q + 16 g: conflict-free.
-constexpr int DEC_KW = 352;                       // >= 30 + DEC_TAPS, a multiple of 32
-constexpr int DEC_NKS = DEC_KW / 32;
-constexpr int DEC_MCH = 4096;                     // outputs per block: 4 waves x 4 iterations x 256
-constexpr int DEC_MXS = 2 * DEC_MCH + DEC_KW;     // input samples per block
-
-typedef __attribute__((ext_vector_type(8))) __bf16 cq_bf16x8;
-__device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cq_bf16x8, a), __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
-}
-
-__global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, int in_pad, float* __restrict__ out,
-                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag, int zero_pads,
-                                                                float* __restrict__ maxbuf, int n_harm) {
-    __shared__ __attribute__((aligned(16))) unsigned short xh[DEC_MXS + 8], xm[DEC_MXS + 8], xl[DEC_MXS + 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    if (zero_pads) cqt_zero_pads(out + (int64_t)b * out_stride, n_out, out_stride, pad);
-    if (maxbuf && blockIdx.x == 0 && tid < n_harm) maxbuf[b * n_harm + tid] = 0.f;     // first level straight from the caller's audio: no level-0 kernel resets them
-    const int64_t m0 = (int64_t)blockIdx.x * DEC_MCH;
-    const float* src = in + (int64_t)b * in_stride + in_pad;
-    const int64_t base = 2 * m0 - DEC_HALF;
-    // all loads of a thread first (clamped addresses, the zeroing applied afterwards): a load -> test -> store loop pays one memory
-    // round trip per iteration
-    constexpr int NPAIR = (DEC_MXS / 2 + 255) / 256;
-    float ld0[NPAIR], ld1[NPAIR];
-#pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-        const int64_t g0 = base + 2 * (tid + 256 * k), g1 = g0 + 1;
-        ld0[k] = src[min(max(g0, (int64_t)0), n_in - 1)];
-        ld1[k] = src[min(max(g1, (int64_t)0), n_in - 1)];
-    }
-#pragma unroll
-    for (int k = 0; k < NPAIR; ++k) {
-        const int i = 2 * (tid + 256 * k);
-        if (i >= DEC_MXS) break;
-        const int64_t g0 = base + i, g1 = g0 + 1;
-        const float v0 = (g0 >= 0 && g0 < n_in) ? ld0[k] : 0.f, v1 = (g1 >= 0 && g1 < n_in) ? ld1[k] : 0.f;
-        const uint32_t hi = pack_bf16x2(v0, v1);
-        const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
-        uint32_t mid, lo;
-        split_bf16x2(r0, r1, mid, lo);
-        *reinterpret_cast<uint32_t*>(xh + i) = hi;
-        *reinterpret_cast<uint32_t*>(xm + i) = mid;
-        *reinterpret_cast<uint32_t*>(xl + i) = lo;
-    }
-    uint4 th[DEC_NKS], tm[DEC_NKS], tl[DEC_NKS];   // Toeplitz fragments: [ks][plane][lane]
-#pragma unroll
-    for (int ks = 0; ks < DEC_NKS; ++ks) {
-        th[ks] = tfrag[(ks * 3 + 0) * 64 + lane]; tm[ks] = tfrag[(ks * 3 + 1) * 64 + lane]; tl[ks] = tfrag[(ks * 3 + 2) * 64 + lane];
-    }
-    __syncthreads();
-    const int q = lane & 15, g = lane >> 4;
-    float* dst = out + (int64_t)b * out_stride + pad;
-    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
-#pragma unroll 1
-    for (int it = 0; it < DEC_MCH / 1024; ++it) {
-        const int o0 = (it * 4 + wave) * 256;                       // first output of this wave's 256, relative to the block
-        const int s0 = 2 * o0 + 32 * q + 8 * g;                      // first sample of this lane's fragments
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < DEC_NKS; ++ks) {
-            const uint4 bh = *reinterpret_cast<const uint4*>(xh + s0 + 32 * ks), bm = *reinterpret_cast<const uint4*>(xm + s0 + 32 * ks),
-                        bl = *reinterpret_cast<const uint4*>(xl + s0 + 32 * ks);
-            acc = cq_mfma(tl[ks], bh, acc);                            // smallest terms first
-            acc = cq_mfma(th[ks], bl, acc);
-            acc = cq_mfma(tm[ks], bm, acc);
-            acc = cq_mfma(tm[ks], bh, acc);
-            acc = cq_mfma(th[ks], bm, acc);
-            acc = cq_mfma(th[ks], bh, acc);
-        }
-        const int64_t m = m0 + o0 + 16 * q + 4 * g;
-        const float r2 = 1.41421356237309505f;
-        if (vec_ok && m + 3 < n_out) {
-            *reinterpret_cast<float4*>(dst + m) = make_float4(r2 * acc[0], r2 * acc[1], r2 * acc[2], r2 * acc[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (m + r < n_out) dst[m + r] = r2 * acc[r];
-        }
     }
 }
 
@@ -780,12 +682,11 @@ extern "C" int amtx_cqt_forward(const amtx_cqt_plan* p, const float* audio, int6
             hipLaunchKernelGGL(cqt_level0_kernel, dim3(nb, B), dim3(256), 0, s, audio, num_samples, audio_stride, pyr, d.stride[0], p->pad,
                                zero_pads, maxbuf, p->n_harm);
         } else {
-            const unsigned nb = (unsigned)((d.len[l] + DEC_MCH - 1) / DEC_MCH);
             const bool from_audio = direct0 && l == 1;
-            hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, B), dim3(256), 0, s,
-                               from_audio ? audio : (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1], from_audio ? audio_stride : d.stride[l - 1],
-                               from_audio ? 0 : p->pad, pyr, d.len[l], d.stride[l], p->pad, (const uint4*)p->d_tfrag, zero_pads,
-                               from_audio ? maxbuf : (float*)nullptr, p->n_harm);
+            int rc = amtx_launch_cqt_decimate(from_audio ? audio : (const float*)(ws + d.pyr_off[l - 1]), d.len[l - 1], from_audio ? audio_stride : d.stride[l - 1],
+                                              from_audio ? 0 : p->pad, pyr, d.len[l], d.stride[l], p->pad, p->d_tfrag, zero_pads,
+                                              from_audio ? maxbuf : (float*)nullptr, p->n_harm, B, s);
+            if (rc != AMTX_OK) return rc;
         }
         AMTX_CHECK_LAUNCH();
         if (!zero_pads) {      // librosa 0.9: reflecting centre pad, from the level's own samples

@@ -1,0 +1,392 @@
+// The half-band decimator of the CQT pyramid (cqt.hip: one call per level; the 301-tap Kaiser filter is the project's documented stand-in for
+// the soxr resampler behind librosa.vqt) on the matrix cores.
+//
+// A translation unit of its own because it is compiled with -fno-slp-vectorize (amt_tools_amd/build.py): the producer waves of
+// cqt_decimate2_kernel split raw samples into bf16 planes beside the matrix waves of the same SIMDs, and the packed f32 subtractions the SLP
+// vectorizer makes of that (v_pk_add_f32) cost 2465 instead of 1422 cycles per tile there -- while cqt.hip's basis kernel must keep the
+// flags of gemm.hip (its magnitude epilogue is checked bit for bit against the GEMM path's).
+
+#include "amtx_kernels.h"
+
+#include <cstdlib>
+
+#include <algorithm>
+
+namespace {
+
+// zero centre paddings of a decimated level, written by the first / last block of the kernel that produces the level
+__device__ __forceinline__ void cqt_zero_pads(float* __restrict__ row, int64_t n_out, int64_t out_stride, int pad) {
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < pad; i += 256) row[i] = 0.f;
+    if (blockIdx.x == gridDim.x - 1)
+        for (int64_t i = pad + n_out + threadIdx.x; i < out_stride; i += 256) row[i] = 0.f;
+}
+
+// out[m] = sqrt(2) * sum_k h[k] in[2m + k - DEC_HALF], zero outside [0, n_in): the half-band decimation of the pyramid.  (A register-blocked
+// vector-ALU FIR did this until round 2, 1.62 ms per HCQT call; the matrix-core kernel below replaced it and its A/B switch is gone.)
+
+// The same decimation on the matrix cores.  For a block of 16 consecutive outputs y[16 q + i] = sum_k h[k] in[32 q + 2 i + k - HALF]
+// is a 16 x KW Toeplitz matrix T[i][j] = h[j - 2 i] (constant: fragments built once per plan) times the window
+// in[32 q - HALF .. + KW); 16 such blocks q are the 16 columns of one MFMA, so 256 outputs cost NKS x 6 MFMAs and 3 NKS 16-byte
+// LDS reads per lane instead of ~1200 vector FMAs per lane.  Operands are split into THREE bf16 planes (hi + mid + lo = all 24
+// mantissa bits) and the six products down to 2^-24 are kept: the decimator feeds up to seven further stages and the -80 dB floor
+// of the log-magnitude map, and with the two-plane split of the other kernels (2^-17 per operand) the 8-octave CQT of config 1
+// missed its 1e-3 tolerance (1.07e-3).  The input tile is split once at staging; windows of neighbouring columns overlap in LDS,
+// lanes read 16 contiguous bytes at 64 q + 16 g: conflict-free.
+constexpr int DEC_MCH = 4096;                     // outputs per block: 4 waves x 4 iterations x 256
+constexpr int DEC_MXS = 2 * DEC_MCH + DEC_KW;     // input samples per block
+
+typedef __attribute__((ext_vector_type(8))) __bf16 cq_bf16x8;
+__device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cq_bf16x8, a), __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void cqt_decimate_mfma_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, int in_pad, float* __restrict__ out,
+                                                                int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag, int zero_pads,
+                                                                float* __restrict__ maxbuf, int n_harm) {
+    __shared__ __attribute__((aligned(16))) unsigned short xh[DEC_MXS + 8], xm[DEC_MXS + 8], xl[DEC_MXS + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    if (zero_pads) cqt_zero_pads(out + (int64_t)b * out_stride, n_out, out_stride, pad);
+    if (maxbuf && blockIdx.x == 0 && tid < n_harm) maxbuf[b * n_harm + tid] = 0.f;     // first level straight from the caller's audio: no level-0 kernel resets them
+    const int64_t m0 = (int64_t)blockIdx.x * DEC_MCH;
+    const float* src = in + (int64_t)b * in_stride + in_pad;
+    const int64_t base = 2 * m0 - DEC_HALF;
+    // all loads of a thread first (clamped addresses, the zeroing applied afterwards): a load -> test -> store loop pays one memory
+    // round trip per iteration
+    constexpr int NPAIR = (DEC_MXS / 2 + 255) / 256;
+    float ld0[NPAIR], ld1[NPAIR];
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+        const int64_t g0 = base + 2 * (tid + 256 * k), g1 = g0 + 1;
+        ld0[k] = src[min(max(g0, (int64_t)0), n_in - 1)];
+        ld1[k] = src[min(max(g1, (int64_t)0), n_in - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NPAIR; ++k) {
+        const int i = 2 * (tid + 256 * k);
+        if (i >= DEC_MXS) break;
+        const int64_t g0 = base + i, g1 = g0 + 1;
+        const float v0 = (g0 >= 0 && g0 < n_in) ? ld0[k] : 0.f, v1 = (g1 >= 0 && g1 < n_in) ? ld1[k] : 0.f;
+        const uint32_t hi = pack_bf16x2(v0, v1);
+        const float r0 = v0 - __uint_as_float(hi << 16), r1 = v1 - __uint_as_float(hi & 0xffff0000u);
+        uint32_t mid, lo;
+        split_bf16x2(r0, r1, mid, lo);
+        *reinterpret_cast<uint32_t*>(xh + i) = hi;
+        *reinterpret_cast<uint32_t*>(xm + i) = mid;
+        *reinterpret_cast<uint32_t*>(xl + i) = lo;
+    }
+    uint4 th[DEC_NKS], tm[DEC_NKS], tl[DEC_NKS];   // Toeplitz fragments: [ks][plane][lane]
+#pragma unroll
+    for (int ks = 0; ks < DEC_NKS; ++ks) {
+        th[ks] = tfrag[(ks * 3 + 0) * 64 + lane]; tm[ks] = tfrag[(ks * 3 + 1) * 64 + lane]; tl[ks] = tfrag[(ks * 3 + 2) * 64 + lane];
+    }
+    __syncthreads();
+    const int q = lane & 15, g = lane >> 4;
+    float* dst = out + (int64_t)b * out_stride + pad;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+#pragma unroll 1
+    for (int it = 0; it < DEC_MCH / 1024; ++it) {
+        const int o0 = (it * 4 + wave) * 256;                       // first output of this wave's 256, relative to the block
+        const int s0 = 2 * o0 + 32 * q + 8 * g;                      // first sample of this lane's fragments
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < DEC_NKS; ++ks) {
+            const uint4 bh = *reinterpret_cast<const uint4*>(xh + s0 + 32 * ks), bm = *reinterpret_cast<const uint4*>(xm + s0 + 32 * ks),
+                        bl = *reinterpret_cast<const uint4*>(xl + s0 + 32 * ks);
+            acc = cq_mfma(tl[ks], bh, acc);                            // smallest terms first
+            acc = cq_mfma(th[ks], bl, acc);
+            acc = cq_mfma(tm[ks], bm, acc);
+            acc = cq_mfma(tm[ks], bh, acc);
+            acc = cq_mfma(th[ks], bm, acc);
+            acc = cq_mfma(th[ks], bh, acc);
+        }
+        const int64_t m = m0 + o0 + 16 * q + 4 * g;
+        const float r2 = 1.41421356237309505f;
+        if (vec_ok && m + 3 < n_out) {
+            *reinterpret_cast<float4*>(dst + m) = make_float4(r2 * acc[0], r2 * acc[1], r2 * acc[2], r2 * acc[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (m + r < n_out) dst[m + r] = r2 * acc[r];
+        }
+    }
+}
+
+// ---- the decimator, second form (round 5): same arithmetic, same bits, less around it.  The kernel above issues, per 4096 outputs, 34 scalar
+// loads + ~1100 vector instructions of 64-bit clamping / splitting per thread with nothing else to do until they land, re-reads the 33 KB of
+// Toeplitz fragments from L2 in every wave of every block (4 x the block's input), and its fragment reads are two-way bank conflicted
+// (lane (q, g) at byte 64 q + 16 g: the 16-lane groups of ds_read_b128 fold q and q + 12 onto one slot) -- as many LDS cycles as matrix
+// cycles.  Here one persistent 512-thread block per CU is split by role:
+//   - waves 4-7 PRODUCE: the samples of the tiles k + 1 and k + 2 travel HBM -> LDS by DMA (global_load_lds_dword: any 4-byte alignment --
+//     the reference's 319999-sample clips put three rows of four off 16-byte boundaries -- and no registers) while tile k is split into its
+//     three planes by 16-byte LDS reads / 8-byte writes; samples outside the clip are zeroed there (the DMA reads clamped addresses).  Each
+//     wave converts the quarter of the raw tile it fetched itself: no barrier between the producers;
+//   - waves 0-3 MULTIPLY, one tile behind: the Toeplitz fragments stay in their registers for the whole launch (132 of them), each works on
+//     512 consecutive outputs with TWO accumulators -- output blocks 2 q and 2 q + 1 in column q, so the fragment of block 2 q + 1 at step
+//     ks is the fragment of block 2 q at step ks + 1: 12 fragment triples per 512 outputs instead of 22, two independent chains;
+//   - ONE barrier per tile (two plane sets); every SIMD holds one wave of each role, so the splitting runs beside the matrix instructions
+//     instead of between them (as two whole-tile blocks per CU, each doing both in turn, the matrix pipes were 59 % busy);
+//   - the planes are stored in 16-byte granules XOR-swizzled by (G >> 4) & 3 so that the fragment reads are conflict-free
+//     (tools/lds_swizzle_check_dec.py).
+// Each output's products are accumulated in the order of the kernel above: bit-identical (tests/test_gpu_cqt.py, AMTX_CQT_DECIM_V1=1 keeps the old one).
+#ifdef AMTX_CQT_TIMING
+// debug build only (tools/build_dbg.sh cqttiming cqt_dec.hip -DAMTX_CQT_TIMING; tools/cqt_phase_prof.py): cycles per phase of wave 0 (multiplying:
+// [0] barrier, [1] matrix loop + stores) and wave 4 (producing: [2] tile setup / pads, [3] wait for the tile's DMA, [4] split, [5] DMA issue,
+// [6] barrier) of every block, [7] tiles
+__device__ unsigned long long g_dec_prof[8];
+#define DQ_TICK(SLOT) do { const unsigned long long now_ = __builtin_readcyclecounter(); dq_acc[SLOT] += now_ - dq_t; dq_t = now_; } while (0)
+extern "C" int amtxdbg_dec_prof(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dec_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_dec_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define DQ_TICK(SLOT) do {} while (0)
+#endif
+constexpr int DEC2_MCH = 2048;                             // outputs per tile: 4 waves x 512
+constexpr int DEC2_MXS = 2 * DEC2_MCH + DEC_KW;            // samples a tile's windows touch
+constexpr int DEC2_PLANE = (DEC2_MXS + 63) / 64 * 64;      // ushorts per plane (the swizzle permutes granules inside groups of eight)
+constexpr int DEC2_NDMA = (DEC2_MXS + 255) / 256;          // DMA instructions per producer wave and tile (64 samples each)
+constexpr int DEC2_QTR = DEC2_NDMA * 64;                   // floats of a raw tile per producer wave
+constexpr int DEC2_RAW = 4 * DEC2_QTR;                     // floats per raw tile
+constexpr int DEC2_NV4 = (DEC2_MXS + 3) / 4;              // 16-byte pieces of a raw tile that are needed
+constexpr int DEC2_NCV = (DEC2_QTR / 4 + 63) / 64;         // pieces per producer lane
+constexpr size_t DEC2_LDS = 2 * DEC2_RAW * sizeof(float) + 2 * 3 * DEC2_PLANE * sizeof(unsigned short);
+static_assert(DEC2_NDMA == 18, "the DMA issue below is written for 18 pieces per wave (4 x 4 + 2)");
+
+// 4 bytes per lane HBM/L2 -> LDS: LDS address = M0 (wave-uniform) + instruction offset + lane * 4 (see glds16 in amtx_common.h for why this is
+// inline asm).  NP pieces with one M0 set-up; piece n reads base + off[n] and lands n * 256 bytes further.  The instruction offset counts for
+// both addresses: the caller passes base 768 bytes low and off[n] = byte offset + 768 - 256 n (unsigned, 32 bits).
+template <int NP>
+__device__ __forceinline__ void dec_glds4(const char* base, const unsigned (&off)[4], unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    if constexpr (NP == 4) {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, %6\n\t"
+                     "global_load_lds_dword %2, %6 offset:256\n\t"
+                     "global_load_lds_dword %3, %6 offset:512\n\t"
+                     "global_load_lds_dword %4, %6 offset:768\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "s"(lds_addr), "s"(base)
+                     : "memory");
+    } else {
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "global_load_lds_dword %1, %4\n\t"
+                     "global_load_lds_dword %2, %4 offset:256\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(off[0]), "v"(off[1]), "s"(lds_addr), "s"(base)
+                     : "memory");
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void cqt_decimate2_kernel(const float* __restrict__ in, int64_t n_in, int64_t in_stride, int in_pad, float* __restrict__ out,
+                                                               int64_t n_out, int64_t out_stride, int pad, const uint4* __restrict__ tfrag, int zero_pads,
+                                                               float* __restrict__ maxbuf, int n_harm, int tiles_per_clip, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char dec_smem[];       // two raw tiles, then two sets of three planes: DEC2_LDS bytes
+    float (*raw)[DEC2_RAW] = reinterpret_cast<float (*)[DEC2_RAW]>(dec_smem);
+    unsigned short (*xp)[3][DEC2_PLANE] = reinterpret_cast<unsigned short (*)[3][DEC2_PLANE]>(dec_smem + 2 * DEC2_RAW * sizeof(float));
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const bool producer = tid >= 256;
+    const int stride = (int)gridDim.x;
+#ifdef AMTX_CQT_TIMING
+    unsigned long long dq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dq_t = __builtin_readcyclecounter();
+#endif
+    if (producer) {
+        const int nlast = (int)n_in - 1;
+        // raw tile: float j = sample 2 m0 - DEC_HALF + j of the row (clamped into the clip; zeroed at the split); wave w fetches and splits
+        // the floats [w QTR, + QTR).  ALWAYS 18 instructions per wave (a tile past the end reads the first row over again): the counted
+        // wait below relies on it.
+        auto dma = [&](int tile, int buf) {
+            const bool real = tile < ntiles;
+            const int b = real ? tile / tiles_per_clip : 0, c = real ? tile % tiles_per_clip : 0;
+            const char* base = reinterpret_cast<const char*>(in + (int64_t)b * in_stride + in_pad) - 768;       // wave-uniform
+            const int s0 = 2 * c * DEC2_MCH - DEC_HALF + wave * DEC2_QTR + lane;
+            const unsigned dst = (unsigned)(uintptr_t)(&raw[buf][wave * DEC2_QTR]);
+#pragma unroll
+            for (int i0 = 0; i0 < DEC2_NDMA; i0 += 4) {
+                unsigned off[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) off[n] = 4u * (unsigned)min(max(s0 + (i0 + n) * 64, 0), nlast) + (768 - 256 * n);
+                if (i0 + 4 <= DEC2_NDMA) dec_glds4<4>(base, off, dst + i0 * 256);
+                else dec_glds4<2>(base, off, dst + i0 * 256);
+            }
+        };
+        int tile = blockIdx.x;
+        dma(tile, 0);
+        dma(tile + stride, 1);
+        for (int cur = 0; tile < ntiles; tile += stride, cur ^= 1) {
+            const int b = tile / tiles_per_clip, c = tile % tiles_per_clip;
+            const int ptid = tid - 256;
+            if (zero_pads) {                                   // the level's zero centre paddings, by the blocks of the clip's first / last tile
+                float* row = out + (int64_t)b * out_stride;
+                if (c == 0)
+                    for (int i = ptid; i < pad; i += 256) row[i] = 0.f;
+                if (c == tiles_per_clip - 1)
+                    for (int64_t i = pad + n_out + ptid; i < out_stride; i += 256) row[i] = 0.f;
+            }
+            if (maxbuf && c == 0 && ptid < n_harm) maxbuf[b * n_harm + ptid] = 0.f;
+            DQ_TICK(2);
+            // this tile's DMA was issued two tiles ago; behind it in this wave's queue: the next tile's 18 pieces (+ pad stores).  Memory
+            // operations of a wave complete in order: at most 18 outstanding = this tile's have landed.
+            wait_vm<DEC2_NDMA>();
+            DQ_TICK(3);
+            {
+                const int s0 = 2 * c * DEC2_MCH - DEC_HALF;     // row sample of raw float 0
+                const bool edge = s0 < 0 || s0 + DEC2_MXS > (int)n_in;
+                const int jlo = s0 < 0 ? -s0 : 0;               // raw floats [jlo, jhi) lie inside the clip
+                const int jhi = min(DEC2_MXS, max((int)n_in - s0, 0));
+                const float4* r4 = reinterpret_cast<const float4*>(raw[cur]);
+                unsigned short *xh = xp[cur][0], *xm = xp[cur][1], *xl = xp[cur][2];
+                // all reads, then the masks of an edge tile in ONE branch, then the conversions (a branch per piece made five read -> wait ->
+                // convert -> write round trips of it: 2700 cycles per tile, more than the matrix loop)
+                float4 v[DEC2_NCV];
+                const int idx0 = wave * (DEC2_QTR / 4) + lane;
+#pragma unroll
+                for (int k = 0; k < DEC2_NCV; ++k) v[k] = r4[min(idx0 + 64 * k, DEC2_RAW / 4 - 1)];
+                if (edge) {
+                    const unsigned span = (unsigned)(jhi - jlo);
+#pragma unroll
+                    for (int k = 0; k < DEC2_NCV; ++k) {
+                        const int j = 4 * (idx0 + 64 * k) - jlo;
+                        v[k].x = (unsigned)(j + 0) < span ? v[k].x : 0.f;
+                        v[k].y = (unsigned)(j + 1) < span ? v[k].y : 0.f;
+                        v[k].z = (unsigned)(j + 2) < span ? v[k].z : 0.f;
+                        v[k].w = (unsigned)(j + 3) < span ? v[k].w : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < DEC2_NCV; ++k) {
+                    const int idx = idx0 + 64 * k;
+                    const uint32_t h0 = pack_bf16x2(v[k].x, v[k].y), h1 = pack_bf16x2(v[k].z, v[k].w);
+                    const float r0 = v[k].x - __uint_as_float(h0 << 16), r1 = v[k].y - __uint_as_float(h0 & 0xffff0000u);
+                    const float r2 = v[k].z - __uint_as_float(h1 << 16), r3 = v[k].w - __uint_as_float(h1 & 0xffff0000u);
+                    uint32_t mid0, lo0, mid1, lo1;
+                    split_bf16x2(r0, r1, mid0, lo0);
+                    split_bf16x2(r2, r3, mid1, lo1);
+                    int G = idx >> 1;                           // the piece's granule (8 samples), swizzled
+                    G ^= ((G >> 4) & 3) << 1;
+                    const int p = (G << 3) | ((idx & 1) << 2);
+                    if ((k < DEC2_NCV - 1 || lane + 64 * k < DEC2_QTR / 4) && idx < DEC2_NV4) {
+                        *reinterpret_cast<uint2*>(xh + p) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(xm + p) = make_uint2(mid0, mid1);
+                        *reinterpret_cast<uint2*>(xl + p) = make_uint2(lo0, lo1);
+                    }
+                }
+            }
+            DQ_TICK(4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's quarter of raw[cur] has been read: refill it
+            dma(tile + 2 * stride, cur);
+            DQ_TICK(5);
+            lds_only_barrier();                                // planes of this tile complete -> waves 0-3; they are through with the last tile's
+            DQ_TICK(6);
+#ifdef AMTX_CQT_TIMING
+            dq_acc[7] += 1;
+#endif
+        }
+        wait_vm<0>();                                          // (the DMA of the two tiles past the end)
+    } else {
+        uint4 th[DEC_NKS], tm[DEC_NKS], tl[DEC_NKS];
+#pragma unroll
+        for (int ks = 0; ks < DEC_NKS; ++ks) {
+            th[ks] = tfrag[(ks * 3 + 0) * 64 + lane]; tm[ks] = tfrag[(ks * 3 + 1) * 64 + lane]; tl[ks] = tfrag[(ks * 3 + 2) * 64 + lane];
+        }
+        const int q = lane & 15, g = lane >> 4;
+        const int o0 = wave * 512;                              // first output of this wave's 512, relative to the tile
+        const int G0 = (2 * o0 + 64 * q + 8 * g) >> 3;          // granule of this lane's fragment of block 2 q at step 0
+        int cur = 0;
+        for (int tile = blockIdx.x; tile < ntiles; tile += stride, cur ^= 1) {
+            const int b = tile / tiles_per_clip, c = tile % tiles_per_clip;
+            const int m0 = c * DEC2_MCH;
+            float* dst = out + (int64_t)b * out_stride + pad;
+            const bool vec_ok = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
+            const uint4 *xh4 = reinterpret_cast<const uint4*>(xp[cur][0]), *xm4 = reinterpret_cast<const uint4*>(xp[cur][1]),
+                        *xl4 = reinterpret_cast<const uint4*>(xp[cur][2]);
+            lds_only_barrier();                                // the producers' barrier of this tile
+            DQ_TICK(0);
+            f32x4_t acca = (f32x4_t){0.f, 0.f, 0.f, 0.f}, accb = acca;
+            // fragment triple F[s] = granule G0 + 4 s of the three planes, s = 0 .. 11; step ks multiplies F[ks] (block 2 q) and F[ks + 1]
+            // (block 2 q + 1).  Reads run DEC2_AHEAD steps ahead of their first use and the matrix instructions alternate between the two
+            // chains, both pinned: left to itself hipcc reads each triple right in front of its first use (an LDS round trip per step) and
+            // pairs instructions of the same chain.
+            constexpr int DEC2_AHEAD = 3;
+            uint4 fh[DEC_NKS + 1], fm[DEC_NKS + 1], fl[DEC_NKS + 1];
+            auto fetch = [&](int sidx) {
+                const int Gs = G0 + 4 * sidx;
+                const int ps = Gs ^ (((Gs >> 4) & 3) << 1);
+                fh[sidx] = xh4[ps]; fm[sidx] = xm4[ps]; fl[sidx] = xl4[ps];
+            };
+#pragma unroll
+            for (int sidx = 0; sidx < DEC2_AHEAD; ++sidx) fetch(sidx);
+#pragma unroll
+            for (int ks = 0; ks < DEC_NKS; ++ks) {
+                if (ks + DEC2_AHEAD <= DEC_NKS) fetch(ks + DEC2_AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = cq_mfma(tl[ks], fh[ks], acca);                 // smallest terms first (the order of cqt_decimate_mfma_kernel)
+                accb = cq_mfma(tl[ks], fh[ks + 1], accb);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = cq_mfma(th[ks], fl[ks], acca);
+                accb = cq_mfma(th[ks], fl[ks + 1], accb);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = cq_mfma(tm[ks], fm[ks], acca);
+                accb = cq_mfma(tm[ks], fm[ks + 1], accb);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = cq_mfma(tm[ks], fh[ks], acca);
+                accb = cq_mfma(tm[ks], fh[ks + 1], accb);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = cq_mfma(th[ks], fm[ks], acca);
+                accb = cq_mfma(th[ks], fm[ks + 1], accb);
+                __builtin_amdgcn_sched_barrier(0);
+                acca = cq_mfma(th[ks], fh[ks], acca);
+                accb = cq_mfma(th[ks], fh[ks + 1], accb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const float r2 = 1.41421356237309505f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4_t acc = h ? accb : acca;
+                const int m = m0 + o0 + 32 * q + 16 * h + 4 * g;
+                if (vec_ok && m + 3 < (int)n_out) {
+                    *reinterpret_cast<float4*>(dst + m) = make_float4(r2 * acc[0], r2 * acc[1], r2 * acc[2], r2 * acc[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < (int)n_out) dst[m + r] = r2 * acc[r];
+                }
+            }
+            DQ_TICK(1);
+        }
+    }
+#ifdef AMTX_CQT_TIMING
+    if ((tid & 255) == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_dec_prof[i], dq_acc[i]);
+#endif
+}
+
+}  // namespace
+
+int amtx_launch_cqt_decimate(const float* in, int64_t n_in, int64_t in_stride, int in_pad, float* out, int64_t n_out, int64_t out_stride, int pad,
+                             const void* tfrag, int zero_pads, float* maxbuf, int n_harm, int batch, hipStream_t s) {
+    AMTX_REQUIRE(in && out && tfrag && n_in >= 1 && n_out >= 1 && batch >= 1 && batch < 65536 && n_harm <= 256, "cqt decimator: bad arguments");
+    static const bool decim_v1 = getenv("AMTX_CQT_DECIM_V1") != nullptr;     // A/B switch: round 4's decimator
+    const int64_t nb2 = (n_out + DEC2_MCH - 1) / DEC2_MCH;
+    if (!decim_v1 && nb2 * batch < (1ll << 30) && n_in < (1ll << 30) - DEC2_MXS) {
+        const int ntiles = (int)(nb2 * batch);
+        static const int dec_blocks = getenv("AMTX_CQT_DECIM_BLOCKS") ? atoi(getenv("AMTX_CQT_DECIM_BLOCKS")) : 256;     // one per CU
+        AMTX_GRANT_LDS(cqt_decimate2_kernel, DEC2_LDS);
+        hipLaunchKernelGGL(cqt_decimate2_kernel, dim3((unsigned)std::min(ntiles, dec_blocks)), dim3(512), DEC2_LDS, s, in, n_in, in_stride, in_pad, out, n_out,
+                           out_stride, pad, (const uint4*)tfrag, zero_pads, maxbuf, n_harm, (int)nb2, ntiles);
+    } else {
+        const unsigned nb = (unsigned)((n_out + DEC_MCH - 1) / DEC_MCH);
+        hipLaunchKernelGGL(cqt_decimate_mfma_kernel, dim3(nb, batch), dim3(256), 0, s, in, n_in, in_stride, in_pad, out, n_out, out_stride, pad,
+                           (const uint4*)tfrag, zero_pads, maxbuf, n_harm);
+    }
+    AMTX_CHECK_LAUNCH();
+    return AMTX_OK;
+}

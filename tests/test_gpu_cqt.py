@@ -127,6 +127,9 @@ for name, mod in (('cqt1', CQT(sample_rate=22050, hop_length=512, n_bins=192, bi
                   ('hcqt_lin', HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, decibels=False))):
     outs[name] = mod.process_batch(torch.from_numpy(y).cuda()).cpu().numpy()
     outs[name + '_one'] = mod.process_audio(y[2][:33333])
+    if name in ('cqt1', 'hcqt3', 'cqt1_09'):        # rows on 16-byte boundaries (the decimator's vector staging), several tiles per clip and level
+        ya = np.stack([synth_clip(5 + i, num_samples=81920) for i in range(2)])
+        outs[name + '_al'] = mod.process_batch(torch.from_numpy(ya).cuda()).cpu().numpy()
 np.savez(sys.argv[1], **outs)
 '''
 
@@ -147,7 +150,30 @@ def test_windowed_basis_kernel_returns_the_bits_of_the_gemm_path(tmp_path):
         files[tag] = str(tmp_path / f'{tag}.npz')
         subprocess.check_call([sys.executable, '-c', _BASIS_AB, files[tag]], env=env, cwd=root)
     a, b = np.load(files['windowed']), np.load(files['gemm'])
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 10
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 13
+    for k in a.files:
+        assert a[k].shape == b[k].shape and a[k].size > 0
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_persistent_decimator_returns_the_bits_of_round_4s(tmp_path):
+    """Round 5: the half-band decimations of the pyramid run on cqt_decimate2_kernel (persistent blocks, 16-byte staging of the tiles
+    inside a clip, two output blocks per matrix column sharing their fragments, swizzled planes); AMTX_CQT_DECIM_V1=1 keeps round 4's
+    kernel.  Every output accumulates the same products in the same order: whole CQT / HCQT / VQT maps must be IDENTICAL -- clips whose
+    rows are 16-byte aligned (vector staging from the caller's audio) and not (70001 samples: scalar staging there, vector staging from
+    the pyramid levels), both padding conventions."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('v2', {}), ('v1', {'AMTX_CQT_DECIM_V1': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _BASIS_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['v2']), np.load(files['v1'])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 13
     for k in a.files:
         assert a[k].shape == b[k].shape and a[k].size > 0
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)

@@ -8,7 +8,7 @@ TAG=$1; SRC=$2; shift 2
 mkdir -p $R/tools/_dbg
 python -c "from amt_tools_amd.build import build; build(verbose=False)"
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function"
-case $SRC in spec.hip|convg.hip) FL="$FL -fno-slp-vectorize";; esac
+case $SRC in spec.hip|convg.hip|cqt_dec.hip) FL="$FL -fno-slp-vectorize";; esac
 BASE=${SRC%.*}
 /opt/rocm/bin/hipcc $FL "$@" -x hip -c $R/amt_tools_amd/csrc/$SRC -o $R/tools/_dbg/${BASE}_$TAG.o
 OBJS=$(ls $R/amt_tools_amd/csrc/*.o | grep -v "/${BASE}.o$")
