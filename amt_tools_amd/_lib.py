@@ -57,6 +57,8 @@ _SIGNATURES = {
     'amtx_of_fuses_db_scale': (_I, [_P]),
     'amtx_of_conv_stack_fused': (_I, [_P, _I, _I]),
     'amtx_of_forward_power': (_I, [_P, _P, _L, _L, _L, _P, _P, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
+    'amtx_of_takes_feats16': (_I, [_P]),
+    'amtx_of_forward_feats16': (_I, [_P, _P, _I, _I, _P, C.c_size_t, _P, _P, _P, _P, _P, _P]),
     'amtx_of_offsets': (_I, [_P, _P, C.c_size_t, _I, _I, _P, _P, _P]),
     'amtx_of_num_stages': (_I, []),
     'amtx_of_stage_name': (C.c_char_p, [_I]),
@@ -89,6 +91,7 @@ _SIGNATURES = {
     'amtx_cqt_num_frames': (_L, [_P, _L]),
     'amtx_cqt_workspace_bytes': (C.c_size_t, [_P, _I, _L]),
     'amtx_cqt_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _P]),
+    'amtx_cqt_forward16': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _P]),
     'amtx_bilstm_h_pack_device': (_I, [_P, _P, _I, _I, _P, _P, _P]),
     'amtx_bilstm_h_train_fwd': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
     'amtx_bilstm_h_train_bwd': (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P]),

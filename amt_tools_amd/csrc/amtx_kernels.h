@@ -72,6 +72,9 @@ struct ConvArgs {
     // c_in = 1 only: `feats` holds raw POWER values and the kernel applies the dB scaling (db_scale_apply, amtx_common.h) while it stages
     // them: f_clip_max[b] = the clip's own maximum, f_ref[b] = the reference power (null: the own maximum).  Null f_clip_max: features as is.
     const float* f_clip_max = nullptr; const float* f_ref = nullptr;
+    // convg.hip's tap-major fused first conv only: the features as [B][T][F][8] 16-bit channels-last (channel slots c_in .. 7 zero) instead of
+    // `feats` (amtx_cqt_forward16 writes them so): a position is one 16-byte load
+    const void* feats16 = nullptr;
     int64_t out_ts = 0;                                  // convg.hip only: elements between consecutive (b, t) rows of `out`; 0 = (F/2) * c_out
     int64_t in_split = 0, out_split = 0;                 // AMTX_T_SPLIT maps (conv.hip, two-plane mode): elements between the hi and the lo plane
 };

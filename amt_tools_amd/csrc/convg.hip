@@ -86,9 +86,13 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // FCL (with KS1 = 3, one plane): the tap-major form of the fused first conv (amtx_conv1g_tapk): features staged channels-last in bf16.
 // CMAX: the most input channels this instantiation stages (sizes the per-thread item slots: 6 -> 9 loads per tile instead of 12; 1 -> 2
 // instead of a rolled ten-slot loop with an early exit); 0 = the variant's limit (8 tap-major, 7 otherwise).
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0>
+// F16IN (tap-major only): the features arrive as that very tile format -- ConvArgs.feats16, [B][T][F][8] 16-bit channels-last, what
+// amtx_cqt_forward16 writes -- and a position is ONE 16-byte load and ONE 16-byte LDS store instead of c_in strided 4-byte loads, conversions
+// and 2-byte stores.
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0, bool F16IN = false>
 __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all, int sh_off) {
     static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
+    static_assert(!F16IN || FCL, "16-bit channels-last features: the tap-major first conv only");
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
     constexpr int NCH = CIN / 8;                 // 16-byte chunks per position
@@ -238,7 +242,9 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     // ---- fused first conv helpers
     constexpr int CMX = CMAX > 0 ? CMAX : (FCL ? 8 : 7);      // channels the item slots are sized for
     constexpr bool EXACT = FCL || CMAX == 1;                  // every slot loads unconditionally (no early exit from the item loops)
-    constexpr int NF1 = FUSE1 ? (CMX * FROWS1 * (FT + 4) + NTH - 1) / NTH : 1;      // feature values per thread (c_in <= 7; tap-major: <= 8)
+    constexpr int NF1 = !FUSE1 ? 1 : F16IN ? (FROWS1 * (FT + 4) + NTH - 1) / NTH      // F16IN: an item is a position (16 bytes)
+                                           : (CMX * FROWS1 * (FT + 4) + NTH - 1) / NTH;   // feature values per thread (c_in <= 7; tap-major: <= 8)
+    using fraw_t = typename std::conditional<F16IN, uint4, float>::type;
     // A thread's feature items are the same tile-relative (channel, row, column) for every tile: decoded once (the div / mod chains
     // per item and tile were a sixth of the kernel), bit 31 = item exists.  The zeroing of values outside the map waits for
     // store_f: a select right behind the load would wait for the load here.
@@ -246,6 +252,12 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
 #pragma unroll
     for (int k = 0; k < NF1; ++k) {
         const int it = tid + k * NTH;
+        if constexpr (F16IN) {
+            const bool has = it < FROWS1 * (FT + 4);
+            const int itc = has ? it : 0;
+            fdesc[k] = (has ? 0x80000000u : 0u) | ((unsigned)(itc / (FT + 4)) << 8) | (unsigned)(itc % (FT + 4));
+            continue;
+        }
         const int itc = it < nfeat ? it : 0;
         int ci, i, j;
         if (a.f_stride_t < a.f_stride_f) {        // frames contiguous (a (B,C,F,T) tensor): consecutive lanes = consecutive frames of one column
@@ -265,15 +277,27 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
 #pragma unroll
         for (int k = 0; k < NF1; ++k) {
             const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
-            foff[k] = ci * (int)a.f_stride_c + i * (int)a.f_stride_t + j * (int)a.f_stride_f;
+            foff[k] = F16IN ? i * F + j : ci * (int)a.f_stride_c + i * (int)a.f_stride_t + j * (int)a.f_stride_f;
         }
     }
-    auto load_f = [&](int tile, float (&fr)[NF1], unsigned& okmask) {
+    auto load_f = [&](int tile, fraw_t (&fr)[NF1], unsigned& okmask) {
         int b, t0, f0;
         coord(tile, b, t0, f0);
-        const float* fb = a.feats + (int64_t)b * a.f_stride_b;
         okmask = 0;
-        if constexpr (FCL) {
+        if constexpr (F16IN) {
+            const uint4* fb = reinterpret_cast<const uint4*>(a.feats16) + (int64_t)b * T * F;      // one uint4 per position
+            const int wb = (t0 - 2) * F + (f0 - 2);
+#pragma unroll
+            for (int k = 0; k < NF1; ++k) {
+                const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                const bool ok = (int)fdesc[k] < 0 && (unsigned)(t0 - 2 + i) < (unsigned)T && (unsigned)(f0 - 2 + j) < (unsigned)F;
+                fr[k] = fb[(unsigned)(ok ? wb + foff[k] : 0)];
+                okmask |= ok ? (1u << k) : 0u;
+            }
+            return;
+        }
+        const float* fb = a.feats + (int64_t)b * a.f_stride_b;
+        if constexpr (FCL && !F16IN) {
             const int wb = (t0 - 2) * (int)a.f_stride_t + (f0 - 2) * (int)a.f_stride_f;   // window origin; negative at the map's edges: only used when valid
             // straight-line: every item slot loads (a slot without an item, or a padding cell, re-reads the clip's first value) -- a
             // guarded load is waited for at the join of its branch, one memory round trip per item (the rolled, branchy form of this loop
@@ -285,7 +309,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                 fr[k] = fb[(unsigned)(ok ? wb + foff[k] : 0)];
                 okmask |= ok ? (1u << k) : 0u;
             }
-        } else {
+        } else if constexpr (!F16IN) {
 #pragma unroll
             for (int k = 0; k < NF1; ++k) {
                 if (!EXACT && k >= nfk) break;
@@ -298,8 +322,17 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             }
         }
     };
-    auto store_f = [&](const float (&fr)[NF1], unsigned okmask) {
-        if constexpr (FCL) {
+    auto store_f = [&](const fraw_t (&fr)[NF1], unsigned okmask) {
+        if constexpr (F16IN) {
+#pragma unroll
+            for (int k = 0; k < NF1; ++k) {
+                const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                const uint4 v = ((okmask >> k) & 1) ? fr[k] : make_uint4(0, 0, 0, 0);
+                if ((int)fdesc[k] < 0) *reinterpret_cast<uint4*>(fs16 + (i * FW + j) * 16) = v;
+            }
+            return;
+        }
+        if constexpr (FCL && !F16IN) {
             // straight-line as well: a slot without an item writes its (zero) value to a scratch line behind the feature tiles
 #pragma unroll
             for (int k = 0; k < NF1; ++k) {
@@ -310,12 +343,14 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             }
             return;
         }
+        if constexpr (!F16IN) {
 #pragma unroll
-        for (int k = 0; k < NF1; ++k) {
-            if (!EXACT && k >= nfk) break;
-            if (fdesc[k] >> 31) {
-                const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
-                fs[(ci * FROWS1 + i) * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
+            for (int k = 0; k < NF1; ++k) {
+                if (!EXACT && k >= nfk) break;
+                if (fdesc[k] >> 31) {
+                    const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                    fs[(ci * FROWS1 + i) * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
+                }
             }
         }
     };
@@ -565,7 +600,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         char* const fs_base = fs16;
         auto xs2 = [&](int i) { return smem + i * (NS * XPLANE); };
         auto fsb = [&](int i) { return fs_base + i * (FROWS1 * FW * 16); };
-        float fraw[NF1];
+        fraw_t fraw[NF1];
         unsigned xok = 0;
         const int stride = (int)gridDim.x;
         int tile = blockIdx.x;
@@ -618,7 +653,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     }
 
     uint4 xraw[FUSE1 ? 1 : NIT][NRAW], wreg[NWIT];
-    float fraw[NF1];
+    fraw_t fraw[NF1];
     unsigned xok = 0;
     // w_all == 3: ONE C_out chunk per block, resident for the launch: blocks i and i + 8 k (the same XCD) walk the same tiles with different
     // chunks (the grid is a multiple of 8 nchunks).  Every tile is staged nchunks times, but no weight ever moves again: what the two-plane
@@ -718,7 +753,7 @@ extern "C" int amtxdbg_convg_prof(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 0>
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 0, bool F16IN = false>
 int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
     const int ntf = (fe + FT - 1) / FT;
@@ -744,7 +779,8 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     const int sh_off = (int)((lds + 15) / 16 * 16);           // [c_out] fp32 shift behind everything else
     lds = (size_t)sh_off + (size_t)a.c_out * sizeof(float);
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
-    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX>;
+    if (F16IN) AMTX_REQUIRE((int64_t)a.T * a.F < (1ll << 27), "conv3x3 (general): a clip's 16-bit feature map must be smaller than 2 GiB");
+    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX, F16IN>;
     AMTX_GRANT_LDS(kern, lds);
     // persistent grid: as many blocks as fit the chip at once (LDS allows 160 KiB / lds per CU), a multiple of 8 per group so a
     // block's tiles stay on its XCD
@@ -762,6 +798,14 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
 
 template <int CI16, int NTC>
 int dispatch_gen(const ConvArgs& a, hipStream_t s) {
+    if (a.feats16) {                                            // fused first conv from 16-bit channels-last features (amtx_cqt_forward16)
+        if constexpr (CI16 == 2) {
+            if (amtx_conv1g_tapk(a.c_in, a.planes) && a.out_type == AMTX_T_BF16)
+                return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true, 0, true>(a, s);
+        }
+        amtx_set_error("conv3x3 (general): 16-bit channels-last features: 2 .. 8 input channels, 32 first-layer channels, one-plane modes only");
+        return AMTX_ERR_UNSUPPORTED;
+    }
     if (a.feats) {                                              // fused first conv
         const int ks1 = (9 * a.c_in + 31) / 32;
         if (amtx_conv1g_tapk(a.c_in, a.planes) && a.out_type == AMTX_T_BF16) {
@@ -882,7 +926,9 @@ bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
 }
 
 int amtx_launch_conv3x3_gen(const ConvArgs& a, int c_in, hipStream_t stream) {
-    AMTX_REQUIRE((a.in || a.feats) && a.wfrag && a.shift && a.out, "conv3x3 (general): null pointer");
+    AMTX_REQUIRE((a.in || a.feats || a.feats16) && a.wfrag && a.shift && a.out, "conv3x3 (general): null pointer");
+    if (a.feats16) AMTX_REQUIRE(!a.feats && !a.f_clip_max && a.w1frag && a.shift1 && ((uintptr_t)a.feats16 % 16) == 0,
+                                "conv3x3 (general): 16-bit features: 16-byte aligned, instead of `feats`, with w1frag / shift1");
     if (a.feats && amtx_conv1g_tapk(a.c_in, a.planes))
         AMTX_REQUIRE(a.f_stride_c >= 0 && a.f_stride_t >= 0 && a.f_stride_f >= 0 &&
                          (int64_t)(a.c_in - 1) * a.f_stride_c + (int64_t)(a.T - 1) * a.f_stride_t + (int64_t)(a.F - 1) * a.f_stride_f < (1ll << 31),

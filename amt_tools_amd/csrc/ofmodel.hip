@@ -626,14 +626,18 @@ static GemmArgs gemm_args(const void* A, int64_t lda, int a_type, const LinearPa
 
 extern "C" int amtx_of_fuses_db_scale(const amtx_of_model* m);
 
+extern "C" int amtx_of_takes_feats16(const amtx_of_model* m);
+
 // clip_max != null: `feats` are raw power values, dB-scaled by the conv kernel while it stages them (amtx_of_forward_power)
-static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t stride_b, int64_t stride_c, int64_t stride_t,
+// feats16 != null: the features as [B][T][F][8] 16-bit channels-last instead of `feats` (amtx_of_forward_feats16)
+static int of_forward_impl(const amtx_of_model* m, const float* feats, const void* feats16, int64_t stride_b, int64_t stride_c, int64_t stride_t,
                            int64_t stride_f, const float* clip_max, const float* ref, int batch, int num_frames, void* workspace,
                            size_t workspace_bytes, float* out_onsets, float* out_multi_pitch, float* logits_onsets,
                            float* logits_multi_pitch, float* logits_pitch_head, void* stream_) {
     AMTX_REQUIRE(m && m->finalized, "amtx_of_forward: model not finalized");
     AMTX_REQUIRE(!clip_max || amtx_of_fuses_db_scale(m), "amtx_of_forward_power: this model does not stage its features in the conv kernel");
-    AMTX_REQUIRE(feats && workspace, "amtx_of_forward: null pointer");
+    AMTX_REQUIRE(!feats16 || amtx_of_takes_feats16(m), "amtx_of_forward_feats16: this model does not stage 16-bit channels-last features");
+    AMTX_REQUIRE((feats || feats16) && workspace, "amtx_of_forward: null pointer");
     AMTX_REQUIRE(batch > 0 && num_frames > 0, "amtx_of_forward: bad batch/num_frames");
     const int B = batch, T = num_frames;
     Workspace w = carve(m, B, T, (char*)workspace);
@@ -685,6 +689,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
         c2.c_in = m->in_channels; c2.w1frag = (const bf16_t*)m->conv1_frag.p; c2.shift1 = (const float*)m->conv1_s.p;
         c2.w1_gs = (int64_t)(m->gen_conv2 ? amtx_conv1g_wfrag_elems(m->in_channels, m->nf1, pl) : amtx_conv1_wfrag_elems(m->in_channels, pl));
         c2.f_clip_max = clip_max; c2.f_ref = ref;
+        if (feats16) { c2.feats = nullptr; c2.feats16 = feats16; }
     }
     const bool fused_stack = m->fuse_stack && amtx_conv_stack_fused_ok(B, T, F, m->n_heads);
     // the fused stack writes its output in planes of 64 channels per pooled frequency column ([F / 4][B T][64]): a k-tile of the two GEMMs
@@ -699,7 +704,7 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, int64_t s
     mark();
 
     ConvArgs c3 = c2;
-    c3.feats = nullptr; c3.w1frag = nullptr; c3.shift1 = nullptr; c3.c_in = 0;
+    c3.feats = nullptr; c3.feats16 = nullptr; c3.w1frag = nullptr; c3.shift1 = nullptr; c3.c_in = 0;
     c3.in = w.a2; c3.wfrag = (const bf16_t*)m->conv3_w.p; c3.shift = (const float*)m->conv3_s.p; c3.out = w.a3;
     c3.F = F2; c3.c_out = m->nf3; c3.in_gs = BT * F2 * m->nf2;
     c3.w_gs = (int64_t)(m->gen_conv ? amtx_conv3x3_gen_wfrag_elems(m->nf2, m->nf3, pl) : amtx_conv3x3_wfrag_elems(m->nf3, pl));
@@ -819,7 +824,7 @@ extern "C" int amtx_of_forward(const amtx_of_model* m, const float* feats, int64
                                int64_t stride_f, int batch, int num_frames, void* workspace, size_t workspace_bytes,
                                float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                                float* logits_pitch_head, void* stream_) {
-    return of_forward_impl(m, feats, stride_b, stride_c, stride_t, stride_f, nullptr, nullptr, batch, num_frames, workspace, workspace_bytes,
+    return of_forward_impl(m, feats, nullptr, stride_b, stride_c, stride_t, stride_f, nullptr, nullptr, batch, num_frames, workspace, workspace_bytes,
                            out_onsets, out_multi_pitch, logits_onsets, logits_multi_pitch, logits_pitch_head, stream_);
 }
 
@@ -828,8 +833,23 @@ extern "C" int amtx_of_forward_power(const amtx_of_model* m, const float* power,
                                      size_t workspace_bytes, float* out_onsets, float* out_multi_pitch, float* logits_onsets,
                                      float* logits_multi_pitch, float* logits_pitch_head, void* stream_) {
     AMTX_REQUIRE(clip_max, "amtx_of_forward_power: clip_max is null");
-    return of_forward_impl(m, power, stride_b, 0, stride_t, stride_f, clip_max, ref, batch, num_frames, workspace, workspace_bytes,
+    return of_forward_impl(m, power, nullptr, stride_b, 0, stride_t, stride_f, clip_max, ref, batch, num_frames, workspace, workspace_bytes,
                            out_onsets, out_multi_pitch, logits_onsets, logits_multi_pitch, logits_pitch_head, stream_);
+}
+
+// 1 when amtx_of_forward_feats16 applies: 2 .. 8 input channels and the first conv fused tap-major into the general conv kernel's 32-channel
+// pipelined variant (convg.hip: one-plane bf16 mode, model_complexity 2) -- the HCQT configuration (BASELINE config 3)
+extern "C" int amtx_of_takes_feats16(const amtx_of_model* m) {
+    return m && m->finalized && m->fuse_conv1 && m->gen_conv2 && !m->f16 && m->planes == 1 && m->nf1 == 32 && amtx_conv1g_tapk(m->in_channels, m->planes) &&
+           m->act_type == AMTX_T_BF16;
+}
+
+extern "C" int amtx_of_forward_feats16(const amtx_of_model* m, const void* feats16, int batch, int num_frames, void* workspace, size_t workspace_bytes,
+                                       float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
+                                       float* logits_pitch_head, void* stream_) {
+    AMTX_REQUIRE(feats16, "amtx_of_forward_feats16: feats16 is null");
+    return of_forward_impl(m, nullptr, feats16, 0, 0, 0, 0, nullptr, nullptr, batch, num_frames, workspace, workspace_bytes, out_onsets, out_multi_pitch,
+                           logits_onsets, logits_multi_pitch, logits_pitch_head, stream_);
 }
 
 // OnsetsFrames2: the offset head's LogisticBank output of the LAST amtx_of_forward on this workspace

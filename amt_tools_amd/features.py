@@ -440,6 +440,29 @@ class _CqtPlanOwner(object):
                                           _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward')
         return out
 
+    def process_batch16(self, audio):
+        """(B, N) float32 CUDA tensor -> (B, T, F, 8) bfloat16: the features of process_batch rounded to bf16 and laid out the way the
+        Onsets & Frames engine's first conv kernel stages them (amtx_cqt_forward16: a position's harmonics in one 16-byte slot, slots
+        C .. 7 zero) -- what OnsetsFrames.run_on_batch hands its engine when the model takes it (amtx_of_forward_feats16)."""
+        import torch
+        assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
+        audio = audio.contiguous()
+        B, N = audio.shape
+        L = _lib.lib()
+        plan = self._get_plan(audio.device)
+        T = _lib.check(L.amtx_cqt_num_frames(plan, N), 'amtx_cqt_num_frames')
+        assert L.amtx_cqt_num_harmonics(plan) <= 8
+        need = L.amtx_cqt_workspace_bytes(plan, B, N)
+        ws = self.__dict__.get('_workspace')
+        if ws is None or ws.numel() < need or ws.device != audio.device:
+            self.__dict__['_workspace'] = None
+            ws = self.__dict__['_workspace'] = _lib.alloc_workspace(need, audio.device)
+        out = torch.empty((B, T, self.n_bins, 8), dtype=torch.bfloat16, device=audio.device)
+        with torch.cuda.device(audio.device):
+            _lib.check(L.amtx_cqt_forward16(plan, _lib.ptr(audio), N, audio.stride(0), B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
+                                            _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward16')
+        return out
+
     def _process_host(self, audio):
         import torch
         dev = torch.device('cuda', self._device_index())

@@ -291,6 +291,22 @@ class PendingFeatures(object):
         return self.module.scale_batch(self.power, self.clip_max, self.ref, model_layout=True)
 
 
+class PendingFeatures16(PendingFeatures):
+    """What OnsetsFrames.pre_proc puts under KEY_FEATS inside run_on_batch when a CQT-family front-end has written its features in the
+    first conv kernel's own staging format (FeatureModule.process_batch16 -> amtx_of_forward_feats16): (B,T,F,8) bfloat16, the harmonics
+    of a position side by side.  `materialize()` is the ordinary fp32 feature tensor as a (B,C,T,F) view, computed from the audio."""
+
+    def __init__(self, module, feats16, audio):
+        self.module, self.feats16, self.audio = module, feats16, audio
+
+    @property
+    def device(self):
+        return self.feats16.device
+
+    def materialize(self):
+        return self.module.process_batch(self.audio).transpose(-1, -2)
+
+
 class _OFEngine(object):
     """ctypes handle of an amtx_of_model + its workspace, bound to one device."""
 
@@ -352,6 +368,9 @@ class _OFEngine(object):
     def fuses_db_scale(self):
         return bool(_lib.lib().amtx_of_fuses_db_scale(self.handle))
 
+    def takes_feats16(self):
+        return bool(_lib.lib().amtx_of_takes_feats16(self.handle))
+
     def conv_stack_fused(self, batch, num_frames):
         """True when a forward pass of this shape runs the three convolution layers as one kernel (csrc/convf.hip)."""
         return bool(_lib.lib().amtx_of_conv_stack_fused(self.handle, int(batch), int(num_frames)))
@@ -360,9 +379,14 @@ class _OFEngine(object):
         """feats: (B,C,T,F) fp32 CUDA tensor (any strides), or PendingFeatures.  Returns binary maps + raw logits."""
         L = _lib.lib()
         pending = feats if isinstance(feats, PendingFeatures) else None
-        if pending is not None:
+        pending16 = isinstance(pending, PendingFeatures16)
+        if pending16:
+            feats = pending.feats16                         # (B,T,F,8): shape and device only
+            B, T = feats.shape[:2]
+        elif pending is not None:
             feats = pending.power.unsqueeze(1)
-        B, Cc, T, Fd = feats.shape
+        if not pending16:
+            B, Cc, T, Fd = feats.shape
         need = L.amtx_of_workspace_bytes(self.handle, B, T)
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = None
@@ -376,7 +400,11 @@ class _OFEngine(object):
         lp = torch.empty((B, T, n_out), **opts) if want_logits else None
         sb, sc, st, sf = feats.stride()
         with torch.cuda.device(feats.device):
-            if pending is not None:
+            if pending16:
+                _lib.check(L.amtx_of_forward_feats16(self.handle, _lib.ptr(feats), B, T, _lib.ptr(self.workspace), self.workspace.numel(),
+                                                     _lib.ptr(onsets), _lib.ptr(multi_pitch), _lib.ptr(lo), _lib.ptr(lm), _lib.ptr(lp),
+                                                     _lib.current_stream(feats.device)), 'amtx_of_forward_feats16')
+            elif pending is not None:
                 _lib.check(L.amtx_of_forward_power(self.handle, _lib.ptr(feats), sb, st, sf, _lib.ptr(pending.clip_max), _lib.ptr(pending.ref), B, T,
                                                    _lib.ptr(self.workspace), self.workspace.numel(), _lib.ptr(onsets), _lib.ptr(multi_pitch),
                                                    _lib.ptr(lo), _lib.ptr(lm), _lib.ptr(lp), _lib.current_stream(feats.device)),
@@ -466,9 +494,14 @@ class OnsetsFrames(TranscriptionModel):
             return None
         if os.environ.get('AMTX_DEFER_DB_SCALE', '1') == '0':     # A/B switch: front-end writes finished features (amtx_spec_scale)
             return None
-        from .features import _SpecPlanOwner
+        from .features import _SpecPlanOwner, _CqtPlanOwner
         module = self.frontend[0].module
-        if not isinstance(module, _SpecPlanOwner) or not getattr(module, 'decibels', False):
+        cqt = isinstance(module, _CqtPlanOwner)
+        if cqt:
+            # CQT family (HCQT: one channel per harmonic): the front-end writes the features in the conv kernel's staging format
+            if os.environ.get('AMTX_CQT_FEATS16', '1') == '0':     # A/B switch: fp32 (B,C,F,T) features, converted by the conv kernel
+                return None
+        elif not isinstance(module, _SpecPlanOwner) or not getattr(module, 'decibels', False):
             return None
         if tools.query_dict(batch, tools.KEY_FEATS) or not tools.query_dict(batch, tools.KEY_AUDIO):
             return None
@@ -478,6 +511,12 @@ class OnsetsFrames(TranscriptionModel):
         audio = batch[tools.KEY_AUDIO]
         if not (torch.is_tensor(audio) and audio.is_cuda and audio.dim() == 2):
             return None
+        if cqt:
+            if not self._get_engine(audio.device).takes_feats16():
+                return None
+            audio = audio.float()
+            batch[tools.KEY_FEATS] = PendingFeatures16(module, module.process_batch16(audio), audio)
+            return batch
         if not self._get_engine(audio.device).fuses_db_scale():
             return None
         power, clip_max = module.power_batch(audio.float())

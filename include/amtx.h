@@ -118,6 +118,17 @@ int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_
                           float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
                           float* logits_pitch_head, void* stream);
 
+/* The same forward pass fed with features the front-end has laid out the way the first conv kernel stages them (amtx_cqt_forward16):
+ * feats16 = [batch][num_frames][dim_in][8] bf16, the input channels (harmonics of an HCQT, amt_tools/features/hvqt.py:107-133) of a
+ * position in one 16-byte slot, slots in_channels .. 7 zero.  The kernel then fetches a position with one load instead of in_channels
+ * strided fp32 loads + conversions; the values are the bf16 roundings it would make of the fp32 features itself, so the results are the
+ * bits of amtx_of_forward.  Only for models where amtx_of_takes_feats16() is 1 (2 .. 8 input channels, model_complexity 2, bf16
+ * precision: BASELINE config 3); AMTX_ERR_ARG otherwise -- callers then run amtx_cqt_forward + amtx_of_forward. */
+int amtx_of_takes_feats16(const amtx_of_model* model);
+int amtx_of_forward_feats16(const amtx_of_model* model, const void* feats16, int batch, int num_frames, void* workspace, size_t workspace_bytes,
+                            float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
+                            float* logits_pitch_head, void* stream);
+
 /* Weight RE-SYNC without leaving the GPU (validate() inside train(), amt_tools/train.py:183-189): after one amtx_of_model_finalize, later
  * weight versions can be handed over as DEVICE pointers (fp32, contiguous, same state_dict names, borrowed until finalize_device returns)
  * and are folded / packed by kernels into the model's existing buffers -- the same bits the host path produces.  Every built
@@ -286,6 +297,11 @@ int64_t amtx_cqt_num_frames(const amtx_cqt_plan* plan, int64_t num_samples);
 size_t amtx_cqt_workspace_bytes(const amtx_cqt_plan* plan, int batch, int64_t num_samples);
 int amtx_cqt_forward(const amtx_cqt_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
                      void* workspace, size_t workspace_bytes, float* out, void* stream);
+/* The same transform with the map laid out for the Onsets & Frames engine's fused first conv (amtx_of_forward_feats16): out16 =
+ * [B][T][n_bins][8] bf16 -- the harmonics of a (frame, bin) position in one 16-byte slot, slots n_harmonics .. 7 zero (n_harmonics <= 8).
+ * The values are amtx_cqt_forward's rounded to bf16 (round to nearest even), i.e. what the conv kernel would make of them itself. */
+int amtx_cqt_forward16(const amtx_cqt_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
+                       void* workspace, size_t workspace_bytes, void* out16, void* stream);
 
 /* RMS normalisation of a batch of clips: tools.rms_norm (tools/utils.py:2789-2814) as applied by
  * tools.load_normalize_audio (tools/io.py:80-82): clip / sqrt(mean(clip^2)), all-zero clips untouched. */

@@ -962,3 +962,79 @@ def test_x3_split_plane_activations_return_the_bits_of_the_fp32_activation_path(
     assert sorted(a.files) == sorted(b.files) and len(a.files) >= 12
     for k in a.files:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+_FEATS16_AB = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd import tools
+from amt_tools_amd.features import HCQT
+from amt_tools_amd.models import OnsetsFrames, PendingFeatures16
+from amt_tools_amd.synth import synth_clip, synth_state_dict
+outs = {}
+mod = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)
+sd = synth_state_dict(5, dim_in=72, in_channels=6, model_complexity=2)
+model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0', precision='bf16')
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+model.frontend = torch.nn.Sequential(mod.frontend())
+model.change_device()
+model.eval()
+seen = []
+fwd = model.forward
+model.forward = lambda feats: (seen.append(type(feats).__name__), fwd(feats))[1]
+for name, B, n in (('small', 3, 512 * 45 - 1), ('tiles', 5, 512 * 100 + 17)):
+    audio = torch.from_numpy(np.stack([synth_clip(20 + i, num_samples=n) for i in range(B)]))
+    with torch.no_grad():
+        out = model.run_on_batch({tools.KEY_AUDIO: audio})
+        T = out[tools.KEY_ONSETS].shape[-1]
+        lab = model.run_on_batch({tools.KEY_AUDIO: audio, tools.KEY_MULTIPITCH: torch.zeros(B, 88, T), tools.KEY_ONSETS: torch.zeros(B, 88, T)})
+    for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH):
+        outs[f'{name}_roll_{k}'] = out[k].cpu().numpy()
+        outs[f'{name}_lab_{k}'] = lab[k].cpu().numpy()
+    outs[f'{name}_loss'] = np.asarray(float(lab[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL]))
+outs['kinds'] = np.asarray(sorted(set(seen)))
+np.savez(sys.argv[1], **outs)
+'''
+
+
+def test_hcqt_features_in_the_conv_kernels_staging_format_return_the_same_bits(tmp_path):
+    """Round 5, BASELINE config 3 in bf16: inside run_on_batch the HCQT front-end writes its map as (B,T,F,8) bf16 -- the six harmonics of a
+    position in one 16-byte slot, the feature tile format of the fused first conv (amtx_cqt_forward16 -> amtx_of_forward_feats16) -- and
+    the conv kernel stages a position with one load.  AMTX_CQT_FEATS16=0 keeps the fp32 (B,C,F,T) map the kernel converts itself.  The
+    bf16 values are the same roundings either way: rolls, logits (labelled batches) and losses must be IDENTICAL; clips of 45 frames and
+    of 101 (seven frame tiles, three column tiles, ragged edges)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('feats16', {}), ('fp32', {'AMTX_CQT_FEATS16': '0'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _FEATS16_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['feats16']), np.load(files['fp32'])
+    assert list(a['kinds']) == ['PendingFeatures16'] and list(b['kinds']) == ['Tensor']        # each arm ran the path it names
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 11
+    for k in a.files:
+        if k != 'kinds':
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a['tiles_roll_onsets'].shape == (5, 88, 101) and 0 < a['tiles_lab_onsets'].std()
+
+
+def test_cqt_forward16_is_the_fp32_map_rounded_to_bf16_channels_last():
+    """amtx_cqt_forward16 against amtx_cqt_forward: out16[b, t, f, h] == bf16(out[b, h, f, t]) bit for bit, slots 6 and 7 zero; dB and linear
+    magnitudes, a bin count above one LDS pass (144 > 120), a one-harmonic CQT."""
+    from amt_tools_amd.features import CQT, HCQT
+    audio = torch.from_numpy(np.stack([synth_clip(40 + i, num_samples=512 * 37 + 5) for i in range(3)])).cuda()
+    for mod in (HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12),
+                HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, decibels=False),
+                CQT(sample_rate=22050, hop_length=512, n_bins=144, bins_per_octave=24)):
+        ref = mod.process_batch(audio)                                       # (B, C, F, T) fp32
+        got = mod.process_batch16(audio)                                     # (B, T, F, 8) bf16
+        C = ref.shape[1]
+        assert got.shape == (3, ref.shape[-1], ref.shape[2], 8) and got.dtype == torch.bfloat16
+        want = ref.permute(0, 3, 2, 1).to(torch.bfloat16)
+        assert torch.equal(got[..., :C].view(torch.int16), want.contiguous().view(torch.int16))
+        assert not got[..., C:].view(torch.int16).any()
