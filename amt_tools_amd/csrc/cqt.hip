@@ -180,7 +180,25 @@ __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restric
 // of 16-byte slots -- which makes every ds_read_b128 lane group conflict-free; hop = 8 needs none, hop = 4 reads two 8-byte halves.
 // Same planes, same product order (hi.hi, hi.lo, lo.hi per 32-deep step, k ascending) and the same epilogue (|re + i im| transposed into
 // mag[b][harmonic][bin][t], per-(clip, harmonic) maxima) as gemm_tile: the same bits.
+#ifdef AMTX_CQT_TIMING
+// debug build only (tools/build_dbg.sh cqtbasis cqt.hip -DAMTX_CQT_TIMING; tools/cqt_basis_prof.py): cycles wave 0 of every block of
+// cqt_basis_kernel spends per phase: [0] tile setup, [1] staging (loads, split, LDS stores), [2] barrier, [3] matrix loop + magnitude stores,
+// [4] maxima + barrier + global atomics, [7] tiles
+__device__ unsigned long long g_bas_prof[8];
+#define BQ_TICK(SLOT) do { const unsigned long long now_ = __builtin_readcyclecounter(); bq_acc[SLOT] += now_ - bq_t; bq_t = now_; } while (0)
+extern "C" int amtxdbg_bas_prof(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bas_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bas_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define BQ_TICK(SLOT) do {} while (0)
+#endif
 constexpr int BAS_MAXLEV = 10;
+constexpr int BAS_AHEAD = 1;            // k-steps the operand reads of cqt_basis_kernel run ahead
 constexpr int BAS_MAXWIN = 16384;         // samples of a tile's window at most (66 KB of LDS with the pads: two blocks per CU)
 struct BasisLevel {
     const float* sig; int64_t sig_gs;      // level signal of clip 0 (sample 0 = first sample of the clip at this level), elements per clip
@@ -266,6 +284,11 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
         }
     // byte offset of this lane's operand inside a frame's window: sample 8 g of k-step 0 (+ 32 samples per k-step), pads included
     auto soff = [&](int s) { return (padded ? s + 8 * (s >> lh) : s) * 2; };
+    // ... split for the matrix loop: frame f starts at byte f * fstride, k-step ks of this lane koff[ks] bytes further
+    const int fstride = 2 * (hop + (padded ? 8 : 0));
+    int koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = soff(ks * 32 + 8 * g);
 
     // ---- tile loop.  Staging: four samples per thread and step (a 16-byte load at any 4-byte boundary: clips of odd length in one buffer), in
     // ROUNDS of six steps whose loads are issued back to back from clamped addresses (a load -> test -> store loop pays one memory round
@@ -277,7 +300,11 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
     constexpr int NST = 6;
     const int ntile = L.tiles_per_clip * a.B;
     if (tid < 16) lmax[tid] = 0u;
+#ifdef AMTX_CQT_TIMING
+    unsigned long long bq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bq_t = __builtin_readcyclecounter();
+#endif
     for (int tile = bid; tile < ntile; tile += nblk) {
+        BQ_TICK(0);
         const int b = tile / L.tiles_per_clip, tt = tile - b * L.tiles_per_clip;
         const int f0 = tt * ft;                                    // first frame of the tile
         const float* sig = L.sig + (int64_t)b * L.sig_gs;
@@ -318,7 +345,9 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
                 }
             }
         }
+        BQ_TICK(1);
         lds_only_barrier();
+        BQ_TICK(2);
         float mx[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
         const int nft = idle ? 0 : min(ft, L.frames - f0 + 15) >> 4;   // 16-frame tiles with real frames (a wave without columns has none)
         float* magb = a.mag + (int64_t)b * a.mag_gs;               // wave-uniform base, 32-bit offsets per lane (a clip's map is < 2^31 elements)
@@ -332,29 +361,43 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) acc[u][c] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                uint4 ah[2], al[2];
+            // operand reads run BAS_AHEAD k-steps ahead of the matrix instructions that use them, both pinned: left to itself hipcc reads a
+            // k-step's four operands right in front of its twelve instructions (an LDS round trip per k-step, ~45 % on top of the matrix time)
+            const int fbase[2] = {fr[0] * fstride, fr[1] * fstride};
+            constexpr int NB = BAS_AHEAD + 1;              // operand sets in flight (a ring)
+            uint4 ah[NB][2], al[NB][2];
+            auto fetch = [&](int ks) {
+                const int sl = ks % NB;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int o = soff(fr[u] * hop + ks * 32 + 8 * g);
+                    const int o = fbase[u] + koff[ks];
                     if (hop >= 8) {
-                        ah[u] = *reinterpret_cast<const uint4*>(smem + o);
-                        al[u] = *reinterpret_cast<const uint4*>(smem + plane + o);
+                        ah[sl][u] = *reinterpret_cast<const uint4*>(smem + o);
+                        al[sl][u] = *reinterpret_cast<const uint4*>(smem + plane + o);
                     } else {                                       // hop 4: windows start at 8-byte boundaries
                         const uint2 h0 = *reinterpret_cast<const uint2*>(smem + o), h1 = *reinterpret_cast<const uint2*>(smem + o + 8);
                         const uint2 l0 = *reinterpret_cast<const uint2*>(smem + plane + o), l1 = *reinterpret_cast<const uint2*>(smem + plane + o + 8);
-                        ah[u] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-                        al[u] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                        ah[sl][u] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                        al[sl][u] = make_uint4(l0.x, l0.y, l1.x, l1.y);
                     }
                 }
+            };
+#pragma unroll
+            for (int ks = 0; ks < BAS_AHEAD; ++ks) fetch(ks);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + BAS_AHEAD < KS) fetch(ks + BAS_AHEAD);
+                __builtin_amdgcn_sched_barrier(0);
                 // per accumulator hi.hi, hi.lo, lo.hi (gemm_tile's order), the four accumulators taking turns
 #pragma unroll
-                for (int pr = 0; pr < 3; ++pr)
+                for (int pr = 0; pr < 3; ++pr) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) acc[u][c] = cq_mfma(pr == 2 ? wl[c][ks] : wh[c][ks], pr == 1 ? al[u] : ah[u], acc[u][c]);
+                        for (int c = 0; c < 2; ++c)
+                            acc[u][c] = cq_mfma(pr == 2 ? wl[c][ks] : wh[c][ks], pr == 1 ? al[ks % NB][u] : ah[ks % NB][u], acc[u][c]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -373,6 +416,7 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
                     }
             }
         }
+        BQ_TICK(3);
         // per-(clip, harmonic) maxima: magnitudes are >= 0, so uint order == float order
 #pragma unroll
         for (int c = 0; c < 2; ++c)
@@ -385,7 +429,15 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
             lmax[tid] = 0u;                                        // for the next tile (ordered behind its barrier)
             if (v != 0u) atomicMax(reinterpret_cast<unsigned*>(a.maxbuf) + (int64_t)b * a.n_harm + tid, v);
         }
+        BQ_TICK(4);
+#ifdef AMTX_CQT_TIMING
+        bq_acc[7] += 1;
+#endif
     }
+#ifdef AMTX_CQT_TIMING
+    if (tid == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_bas_prof[i], bq_acc[i]);
+#endif
 }
 
 struct Level {
