@@ -89,10 +89,16 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // F16IN (tap-major only): the features arrive as that very tile format -- ConvArgs.feats16, [B][T][F][8] 16-bit channels-last, what
 // amtx_cqt_forward16 writes -- and a position is ONE 16-byte load and ONE 16-byte LDS store instead of c_in strided 4-byte loads, conversions
 // and 2-byte stores.
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0, bool F16IN = false>
-__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all, int sh_off) {
+// STRIP (with F16IN): the tile holds THREE strips of 8 output columns -- the same columns f0 .. f0 + 7 of three consecutive 16-frame blocks -- side
+// by side instead of 32 neighbouring columns: strip s sits at tile columns 10 s .. 10 s + 9 (its own halo columns included; 12 s .. 12 s + 11 of
+// the feature tile) and belongs to waves 2 s, 2 s + 1.  What the launcher gives the last <= 8 columns of a map whose width is not a multiple of
+// 32 (the HCQT shape: 72 = 2 x 32 + 8): as a 32-column tile those columns kept two waves of eight busy, a quarter of the kernel's time.
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0, bool F16IN = false, bool STRIP = false>
+__global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all, int sh_off, int f_base) {
     static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
     static_assert(!F16IN || FCL, "16-bit channels-last features: the tap-major first conv only");
+    static_assert(!STRIP || (F16IN && FT == 32 && CI16 == 2), "strip tiles: the pipelined 32-channel variant fed with 16-bit features");
+    constexpr int SPW = 8, NSTRIP = 3;           // output columns of a strip; strips per tile (3 x (8 + 2) <= FT + 2, 3 x (8 + 4) = FT + 4)
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
     constexpr int NCH = CIN / 8;                 // 16-byte chunks per position
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         tile = (int)xcd_remap((unsigned)tile, (unsigned)ntiles);
         const int tf = tile % ntf; tile /= ntf;
         const int tt = tile % ntt; tile /= ntt;
-        b = tile; t0 = tt * GTT; f0 = tf * FT;
+        b = tile; t0 = tt * GTT * (STRIP ? NSTRIP : 1); f0 = f_base + tf * FT;
     };
     // All loads of a thread are issued before the first LDS store (clamped addresses + a select instead of a branch: a branchy
     // loop costs one full memory round trip per item).  Rows t0-1 .. t0+16, columns f0-1 .. f0+FT, zero outside the map.
@@ -231,7 +237,10 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         }
     };
 
-    const int jb = 4 * wave;                                   // first of this wave's four output columns (tile-relative)
+    // first of this wave's four output columns: jb in the tile (strip tiles: strip wave / 2 at tile column 10 (wave / 2), its second half 4
+    // further), jbo relative to the map column f0
+    const int jb = STRIP ? (SPW + 2) * (wave >> 1) + 4 * (wave & 1) : 4 * wave;
+    const int jbo = STRIP ? 4 * (wave & 1) : 4 * wave;
     const int xrow = r16 * PC * 16;                            // byte offset of this lane's row (kh = 0) in a chunk plane
     const int x32 = g * CPLANE;                                // + ks * 4 * CPLANE: chunk 4 ks + g
     const int x16 = (4 * N32 + (g & 1)) * CPLANE;              // tail steps: lane groups (0, 1) and (2, 3) each read the two tail chunks
@@ -253,9 +262,13 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     for (int k = 0; k < NF1; ++k) {
         const int it = tid + k * NTH;
         if constexpr (F16IN) {
+            // bits 0-7 / 8-15: column / row of the position in the feature TILE; bits 16-21 / 22-29: its column / row in the MAP relative to
+            // the tile's (f0 - 2, t0 - 2) -- the same, except in a strip tile
             const bool has = it < FROWS1 * (FT + 4);
             const int itc = has ? it : 0;
-            fdesc[k] = (has ? 0x80000000u : 0u) | ((unsigned)(itc / (FT + 4)) << 8) | (unsigned)(itc % (FT + 4));
+            const int i = itc / (FT + 4), j = itc % (FT + 4);
+            const int mi = STRIP ? i + GTT * (j / (SPW + 4)) : i, mj = STRIP ? j % (SPW + 4) : j;
+            fdesc[k] = (has ? 0x80000000u : 0u) | ((unsigned)mi << 22) | ((unsigned)mj << 16) | ((unsigned)i << 8) | (unsigned)j;
             continue;
         }
         const int itc = it < nfeat ? it : 0;
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
 #pragma unroll
         for (int k = 0; k < NF1; ++k) {
             const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
-            foff[k] = F16IN ? i * F + j : ci * (int)a.f_stride_c + i * (int)a.f_stride_t + j * (int)a.f_stride_f;
+            foff[k] = F16IN ? (int)((fdesc[k] >> 22) & 0xff) * F + (int)((fdesc[k] >> 16) & 0x3f) : ci * (int)a.f_stride_c + i * (int)a.f_stride_t + j * (int)a.f_stride_f;
         }
     }
     auto load_f = [&](int tile, fraw_t (&fr)[NF1], unsigned& okmask) {
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             const int wb = (t0 - 2) * F + (f0 - 2);
 #pragma unroll
             for (int k = 0; k < NF1; ++k) {
-                const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                const int j = (fdesc[k] >> 16) & 0x3f, i = (fdesc[k] >> 22) & 0xff;
                 const bool ok = (int)fdesc[k] < 0 && (unsigned)(t0 - 2 + i) < (unsigned)T && (unsigned)(f0 - 2 + j) < (unsigned)F;
                 fr[k] = fb[(unsigned)(ok ? wb + foff[k] : 0)];
                 okmask |= ok ? (1u << k) : 0u;
@@ -384,6 +397,14 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         for (int q = 0; q < NGRP1; ++q) {
             const int pos = (wave + q * NW) * 16 + r16, posc = pos < NPOS ? pos : NPOS - 1;
             const int i = posc / COLS, j = posc % COLS;
+            if constexpr (STRIP) {
+                // tile column j = strip j / 10, column j % 10 of it; its taps start at feature column 12 s + (j % 10); map row i + 16 s.
+                // Columns 30 .. 33 belong to no strip: a row outside every map
+                const int st = j / (SPW + 2), lc = j % (SPW + 2);
+                gsrc[q] = (i * FW + (SPW + 4) * st + lc) * 16;
+                gij[q] = (st < NSTRIP ? i + GTT * st : 0x7fffff) << 8 | lc;
+                continue;
+            }
             gsrc[q] = FCL ? (i * FW + j) * 16 : i * FP1 + j;     // feature tile offset of the position: bytes (bf16 channels-last) / floats
             gij[q] = i << 8 | j;
         }
@@ -491,8 +512,8 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         // a wave whose four columns all lie past the last pooled column has nothing to store: no matrix work either (F = 229: 28 of the
         // 256 tile columns, 114: 14 of 128, the HCQT shape's 72: 24 of 96; the waves that do work are not faster for it -- each runs at
         // the pace of its own instruction stream -- so this saves energy, not time)
-        if (f0 + jb >= (F & ~1)) return;
-        const int t_out = t0 + r16;
+        if (STRIP ? (wave >= 2 * NSTRIP || t0 + GTT * (wave >> 1) >= T) : f0 + jbo >= (F & ~1)) return;
+        const int t_out = t0 + r16 + (STRIP ? GTT * (wave >> 1) : 0);
         // accumulators start at the folded BatchNorm shift of the lane's channels: chunk channel g * 4 NTC + 4 nt + r
         f32x4_t acc[4][NTC];
         {
@@ -574,7 +595,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         if (t_out < T) {
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                const int fo = (f0 + jb + 2 * pr) >> 1;
+                const int fo = (f0 + jbo + 2 * pr) >> 1;
                 if (fo >= F2) continue;
                 const int64_t o = (int64_t)grp * a.out_gs + ((int64_t)b * T + t_out) * out_ts + (int64_t)fo * a.c_out + ch * 16 * NTC + g * 4 * NTC;
 #pragma unroll
@@ -753,11 +774,13 @@ extern "C" int amtxdbg_convg_prof(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 0, bool F16IN = false>
-int launch_gen(const ConvArgs& a, hipStream_t stream) {
+// f_base / ntf_only: the launch covers the column tiles [f_base, f_base + ntf_only FT) of the map only (0: all of it).  STRIP: ONE column of
+// strip tiles (three 16-frame blocks x 8 columns each) at f_base.
+template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1 = 0, bool FCL = false, int CMAX = 0, bool F16IN = false, bool STRIP = false>
+int launch_gen(const ConvArgs& a, hipStream_t stream, int f_base = 0, int ntf_only = 0) {
     const int fe = a.F & ~1;                                  // columns that reach a pooled output
-    const int ntf = (fe + FT - 1) / FT;
-    const int ntt = (a.T + GTT - 1) / GTT;
+    const int ntf = STRIP ? 1 : ntf_only > 0 ? ntf_only : (fe + FT - 1) / FT;
+    const int ntt = STRIP ? ((a.T + GTT - 1) / GTT + 2) / 3 : (a.T + GTT - 1) / GTT;
     const int64_t ntiles = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(ntiles < (1ll << 31), "conv3x3: grid too large");
     if (KS1 == 0) AMTX_REQUIRE((int64_t)a.T * a.F * 16 * CI16 * (IN_TYPE == AMTX_T_BF16 ? 2 : 4) < (1ll << 32),
@@ -780,7 +803,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
     lds = (size_t)sh_off + (size_t)a.c_out * sizeof(float);
     AMTX_REQUIRE(lds <= 160 * 1024, "conv3x3 (general): tile + weights + features do not fit the LDS (%zu bytes)", lds);
     if (F16IN) AMTX_REQUIRE((int64_t)a.T * a.F < (1ll << 27), "conv3x3 (general): a clip's 16-bit feature map must be smaller than 2 GiB");
-    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX, F16IN>;
+    auto kern = conv3x3_gen_kernel<CI16, NTC, NS, FT, IN_TYPE, OUT_TYPE, KS1, FCL, CMAX, F16IN, STRIP>;
     AMTX_GRANT_LDS(kern, lds);
     // persistent grid: as many blocks as fit the chip at once (LDS allows 160 KiB / lds per CU), a multiple of 8 per group so a
     // block's tiles stay on its XCD
@@ -791,7 +814,7 @@ int launch_gen(const ConvArgs& a, hipStream_t stream) {
         while (gx > 8 * nchunks && gx / nchunks > ntiles) gx -= 8 * nchunks;
         if (gx / nchunks > ntiles) { w_all = 0; gx = std::min<int64_t>(std::max<int64_t>(8, (256 * per_cu / std::max(1, a.groups)) / 8 * 8), ntiles); }
     } else if (gx > ntiles) gx = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all, sh_off);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(16 * FT), lds, stream, a, ntf, ntt, nchunks, (int)ntiles, w_all, sh_off, f_base);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -800,8 +823,18 @@ template <int CI16, int NTC>
 int dispatch_gen(const ConvArgs& a, hipStream_t s) {
     if (a.feats16) {                                            // fused first conv from 16-bit channels-last features (amtx_cqt_forward16)
         if constexpr (CI16 == 2) {
-            if (amtx_conv1g_tapk(a.c_in, a.planes) && a.out_type == AMTX_T_BF16)
+            if (amtx_conv1g_tapk(a.c_in, a.planes) && a.out_type == AMTX_T_BF16) {
+                // a map whose last column tile would hold 8 columns or fewer (72 = 2 x 32 + 8): those columns as strip tiles, in a launch of
+                // their own (AMTX_CONVG_NO_STRIP=1: one launch of 32-column tiles, the A/B switch)
+                static const bool no_strip = getenv("AMTX_CONVG_NO_STRIP") != nullptr;
+                const int fe = a.F & ~1, rem = fe % 32;
+                if (!no_strip && fe > 32 && rem > 0 && rem <= 8) {
+                    int rc = launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true, 0, true>(a, s, 0, fe / 32);
+                    if (rc != AMTX_OK) return rc;
+                    return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true, 0, true, true>(a, s, fe - rem, 0);
+                }
                 return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true, 0, true>(a, s);
+            }
         }
         amtx_set_error("conv3x3 (general): 16-bit channels-last features: 2 .. 8 input channels, 32 first-layer channels, one-plane modes only");
         return AMTX_ERR_UNSUPPORTED;
