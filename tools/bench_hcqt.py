@@ -26,8 +26,9 @@ for _ in range(2): out = step()
 torch.cuda.synchronize()
 # front-end alone
 t0 = time.perf_counter()
+feats16 = model._get_engine(torch.device(dev)).takes_feats16() and os.environ.get('AMTX_CQT_FEATS16', '1') != '0'
 for _ in range(3):
-    with torch.no_grad(): f = model.frontend(audio[:, None, :])
+    with torch.no_grad(): f = mod.process_batch16(audio) if feats16 else model.frontend(audio[:, None, :])
 torch.cuda.synchronize()
 fe = (time.perf_counter() - t0) / 3
 L = _lib.lib(); eng = model._get_engine(torch.device(dev))
