@@ -1038,3 +1038,47 @@ def test_cqt_forward16_is_the_fp32_map_rounded_to_bf16_channels_last():
         want = ref.permute(0, 3, 2, 1).to(torch.bfloat16)
         assert torch.equal(got[..., :C].view(torch.int16), want.contiguous().view(torch.int16))
         assert not got[..., C:].view(torch.int16).any()
+
+
+@pytest.mark.parametrize('F,C,B,T', [(72, 6, 3, 50), (40, 2, 2, 33), (34, 8, 2, 49), (100, 3, 2, 20), (64, 6, 2, 17), (24, 4, 2, 16), (66, 5, 1, 97)])
+def test_engine_takes_16_bit_channels_last_features_bit_for_bit(F, C, B, T):
+    """amtx_of_forward_feats16 against amtx_of_forward on the same random features: the (B,T,F,8) bf16 map is what the conv kernel rounds the
+    fp32 map to itself, so every logit must be IDENTICAL -- widths with a remainder of 8, 2 and 4 columns behind whole 32-column tiles
+    (strip tiles: one, two and three 16-frame strips in the last strip tile, one to four valid columns per wave), a multiple of 32 and a
+    map narrower than one tile (no strip tiles), 2 .. 8 input channels (slots C .. 7 zero)."""
+    from amt_tools_amd.models import OnsetsFrames, PendingFeatures16
+    sd = synth_state_dict(3, dim_in=F, in_channels=C, model_complexity=2)
+    model = OnsetsFrames(F, tools.PianoProfile(), C, 2, device='cuda:0', precision='bf16')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.change_device()
+    model.eval()
+    eng = model._get_engine(torch.device('cuda:0'))
+    assert eng.takes_feats16()
+    rng = np.random.default_rng(F * 100 + C)
+    feats = torch.from_numpy(rng.random((B, C, F, T)).astype(np.float32)).cuda()
+    feats[0, :, :, : T // 3] = 0.0                                        # silence at the start of a clip
+    f16 = torch.zeros((B, T, F, 8), dtype=torch.bfloat16, device='cuda:0')
+    f16[..., :C] = feats.permute(0, 3, 2, 1).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = eng.forward(feats.transpose(-1, -2))
+        got = eng.forward(PendingFeatures16(None, f16, None))
+    for r, g_, name in zip(ref, got, ('onsets_roll', 'multi_pitch_roll', 'onsets', 'multi_pitch', 'pitch_head')):
+        assert torch.equal(r, g_), name
+    assert ref[2].std() > 0
+
+
+def test_feats16_entry_refuses_models_it_is_not_built_for():
+    """amtx_of_takes_feats16 is 0 for the x3 precision (two planes) and for a one-channel model, and amtx_of_forward_feats16 then fails loudly
+    instead of computing something else."""
+    from amt_tools_amd import _lib
+    from amt_tools_amd.models import OnsetsFrames, PendingFeatures16
+    for F, C, prec in ((72, 6, 'x3'), (229, 1, 'bf16')):
+        sd = synth_state_dict(3, dim_in=F, in_channels=C, model_complexity=2)
+        model = OnsetsFrames(F, tools.PianoProfile(), C, 2, device='cuda:0', precision=prec)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        model.change_device()
+        model.eval()
+        eng = model._get_engine(torch.device('cuda:0'))
+        assert not eng.takes_feats16()
+        with pytest.raises(_lib.AmtxError):
+            eng.forward(PendingFeatures16(None, torch.zeros((1, 16, F, 8), dtype=torch.bfloat16, device='cuda:0'), None))
