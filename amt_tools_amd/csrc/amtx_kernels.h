@@ -20,11 +20,11 @@ struct GemmArgs {
     int64_t M; int N, K;
     int groups; int64_t a_gs, w_gs, bias_gs, c_gs;       // per-group strides in elements (grid.z = groups)
     // optional magnitude epilogue (fp32-A / fp32-C kernel only; the CQT basis products): columns (2p, 2p+1) are (re, im) of output
-    // pair p and what is stored is sqrt(re^2 + im^2), TRANSPOSED: pair_out[grp * pair_gs + pair_map[p].x * pair_pitch + m] for rows
+    // pair p and what is stored is the POWER re^2 + im^2 (round 5; the magnitude until then), TRANSPOSED: pair_out[grp * pair_gs + pair_map[p].x * pair_pitch + m] for rows
     // m < pair_rows[pair_map[p].y]; C is not written.
     const int2* pair_map = nullptr; float* pair_out = nullptr; int64_t pair_gs = 0, pair_pitch = 0;
     int pair_rows[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    // optional with the magnitude epilogue: running maximum of the stored magnitudes per (group, pair_map[p].y): pair_max[grp * pair_nh + y]
+    // optional with the magnitude epilogue: running maximum of the stored powers per (group, pair_map[p].y): pair_max[grp * pair_nh + y]
     // (atomic max on the float bits; the caller zeroes it first)
     float* pair_max = nullptr; int pair_nh = 0;
     // optional piano-roll epilogue (bf16-A / fp32-C direct-to-LDS kernel, amtx_gemm_has_roll_epilogue): rows are (clip, frame) with roll_T

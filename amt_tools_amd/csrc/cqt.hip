@@ -46,6 +46,14 @@ double bessel_i0(double x) {
 }
 
 // ---------------------------------------------------------------- kernels
+// maximum over the 16 lanes of a DPP row, in every lane of it
+__device__ __forceinline__ float row_max_f32(float v) {
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));   // row_half_mirror
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false)));   // row_mirror
+    return v;
+}
 typedef __attribute__((ext_vector_type(8))) __bf16 cq_bf16x8;
 __device__ __forceinline__ f32x4_t cq_mfma(uint4 a, uint4 b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cq_bf16x8, a), __builtin_bit_cast(cq_bf16x8, b), c, 0, 0, 0);
@@ -86,24 +94,27 @@ __global__ __launch_bounds__(256) void cqt_pad_kernel(float* __restrict__ pyr, i
     }
 }
 
-// amplitude_to_db(ref = max) -> clamp -80 -> /80 + 1 (or plain magnitude), truncated to t_out frames
+// amplitude_to_db(ref = max) -> clamp -80 -> /80 + 1 (or plain magnitude), truncated to t_out frames; from the POWER map
 __global__ __launch_bounds__(256) void cqt_scale_kernel(const float* __restrict__ mag, const float* __restrict__ maxbuf, int n_bins, int64_t t_buf,
                                                         int64_t t_out, int decibels, float* __restrict__ out) {
     const int bh = blockIdx.y;
-    const float ref = maxbuf[bh];
+    const float ref = maxbuf[bh];                            // `mag` and `maxbuf` hold POWERS (re^2 + im^2 as the basis products' epilogue leaves them:
+                                                             // no root there, no square here)
     const float amin2 = 1e-10f;                              // amin = 1e-5 on magnitude
-    const float offs = 10.0f * log10f(fmaxf(amin2, ref * ref));
-    const float floor_db = (10.0f * log10f(fmaxf(amin2, ref * ref)) - offs) - 80.0f;
+    const float offs = 10.0f * log10f(fmaxf(amin2, ref));
+    const float floor_db = (10.0f * log10f(fmaxf(amin2, ref)) - offs) - 80.0f;
     const int64_t total = (int64_t)n_bins * t_out;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int k = (int)(i / t_out);
         const int64_t t = i - (int64_t)k * t_out;
         const float a = mag[((int64_t)bh * n_bins + k) * t_buf + t];
-        float v = a;
+        float v;
         if (decibels) {
-            float db = 10.0f * log10f(fmaxf(amin2, a * a)) - offs;
+            float db = 10.0f * log10f(fmaxf(amin2, a)) - offs;
             db = fmaxf(db, floor_db);
             v = db / 80.0f + 1.0f;
+        } else {
+            v = sqrtf(a);
         }
         out[((int64_t)bh * n_bins + k) * t_out + t] = v;
     }
@@ -127,10 +138,10 @@ __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restric
     float* refs = reinterpret_cast<float*>(smem + (size_t)SC16_TT * rs * 16);
     const float amin2 = 1e-10f;                              // amin = 1e-5 on magnitude
     if (tid < n_harm) {
-        const float ref = maxbuf[b * n_harm + tid];
-        const float offs = 10.0f * log10f(fmaxf(amin2, ref * ref));
+        const float ref = maxbuf[b * n_harm + tid];            // a power, like `mag` (cqt_scale_kernel)
+        const float offs = 10.0f * log10f(fmaxf(amin2, ref));
         refs[2 * tid] = offs;
-        refs[2 * tid + 1] = (10.0f * log10f(fmaxf(amin2, ref * ref)) - offs) - 80.0f;
+        refs[2 * tid + 1] = (10.0f * log10f(fmaxf(amin2, ref)) - offs) - 80.0f;
     }
     for (int i = tid; i < SC16_TT * rs; i += 256) tile[i] = make_uint4(0, 0, 0, 0);
     const int tt = tid & 31, r = tid >> 5;
@@ -150,11 +161,13 @@ __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restric
 #pragma unroll
                 for (int u = 0; u < SC16_U; ++u) {
                     const int k = k0 + 8 * u;
-                    float v = a[u];
+                    float v;
                     if (decibels) {
-                        float db = 10.0f * log10f(fmaxf(amin2, a[u] * a[u])) - offs;
+                        float db = 10.0f * log10f(fmaxf(amin2, a[u])) - offs;
                         db = fmaxf(db, floor_db);
                         v = db / 80.0f + 1.0f;
+                    } else {
+                        v = sqrtf(a[u]);
                     }
                     if (k < nb) reinterpret_cast<unsigned short*>(tile + tt * rs + k)[h] = (unsigned short)pack_bf16x2(v, 0.f);
                 }
@@ -176,9 +189,9 @@ __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restric
 // stages the signal of FT consecutive frames of one clip ONCE (coalesced fp32 loads, one split per sample, two 16-bit planes in LDS) and
 // every row's MFMA operand is a 16-byte window of that copy; the level's basis (<= 256 columns x K, two planes) sits in the waves'
 // registers for the whole launch.  Frames run down the lanes (lane & 15), so a frame's window starts hop samples after its neighbour's:
-// the copy is stored with 8 pad samples behind every hop samples (hop >= 16) -- a frame stride of (hop + 8) x 2 bytes = an odd number
-// of 16-byte slots -- which makes every ds_read_b128 lane group conflict-free; hop = 8 needs none, hop = 4 reads two 8-byte halves.
-// Same planes, same product order (hi.hi, hi.lo, lo.hi per 32-deep step, k ascending) and the same epilogue (|re + i im| transposed into
+// the copy is stored with 16 pad samples behind every hop samples (hop >= 32) -- a frame stride of 2 (mod 4) 16-byte slots, see bas_pad --
+// which makes every ds_read_b128 lane group conflict-free; hop = 16 and 8 need none, hop = 4 reads two 8-byte halves.
+// Same planes, same product order (hi.hi, hi.lo, lo.hi per 32-deep step, k ascending) and the same epilogue (|re + i im|^2 transposed into
 // mag[b][harmonic][bin][t], per-(clip, harmonic) maxima) as gemm_tile: the same bits.
 #ifdef AMTX_CQT_TIMING
 // debug build only (tools/build_dbg.sh cqtbasis cqt.hip -DAMTX_CQT_TIMING; tools/cqt_basis_prof.py): cycles wave 0 of every block of
@@ -197,6 +210,11 @@ extern "C" int amtxdbg_bas_prof(unsigned long long* out8, int reset) {
 #else
 #define BQ_TICK(SLOT) do {} while (0)
 #endif
+// pad samples behind every `hop` samples of the staged copy: the frame stride must be 2 (mod 4) 16-byte slots for the operand reads to be
+// conflict-free -- ds_read_b128 serves lanes {0-3, 12-15} of one k-group together with lanes {4-11} of the NEXT (one slot further), so an odd
+// stride (the 8 samples of the first version: 9, 5, 3 slots) put seven of every eight of them on a slot twice: 48 % of the kernel's LDS
+// cycles were conflicts, and its operand reads as many cycles as its matrix instructions (tools/lds_swizzle_check_basis.py)
+__host__ __device__ constexpr int bas_pad(int hop) { return hop >= 32 ? 16 : 0; }
 constexpr int BAS_MAXLEV = 10;
 constexpr int BAS_AHEAD = 1;            // k-steps the operand reads of cqt_basis_kernel run ahead
 constexpr int BAS_MAXWIN = 16384;         // samples of a tile's window at most (66 KB of LDS with the pads: two blocks per CU)
@@ -237,9 +255,9 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
     // not overlap and only the K samples of every frame are staged, back to back)
     const int ghop = L.hop, ft = L.ft;
     const int hop = min(ghop, K), lh = __builtin_ctz(hop);        // powers of two
-    const int padded = hop >= 16;                                  // 8 pad samples behind every `hop`
+    const int pad = bas_pad(hop);                                  // pad samples behind every `hop`
     const int ws = (ft - 1) * hop + K;                             // samples of a tile's window
-    const int wsp = padded ? ws + 8 * ((ws + hop - 1) / hop) : ws; // ... in LDS
+    const int wsp = ws + pad * ((ws + hop - 1) / hop);             // ... in LDS
     const int plane = ((wsp + 7) & ~7) * 2;                        // bytes per plane
     unsigned* lmax = reinterpret_cast<unsigned*>(smem + 2 * plane);
 
@@ -283,9 +301,9 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
             ro[c][h] = pm[c][h].x * (int)a.mag_pitch;            // row offset inside the clip's map
         }
     // byte offset of this lane's operand inside a frame's window: sample 8 g of k-step 0 (+ 32 samples per k-step), pads included
-    auto soff = [&](int s) { return (padded ? s + 8 * (s >> lh) : s) * 2; };
+    auto soff = [&](int s) { return (s + pad * (s >> lh)) * 2; };
     // ... split for the matrix loop: frame f starts at byte f * fstride, k-step ks of this lane koff[ks] bytes further
-    const int fstride = 2 * (hop + (padded ? 8 : 0));
+    const int fstride = 2 * (hop + pad);
     int koff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) koff[ks] = soff(ks * 32 + 8 * g);
@@ -297,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
     // the clamped load by the distance it was moved.  The block's barriers wait for LDS traffic only (the stores of a tile's magnitudes
     // and the maxima's atomics stay in flight), and the other block of the CU covers a tile's load round trips.
     struct __attribute__((packed, aligned(4))) f32x4_a4 { float x, y, z, w; };
-    constexpr int NST = 6;
+    constexpr int NST = 6, NSTF = 9;             // loads per round: the general path / a tile inside the signal (fewer temporaries: 36 registers of loads fit)
     const int ntile = L.tiles_per_clip * a.B;
     if (tid < 16) lmax[tid] = 0u;
 #ifdef AMTX_CQT_TIMING
@@ -311,6 +329,32 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
         const int64_t s0 = (int64_t)f0 * ghop - K / 2 + L.off;     // first sample of the window (index into sig)
         // staged index i -> signal index: identity while the windows overlap, frame-wise (hop > K) otherwise
         auto sidx = [&](int i) { return s0 + (ghop > K ? (int64_t)(i >> lh) * ghop + (i & (hop - 1)) : (int64_t)i); };
+        // a tile whose whole window lies inside the signal (all but a clip's first and last tiles): no clamping, no picking -- a third of the
+        // instructions of the general case below (which was 37 % of the kernel's vector instructions)
+        const int64_t s_end = s0 + (ghop > K ? (int64_t)(ft - 1) * ghop + K : (int64_t)ws);
+        if (s0 >= 0 && s_end <= L.len) {
+            const float* st = sig + s0;                            // wave-uniform base, 32-bit offsets per lane
+            for (int base = 0; base < ws; base += 1024 * NSTF) {
+                f32x4_a4 rr[NSTF];
+#pragma unroll
+                for (int n = 0; n < NSTF; ++n) {
+                    const int i = min(base + 4 * tid + 1024 * n, ws - 4);
+                    rr[n] = *reinterpret_cast<const f32x4_a4*>(st + (unsigned)(ghop > K ? (i >> lh) * ghop + (i & (hop - 1)) : i));
+                }
+#pragma unroll
+                for (int n = 0; n < NSTF; ++n) {
+                    const int i = base + 4 * tid + 1024 * n;
+                    uint32_t h0, h1, l0, l1;
+                    split_bf16x2(rr[n].x, rr[n].y, h0, l0);
+                    split_bf16x2(rr[n].z, rr[n].w, h1, l1);
+                    if (i < ws) {
+                        const int o = soff(i);
+                        *reinterpret_cast<uint2*>(smem + o) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(smem + plane + o) = make_uint2(l0, l1);
+                    }
+                }
+            }
+        } else
         for (int base = 0; base < ws; base += 1024 * NST) {
             f32x4_a4 rr[NST];
 #pragma unroll
@@ -409,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
                     for (int h = 0; h < 2; ++h) {
                         if (m < rl[c][h]) {
                             const float re = acc[u][c][2 * h], im = acc[u][c][2 * h + 1];
-                            const float v = sqrtf(re * re + im * im);
+                            const float v = re * re + im * im;           // power: the scaling kernels take its logarithm (or its root)
                             magb[(unsigned)(ro[c][h] + m)] = v;
                             mx[c][h] = fmaxf(mx[c][h], v);
                         }
@@ -418,11 +462,15 @@ __global__ __launch_bounds__(256, 2) void cqt_basis_kernel(BasisArgs a, BasisLev
         }
         BQ_TICK(3);
         // per-(clip, harmonic) maxima: magnitudes are >= 0, so uint order == float order
+        // the 16 lanes of a row (one lane group g) hold the same four filters: their maximum by DPP, one LDS atomic per row and filter (64
+        // lanes on <= 6 addresses each were half of the kernel's LDS bank-conflict cycles)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-                if (mx[c][h] > 0.f) atomicMax(lmax + (pm[c][h].y & 15), __float_as_uint(mx[c][h]));
+            for (int h = 0; h < 2; ++h) {
+                const float m = row_max_f32(mx[c][h]);
+                if (fl == 0 && m > 0.f) atomicMax(lmax + (pm[c][h].y & 15), __float_as_uint(m));
+            }
         lds_only_barrier();                                        // everybody is done with the staged copy, the maxima are in
         if (tid < 16) {
             const unsigned v = lmax[tid];
@@ -850,7 +898,7 @@ static int cqt_forward_impl(const amtx_cqt_plan* p, const float* audio, int64_t 
                 if (bl.frames <= 0 || p->levels[l].nfft != kk) continue;
                 const int hs = std::min(bl.hop, kk);               // frame stride of the staged copy (cqt_basis_kernel)
                 const int ws_s = (bl.ft - 1) * hs + kk;
-                const int wsp = hs >= 16 ? ws_s + 8 * ((ws_s + hs - 1) / hs) : ws_s;
+                const int wsp = ws_s + bas_pad(hs) * ((ws_s + hs - 1) / hs);
                 lds = std::max(lds, (size_t)((wsp + 7) & ~7) * 2 * 2 + 64);
                 ls.lev[ls.n++] = l;
             }
@@ -883,7 +931,7 @@ static int cqt_forward_impl(const amtx_cqt_plan* p, const float* audio, int64_t 
     for (int l = 0; l < nl; ++l) {
         const Level& L = p->levels[l];
         if (L.banks.empty()) continue;
-        // the basis product with the magnitude epilogue: |re + i im| of every filter goes straight into mag[b][harmonic][bin][t]
+        // the basis product with the power epilogue: |re + i im|^2 of every filter goes straight into mag[b][harmonic][bin][t]
         // (transposed, truncated to the harmonic's frame count); the complex response never touches HBM (it was written by the GEMM
         // and read back by a magnitude / transpose kernel: 0.4 GB per level and 512 clips, a third of the front-end's traffic)
         GemmArgs g;

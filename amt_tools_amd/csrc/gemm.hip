@@ -220,12 +220,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int grp, int bx, in
                 const int64_t m = m0 + wm * 64 + mt * 16 + (lane & 15);
                 const f32x4_t v = acc[nt][mt];
                 if (m < g.pair_rows[pa.y & 15]) {
-                    const float a = sqrtf(v[0] * v[0] + v[1] * v[1]);
+                    const float a = v[0] * v[0] + v[1] * v[1];       // POWER: the consumer (cqt.hip's scaling kernels) takes the logarithm of it, or the root
                     po[(int64_t)pa.x * g.pair_pitch + m] = a;
                     ma = fmaxf(ma, a);
                 }
                 if (n + 2 < g.N && m < g.pair_rows[pb.y & 15]) {
-                    const float a = sqrtf(v[2] * v[2] + v[3] * v[3]);
+                    const float a = v[2] * v[2] + v[3] * v[3];
                     po[(int64_t)pb.x * g.pair_pitch + m] = a;
                     mb = fmaxf(mb, a);
                 }

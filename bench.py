@@ -498,6 +498,8 @@ def hcqt_leg(device, clips=512, steps=5):
         torch.cuda.synchronize()
         # the front-end alone, in the form run_on_batch uses it: (B,T,F,8) bf16 in the first conv's staging format when the engine takes that
         feats16 = model._get_engine(torch.device(device)).takes_feats16()
+        (mod.process_batch16 if feats16 else mod.process_batch)(audio)      # untimed: first call of this form (allocations)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
             if feats16:
