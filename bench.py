@@ -655,6 +655,7 @@ def run_infer(args, rank, world, device):
         torch.cuda.empty_cache()
         config['train_step_ms_1gpu'] = train_step_probe(device)
         config['train_step_workload'] = 'OnsetsFrames(mc=2)+MelSpec(229) fwd+bwd+Adam, 8 clips x 625 frames per GPU, 10 steps after 3 warm-up steps (python bench.py --mode train)'
+        config['train_allreduce_probe'] = train_allreduce_probe()
     return res
 
 
@@ -711,6 +712,26 @@ def train_step_probe(device, steps=10, warmup=3):
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+def train_allreduce_probe(timeout=240):
+    """The training step's gradient exchange timed somewhere even when the driver has one GPU: `bench.py --mode train
+    --force-dist` as a CHILD process (a one-rank RCCL group, every collective of the N-GPU step really issued; a child so that a stuck
+    rendezvous can only cost this probe its time limit) -- returns its step time, all-reduce time and bytes, or the reason it has none."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--mode', 'train', '--force-dist', '--steps', '5', '--warmup', '2', '--cpu-seconds', '0']
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout)
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')][-1]
+        c = json.loads(line)['config']
+        return {'ms_per_step_with_rccl_group': json.loads(line)['ms_per_step'], 'allreduce_ms_per_step': c['allreduce_ms_per_step'],
+                'allreduce_bytes': c.get('allreduce_bytes'), 'collectives_per_step': c['collectives_per_step'], 'process_group': c['process_group'],
+                'rccl_ranks': c['rccl_ranks'], 'command': 'python bench.py --mode train --force-dist --steps 5 --warmup 2'}
+    except Exception as e:                                      # noqa: BLE001 -- a probe: report, never fail the line
+        return {'error': f'{type(e).__name__}: {e}'[:200]}
+
+
 def run_train(args, rank, world, device):
     B = args.clips
     step, opt = _train_setup(device, rank, B, args.of2)
@@ -754,6 +775,7 @@ def run_train(args, rank, world, device):
                                f'(synth_labels), audio resident in HBM', 'clips_per_gpu_per_step': B, 'global_batch': world * B,
                    'frames_per_s': fps, 'parallelism': f'dp{world}: one flat fp32 gradient all-reduce per step', 'rccl_ranks': world,
                    'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank], 'allreduce_ms_per_step': allreduce_ms,
+                   'allreduce_bytes': (int(opt._flat.numel()) * 4 if getattr(opt, '_flat', None) is not None else None),
                    'collectives_per_step': opt.collectives_run / max(1, args.steps + args.warmup + (5 if allreduce_ms is not None else 0)),
                    'process_group': (args.backend if _dist_on() else None),
                    'loss': float(loss.detach()), 'backward': training_backend()},
