@@ -513,13 +513,39 @@ def hcqt_leg(device, clips=512, steps=5):
             out = model.run_on_batch({tools.KEY_AUDIO: audio})
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        # the engine's stages by its own HIP events (a second, untimed pair of passes), for the leg's own roofline blocks
+        from amt_tools_amd import _lib
+        L = _lib.lib()
+        eng = model._get_engine(torch.device(device))
+        _lib.check(L.amtx_of_profile_enable(eng.handle, 1))
+        for _ in range(2):
+            model.run_on_batch({tools.KEY_AUDIO: audio})
+        torch.cuda.synchronize()
+        sms = (C.c_double * L.amtx_of_num_stages())()
+        nfw = C.c_int(0)
+        _lib.check(L.amtx_of_profile_read(eng.handle, sms, C.byref(nfw)))
+        _lib.check(L.amtx_of_profile_enable(eng.handle, 0))
+        stages = {L.amtx_of_stage_name(i).decode(): sms[i] / max(1, nfw.value) for i in range(L.amtx_of_num_stages()) if sms[i] > 0}
     T = out[tools.KEY_ONSETS].shape[-1]
     fps = clips * T / dt
     del model, out, audio
     torch.cuda.empty_cache()
+    # per-kernel rooflines of the leg.  conv1 + conv2 of the two heads (one stage, convg.hip's fused kernel): 2 heads x 2 x
+    # (6 x 9 x 32 + 32 x 9 x 32) x 72 bins = 3.15 MFLOP per frame.  Front-end: audio in (512 samples x 4 B per frame) + the feature map out
+    # (72 bins x 16 B in the staging format, 6 x 72 x 4 B otherwise) against HBM
+    conv_ms = stages.get('conv2_pool', 0.0) + stages.get('conv1', 0.0)
+    conv_flops = 2 * 2 * (6 * 9 * 32 + 32 * 9 * 32) * 72 * clips * T
+    fe_bytes = (HOP * 4 + (72 * 16 if feats16 else 6 * 72 * 4)) * clips * T
+    rl = {'conv1_conv2': {'kernel': 'conv3x3_gen_kernel (fused first conv + conv2, both heads)', 'bound': 'mfma', 'achieved': conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else None,
+                          'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS if conv_ms else None,
+                          'avg_launch_ms': conv_ms, 'algorithmic_flops': conv_flops},
+          'frontend': {'kernel': 'HCQT front-end (7 decimations, basis products, scaling)', 'bound': 'hbm', 'achieved': fe_bytes / (fe_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                       'frac': fe_bytes / (fe_ms * 1e-3) / 1e9 / 8000.0, 'ms': fe_ms, 'algorithmic_bytes': fe_bytes,
+                       'note': 'algorithmic bytes = audio in + feature map out; the pyramid levels and the power map in between are the traffic on top (profiles/r05ze_hcqt_pmc.txt)'}}
     # OF1 + HCQT(6 x 72) = 10.3 MFLOP per frame
     return {'frames_per_s': fps, 'ms_per_step': dt * 1e3, 'clips_per_step': clips, 'frames_per_clip': int(T), 'frontend_ms_per_step': fe_ms,
             'features': '(B,T,F,8) bf16, amtx_cqt_forward16 -> amtx_of_forward_feats16' if feats16 else '(B,C,F,T) fp32',
+            'engine_stage_ms': stages, 'roofline': rl,
             'frac_of_mfma_roof': fps * 10.3e6 / 2.5e15,
             'workload': 'BASELINE config 3: OnsetsFrames(mc=2, dim_in 72, 6 channels) + HCQT(6 harmonics x 72 bins, hop 512) inference, bf16, '
                         'audio resident in HBM -> piano rolls'}
