@@ -127,6 +127,9 @@ for name, mod in (('cqt1', CQT(sample_rate=22050, hop_length=512, n_bins=192, bi
                   ('hcqt_lin', HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, decibels=False))):
     outs[name] = mod.process_batch(torch.from_numpy(y).cuda()).cpu().numpy()
     outs[name + '_one'] = mod.process_audio(y[2][:33333])
+    if name in ('cqt1', 'hcqt3'):                   # short clips: every level a single (edge) tile, the deepest a few dozen samples; five clips
+        ys = np.stack([synth_clip(9 + i, num_samples=9001) for i in range(5)])
+        outs[name + '_short'] = mod.process_batch(torch.from_numpy(ys).cuda()).cpu().numpy()
     if name in ('cqt1', 'hcqt3', 'cqt1_09'):        # rows on 16-byte boundaries (the decimator's vector staging), several tiles per clip and level
         ya = np.stack([synth_clip(5 + i, num_samples=81920) for i in range(2)])
         outs[name + '_al'] = mod.process_batch(torch.from_numpy(ya).cuda()).cpu().numpy()
@@ -150,7 +153,7 @@ def test_windowed_basis_kernel_returns_the_bits_of_the_gemm_path(tmp_path):
         files[tag] = str(tmp_path / f'{tag}.npz')
         subprocess.check_call([sys.executable, '-c', _BASIS_AB, files[tag]], env=env, cwd=root)
     a, b = np.load(files['windowed']), np.load(files['gemm'])
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 13
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 15
     for k in a.files:
         assert a[k].shape == b[k].shape and a[k].size > 0
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
@@ -173,7 +176,7 @@ def test_persistent_decimator_returns_the_bits_of_round_4s(tmp_path):
         files[tag] = str(tmp_path / f'{tag}.npz')
         subprocess.check_call([sys.executable, '-c', _BASIS_AB, files[tag]], env=env, cwd=root)
     a, b = np.load(files['v2']), np.load(files['v1'])
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 13
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 15
     for k in a.files:
         assert a[k].shape == b[k].shape and a[k].size > 0
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
