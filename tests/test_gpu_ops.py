@@ -30,7 +30,8 @@ def _tol(planes, scale):
 
 
 @pytest.mark.parametrize('planes', [1, 2])
-@pytest.mark.parametrize('m,n,k', [(300, 512, 3648), (1000, 1024, 512), (257, 88, 256), (64, 1024, 176), (5, 88, 512)])
+@pytest.mark.parametrize('m,n,k', [(300, 512, 3648), (1000, 1024, 512), (257, 88, 256), (64, 1024, 176), (5, 88, 512),
+                                   (2500, 88, 256), (1300, 88, 3648), (4099, 88, 512), (1024, 4, 128)])      # (the skinny-N kernel: N <= 128, M >= 1024)
 def test_linear(planes, m, n, k):
     L = _lib.lib()
     g = torch.Generator().manual_seed(m + n + k)
@@ -294,3 +295,47 @@ def test_pianoroll_threshold_and_probabilities():
     assert out[0, 0, 0] == 1 and out[0, 0, 1] == 1 and out[0, 0, 2] == 0
     _lib.check(L.amtx_pianoroll_fwd(_lib.ptr(ld_d), ld, col0, b, t, keys, -1.0, _lib.ptr(out), _stream()))
     assert (out.cpu() - act).abs().max().item() < 1e-6
+
+
+_SKINNY_AB = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd import _lib
+L = _lib.lib()
+outs = {}
+for m, n, k in ((2500, 88, 256), (1300, 88, 3648), (4099, 88, 512), (1024, 4, 128), (70000, 88, 1024)):
+    g = torch.Generator().manual_seed(m + n + k)
+    a = torch.randn(m, k, generator=g).cuda().to(torch.bfloat16).contiguous()
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).numpy()
+    bias = torch.randn(n, generator=g).cuda()
+    packed = np.zeros(L.amtx_linear_packed_elems(n, k, 1), dtype=np.uint16)
+    _lib.check(L.amtx_linear_pack(_lib.ptr(w), n, k, 1, _lib.ptr(packed)))
+    wp = torch.from_numpy(packed.view(np.int16)).cuda()
+    c = torch.zeros(m, n + 4, device='cuda')
+    _lib.check(L.amtx_linear_fwd(_lib.ptr(a), k, 0, _lib.ptr(wp), 1, _lib.ptr(bias), _lib.ptr(c), n + 4, 1, m, n, k, _lib.current_stream()))
+    outs[f'{m}_{n}_{k}'] = c.cpu().numpy()
+np.savez(sys.argv[1], **outs)
+'''
+
+
+def test_skinny_gemm_returns_the_bits_of_the_two_buffer_kernel(tmp_path):
+    """Round 5: products with N <= 128 (the LogisticBanks, the folded pitch head) run on gemm_skinny_kernel (one block per CU, every wave
+    streaming the A rows of its own 32-row slice through a private LDS ring two k-tiles ahead); AMTX_GEMM_NO_SKINNY=1 keeps
+    gemm_glds_kernel<., 128>.  Same fragments, same k order: IDENTICAL outputs, ragged M, several row tiles per block (70 000 rows = 274 tiles on
+    256 blocks), short and long K."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('skinny', {}), ('glds', {'AMTX_GEMM_NO_SKINNY': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _SKINNY_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['skinny']), np.load(files['glds'])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 5
+    for k in a.files:
+        assert np.abs(a[k]).max() > 0
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
