@@ -17,6 +17,7 @@ STAGES = {
     'gemm_glds_kernel<0, 256>': ['fc1_gemm'],
     'spec_power_ring_kernel<8, 4, 8, 20, 32>': ['spec_power'],
     'gemm_glds_kernel<1, 128>': ['rec_head_gemm', 'pitch_head_gemm', 'adj_head_gemm'],
+    'gemm_skinny_kernel': ['rec_head_gemm', 'pitch_head_gemm', 'adj_head_gemm'],      # round 5: N <= 128
     'gemm_pp_kernel<0>': ['rec_xproj_gemm', 'adj_xproj_gemm'],
     'bilstm4_kernel<1, 0, 0, 2>': ['rec_bilstm', 'adj_bilstm'],
 }
