@@ -1108,13 +1108,186 @@ __global__ __launch_bounds__(512, 1) void gemm_skinny_kernel(GemmArgs g, int nti
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the two stages issued past the end
 }
 
-int launch_skinny(const GemmArgs& g, hipStream_t stream) {
+// The same for two-plane operands (x3: A in AMTX_T_SPLIT planes, two-plane weights): 32-deep stages in gemm_split_kernel's layout ([hi | lo] x rows
+// x 64 bytes, its chunk swizzles), the same six DMA instructions per wave and stage (A: 2 planes x 2 pieces of 16 rows, W: 16 rows of each
+// plane), three MFMAs per fragment pair in gemm_tile's order (hi.hi, hi.lo, lo.hi): the bits of the generic kernel these shapes ran on.
+__global__ __launch_bounds__(512, 1) void gemm_skinny_split_kernel(GemmArgs g, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [W ring][8 waves x A ring][bias]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.z;
+    const bf16_t* Abase = reinterpret_cast<const bf16_t*>(g.A) + (int64_t)grp * g.a_gs;      // hi plane; lo plane a_split elements further
+    const bf16_t* Wbase = g.W + (int64_t)grp * g.w_gs;
+    char* Cbase = reinterpret_cast<char*>(g.C) + (int64_t)grp * g.c_gs * 4;
+    float* bias_s = reinterpret_cast<float*>(smem + SKD * SKW + 8 * SKD * SKA);
+    if (tid < 128) bias_s[tid] = (g.bias && tid < g.N) ? g.bias[(int64_t)grp * g.bias_gs + tid] : 0.f;     // (visible after the first stage's barrier)
+    const int64_t w_plane = (int64_t)g.n_pad * g.k_pad;
+    const int nk = g.k_pad / RBK;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int stride = (int)gridDim.x;
+    const int nmine = (ntiles - (int)blockIdx.x + stride - 1) / stride;       // row tiles of this block
+    const int total = nmine * nk;                                             // its stages
+
+    // W: this wave DMAs rows [16 wave, + 16) of both planes of a stage: one piece of 16 rows x 4 chunks each
+    const bf16_t* w_src;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        w_src = Wbase + (int64_t)row * g.k_pad + ((lane & 3) ^ rswz((row >> 4) & 3)) * 8;
+    }
+    const unsigned w_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem) + wave * 1024;
+    const unsigned a_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void_t*)smem) + SKD * SKW + wave * (SKD * SKA);
+    // A: per plane 2 pieces x 16 rows of the wave's 32; row pointers of the row tile the prefetch stream is in
+    const bf16_t* a_src[2];
+    auto set_rows = [&](int j) {                                  // j-th row tile of this block (past the end: the last one again)
+        const int64_t tm0 = (int64_t)((int)blockIdx.x + min(j, nmine - 1) * stride) * 256 + wave * 32;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int row = n * 16 + (lane >> 2);
+            const int64_t mr = min(tm0 + row, g.M - 1);           // rows past M are never stored; keep the read in bounds
+            a_src[n] = Abase + mr * g.lda + ((lane & 3) ^ rswz((row >> 2) & 3)) * 8;
+        }
+    };
+    int pj = 0, pkt = 0;                                          // the prefetch stream's row tile and k-stage
+    auto issue = [&](int slot) {
+        const int k0 = pkt * RBK;
+        glds16x2(a_src[0] + k0, a_src[1] + k0, a_lds + slot * SKA);
+        glds16x2(a_src[0] + g.a_split + k0, a_src[1] + g.a_split + k0, a_lds + slot * SKA + SKA / 2);
+        glds16(w_src + k0, w_lds + slot * SKW);
+        glds16(w_src + w_plane + k0, w_lds + slot * SKW + SKW / 2);
+        if (++pkt == nk) { pkt = 0; ++pj; set_rows(pj); }
+    };
+    set_rows(0);
+    issue(0);
+    issue(1);
+
+    f32x4_t acc[2][4][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+    int cj = 0, ckt = 0;                                          // the compute stream's row tile and k-tile
+    for (int base = 0; base < total; base += SKD) {
+#pragma unroll
+        for (int u = 0; u < SKD; ++u) {
+            if (base + u >= total) break;                         // (block-uniform)
+            // stage base + u was issued two iterations ago; behind it in this wave's queue: one iteration's six instructions (+ stores)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            lds_only_barrier();                                   // every wave's share of the W stage has landed; last iteration's reads are done
+                                                                  // (not __syncthreads: its fence would wait for the epilogue's stores AND the ring)
+            issue((u + 2) % SKD);                                 // stage base + u + 2 -> the slot stage base + u - 1 was read from
+            const char* wb = smem + u * SKW;
+            const char* ab = smem + SKD * SKW + wave * (SKD * SKA) + u * SKA;
+            {
+                uint4 ah[2], al[2], wh[2][4], wl[2][4];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int o = (t * 16 + frow) * 64 + ((fchunk ^ rswz((frow >> 2) & 3)) << 4);
+                    ah[t] = *reinterpret_cast<const uint4*>(ab + o);
+                    al[t] = *reinterpret_cast<const uint4*>(ab + SKA / 2 + o);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int o = (h * 64 + 16 * (frow >> 2) + 4 * t + (frow & 3)) * 64 + ((fchunk ^ rswz(frow >> 2)) << 4);
+                        wh[h][t] = *reinterpret_cast<const uint4*>(wb + o);
+                        wl[h][t] = *reinterpret_cast<const uint4*>(wb + SKW / 2 + o);
+                    }
+                // the three products as three passes over the 16 accumulators (consecutive MFMAs never share one); per accumulator hi.hi, hi.lo, lo.hi
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) acc[h][nt][mt] = mfma16(wh[h][nt], ah[mt], acc[h][nt][mt]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) acc[h][nt][mt] = mfma16(wh[h][nt], al[mt], acc[h][nt][mt]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) acc[h][nt][mt] = mfma16(wl[h][nt], ah[mt], acc[h][nt][mt]);
+            }
+            if (++ckt < nk) continue;
+            // ---- a row tile is complete: epilogue (gemm_glds_kernel's, for this wave's 32 rows and both 64-column halves)
+            const int64_t m0 = (int64_t)((int)blockIdx.x + cj * stride) * 256 + wave * 32;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int nb = h * 64 + 16 * (lane >> 4);
+                if (nb >= g.N + (g.copy16 ? g.copy16_pad : 0)) continue;
+                float bv[4][4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[nt][r] = bias_s[min(nb + 4 * nt + r, 127)];
+                const bool wide = nb + 16 <= g.N && ((g.ldc * 4) % 16) == 0;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int64_t m = m0 + mt * 16 + (lane & 15);
+                    if (m >= g.M) continue;
+                    char* dst = Cbase + (m * g.ldc + nb) * 4;
+                    float o[4][4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[nt][r] = acc[h][nt][mt][r] + bv[nt][r];
+                    if (g.C) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            if (wide || nb + 4 * nt < g.N) reinterpret_cast<float4*>(dst)[nt] = make_float4(o[nt][0], o[nt][1], o[nt][2], o[nt][3]);
+                    }
+                    if (g.copy16) {
+                        bf16_t* cp = g.copy16 + m * g.copy16_ld + g.copy16_col0 + (int64_t)grp * g.copy16_gs + nb;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int n4 = nb + 4 * nt;
+                            if (n4 < g.N) reinterpret_cast<uint2*>(cp)[nt] = make_uint2(pack_bf16x2(o[nt][0], o[nt][1]), pack_bf16x2(o[nt][2], o[nt][3]));
+                            else if (n4 < g.N + g.copy16_pad) reinterpret_cast<uint2*>(cp)[nt] = make_uint2(0u, 0u);
+                        }
+                    }
+                    if (g.roll_out && grp == g.roll_group) {
+                        const unsigned bclip = (unsigned)m / (unsigned)g.roll_T, tfrm = (unsigned)m - bclip * (unsigned)g.roll_T;
+                        float* ro = g.roll_out + ((int64_t)bclip * g.N + nb) * g.roll_T + tfrm;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (nb + 4 * nt + r < g.N) {
+                                    const float sg = 1.0f / (1.0f + expf(-o[nt][r]));
+                                    ro[(int64_t)(4 * nt + r) * g.roll_T] = g.roll_thr < 0.f ? sg : (sg < g.roll_thr ? 0.f : 1.f);
+                                }
+                    }
+                }
+            }
+            zero_acc();
+            ckt = 0;
+            ++cj;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the two stages issued past the end
+}
+
+int launch_skinny(const GemmArgs& g, hipStream_t stream, bool split) {
     const int64_t ntiles = (g.M + 255) / 256;
     AMTX_REQUIRE(ntiles < (1ll << 31), "gemm: too many output tiles");
     int64_t gx = std::max<int64_t>(1, 256 / std::max(1, g.groups));
     if (gx > ntiles) gx = ntiles;
-    AMTX_GRANT_LDS(gemm_skinny_kernel, SK_LDS);
-    hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(512), SK_LDS, stream, g, (int)ntiles);
+    if (split) {
+        AMTX_GRANT_LDS(gemm_skinny_split_kernel, SK_LDS);
+        hipLaunchKernelGGL(gemm_skinny_split_kernel, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(512), SK_LDS, stream, g, (int)ntiles);
+    } else {
+        AMTX_GRANT_LDS(gemm_skinny_kernel, SK_LDS);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)gx, 1, (unsigned)g.groups), dim3(512), SK_LDS, stream, g, (int)ntiles);
+    }
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -1250,7 +1423,7 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
         // skinny N: one 128-column tile, fp32 C -- the LogisticBanks and the pitch head (AMTX_GEMM_NO_SKINNY=1: the A/B switch)
         static const bool no_skinny = getenv("AMTX_GEMM_NO_SKINNY") != nullptr;
         if (!no_skinny && g.n_pad == 128 && g.c_type == AMTX_T_F32 && g.M >= 1024 && g.K >= 2 * GBK && g.M < (1ll << 31) * 256)
-            return launch_skinny(g, stream);
+            return launch_skinny(g, stream, false);
         if (g.a_plane) {      // planar A: the two-buffer direct-to-LDS kernel only
             if (g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256)
                 return g.c_type == AMTX_T_BF16 ? launch_glds<AMTX_T_BF16, 256>(g, stream) : launch_glds<AMTX_T_F32, 256>(g, stream);
@@ -1279,6 +1452,11 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
             (g.ldc * 4) % 16 == 0)
             return g.c_type == AMTX_T_SPLIT ? launch_split<AMTX_T_SPLIT>(g, stream) : launch_split<AMTX_T_F32>(g, stream);
         AMTX_REQUIRE(g.c_type != AMTX_T_BF16, "gemm: two-plane A writes fp32 or two-plane C");
+        // skinny N (the x3 LogisticBanks and pitch head): the two-plane variant of gemm_skinny_kernel
+        static const bool no_skinny2 = getenv("AMTX_GEMM_NO_SKINNY") != nullptr;
+        if (!no_skinny2 && !no_split_dma && g.n_pad == 128 && g.c_type == AMTX_T_F32 && g.M >= 1024 && g.K == g.k_pad && g.K >= 2 * RBK && (g.lda % 8) == 0 &&
+            g.M < (1ll << 31) * 256)
+            return launch_skinny(g, stream, true);
         return g.c_type == AMTX_T_SPLIT ? launch<AMTX_T_SPLIT, AMTX_T_SPLIT, 2>(g, stream) : launch<AMTX_T_SPLIT, AMTX_T_F32, 2>(g, stream);
     }
     AMTX_REQUIRE(g.c_type != AMTX_T_SPLIT, "gemm: two-plane C needs two-plane A");

@@ -65,10 +65,12 @@ def test_linear(planes, m, n, k):
 SPLIT = 2
 
 
-@pytest.mark.parametrize('m,n,k', [(300, 512, 3648), (1000, 1024, 512), (777, 1024, 192), (256, 256, 64), (257, 88, 256), (64, 1024, 192), (5, 88, 512)])
+@pytest.mark.parametrize('m,n,k', [(300, 512, 3648), (1000, 1024, 512), (777, 1024, 192), (256, 256, 64), (257, 88, 256), (64, 1024, 192), (5, 88, 512),
+                                   (2500, 88, 256), (1300, 88, 3648), (4099, 88, 512), (70000, 88, 64)])     # (the skinny-N two-plane kernel: N <= 128, M >= 1024)
 def test_linear_split_planes(m, n, k):
     """The x3 precision's own activation format (round 5): A as two 16-bit planes (amtx_split_planes), two-plane weights.  Whole 256-column
-    tiles with M >= 256 run on the direct-to-LDS two-plane kernel (gemm_split_kernel), the rest on the generic kernel's split-A loader.
+    tiles with M >= 256 run on the direct-to-LDS two-plane kernel (gemm_split_kernel), N <= 128 with M >= 1024 on gemm_skinny_split_kernel, the
+    rest on the generic kernel's split-A loader.
     Checked against (1) a float64 product of the fp32 values -- fp32-class tolerance -- and (2) the fp32-A two-plane path
     (amtx_linear_fwd, planes = 2) on the same values: the SAME BITS (same planes, same product order hi.hi, hi.lo, lo.hi per 32-deep step);
     (3) the split C epilogue returns hi + lo == the fp32 C rounded the way split_bf16x2 does."""
