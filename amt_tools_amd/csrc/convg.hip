@@ -89,7 +89,7 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // F16IN (tap-major only): the features arrive as that very tile format -- ConvArgs.feats16, [B][T][F][8] 16-bit channels-last, what
 // amtx_cqt_forward16 writes -- and a position is ONE 16-byte load and ONE 16-byte LDS store instead of c_in strided 4-byte loads, conversions
 // and 2-byte stores.
-// STRIP (with F16IN): the tile holds THREE strips of 8 output columns -- the same columns f0 .. f0 + 7 of three consecutive 16-frame blocks -- side
+// STRIP (with F16IN, or with a one-channel fp32 first conv): the tile holds THREE strips of 8 output columns -- the same columns f0 .. f0 + 7 of three consecutive 16-frame blocks -- side
 // by side instead of 32 neighbouring columns: strip s sits at tile columns 10 s .. 10 s + 9 (its own halo columns included; 12 s .. 12 s + 11 of
 // the feature tile) and belongs to waves 2 s, 2 s + 1.  What the launcher gives the last <= 8 columns of a map whose width is not a multiple of
 // 32 (the HCQT shape: 72 = 2 x 32 + 8): as a 32-column tile those columns kept two waves of eight busy, a quarter of the kernel's time.
@@ -97,7 +97,7 @@ template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1,
 __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all, int sh_off, int f_base) {
     static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
     static_assert(!F16IN || FCL, "16-bit channels-last features: the tap-major first conv only");
-    static_assert(!STRIP || (F16IN && FT == 32 && CI16 == 2), "strip tiles: the pipelined 32-channel variant fed with 16-bit features");
+    static_assert(!STRIP || (FT == 32 && KS1 > 0 && NS == 1 && (F16IN || (!FCL && CMAX == 1))), "strip tiles: 32-column tiles with a fused first conv from 16-bit features or from one fp32 channel");
     constexpr int SPW = 8, NSTRIP = 3;           // output columns of a strip; strips per tile (3 x (8 + 2) <= FT + 2, 3 x (8 + 4) = FT + 4)
     constexpr int NTH = 16 * FT;                 // one wave per 4 output columns
     constexpr int CIN = 16 * CI16;
@@ -272,6 +272,13 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             continue;
         }
         const int itc = it < nfeat ? it : 0;
+        if constexpr (STRIP) {       // one channel: bits 16-21 / 22-29 = the item's column / row in the MAP relative to (f0 - 2, t0 - 2), as for F16IN
+            int i, j;
+            if (a.f_stride_t < a.f_stride_f) { i = itc % FROWS1; j = (itc / FROWS1) % (FT + 4); }
+            else { j = itc % (FT + 4); i = (itc / (FT + 4)) % FROWS1; }
+            fdesc[k] = (it < nfeat ? 0x80000000u : 0u) | ((unsigned)(i + GTT * (j / (SPW + 4))) << 22) | ((unsigned)(j % (SPW + 4)) << 16) | ((unsigned)i << 8) | (unsigned)j;
+            continue;
+        }
         int ci, i, j;
         if (a.f_stride_t < a.f_stride_f) {        // frames contiguous (a (B,C,F,T) tensor): consecutive lanes = consecutive frames of one column
             i = itc % FROWS1; j = (itc / FROWS1) % (FT + 4); ci = itc / (FROWS1 * (FT + 4));
@@ -326,7 +333,8 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
 #pragma unroll
             for (int k = 0; k < NF1; ++k) {
                 if (!EXACT && k >= nfk) break;
-                const int j = fdesc[k] & 0xff, i = (fdesc[k] >> 8) & 0xff, ci = (fdesc[k] >> 16) & 0xff;
+                const int j = STRIP ? (fdesc[k] >> 16) & 0x3f : fdesc[k] & 0xff, i = STRIP ? (fdesc[k] >> 22) & 0xff : (fdesc[k] >> 8) & 0xff;
+                const int ci = STRIP ? 0 : (fdesc[k] >> 16) & 0xff;
                 const int t = t0 - 2 + i, f = f0 - 2 + j;
                 const bool ok = (fdesc[k] >> 31) && t >= 0 && t < T && f >= 0 && f < F;
                 const int tc = min(max(t, 0), T - 1), fc = min(max(f, 0), F - 1);
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
             for (int k = 0; k < NF1; ++k) {
                 if (!EXACT && k >= nfk) break;
                 if (fdesc[k] >> 31) {
-                    const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
+                    const int j = fdesc[k] & 0xff, ci = STRIP ? 0 : (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
                     fs[(ci * FROWS1 + i) * FP1 + j] = ((okmask >> k) & 1) ? fr[k] : 0.f;
                 }
             }
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                 // tile column j = strip j / 10, column j % 10 of it; its taps start at feature column 12 s + (j % 10); map row i + 16 s.
                 // Columns 30 .. 33 belong to no strip: a row outside every map
                 const int st = j / (SPW + 2), lc = j % (SPW + 2);
-                gsrc[q] = (i * FW + (SPW + 4) * st + lc) * 16;
+                gsrc[q] = FCL ? (i * FW + (SPW + 4) * st + lc) * 16 : i * FP1 + (SPW + 4) * st + lc;
                 gij[q] = (st < NSTRIP ? i + GTT * st : 0x7fffff) << 8 | lc;
                 continue;
             }
@@ -847,8 +855,18 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
             }
             return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 3, true>(a, s);
         }
-        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && a.c_in == 1)     // one input channel (2 .. 8 channels: the tap-major variant above)
+        if (a.planes == 1 && a.out_type == AMTX_T_BF16 && a.c_in == 1) {   // one input channel (2 .. 8 channels: the tap-major variant above)
+            if constexpr (CI16 == 3) {       // OnsetsFrames2 as shipped (model_complexity 3, 229 mel bins = 7 x 32 + 4 columns that reach a pooled output)
+                static const bool no_strip = getenv("AMTX_CONVG_NO_STRIP") != nullptr;
+                const int fe = a.F & ~1, rem = fe % 32;
+                if (!no_strip && fe > 32 && rem > 0 && rem <= 8) {
+                    int rc = launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1>(a, s, 0, fe / 32);
+                    if (rc != AMTX_OK) return rc;
+                    return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1, false, true>(a, s, fe - rem, 0);
+                }
+            }
             return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1>(a, s);
+        }
         if (a.planes == 2 && a.out_type == AMTX_T_F32) {
             if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
             if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);

@@ -1082,3 +1082,48 @@ def test_feats16_entry_refuses_models_it_is_not_built_for():
         assert not eng.takes_feats16()
         with pytest.raises(_lib.AmtxError):
             eng.forward(PendingFeatures16(None, torch.zeros((1, 16, F, 8), dtype=torch.bfloat16, device='cuda:0'), None))
+
+
+_STRIP_MC3_AB = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from amt_tools_amd import tools
+from amt_tools_amd.models import OnsetsFrames2
+from amt_tools_amd.synth import synth_state_dict
+outs = {}
+sd = synth_state_dict(7, dim_in=229, in_channels=1, model_complexity=3, offsets=True)
+model = OnsetsFrames2(229, tools.PianoProfile(), 1, 3, device='cuda:0', precision='bf16')
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+model.change_device()
+model.eval()
+for name, B, T in (('a', 2, 50), ('b', 3, 97), ('c', 1, 16)):
+    rng = np.random.default_rng(B * 100 + T)
+    feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32)).cuda()
+    with torch.no_grad():
+        lg = model.engine_logits(feats)
+    for k, v in lg.items():
+        outs[f'{name}_{k}'] = v.cpu().numpy()
+np.savez(sys.argv[1], **outs)
+'''
+
+
+def test_strip_tiles_of_the_one_channel_first_conv_return_the_same_bits(tmp_path):
+    """OnsetsFrames2 as shipped (model_complexity 3, 229 mel bins): conv2's last column tile holds 4 of its 228 pooled-from columns; those
+    run as strip tiles (three 16-frame blocks side by side) in a launch of their own.  AMTX_CONVG_NO_STRIP=1: one launch of 32-column tiles.
+    Same arithmetic per output: every logit IDENTICAL; 50, 97 and 16 frames = strip tiles with one, two and three strips."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, extra in (('strip', {}), ('plain', {'AMTX_CONVG_NO_STRIP': '1'})):
+        env = dict(os.environ)
+        env.update(extra)
+        files[tag] = str(tmp_path / f'{tag}.npz')
+        subprocess.check_call([sys.executable, '-c', _STRIP_MC3_AB, files[tag]], env=env, cwd=root)
+    a, b = np.load(files['strip']), np.load(files['plain'])
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 15
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert a['a_onsets'].std() > 0
