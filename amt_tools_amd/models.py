@@ -486,10 +486,11 @@ class OnsetsFrames(TranscriptionModel):
         return batch
 
     def _deferred_scale(self, batch):
-        """Inside run_on_batch, eval mode, raw audio only, a dB-scaled log-mel / STFT front-end of this package on the GPU and an engine
-        whose first conv stages the features itself: the front-end stops after its power kernel and the dB scaling happens inside the
-        conv kernel (PendingFeatures; one kernel launch and one write + read of the feature tensor less per batch).  Returns the
-        pre-processed batch, or None when any of that does not hold (the ordinary path then runs)."""
+        """Inside run_on_batch, eval mode, raw audio only, a front-end of this package on the GPU and an engine whose first conv stages the
+        features itself.  dB-scaled log-mel / STFT: the front-end stops after its power kernel and the dB scaling happens inside the conv
+        kernel (PendingFeatures; one kernel launch and one write + read of the feature tensor less per batch).  CQT family (HCQT / HVQT: one
+        channel per harmonic) in bf16 precision: the front-end writes its map in the conv kernel's own staging format (PendingFeatures16).
+        Returns the pre-processed batch, or None when none of that holds (the ordinary path then runs)."""
         if self.training or len(self.frontend) != 1 or not isinstance(self.frontend[0], SpectralFrontend):
             return None
         if os.environ.get('AMTX_DEFER_DB_SCALE', '1') == '0':     # A/B switch: front-end writes finished features (amtx_spec_scale)
