@@ -1433,7 +1433,8 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
         // AMTX_GEMM_NO_PP=1 disables it
         static const bool force_pp = getenv("AMTX_GEMM_PP") != nullptr, no_pp = getenv("AMTX_GEMM_NO_PP") != nullptr;
         // measured on MI355X (tools/bench_gemm.py, M = 320000, N = 1024): K = 512: 0.49 ms vs 0.53 (two 64-deep buffers);
-        // K = 192: 0.255 vs 0.271 ms; K = 3648 (N = 512): 1.21 vs 1.20 ms
+        // K = 192: 0.255 vs 0.271 ms; K = 3648 (N = 512): 1.21 vs 1.20 ms.  (Round 5: 128 x 128 tiles, two blocks per CU, for the short K: 0.356 /
+        // 0.611 ms -- worse.)
         if (!no_pp && (force_pp || g.K <= 1024) && g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.n_pad <= RING_MAX_NPAD &&
             g.K >= 4 * RBK && (g.ldc * amtx_tsize(g.c_type)) % 16 == 0)
             return g.c_type == AMTX_T_BF16 ? launch_pp<AMTX_T_BF16>(g, stream) : launch_pp<AMTX_T_F32>(g, stream);
