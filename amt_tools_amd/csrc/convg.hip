@@ -611,7 +611,14 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaxf(acc[2 * pr][nt][r], acc[2 * pr + 1][nt][r]), 0.f);
-                    if (OUT_TYPE == AMTX_T_BF16)
+                    if (OUT_TYPE == AMTX_T_SPLIT) {             // the next layer's two 16-bit planes (x3: conv3 and everything behind it take AMTX_T_SPLIT maps)
+                        uint2 hi, lo;
+                        split_bf16x2(v[0], v[1], hi.x, lo.x);
+                        split_bf16x2(v[2], v[3], hi.y, lo.y);
+                        bf16_t* dsth = reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt;
+                        *reinterpret_cast<uint2*>(dsth) = hi;
+                        *reinterpret_cast<uint2*>(dsth + a.out_split) = lo;
+                    } else if (OUT_TYPE == AMTX_T_BF16)
                         *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.out) + o + 4 * nt) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                     else
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4 * nt) = make_float4(v[0], v[1], v[2], v[3]);
@@ -870,6 +877,12 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
         if (a.planes == 2 && a.out_type == AMTX_T_F32) {
             if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
             if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);
+        }
+        if constexpr (CI16 == 2) {       // x3 with a multi-channel first conv (HCQT): a2 as split planes for convx.hip's conv3
+            if (a.planes == 2 && a.out_type == AMTX_T_SPLIT && a.out_split > 0) {
+                if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_SPLIT, 1>(a, s);
+                if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_SPLIT, 2>(a, s);
+            }
         }
         amtx_set_error("conv3x3 (general): fused first conv: unsupported c_in / precision");
         return AMTX_ERR_UNSUPPORTED;

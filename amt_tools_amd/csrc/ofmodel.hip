@@ -237,7 +237,10 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     // A/B switch: AMTX_NO_CONV_FUSE=1 keeps conv.hip's two kernels (conv1+conv2, conv3) at every batch size
     m->fuse_stack = !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && m->planes == 1 && getenv("AMTX_NO_CONV_FUSE") == nullptr;
     // A/B switch: AMTX_X3_NO_SPLIT=1 keeps fp32 activations between the two-plane kernels (round 4's data path)
-    m->split_acts = m->planes == 2 && !m->gen_conv && !m->gen_conv2 && m->fuse_conv1 && in_channels == 1 && getenv("AMTX_X3_NO_SPLIT") == nullptr;
+    // (one input channel: conv.hip / convx.hip write the planes; 2 .. 7 input channels at 32 / 32 / 64 channels -- HCQT --: convg.hip's two-plane
+    // kernel writes a2 as planes, convx.hip's conv3 and the GEMMs behind it are the same)
+    m->split_acts = m->planes == 2 && !m->gen_conv && m->fuse_conv1 && getenv("AMTX_X3_NO_SPLIT") == nullptr &&
+                    ((!m->gen_conv2 && in_channels == 1) || (m->gen_conv2 && in_channels > 1 && (9 * in_channels + 31) / 32 <= 2));
     *out = m;
     return AMTX_OK;
 }

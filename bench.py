@@ -551,6 +551,38 @@ def hcqt_leg(device, clips=512, steps=5):
                         'audio resident in HBM -> piano rolls'}
 
 
+def hcqt_x3_leg(device, clips=512, steps=3):
+    """BASELINE config 3 in the engine precision that is inside north_star's 1e-4 (x3: split-bf16, three MFMAs per product): the same audio ->
+    HCQT -> OnsetsFrames pass as hcqt_leg, fp32 (B,C,F,T) features."""
+    from amt_tools_amd import tools
+    from amt_tools_amd.features import HCQT
+    from amt_tools_amd.models import OnsetsFrames
+    from amt_tools_amd.synth import synth_clip, synth_state_dict
+    mod = HCQT(sample_rate=SR, hop_length=HOP, n_bins=72, bins_per_octave=12, device=device)
+    model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device=device, precision='x3')
+    sd = synth_state_dict(0, dim_in=72, in_channels=6, model_complexity=2)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model.frontend = torch.nn.Sequential(mod.frontend())
+    model.change_device()
+    model.eval()
+    base = np.stack([synth_clip(i) for i in range(8)])
+    audio = torch.from_numpy(base).to(device).repeat((clips + 7) // 8, 1)[:clips].contiguous()
+    with torch.no_grad():
+        for _ in range(2):
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model.run_on_batch({tools.KEY_AUDIO: audio})
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    T = out[tools.KEY_ONSETS].shape[-1]
+    del model, out, audio
+    torch.cuda.empty_cache()
+    return {'frames_per_s': clips * T / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': clips,
+            'note': 'engine precision x3 (inside 1e-4 of the fp32 reference: tests/test_gpu_model.py::test_config3_hcqt_frontend_fused_into_the_model)'}
+
+
 def run_infer(args, rank, world, device):
     from amt_tools_amd import _lib, tools
     from amt_tools_amd.synth import synth_clip
@@ -675,6 +707,7 @@ def run_infer(args, rank, world, device):
     if world == 1 and not args.no_hcqt and args.precision == 'bf16':
         config['hcqt'] = hcqt_leg(device)
         config['hcqt_frames_per_s'] = config['hcqt']['frames_per_s']
+        config['hcqt']['x3'] = hcqt_x3_leg(device)
     if world == 1 and not args.no_train_probe:
         # BASELINE metric (ii), train step time, at N = 1 (the DP = 8 figure needs the 8-GPU node: python bench.py --mode train --gpus 8)
         del model, out

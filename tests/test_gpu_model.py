@@ -922,14 +922,15 @@ from amt_tools_amd import tools
 from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
 from amt_tools_amd.synth import synth_state_dict
 outs = {}
-for name, cls, B, T in (('of1', OnsetsFrames, 3, 70), ('of1_big', OnsetsFrames, 9, 333), ('of2', OnsetsFrames2, 2, 45)):
-    sd = synth_state_dict(11, dim_in=229, in_channels=1, model_complexity=2, offsets=(cls is OnsetsFrames2))
-    model = cls(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision='x3')
+for name, cls, B, T, F, C in (('of1', OnsetsFrames, 3, 70, 229, 1), ('of1_big', OnsetsFrames, 9, 333, 229, 1), ('of2', OnsetsFrames2, 2, 45, 229, 1),
+                              ('hcqt', OnsetsFrames, 3, 70, 72, 6), ('hcqt_big', OnsetsFrames, 7, 401, 72, 6), ('ch3', OnsetsFrames, 2, 33, 40, 3)):
+    sd = synth_state_dict(11, dim_in=F, in_channels=C, model_complexity=2, offsets=(cls is OnsetsFrames2))
+    model = cls(F, tools.PianoProfile(), C, 2, device='cuda:0', precision='x3')
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     model.change_device()
     model.eval()
     rng = np.random.default_rng(3)
-    feats = torch.from_numpy(rng.random((B, 1, 229, T)).astype(np.float32))
+    feats = torch.from_numpy(rng.random((B, C, F, T)).astype(np.float32))
     with torch.no_grad():
         out = model.run_on_batch({tools.KEY_FEATS: feats})
         lg = model.engine_logits(feats.cuda())
@@ -947,7 +948,8 @@ def test_x3_split_plane_activations_return_the_bits_of_the_fp32_activation_path(
     (conv2 -> conv3 -> fc1 -> input projection; AMTX_T_SPLIT) and the GEMMs DMA them into LDS; AMTX_X3_NO_SPLIT=1 keeps round 4's fp32
     activations, split by every consumer.  The planes are what the consumers computed themselves and the product order is the same, so
     logits, rolls and offset probabilities must be IDENTICAL -- for batches whose GEMM rows are below and above one 256-row tile, with and
-    without the offset head."""
+    without the offset head, and for models with several input channels (the HCQT shape, 6 x 72, and 3 x 40: convg.hip's two-plane kernel
+    writes the a2 planes there)."""
     import os
     import subprocess
     import sys

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """BASELINE config 3 throughput: audio (resident in HBM) -> HIP HCQT (6 harmonics x 72 bins) as model.frontend ->
-OnsetsFrames(dim_in=72, in_channels=6), bf16.  Usage: python tools/bench_hcqt.py [clips=128]"""
+OnsetsFrames(dim_in=72, in_channels=6).  Usage: python tools/bench_hcqt.py [clips=128] [precision=bf16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
@@ -12,7 +12,8 @@ from amt_tools_amd.synth import synth_clip, synth_state_dict, CLIP_FRAMES
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = 'cuda:0'
 mod = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, device=dev)
-model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device=dev, precision='bf16')
+PREC = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
+model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device=dev, precision=PREC)
 sd = synth_state_dict(0, dim_in=72, in_channels=6, model_complexity=2)
 model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
 model.frontend = torch.nn.Sequential(mod.frontend())
