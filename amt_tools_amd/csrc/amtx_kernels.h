@@ -104,10 +104,10 @@ void amtx_conv3x3_gen_pack_host(const float* w /*(c_out,c_in,3,3)*/, const float
 int amtx_launch_conv3x3_gen(const ConvArgs& c, int c_in, hipStream_t stream);
 // fused first conv of the general kernel (ConvArgs.feats / c_in / w1frag / shift1 as for conv.hip; `c_in` above = its output channels)
 // Two K orders: the weight tensor's own (ci, kh, kw) padded to whole 32-deep steps (one-channel inputs, and the two-plane x3 mode), and -- for
-// 2 .. 8 input channels in the one-plane modes -- TAP-MAJOR with the channels padded to 8 (k = 8 tap + ci, 9 taps -> 3 steps): the kernel then
+// 2 .. 8 input channels (round 5: in the two-plane mode too, both planes of the features staged once) -- TAP-MAJOR with the channels padded to 8 (k = 8 tap + ci, 9 taps -> 3 steps): the kernel then
 // stages its feature tile channels-last in bf16 and a lane's 8 K values of a step are ONE 16-byte LDS read (round 4; before, 16 scalar
 // gathers + 8 conversions per 16 positions made the first conv 41 % of the HCQT model's conv2 kernel).
-static inline __host__ __device__ bool amtx_conv1g_tapk(int c_in, int planes) { return planes == 1 && c_in >= 2 && c_in <= 8; }
+static inline __host__ __device__ bool amtx_conv1g_tapk(int c_in, int planes) { return (planes == 1 || planes == 2) && c_in >= 2 && c_in <= 8; }
 size_t amtx_conv1g_wfrag_elems(int c_in, int c_mid, int planes);
 void amtx_conv1g_pack_host(const float* w /*(c_mid,c_in,3,3)*/, const float* scale, int c_in, int c_mid, int planes, bf16_t* out);
 bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes);

@@ -30,6 +30,9 @@ namespace {
 #ifndef CONVG_FCL_GP
 #define CONVG_FCL_GP 5
 #endif
+#ifndef CONVG_FCL_GP2
+#define CONVG_FCL_GP2 6              // ... in the two-plane mode (six groups per wave: all at once, 315 registers; 2: 4.67, 3: 4.65, 6: 4.54 ms per 512 HCQT clips)
+#endif
 #ifndef CONVG_FCL_MINW
 #define CONVG_FCL_MINW 1            // waves per SIMD the 32-channel tap-major variant is compiled for: 4 = two 512-thread blocks per CU (<= 128 VGPRs)
 #endif
@@ -95,7 +98,7 @@ constexpr int g_wfrags_per_tile(int ci16) { return 9 * (ci16 / 2) + 5 * (ci16 % 
 // 32 (the HCQT shape: 72 = 2 x 32 + 8): as a 32-column tile those columns kept two waves of eight busy, a quarter of the kernel's time.
 template <int CI16, int NTC, int NS, int FT, int IN_TYPE, int OUT_TYPE, int KS1, bool FCL = false, int CMAX = 0, bool F16IN = false, bool STRIP = false>
 __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) void conv3x3_gen_kernel(ConvArgs a, int ntf, int ntt, int nchunks, int ntiles, int w_all, int sh_off, int f_base) {
-    static_assert(!FCL || (KS1 == 3 && NS == 1), "tap-major first conv: three 32-deep steps, one plane");
+    static_assert(!FCL || KS1 == 3, "tap-major first conv: three 32-deep steps");
     static_assert(!F16IN || FCL, "16-bit channels-last features: the tap-major first conv only");
     static_assert(!STRIP || (FT == 32 && KS1 > 0 && NS == 1 && (F16IN || (!FCL && CMAX == 1))), "strip tiles: 32-column tiles with a fused first conv from 16-bit features or from one fp32 channel");
     constexpr int SPW = 8, NSTRIP = 3;           // output columns of a strip; strips per tile (3 x (8 + 2) <= FT + 2, 3 x (8 + 4) = FT + 4)
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     constexpr int NNT1 = (NPOS + 15) / 16;                    // 16-position groups of the fused first conv
     constexpr int NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool PIPE = FCL && CI16 == 2;      // two-tile software pipeline (below): two input tiles and two feature tiles in LDS
+    constexpr bool PIPE = FCL && CI16 == 2 && NS == 1;      // two-tile software pipeline (below): two input tiles and two feature tiles in LDS
     char* xs = smem;
     char* ws = smem + (PIPE ? 2 : 1) * NS * XPLANE;
 
@@ -139,11 +142,12 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
     // FCL: the feature tile as bf16 [FROWS1][FT + 4][8 channel slots]: 16 bytes per position = one k-group of a tap
     char* fs16 = w1s + W1BYTES;
     constexpr int FW = FT + 4;
-    char* const fscratch = w1s + W1BYTES + (PIPE ? 2 : 1) * FROWS1 * FW * 16;      // 128 bytes behind the feature tile(s): slots without an item
+    constexpr int FSPL = FROWS1 * FW * 16;       // bytes of one plane of the channels-last feature tile (two-plane mode: hi plane, then lo plane)
+    char* const fscratch = w1s + W1BYTES + (PIPE ? 2 : 1) * NS * FSPL;             // NS x 128 bytes behind the feature tile(s): slots without an item
     const int c_in1 = a.c_in;
     const int nfeat = c_in1 * FROWS1 * (FT + 4);
     if (FCL) {   // channel slots c_in .. 7 meet zero weights, but NaN x 0 is NaN: zero the tile once (the staging only writes real channels)
-        for (int it = tid; it < FROWS1 * FW; it += NTH) reinterpret_cast<uint4*>(fs16)[it] = make_uint4(0, 0, 0, 0);
+        for (int it = tid; it < NS * FROWS1 * FW; it += NTH) reinterpret_cast<uint4*>(fs16)[it] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
     if (FUSE1) {
@@ -360,6 +364,12 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                 const int j = fdesc[k] & 0xff, ci = (fdesc[k] >> 16) & 0xff, i = (fdesc[k] >> 8) & 0xff;
                 const float v = ((okmask >> k) & 1) ? fr[k] : 0.f;
                 char* dst = (int)fdesc[k] < 0 ? fs16 + ((i * FW + j) * 8 + ci) * 2 : fscratch + (tid & 63) * 2;
+                if constexpr (NS == 2) {                      // both planes of the value, split ONCE (the K-major form split it at every gather)
+                    uint32_t vh, vl;
+                    split_bf16x2(v, 0.f, vh, vl);
+                    *reinterpret_cast<uint16_t*>(dst) = (uint16_t)vh;
+                    *reinterpret_cast<uint16_t*>((int)fdesc[k] < 0 ? dst + FSPL : dst + 128) = (uint16_t)vl;
+                } else
                 *reinterpret_cast<uint16_t*>(dst) = (uint16_t)pack_bf16x2(v, 0.f);
             }
             return;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
         // groups in flight at once: their LDS reads, then their MFMA chains (independent of each other), then their epilogues.  The tap-major
         // form reads three 16-byte chunks per group instead of sixteen scalars: all of a wave's groups fit the registers at once, and five
         // serial read -> MFMA -> convert -> store chains (~1000 cycles each) become one pass
-        constexpr int NIT1 = (NNT1 + NW - 1) / NW, GP = FCL ? (CI16 <= 2 ? CONVG_FCL_GP : 2) : ((KS1 * NS > 2) ? 1 : 2);   // (48 / 64 mid channels: two at a time, or the accumulators spill)
+        constexpr int NIT1 = (NNT1 + NW - 1) / NW, GP = FCL ? (CI16 <= 2 ? (NS == 1 ? CONVG_FCL_GP : CONVG_FCL_GP2) : 2) : ((KS1 * NS > 2) ? 1 : 2);   // (48 / 64 mid channels: two at a time, or the accumulators spill)
         static_for<0, (NIT1 + GP - 1) / GP>([&](auto gc) {
             constexpr int it0 = decltype(gc)::value * GP;
             constexpr int cnt = it0 + GP <= NIT1 ? GP : NIT1 - it0;
@@ -454,6 +464,7 @@ __global__ __launch_bounds__(16 * FT, (FCL && CI16 == 2) ? CONVG_FCL_MINW : 1) v
                     static_for<0, KS1>([&](auto kc) {
                         constexpr int ks = decltype(kc)::value;
                         ph[i_][ks] = *reinterpret_cast<const uint4*>(fs16 + gsrc[it0 + i_] + tapoff[ks]);
+                        if constexpr (NS == 2) pl[i_][ks] = *reinterpret_cast<const uint4*>(fs16 + FSPL + gsrc[it0 + i_] + tapoff[ks]);
                     });
                     return;
                 }
@@ -802,9 +813,9 @@ int launch_gen(const ConvArgs& a, hipStream_t stream, int f_base = 0, int ntf_on
                                "conv3x3 (general): a clip's input map must be smaller than 4 GiB");
     const int nchunks = a.c_out / (16 * NTC);
     const size_t lds_x = (size_t)NS * (16 * CI16 / 8) * g_cplane(FT), wchunk = (size_t)NTC * NS * g_wfrags_per_tile(CI16) * 1024;
-    const size_t lds_f = KS1 > 0 ? (FCL ? (size_t)(GROWS + 2) * (FT + 4) * 16 + 128 : (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float)) +
+    const size_t lds_f = KS1 > 0 ? (FCL ? (size_t)NS * ((GROWS + 2) * (FT + 4) * 16 + 128) : (size_t)a.c_in * (GROWS + 2) * (FT + 5) * sizeof(float)) +
                                    (size_t)CI16 * KS1 * NS * 1024 + 16 * CI16 * 4 : 0;
-    constexpr bool PIPE = FCL && CI16 == 2;                   // two input tiles + two feature tiles, one resident weight chunk
+    constexpr bool PIPE = FCL && CI16 == 2 && NS == 1;        // two input tiles + two feature tiles, one resident weight chunk
     const size_t lds_sh = 16 + (size_t)a.c_out * sizeof(float);
     static const bool no_wdma = getenv("AMTX_CONVG_NO_WDMA") != nullptr;     // A/B switch
     int w_all = !PIPE && nchunks > 1 && lds_x + nchunks * wchunk + lds_f + lds_sh <= 160 * 1024;
@@ -874,16 +885,15 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
             }
             return launch_gen<CI16, NTC, 1, 32, AMTX_T_BF16, AMTX_T_BF16, 1, false, 1>(a, s);
         }
-        if (a.planes == 2 && a.out_type == AMTX_T_F32) {
-            if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);
-            if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 2>(a, s);
-        }
-        if constexpr (CI16 == 2) {       // x3 with a multi-channel first conv (HCQT): a2 as split planes for convx.hip's conv3
-            if (a.planes == 2 && a.out_type == AMTX_T_SPLIT && a.out_split > 0) {
-                if (ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_SPLIT, 1>(a, s);
-                if (ks1 == 2) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_SPLIT, 2>(a, s);
+        // two-plane modes.  2 .. 8 input channels: tap-major as well (round 5: the K-major form gathered and split 8 fp32 values per lane, k-step
+        // and 16 positions -- 52 % of the HCQT model's x3 conv2; the packed weights follow amtx_conv1g_tapk, so there is no run-time switch back)
+        if (a.planes == 2 && amtx_conv1g_tapk(a.c_in, 2)) {
+            if (a.out_type == AMTX_T_F32) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 3, true>(a, s);
+            if constexpr (CI16 == 2) {   // a2 as split planes for convx.hip's conv3
+                if (a.out_type == AMTX_T_SPLIT && a.out_split > 0) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_SPLIT, 3, true>(a, s);
             }
         }
+        if (a.planes == 2 && a.out_type == AMTX_T_F32 && ks1 == 1) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 1>(a, s);      // one input channel
         amtx_set_error("conv3x3 (general): fused first conv: unsupported c_in / precision");
         return AMTX_ERR_UNSUPPORTED;
     }
@@ -959,7 +969,10 @@ void amtx_conv1g_pack_host(const float* w, const float* scale, int c_in, int c_m
                     for (int j = 0; j < 8; ++j) {
                         const int co = 16 * nt + (l & 15), tap = 4 * ks + (l >> 4);
                         const float v = (tap < 9 && j < c_in) ? w[((size_t)co * c_in + j) * 9 + tap] * (scale ? scale[co] : 1.0f) : 0.0f;
-                        out[((size_t)(nt * 3 + ks)) * 512 + (size_t)l * 8 + j] = f32_to_bf16_rn(v);
+                        const bf16_t hi = f32_to_bf16_rn(v);
+                        const size_t base = ((size_t)(nt * 3 + ks) * planes) * 512 + (size_t)l * 8 + j;
+                        out[base] = hi;
+                        if (planes == 2) out[base + 512] = f32_to_bf16_rn(v - bf16_to_f32(hi));
                     }
         return;
     }
@@ -982,8 +995,8 @@ bool amtx_conv3x3_gen_can_fuse1(int c_in, int c_mid, int c_out, int planes) {
     const bool tapk = amtx_conv1g_tapk(c_in, planes);
     if (c_in < 1 || c_in > (tapk ? 8 : 7) || !amtx_conv3x3_gen_ntc(c_mid, c_out)) return false;
     const int ft = planes == 2 ? 16 : 32, ntc = amtx_conv3x3_gen_ntc(c_mid, c_out);
-    const bool pipe = tapk && c_mid == 32;      // two input tiles and two feature tiles (conv3x3_gen_kernel PIPE)
-    const size_t feat = tapk ? (size_t)(pipe ? 2 : 1) * (GROWS + 2) * (ft + 4) * 16 + 128 : (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
+    const bool pipe = tapk && c_mid == 32 && planes == 1;      // two input tiles and two feature tiles (conv3x3_gen_kernel PIPE)
+    const size_t feat = tapk ? (size_t)(pipe ? 2 : 1) * planes * ((GROWS + 2) * (ft + 4) * 16 + 128) : (size_t)c_in * (GROWS + 2) * (ft + 5) * sizeof(float);
     const size_t lds = (size_t)(pipe ? 2 : 1) * planes * (c_mid / 8) * g_cplane(ft) + (size_t)ntc * planes * g_wfrags_per_tile(c_mid / 16) * 1024 + feat +
                        (size_t)(c_mid / 16) * (tapk ? 3 : (9 * c_in + 31) / 32) * planes * 1024 + c_mid * 4 + 16 + (size_t)c_out * 4;   // + this layer's shift
     return lds <= 160 * 1024;

@@ -150,7 +150,7 @@ __global__ void conv1g_pack_kernel(const float* w, const float* scale, int c_in,
             const int ks = r % 3, nt = r / 3;
             const int co = 16 * nt + (l & 15), tap = 4 * ks + (l >> 4);
             const float v = (tap < 9 && j < c_in) ? w[((size_t)co * c_in + j) * 9 + tap] * (scale ? scale[co] : 1.0f) : 0.0f;
-            put16(out, ((size_t)(nt * 3 + ks)) * 512 + (size_t)l * 8 + j, 512, 1, v);
+            put16(out, ((size_t)(nt * 3 + ks) * planes) * 512 + (size_t)l * 8 + j, 512, planes, v);
         }
         return;
     }

@@ -35,7 +35,7 @@ if 'conv3' in sys.argv[2:]:
     model, feats, sd = _Op(), None, None
 elif 'hcqt' in sys.argv[2:]:
     from amt_tools_amd.models import OnsetsFrames
-    model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0', precision='bf16')
+    model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0', precision=('x3' if 'x3' in sys.argv[2:] else 'bf16'))
     sd = synth_state_dict(0, dim_in=72, in_channels=6, model_complexity=2)
     feats = torch.rand(B, 6, 72, 625, device='cuda:0')
 else:
