@@ -887,6 +887,7 @@ int dispatch_gen(const ConvArgs& a, hipStream_t s) {
         }
         // two-plane modes.  2 .. 8 input channels: tap-major as well (round 5: the K-major form gathered and split 8 fp32 values per lane, k-step
         // and 16 positions -- 52 % of the HCQT model's x3 conv2; the packed weights follow amtx_conv1g_tapk, so there is no run-time switch back)
+        // (32-column tiles for the 32-channel shape -- eight waves, 149 KB of LDS, 256 registers with 12 spilled -- measured the same: 4.80 vs 4.83 ms)
         if (a.planes == 2 && amtx_conv1g_tapk(a.c_in, 2)) {
             if (a.out_type == AMTX_T_F32) return launch_gen<CI16, NTC, 2, 16, AMTX_T_F32, AMTX_T_F32, 3, true>(a, s);
             if constexpr (CI16 == 2) {   // a2 as split planes for convx.hip's conv3
