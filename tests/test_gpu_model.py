@@ -985,7 +985,7 @@ model.eval()
 seen = []
 fwd = model.forward
 model.forward = lambda feats: (seen.append(type(feats).__name__), fwd(feats))[1]
-for name, B, n in (('small', 3, 512 * 45 - 1), ('tiles', 5, 512 * 100 + 17)):
+for name, B, n in (('small', 3, 512 * 45 - 1), ('tiles', 5, 512 * 100 + 17), ('tiny', 2, 4097)):
     audio = torch.from_numpy(np.stack([synth_clip(20 + i, num_samples=n) for i in range(B)]))
     with torch.no_grad():
         out = model.run_on_batch({tools.KEY_AUDIO: audio})
@@ -1005,7 +1005,7 @@ def test_hcqt_features_in_the_conv_kernels_staging_format_return_the_same_bits(t
     position in one 16-byte slot, the feature tile format of the fused first conv (amtx_cqt_forward16 -> amtx_of_forward_feats16) -- and
     the conv kernel stages a position with one load.  AMTX_CQT_FEATS16=0 keeps the fp32 (B,C,F,T) map the kernel converts itself.  The
     bf16 values are the same roundings either way: rolls, logits (labelled batches) and losses must be IDENTICAL; clips of 45 frames and
-    of 101 (seven frame tiles, three column tiles, ragged edges)."""
+    of 101 (seven frame tiles, three column tiles, ragged edges), and of 9 (less than one tile of anything)."""
     import os
     import subprocess
     import sys
@@ -1018,7 +1018,7 @@ def test_hcqt_features_in_the_conv_kernels_staging_format_return_the_same_bits(t
         subprocess.check_call([sys.executable, '-c', _FEATS16_AB, files[tag]], env=env, cwd=root)
     a, b = np.load(files['feats16']), np.load(files['fp32'])
     assert list(a['kinds']) == ['PendingFeatures16'] and list(b['kinds']) == ['Tensor']        # each arm ran the path it names
-    assert sorted(a.files) == sorted(b.files) and len(a.files) == 11
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 16
     for k in a.files:
         if k != 'kinds':
             np.testing.assert_array_equal(a[k], b[k], err_msg=k)
