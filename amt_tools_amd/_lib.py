@@ -47,6 +47,7 @@ _SIGNATURES = {
     'amtx_spec_power': (_I, [_P, _P, _L, _L, _I, _P, _P, _P]),
     'amtx_spec_scale': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _P, _P]),
     'amtx_of_model_create': (_I, [C.POINTER(_P), _I, _I, _I, _I, _I, _I]),
+    'amtx_has_f16': (_I, []),
     'amtx_of_model_destroy': (_I, [_P]),
     'amtx_of_model_set_tensor': (_I, [_P, C.c_char_p, _P, _L]),
     'amtx_of_model_finalize': (_I, [_P]),

@@ -34,9 +34,14 @@ def _deps():
 FILE_FLAGS = {'spec.hip': ['-fno-slp-vectorize'], 'convg.hip': ['-fno-slp-vectorize'], 'cqt_dec.hip': ['-fno-slp-vectorize']}
 
 
-# Compiled a second time with -DAMTX_F16 (IEEE half operands instead of bf16, public functions suffixed _f16: csrc/amtx_f16_names.h):
-# the engine's precision 'f16'
+# OPTIONAL (AMTX_BUILD_F16=1): compiled a second time with -DAMTX_F16 (IEEE half operands instead of bf16, public functions suffixed _f16:
+# csrc/amtx_f16_names.h) = the engine's precision 'f16'.  Off by default since round 6: it recompiles the six largest kernel files for a
+# mode no BASELINE config names; without it amtx_has_f16() is 0 and amtx_of_model_create refuses AMTX_PREC_F16.
 F16_TWINS = ('conv.hip', 'convf.hip', 'convg.hip', 'gemm.hip', 'lstm.hip', 'pack.hip')
+WITH_F16 = os.environ.get('AMTX_BUILD_F16', '0') not in ('', '0')
+if WITH_F16:
+    FLAGS.append('-DAMTX_WITH_F16')
+STAMP = os.path.join(CSRC, '.build_flags')
 
 
 def _compile(src, hdr_mtime, verbose, f16=False):
@@ -54,10 +59,24 @@ def _compile(src, hdr_mtime, verbose, f16=False):
 def build(verbose=True, jobs=4):
     """Compile + link; rebuilds only what changed.  Returns the path of libamtx.so."""
     hdr_mtime = _deps()
+    # objects are only as fresh as the flags they were compiled with: a changed flag set (AMTX_BUILD_F16, AMTX_EXTRA_FLAGS) rebuilds all
+    flags_now = ' '.join(FLAGS)
+    try:
+        with open(STAMP) as f:
+            flags_then = f.read()
+    except OSError:
+        flags_then = None
+    relink = flags_then != flags_now
+    if relink:
+        for f in os.listdir(CSRC):
+            if f.endswith('.o'):
+                os.remove(os.path.join(CSRC, f))
+        with open(STAMP, 'w') as f:
+            f.write(flags_now)
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        jobs_ = [(s, False) for s in _sources()] + [(s, True) for s in F16_TWINS]
+        jobs_ = [(s, False) for s in _sources()] + ([(s, True) for s in F16_TWINS] if WITH_F16 else [])
         objs = list(ex.map(lambda j: _compile(j[0], hdr_mtime, verbose, j[1]), jobs_))
-    if not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+    if relink or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)

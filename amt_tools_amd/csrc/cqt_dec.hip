@@ -378,7 +378,14 @@ int amtx_launch_cqt_decimate(const float* in, int64_t n_in, int64_t in_stride, i
     const int64_t nb2 = (n_out + DEC2_MCH - 1) / DEC2_MCH;
     if (!decim_v1 && nb2 * batch < (1ll << 30) && n_in < (1ll << 30) - DEC2_MXS) {
         const int ntiles = (int)(nb2 * batch);
-        static const int dec_blocks = getenv("AMTX_CQT_DECIM_BLOCKS") ? atoi(getenv("AMTX_CQT_DECIM_BLOCKS")) : 256;     // one per CU
+        // one persistent block per CU; the tuning switch is clamped to [1, 1024] and anything that does not parse as such keeps the default
+        static const int dec_blocks = [] {
+            const char* e = getenv("AMTX_CQT_DECIM_BLOCKS");
+            if (!e || !*e) return 256;
+            char* end = nullptr;
+            const long v = strtol(e, &end, 10);
+            return (end && *end == 0 && v >= 1 && v <= 1024) ? (int)v : 256;
+        }();
         AMTX_GRANT_LDS(cqt_decimate2_kernel, DEC2_LDS);
         hipLaunchKernelGGL(cqt_decimate2_kernel, dim3((unsigned)std::min(ntiles, dec_blocks)), dim3(512), DEC2_LDS, s, in, n_in, in_stride, in_pad, out, n_out,
                            out_stride, pad, (const uint4*)tfrag, zero_pads, maxbuf, n_harm, (int)nb2, ntiles);

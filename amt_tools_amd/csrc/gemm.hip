@@ -1449,8 +1449,11 @@ int amtx_launch_gemm(const GemmArgs& g, hipStream_t stream) {
         AMTX_REQUIRE(!g.pair_map && !g.roll_out && !g.copy16 && g.C, "gemm: two-plane A has the plain epilogues only");
         // the direct-to-LDS two-plane kernel: whole 256-column tiles, whole 32-deep stages of real A columns
         static const bool no_split_dma = getenv("AMTX_GEMM_NO_SPLIT_DMA") != nullptr;   // A/B switch: the generic kernel on the same planes
+        // C rows are stored 16 bytes at a time: fp32 C needs ldc % 4 == 0, the 2-byte planes of a two-plane C need ldc % 8 == 0 and a plane
+        // stride that keeps the second plane 16-byte aligned; anything else takes the generic kernel (8-byte stores)
+        const bool c_aligned = g.c_type == AMTX_T_SPLIT ? ((g.ldc * 2) % 16 == 0 && (g.c_split % 8) == 0) : ((g.ldc * 4) % 16 == 0);
         if (!no_split_dma && g.n_pad % 256 == 0 && g.N % 256 == 0 && g.M >= 256 && g.K == g.k_pad && (g.lda % 8) == 0 && g.c_type != AMTX_T_BF16 &&
-            (g.ldc * 4) % 16 == 0)
+            c_aligned)
             return g.c_type == AMTX_T_SPLIT ? launch_split<AMTX_T_SPLIT>(g, stream) : launch_split<AMTX_T_F32>(g, stream);
         AMTX_REQUIRE(g.c_type != AMTX_T_BF16, "gemm: two-plane A writes fp32 or two-plane C");
         // skinny N (the x3 LogisticBanks and pitch head): the two-plane variant of gemm_skinny_kernel

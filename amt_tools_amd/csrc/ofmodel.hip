@@ -198,12 +198,25 @@ Workspace carve(const amtx_of_model* m, int B, int T, char* base) {
 
 }  // namespace
 
+// 1 when the half-operand twins of conv / convf / convg / gemm / lstm / pack.hip are linked in (precision AMTX_PREC_F16 available)
+extern "C" int amtx_has_f16(void) {
+#ifdef AMTX_WITH_F16
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_channels, int model_complexity, int n_out,
                                     int has_offsets, int precision) {
     AMTX_REQUIRE(out, "amtx_of_model_create: null model pointer");
     *out = nullptr;
     AMTX_REQUIRE(precision == AMTX_PREC_BF16 || precision == AMTX_PREC_X3 || precision == AMTX_PREC_F16, "amtx_of_model_create: bad precision");
     AMTX_REQUIRE(dim_in >= 4 && in_channels >= 1 && n_out > 0 && n_out % 4 == 0, "amtx_of_model_create: bad dims");
+    if (precision == AMTX_PREC_F16 && !amtx_has_f16()) {
+        amtx_set_error("amtx_of_model_create: precision f16 needs a library built with the half-operand kernel twins (AMTX_BUILD_F16=1 python -m amt_tools_amd.build)");
+        return AMTX_ERR_UNSUPPORTED;
+    }
     if (model_complexity < 2 || model_complexity > 5) {
         amtx_set_error("amtx_of_model_create: model_complexity 2 (32/32/64-channel convolutions, LSTM hidden 128), 3 (48/48/96, hidden 256) and "
                        "4 (64/64/128, hidden 384), 5 (80/80/160, hidden 512) are implemented, with or without the OnsetsFrames2 offset head (got model_complexity=%d)", model_complexity);

@@ -8,9 +8,10 @@ stay unchanged, so the exchange step lives in an object `train()` already calls:
     identical initial weights on every rank, each rank draws its own clips
     train.py:130  loss.backward()            -- local gradients
     train.py:137  optimizer.step()           -- DataParallelOptimizer.step():
-                                                 flatten grads -> ONE all-reduce (sum) over the flat fp32
-                                                 buffer (4.85 M values = 19.4 MB for OF1) -> / world ->
-                                                 unflatten -> inner optimizer step
+                                                 grads -> persistent flat fp32 buffer (one multi-tensor copy)
+                                                 -> ONE in-place all-reduce (sum; 4.85 M values = 19.4 MB
+                                                 for OF1) -> / world -> param.grad = view of the buffer
+                                                 -> inner optimizer step
 
 The loss is already a batch mean (amt_tools/models/common.py:582), so averaging gradients over ranks is
 the gradient of the mean over the global batch.
@@ -120,8 +121,43 @@ class DataParallelOptimizer(torch.optim.Optimizer):
             return dist.get_world_size(self._group)
         return 1
 
+    def _layout(self, params, bufs):
+        """The flat exchange buffer and the cached views into it, rebuilt only when the parameter set, a parameter's memory layout or the
+        device changes (train.py:111 re-initialises param_groups with the SAME parameter objects, so a resume keeps the cache)."""
+        key = (tuple(id(p) for p in params), tuple(p.stride() for p in params), tuple(id(b) for b in bufs), params[0].device)
+        lay = self.__dict__.get('_lay')
+        if lay is not None and lay['key'] == key:
+            return lay
+        numel = sum(p.numel() for p in params) + sum(b.numel() for b in bufs)
+        flat = torch.zeros(numel, dtype=torch.float32, device=params[0].device)
+        views, off = [], 0
+        for p in params:
+            n = p.numel()
+            seg = flat[off:off + n]
+            # a gradient keeps its parameter's memory layout (autograd's layout contract; the GPU training path holds conv weights channels-last):
+            # the view has the parameter's own strides, so the optimizer's multi-tensor kernels see matching layouts and stay on their fast path
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view(p.shape))
+            off += n
+        n_grad = off
+        bviews = []
+        for b in bufs:
+            n = b.numel()
+            bviews.append(flat[off:off + n].view(b.shape))
+            off += n
+        lay = {'key': key, 'flat': flat, 'views': views, 'bviews': bviews, 'n_grad': n_grad}
+        self.__dict__['_lay'] = lay
+        self.__dict__['_flat'] = flat
+        return lay
+
     @torch.no_grad()
     def allreduce_gradients(self):
+        """Gradients (+ floating-point buffers) averaged over ranks with ONE in-place all-reduce of the flat buffer.  Round 6: the flat buffer
+        and its per-parameter views are allocated once; after the exchange every `param.grad` IS its view (the optimizer reads the averaged
+        gradients straight out of the flat buffer -- no copy back, no per-step view construction, no per-step zero fill).  `zero_grad()`
+        (set_to_none, the torch default train.py:125 uses) drops those references and the next backward produces fresh gradients, which one
+        multi-tensor copy moves into the buffer; a gradient that is still its view (a second exchange without a backward in between) is left
+        where it is."""
         world = self._world()
         forced = self.__dict__.get('_force', False) and dist.is_available() and dist.is_initialized()
         if world == 1 and not forced:
@@ -130,42 +166,28 @@ class DataParallelOptimizer(torch.optim.Optimizer):
         if not params:
             return
         bufs = self.__dict__.get('_buffers', [])
-        numel = sum(p.numel() for p in params) + sum(b.numel() for b in bufs)
-        flat = self._flat
-        if flat is None or flat.numel() != numel or flat.device != params[0].device:
-            flat = torch.zeros(numel, dtype=torch.float32, device=params[0].device)
-            self.__dict__['_flat'] = flat
-        # one multi-tensor copy into the flat buffer and one back (a Python loop of ~60 small copies each way kept the host busy
-        # for longer than the all-reduce itself takes over xGMI)
-        views, off = [], 0
-        for p in params:
-            n = p.numel()
-            views.append(flat[off:off + n].view(p.shape))
-            off += n
-        have = [i for i, p in enumerate(params) if p.grad is not None]
-        for i, p in enumerate(params):
-            if p.grad is None:
-                views[i].zero_()
-        if have:
-            torch._foreach_copy_([views[i] for i in have], [params[i].grad for i in have])
-        bviews = []
-        for b in bufs:
-            n = b.numel()
-            bviews.append(flat[off:off + n].view(b.shape))
-            off += n
+        lay = self._layout(params, bufs)
+        flat, views, bviews = lay['flat'], lay['views'], lay['bviews']
+        src, dst = [], []
+        for p, v in zip(params, views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+                src.append(g)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
         if bufs:
             torch._foreach_copy_(bviews, [b.detach() for b in bufs])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self._group)
         self.__dict__['collectives_run'] = self.__dict__.get('collectives_run', 0) + 1
         if world > 1:                 # x / 1 is exact anyway; skipping it keeps the one-rank run's kernel list short
             flat.div_(world)
-        if have:
-            torch._foreach_copy_([params[i].grad for i in have], [views[i] for i in have])
+        for p, v in zip(params, views):
+            p.grad = v
         if bufs:
             torch._foreach_copy_([b.detach() for b in bufs], bviews)
-        for i, p in enumerate(params):
-            if p.grad is None:
-                p.grad = views[i].clone()
 
     def step(self, closure=None):
         loss = None

@@ -18,8 +18,11 @@ Execution paths
   LogisticBank loss; `autograd.training_backend()` names what still runs on ATen.
 * CPU devices -> stock torch ops on the same parameters (ATen; the reference's own arithmetic).
 
-`precision='bf16'` (default; bf16 MFMA operands, fp32 accumulate) or `'x3'` (split-bf16, fp32-class
-accuracy) selects the engine's dense arithmetic.
+`precision` selects the inference engine's dense arithmetic.  `'x3'` (DEFAULT since round 6: split-bf16, three bf16 MFMAs per
+product, fp32 accumulate) is the mode whose activations are inside north_star's 1e-4 of the fp32 CPU reference -- it is what a user
+who swaps the reference classes for these gets.  `'bf16'` (bf16 MFMA operands, fp32 accumulate) is the throughput mode BASELINE
+config 2 names: 2.8x the frames/s, sigmoid outputs within 7e-3, 1.4e-3 of the thresholded piano-roll cells differ (bench.py and
+tests/test_gpu_model.py print both) -- opt in with `precision='bf16'`.  `'f16'` exists only in a library built with AMTX_BUILD_F16=1.
 """
 
 import ctypes as C
@@ -441,7 +444,7 @@ class OnsetsFrames(TranscriptionModel):
     has_offsets = False
 
     def __init__(self, dim_in, profile, in_channels=1, model_complexity=2, detach_heads=False, device='cpu',
-                 precision='bf16'):
+                 precision='x3'):
         super().__init__(dim_in, profile, in_channels, model_complexity, 1, device)
         assert precision in ('bf16', 'x3', 'f16')
         self.detach_heads = detach_heads
@@ -465,6 +468,7 @@ class OnsetsFrames(TranscriptionModel):
         state.pop('_side_stream', None)
         state.pop('_overlap_armed', None)
         state.pop('_fb_last_forward', None)
+        state.pop('_overlap_latched_off', None)
         return state
 
     def _get_engine(self, device):
@@ -514,6 +518,10 @@ class OnsetsFrames(TranscriptionModel):
             return None
         if cqt:
             if not self._get_engine(audio.device).takes_feats16():
+                return None
+            # amtx_of_forward_feats16 takes a bare (B,T,F,8) pointer and indexes it with the MODEL's dim_in / in_channels: a front-end of
+            # another shape goes through the ordinary path, whose strides and shapes are explicit (and which raises on a mismatch)
+            if int(getattr(module, 'n_bins', -1)) != int(self.dim_in) or int(module.get_num_channels()) != int(self.in_channels):
                 return None
             audio = audio.float()
             batch[tools.KEY_FEATS] = PendingFeatures16(module, module.process_batch16(audio), audio)
@@ -599,6 +607,8 @@ class OnsetsFrames(TranscriptionModel):
         output[tools.KEY_MULTIPITCH] = self.adjoin(joint)
         if fb0 is not None:
             self.__dict__['_fb_last_forward'] = _ag.fallback_total() - fb0     # 0: the next training forward may overlap its heads
+            if self.__dict__['_fb_last_forward']:
+                self.__dict__['_overlap_latched_off'] = True                   # sticky: see _overlap_heads
         return output
 
     def _overlap_heads(self, feats):
@@ -622,7 +632,13 @@ class OnsetsFrames(TranscriptionModel):
                 and torch.distributed.get_world_size() > 1:
             return False
         # THIS model's previous training forward must have run without an ATen fallback (the count is bracketed per forward in forward():
-        # other models, or a validation pass, do not switch the overlap off for the rest of the process)
+        # other models, or a validation pass, do not switch the overlap off for the rest of the process).  The switch is STICKY per model:
+        # one training forward of this model that recorded a fallback (an odd-shaped batch sent a layer to MIOpen / hipBLASLt) latches the
+        # overlap off for the life of the object -- a vendor-library kernel under two streams is the hang tools/two_stream_repro.py found,
+        # and a batch shape that fell back once can come by again at any step.  The bracket covers forward() only: LogisticBank.get_loss in
+        # post_proc is not in it, and needs not be (its ATen branch is elementwise BCE on the main stream, after the streams have joined).
+        if self.__dict__.get('_overlap_latched_off', False):
+            return False
         if self.__dict__.get('_fb_last_forward', None) != 0:
             return False
         return True
@@ -690,7 +706,7 @@ class OnsetsFrames2(OnsetsFrames):
 
     has_offsets = True
 
-    def __init__(self, dim_in, profile, in_channels=1, model_complexity=3, detach_heads=True, device='cpu', precision='bf16'):
+    def __init__(self, dim_in, profile, in_channels=1, model_complexity=3, detach_heads=True, device='cpu', precision='x3'):
         super().__init__(dim_in, profile, in_channels, model_complexity, detach_heads, device, precision)
         dim_out = self.profile.get_range_len()
         self.offset_head = nn.Sequential(AcousticModel(self.dim_in, self.dim_am, self.in_channels, self.model_complexity),

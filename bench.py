@@ -435,7 +435,23 @@ def parity_leg(model, audio, out_bf16, device, oracle_rolls):
         res['x3_max_abs_logit_err_vs_cpu_oracle'] = err
     del mx
     torch.cuda.empty_cache()
-    # precision 'f16': the headline kernels with IEEE half operands (same matrix rate, three more mantissa bits), at the headline batch
+    # precision 'f16' (optional build, AMTX_BUILD_F16=1): the headline kernels with IEEE half operands, at the headline batch
+    if not L.amtx_has_f16():
+        if oracle_rolls:
+            n = min(nd, len(oracle_rolls))
+            lx = model.engine_logits(model.frontend(audio[:n].unsqueeze(-2)))
+            e = 0.0
+            for i in range(n):
+                e = max(e, float(np.abs(lx['onsets'][i].cpu().numpy() - oracle_rolls[i][2]).max()),
+                        float(np.abs(lx['multi_pitch'][i].cpu().numpy() - oracle_rolls[i][3]).max()))
+            res['bf16_max_abs_logit_err_vs_cpu_oracle'] = e
+            res['precision_modes'] = [
+                {'mode': 'bf16 (headline; opt-in: precision="bf16")', 'frames_per_s': None, 'cell_mismatch_rate_vs_cpu_oracle': res.get('bf16_cell_mismatch_rate_vs_cpu_oracle'),
+                 'max_abs_logit_err_vs_cpu_oracle': e},
+                {'mode': 'x3 (meets 1e-4; the default of the drop-in classes)', 'clips_per_step': res['x3_clips_per_step'], 'frames_per_s': res['x3_frames_per_s'],
+                 'cell_mismatch_rate_vs_cpu_oracle': res.get('x3_cell_mismatch_rate_vs_cpu_oracle'),
+                 'max_abs_logit_err_vs_cpu_oracle': res.get('x3_max_abs_logit_err_vs_cpu_oracle')}]
+        return res
     mf, _, _ = build_model(device, 'f16')
     bf = {tools.KEY_AUDIO: audio}
     with torch.no_grad():

@@ -92,6 +92,9 @@ typedef struct amtx_of_model amtx_of_model;
  * 358-364); anything else answers AMTX_ERR_UNSUPPORTED */
 int amtx_of_model_create(amtx_of_model** model, int dim_in, int in_channels, int model_complexity, int n_out,
                          int has_offsets, int precision /* AMTX_PREC_* */);
+/* 1 when the library was built with the half-operand kernel twins (AMTX_BUILD_F16=1): only then does amtx_of_model_create accept
+ * AMTX_PREC_F16 (AMTX_ERR_UNSUPPORTED otherwise).  The default build has bf16 and x3 only -- no BASELINE config names f16. */
+int amtx_has_f16(void);
 int amtx_of_model_destroy(amtx_of_model* model);
 /* hand over one tensor of the reference's state_dict under its own key (HOST pointer, fp32, row-major) */
 int amtx_of_model_set_tensor(amtx_of_model* model, const char* name, const float* host_data, int64_t numel);
@@ -173,7 +176,9 @@ int amtx_linear_fwd(const void* a, int64_t lda, int a_type, const uint16_t* w_pa
 /* Element type 2 = "split" (the x3 precision's activation format since round 5): TWO 16-bit planes, hi = bf16(x) at the base pointer and
  * lo = bf16(x - hi) `split` elements behind it; four bytes per element like fp32.  amtx_split_planes writes them from fp32 rows (columns
  * n .. ld_dst zero); amtx_linear_fwd_split is amtx_linear_fwd with a split A (planes = 2 weights) and an fp32 (1) or split (2) C:
- * whole 256-column tiles with k == its packed width run on the direct-to-LDS two-plane kernel, everything else on the generic one. */
+ * whole 256-column tiles with k == its packed width run on the direct-to-LDS two-plane kernel, everything else on the generic one.
+ * Alignment: ldc % 4 == 0 always; the direct-to-LDS kernel stores 16 bytes at a time, so with a split C it is only chosen when
+ * ldc % 8 == 0 and c_split % 8 == 0 (otherwise the generic kernel, 8-byte stores, runs -- same bits). */
 int amtx_split_planes(const float* src, int64_t ld_src, int n, uint16_t* dst, int ld_dst, int64_t split, int64_t rows, void* stream);
 int amtx_linear_fwd_split(const void* a, int64_t lda, int64_t a_split, const uint16_t* w_packed, const float* bias, void* c, int64_t ldc,
                           int c_type, int64_t c_split, int64_t m, int n, int k, void* stream);

@@ -14,6 +14,26 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def has_f16():
+    """The library carries the optional half-operand kernel twins (built with AMTX_BUILD_F16=1; off by default since round 6)."""
+    try:
+        from amt_tools_amd import _lib
+        return bool(_lib.lib().amtx_has_f16())
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    import re
+    f16 = None
+    for item in items:
+        if re.search(r'(^|[\[\-_])f16($|[\]\-_])', item.name):
+            if f16 is None:
+                f16 = has_f16()
+            if not f16:
+                item.add_marker(pytest.mark.skip(reason="precision 'f16' is an optional build (AMTX_BUILD_F16=1 python -m amt_tools_amd.build)"))
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

@@ -243,3 +243,49 @@ def test_forced_one_rank_collective_returns_the_same_bits(tmp_path):
     assert n0 == 0 and n1 == 3
     for k, v in plain.items():
         assert torch.equal(v, forced[k]), k
+
+
+def _flat_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    model = _make_model(seed=0, freeze_bn=False)
+    model.to(memory_format=torch.channels_last)            # the GPU training layout of the conv weights (models.py change_device)
+    model.train()
+    opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=1e-2, buffers=model.buffers(), force_collective=True)
+    res = {}
+    ptrs = []
+    for it in range(3):
+        opt.zero_grad(set_to_none=(it != 2))               # the last step keeps the gradients (zeroed in place, inside the flat buffer)
+        if it == 2:
+            res['kept_grads_are_zeroed_views'] = all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+        model.run_on_batch(_cat([_batch(2 * it), _batch(2 * it + 1)]))[tools.KEY_LOSS][tools.KEY_LOSS_TOTAL].backward()
+        opt.step()
+        flat = opt._flat
+        ptrs.append(flat.data_ptr())
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        res[f'grads_in_flat_{it}'] = all(lo <= p.grad.data_ptr() < hi for p in model.parameters())
+        res[f'strides_match_{it}'] = all(p.grad.stride() == p.stride() for p in model.parameters())
+    res['flat_allocated_once'] = len(set(ptrs)) == 1
+    res['numel'] = int(opt._flat.numel())
+    res['expected_numel'] = sum(p.numel() for p in model.parameters()) + sum(b.numel() for b in model.buffers() if b.dtype.is_floating_point)
+    # a second exchange without a backward in between: gradients are already their views, nothing to copy, values unchanged (sum over one rank)
+    before = [p.grad.clone() for p in model.parameters()]
+    opt.allreduce_gradients()
+    res['idempotent'] = all(torch.equal(a, p.grad) for a, p in zip(before, model.parameters()))
+    res['collectives'] = opt.collectives_run
+    dist.destroy_process_group()
+    torch.save(res, out)
+
+
+@pytest.mark.timeout(300)
+def test_gradients_live_in_the_flat_buffer(tmp_path):
+    """Round 6: ONE flat fp32 buffer allocated once; after the exchange every param.grad is a view into it with the
+    parameter's own strides (channels-last conv weights included), zero_grad(set_to_none=False) zeroes it in place, and no copy back."""
+    out = str(tmp_path / 'flat.pt')
+    mp.spawn(_flat_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    res = torch.load(out)
+    assert res['flat_allocated_once'] and res['numel'] == res['expected_numel']
+    assert res['kept_grads_are_zeroed_views'] and res['idempotent'] and res['collectives'] == 4
+    for it in range(3):
+        assert res[f'grads_in_flat_{it}'] and res[f'strides_match_{it}'], it

@@ -49,7 +49,7 @@ def test_power_path_and_cqt_workspace_guard_bands(guards):
     mod = MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048)
     sd = synth_state_dict(3, dim_in=229, in_channels=1, model_complexity=2)
     for B, n in ((3, 512 * 20), (140, 512 * 60), (2, 5000)):
-        model = M.OnsetsFrames(229, tools.PianoProfile(), 1, 2, device='cuda:0')
+        model = M.OnsetsFrames(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision='bf16')
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         model.frontend = torch.nn.Sequential(mod.frontend())
         model.change_device()

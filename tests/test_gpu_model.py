@@ -352,7 +352,7 @@ def test_device_side_weight_sync_falls_back_where_it_is_not_built(monkeypatch):
     new weights all the same."""
     import amt_tools_amd.models as M
     monkeypatch.setenv('AMTX_NO_CONVG_MC2', '1')
-    model = M.OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0')
+    model = M.OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0', precision='bf16')
     model.change_device()
     model.eval()
     feats = torch.rand(2, 6, 72, 20, device='cuda')
@@ -537,7 +537,7 @@ def test_forward_power_is_refused_loudly_where_the_conv_kernel_does_not_stage_fe
     audio = torch.from_numpy(np.stack([synth_clip(i, num_samples=512 * 20) for i in range(2)])).cuda()
     for mc, fuses in ((2, True), (3, False)):
         sd = synth_state_dict(3, dim_in=229, in_channels=1, model_complexity=mc)
-        model = OnsetsFrames(229, tools.PianoProfile(), 1, mc, device='cuda:0')
+        model = OnsetsFrames(229, tools.PianoProfile(), 1, mc, device='cuda:0', precision='bf16')
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         model.frontend = torch.nn.Sequential(mod.frontend())
         model.change_device()
