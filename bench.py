@@ -102,6 +102,9 @@ def parse(argv=None):
     ap.add_argument('--force-dist', action='store_true', help='create the process group (default backend nccl = RCCL) and run every collective of the '
                                                               'N > 1 path -- timing barrier, MAX / gather of the elapsed times and, in train mode, the '
                                                               'flat gradient all-reduce inside optimizer.step() -- also at --gpus 1: RCCL under test on a one-GPU box')
+    ap.add_argument('--dump', default=None, help='test only: directory; every rank writes what it computed (infer: its piano rolls per clip, train: its '
+                                                 'weights after the last step) as rank<r>.npz -- tests/test_gpu_multirank.py compares ranks with a one-process run')
+    ap.add_argument('--dropout-off', action='store_true', help='test only (train): Dropout p = 0, so that runs of different world sizes are comparable')
     ap.add_argument('--fail-rank', type=int, default=-1, help='test only (with --dry-run): this rank exits with an error before the rendezvous')
     ap.add_argument('--dry-run', action='store_true', help='test only (CPU): ranks rendezvous over gloo and rank 0 prints a line '
                                                            'without touching a GPU -- exercises the launcher and the relay')
@@ -203,12 +206,48 @@ def init_ranks(args):
         os.environ.setdefault('MASTER_PORT', str(_free_port()) if world == 1 else '29500')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        if args.backend == 'nccl' and rank == 0 and 'NCCL_DEBUG' not in os.environ:
+            # which algorithm / protocol RCCL picks for the 19.4 MB gradient all-reduce (ring vs tree vs direct) decides
+            # whether a hand-rolled exchange is worth writing: rank 0 logs RCCL's tuning decisions into a file that rccl_choices() parses
+            # into the result line, so the first multi-GPU run answers the question without a second one
+            import tempfile
+            _RCCL_LOG['path'] = os.path.join(tempfile.gettempdir(), f'amtx_rccl_{os.getpid()}.log')
+            os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,TUNING', NCCL_DEBUG_FILE=_RCCL_LOG['path'])
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(device))
         else:
             dist.init_process_group(args.backend)
         assert dist.get_world_size() == args.gpus
     return rank, world, device
+
+
+_RCCL_LOG = {'path': None}
+
+
+def rccl_choices(nbytes=None, limit=12):
+    """What rank 0's RCCL logged (NCCL_DEBUG=INFO, subsystems INIT + TUNING): version, channel / topology summary lines and the
+    '<bytes> Bytes -> Algo <a> proto <p>' decisions (all sizes seen; `for_allreduce_bytes` = the ones of the gradient all-reduce's size)."""
+    import re
+    path = _RCCL_LOG.get('path')
+    if not path or not os.path.exists(path):
+        return None
+    algo, init = {}, []
+    try:
+        with open(path, errors='replace') as f:
+            for line in f:
+                m = re.search(r'(\d+) Bytes -> Algo (\S+) proto (\S+)(.*)', line)
+                if m:
+                    key = (int(m.group(1)), m.group(2), m.group(3))
+                    algo[key] = algo.get(key, 0) + 1
+                elif re.search(r'(RCCL|NCCL) version|Channel|Trees|Rings|comm 0x\S+ rank|xgmi|XGMI|nranks', line) and len(init) < limit:
+                    init.append(line.strip()[-200:])
+    except OSError:
+        return None
+    rows = [{'bytes': k[0], 'algo': k[1], 'proto': k[2], 'times': n} for k, n in sorted(algo.items())]
+    rec = {'log': path, 'env': 'NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,TUNING (rank 0)', 'decisions': rows[:limit * 2], 'init_lines': init}
+    if nbytes is not None:
+        rec['for_allreduce_bytes'] = [r for r in rows if r['bytes'] == nbytes]
+    return rec
 
 
 def _dist_on():
@@ -264,6 +303,29 @@ def build_model(device, precision):
 # ------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline (oracle = checker; here it is the thing timed, on the host cores, rank 0 at N = 1 only)
 # ------------------------------------------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def sustained_matrix_rate():
+    """(TFLOP/s, source) of the committed microbenchmark tools/mfma_sustained.py: the bf16 MFMA rate this chip sustains on random operands out
+    of registers (its clock settles to the power budget, well under the 2.4 GHz the nominal 2.5 PFLOP/s assumes); None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'mfma_sustained.json')) as f:
+            rec = json.load(f)
+        return float(rec['sustained_bf16_tflops_random']), 'profiles/mfma_sustained.json (tools/mfma_sustained.py: register-resident v_mfma stream, random operands)'
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(budget_s, sd, keep=8):
     """Oracle on the host cores: numpy front-end restatement + torch-CPU fp32 model restatement (its recurrences through ATen's
     nn.LSTM, what the reference itself runs on a CPU), one clip per call (the reference's run_offline pattern,
@@ -299,7 +361,8 @@ def cpu_baseline(budget_s, sd, keep=8):
         n += 1
         if t_total > budget_s:
             break
-    rec = {'value': n * CLIP_FRAMES / t_total, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+    rec = {'value': n * CLIP_FRAMES / t_total, 'unit': 'frames/s', 'cores': cores, 'cores_available': os.cpu_count(), 'cpu_model': cpu_model_name(),
+           'kind': 'port',
            'sample': f'{n} synthetic clips x {CLIP_FRAMES} frames in {t_total:.1f} s of oracle time (clip synthesis excluded), one clip per '
                      f'call, fp32, numpy front-end (share {t_fe / t_total:.2f}) + torch-CPU model restatement with ATen nn.LSTM recurrences',
            # the front-end / model split, and the batch-of-8 call next to the one-clip-per-call pattern
@@ -345,7 +408,8 @@ def cpu_train_baseline(budget_s):
     step_s = min(times[1:]) if len(times) > 1 else times[0]
     # `value` is what was measured (a 2-clip step); the linear extrapolation to the 8-clip batch over-states the CPU time (the LSTM time
     # steps amortise over the batch) and lives in its own, clearly named field
-    return {'value': step_s * 1e3, 'unit': f'ms/step at {Bc} clips per step', 'cores': cores, 'kind': 'port', 'clips_per_step': Bc,
+    return {'value': step_s * 1e3, 'unit': f'ms/step at {Bc} clips per step', 'cores': cores, 'cores_available': os.cpu_count(), 'cpu_model': cpu_model_name(),
+            'kind': 'port', 'clips_per_step': Bc,
             'extrapolated_8clip_ms': step_s * 1e3 * 8 / Bc,
             'sample': f'torch-CPU fp32 fwd+bwd+Adam on {Bc} clips x {CLIP_FRAMES} frames of oracle features: {step_s:.2f} s per step '
                       f'(best of {max(1, len(times) - 1)} after one warm-up step); extrapolated_8clip_ms = x{8 // Bc}, an upper bound'}
@@ -605,7 +669,8 @@ def run_infer(args, rank, world, device):
 
     model, mel, sd = build_model(device, args.precision)
     B = args.clips
-    base = np.stack([synth_clip(rank * DISTINCT_CLIPS + i) for i in range(DISTINCT_CLIPS)])
+    # clips are dealt round-robin over ranks (clip g belongs to rank g % world): rank r's i-th distinct clip is clip i world + r
+    base = np.stack([synth_clip(i * world + rank) for i in range(DISTINCT_CLIPS)])
     audio = torch.from_numpy(base).to(device).repeat((B + DISTINCT_CLIPS - 1) // DISTINCT_CLIPS, 1)[:B].contiguous()
     batch = {tools.KEY_AUDIO: audio}
 
@@ -637,6 +702,11 @@ def run_infer(args, rank, world, device):
     gc.enable()
     per_rank = gather_over_ranks(elapsed, world, device, args.backend)
     elapsed = max_over_ranks(elapsed, world, device, args.backend)
+    if args.dump:
+        os.makedirs(args.dump, exist_ok=True)
+        nd = min(B, DISTINCT_CLIPS)
+        np.savez(os.path.join(args.dump, f'rank{rank}.npz'), onsets=out[tools.KEY_ONSETS][:nd].cpu().numpy().astype(np.uint8),
+                 multi_pitch=out[tools.KEY_MULTIPITCH][:nd].cpu().numpy().astype(np.uint8), clip_ids=np.arange(nd) * world + rank)
 
     stage_ms = (C.c_double * L.amtx_of_num_stages())()
     nfw = C.c_int(0)
@@ -688,12 +758,17 @@ def run_infer(args, rank, world, device):
         hbm_measured = (tot * B, src)
     except (OSError, ValueError, KeyError):
         pass
+    sus = sustained_matrix_rate()
+    if sus is not None and roof['bound'] == 'mfma':
+        roof['sustained_peak'] = sus[0]
+        roof['frac_of_sustained_matrix_rate'] = roof['achieved'] / sus[0]
+        roof['sustained_peak_source'] = sus[1]
     roof['avg_launch_ms'] = per_launch[dom]
     roof['kernel_ms_per_step'] = {k: round(v, 4) for k, v in sorted(per_launch.items(), key=lambda kv: -kv[1])}
     fps = total_frames / elapsed
     ms_per_step = elapsed / args.steps * 1e3
     config = {'workload': 'OnsetsFrames(mc=2)+MelSpec(229 bins, n_fft 2048, hop 512) inference, synthetic 22.05 kHz clips of 319999 '
-                          'samples (625 frames; 64 distinct clips per rank tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
+                          'samples (625 frames; 64 distinct clips per rank -- clip g of the job belongs to rank g % world -- tiled into separate HBM buffers), audio resident in HBM -> piano rolls',
               'clips_per_gpu_per_step': B, 'frames_per_clip': CLIP_FRAMES, 'parallelism': f'clip-sharded x{world}, no collectives',
               'rccl_ranks': world, 'process_group': (args.backend if _dist_on() else None), 'per_rank_frames_per_s': [B * CLIP_FRAMES * args.steps / t for t in per_rank],
               'whole_path_frac_of_mfma_roof': fps / world * MODEL_FLOPS_PER_FRAME / 2.5e15,
@@ -701,6 +776,8 @@ def run_infer(args, rank, world, device):
               'flops_per_frame': {'reference_algorithmic': MODEL_FLOPS_PER_FRAME, 'executed': EXECUTED_FLOPS_PER_FRAME,
                                   'note': 'pitch head fc1 + LogisticBank folded into one linear layer at weight load (eval mode has nothing between them)'},
               'whole_path_frac_of_compulsory_hbm_roof': fps / world * 2752 / 8.0e12}
+    if sus is not None:
+        config['whole_path_frac_of_sustained_matrix_rate'] = fps / world * MODEL_FLOPS_PER_FRAME / (sus[0] * 1e12)
     if hbm_measured is not None:
         # bytes this build really moves per step (sum of the PMC-counted kernels) over the step time, against 8 TB/s
         config['whole_path_hbm_frac_measured'] = hbm_measured[0] / (ms_per_step * 1e-3) / 8.0e12
@@ -728,7 +805,8 @@ def run_infer(args, rank, world, device):
         # BASELINE metric (ii), train step time, at N = 1 (the DP = 8 figure needs the 8-GPU node: python bench.py --mode train --gpus 8)
         del model, out
         torch.cuda.empty_cache()
-        config['train_step_ms_1gpu'] = train_step_probe(device)
+        config['train'] = train_step_probe(device)
+        config['train_step_ms_1gpu'] = config['train']['ms_per_step']
         config['train_step_workload'] = 'OnsetsFrames(mc=2)+MelSpec(229) fwd+bwd+Adam, 8 clips x 625 frames per GPU, 10 steps after 3 warm-up steps (python bench.py --mode train)'
         config['train_allreduce_probe'] = train_allreduce_probe()
     return res
@@ -737,7 +815,7 @@ def run_infer(args, rank, world, device):
 # ------------------------------------------------------------------------------------------------------------------------------
 # training mode (BASELINE metric ii)
 # ------------------------------------------------------------------------------------------------------------------------------
-def _train_setup(device, rank, B, of2):
+def _train_setup(device, rank, B, of2, dropout_off=False):
     """Model, optimizer and one synthetic labelled batch of the training step (amt_tools/train.py:122-141); returns step()."""
     from amt_tools_amd import tools
     from amt_tools_amd.dp import DataParallelOptimizer, broadcast_parameters
@@ -753,6 +831,10 @@ def _train_setup(device, rank, B, of2):
     model.frontend = torch.nn.Sequential(MelSpec(sample_rate=SR, hop_length=HOP, n_mels=N_MELS, n_fft=N_FFT, device=device).frontend())
     model.change_device()
     broadcast_parameters(model)
+    if dropout_off:
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
     model.train()
     opt = DataParallelOptimizer(model.parameters(), torch.optim.Adam, lr=6e-4, buffers=model.buffers(),   # BatchNorm policy: amt_tools_amd/dp.py
                                 force_collective=True if _dist_on() else None)
@@ -771,11 +853,47 @@ def _train_setup(device, rank, B, of2):
         opt.step()
         return loss
 
+    step.model = model
     return step, opt
 
 
+def recurrence_latency_probe(device, B=8, T=CLIP_FRAMES, H=128, reps=5):
+    """The training step's dependency chain, measured: the persistent BiLSTM kernels of one recurrence (amtx_bilstm_h_train_fwd / _bwd, 8 clips x
+    625 steps, hidden 128, both directions in one launch) timed on their own with HIP events on the launch stream -> microseconds per time step."""
+    from amt_tools_amd import _lib
+    L = _lib.lib()
+    dev = torch.device(device)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    xproj = (torch.randn(1, B * T, 8 * H, generator=g) * 0.5).to(dev)
+    whf, whb = [(torch.randn(4 * H, H, generator=g) * 0.05).to(dev) for _ in range(2)]
+    n = int(L.amtx_bilstm_h_packed_elems(H, 2))
+    ff = torch.empty((1, n), dtype=torch.int16, device=dev)
+    fb = torch.empty((1, n), dtype=torch.int16, device=dev)
+    out = torch.empty((1, B, T, 2 * H), dtype=torch.float32, device=dev)
+    save = torch.empty((1, B, T, 2, 5, H), dtype=torch.float32, device=dev)
+    dout = (torch.randn(1, B, T, 2 * H, generator=g) * 0.1).to(dev)
+    dxp = torch.empty_like(xproj)
+    st = _lib.current_stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.amtx_bilstm_h_pack_device(_lib.ptr(whf), _lib.ptr(whb), H, 2, _lib.ptr(ff), _lib.ptr(fb), st), 'amtx_bilstm_h_pack_device')
+        res = {}
+        for name, call in (('fwd', lambda: L.amtx_bilstm_h_train_fwd(_lib.ptr(xproj), _lib.ptr(ff), H, 2, _lib.ptr(out), _lib.ptr(save), B, T, 1, st)),
+                           ('bwd', lambda: L.amtx_bilstm_h_train_bwd(_lib.ptr(dout), _lib.ptr(save), _lib.ptr(fb), H, 2, _lib.ptr(dxp), B, T, 1, st))):
+            _lib.check(call(), name)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                _lib.check(call(), name)
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = e0.elapsed_time(e1) / reps
+    return {'fwd_kernel_ms': res['fwd'], 'bwd_kernel_ms': res['bwd'], 'fwd_us_per_step': res['fwd'] * 1e3 / T, 'bwd_us_per_step': res['bwd'] * 1e3 / T}
+
+
 def train_step_probe(device, steps=10, warmup=3):
-    """BASELINE metric (ii) at N = 1 inside the default line: ms per fwd + bwd + Adam step, 8 clips x 625 frames."""
+    """BASELINE metric (ii) at N = 1 inside the default line: ms per fwd + bwd + Adam step, 8 clips x 625 frames -- with the step's flops, its
+    fraction of the matrix roof and the LATENCY MODEL SURVEY 8(d) asks for: the step is a chain of 4 x 625 dependent recurrence steps (onset head
+    and refinement stage, forward and backward), whose per-step time is measured on the kernels themselves."""
     step, _ = _train_setup(device, 0, 8, False)
     for _ in range(warmup):
         step()
@@ -784,7 +902,28 @@ def train_step_probe(device, steps=10, warmup=3):
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del step
+    frames = 8 * CLIP_FRAMES
+    flops = TRAIN_FLOPS_PER_FRAME * frames
+    rec = {'ms_per_step': ms, 'clips_per_step': 8, 'frames_per_step': frames, 'flops_per_step': flops, 'achieved_tflops': flops / (ms * 1e-3) / 1e12,
+           'frac_of_mfma_roof': flops / (ms * 1e-3) / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+           'note': 'flops_per_step = 80 MFLOP per clip-frame (SURVEY 8d: ~3x forward) x 5000 frames; the products run as 3 bf16 MFMAs each (split-bf16), '
+                   'not counted.  At 8 clips per GPU the step is bound by its dependency chain, not by either roof: see latency_model'}
+    sus = sustained_matrix_rate()
+    if sus is not None:
+        rec['frac_of_sustained_matrix_rate'] = rec['achieved_tflops'] / sus[0]
+    try:
+        lat = recurrence_latency_probe(device)
+        chain = 2 * (lat['fwd_kernel_ms'] + lat['bwd_kernel_ms'])
+        lat.update({'dependent_steps': 4 * CLIP_FRAMES, 'recurrence_chain_ms': chain, 'share_of_step': chain / ms,
+                    'model': 'step >= 2 x (fwd + bwd recurrence kernel) = 4 x 625 dependent time steps (onset head + refinement stage, each way); each '
+                             'recurrence occupies 4 of 256 CUs (2 directions x 8 clips / 4 clips per block), the dense layers between them cannot start '
+                             'before their recurrence ends (autograd order), the pitch head overlaps on a side stream'})
+        rec['latency_model'] = lat
+    except Exception as e:                                      # noqa: BLE001 -- a probe: report, never fail the line
+        rec['latency_model'] = {'error': f'{type(e).__name__}: {e}'[:200]}
+    return rec
 
 
 def train_allreduce_probe(timeout=240):
@@ -809,7 +948,7 @@ def train_allreduce_probe(timeout=240):
 
 def run_train(args, rank, world, device):
     B = args.clips
-    step, opt = _train_setup(device, rank, B, args.of2)
+    step, opt = _train_setup(device, rank, B, args.of2, args.dropout_off)
 
     for _ in range(args.warmup):
         loss = step()
@@ -834,6 +973,11 @@ def run_train(args, rank, world, device):
             opt.allreduce_gradients()
         barrier(world)
         allreduce_ms = max_over_ranks((time.perf_counter() - t1) / 5 * 1e3, world, device, args.backend)
+    if args.dump:
+        os.makedirs(args.dump, exist_ok=True)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(args.dump, f'rank{rank}.npz'), loss=float(loss.detach()),
+                 **{k: v.detach().float().cpu().contiguous().numpy() for k, v in step.model.state_dict().items() if not k.startswith('frontend.')})
     if rank != 0:
         return None
     ms = elapsed / args.steps * 1e3
@@ -853,6 +997,7 @@ def run_train(args, rank, world, device):
                    'allreduce_bytes': (int(opt._flat.numel()) * 4 if getattr(opt, '_flat', None) is not None else None),
                    'collectives_per_step': opt.collectives_run / max(1, args.steps + args.warmup + (5 if allreduce_ms is not None else 0)),
                    'process_group': (args.backend if _dist_on() else None),
+                   'rccl': rccl_choices(int(opt._flat.numel()) * 4 if getattr(opt, '_flat', None) is not None else None),
                    'loss': float(loss.detach()), 'backward': training_backend()},
         'roofline': {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None,

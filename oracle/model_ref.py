@@ -73,12 +73,13 @@ LSTM_IMPL = 'loop'      # 'loop': the explicit time loop above (the restatement 
 
 
 def _lstm_aten(x, sd, p):
+    """The same weights through ATen's fused CPU LSTM (what nn.LSTM.forward calls: torch._VF.lstm), functional form: differentiable with
+    respect to the `sd` tensors, so the full-size training-step parity test (8 clips x 625 frames, every parameter gradient) can use it."""
     H = sd[p + 'weight_hh_l0'].shape[1]
-    mod = torch.nn.LSTM(input_size=x.shape[-1], hidden_size=H, batch_first=True, bidirectional=True)
-    with torch.no_grad():
-        for name, _ in list(mod.named_parameters()):
-            getattr(mod, name).copy_(sd[p + name])
-    return mod(x)[0]
+    names = ('weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l0_reverse', 'weight_hh_l0_reverse',
+             'bias_ih_l0_reverse', 'bias_hh_l0_reverse')
+    z = x.new_zeros(2, x.shape[0], H)
+    return torch._VF.lstm(x, (z, z), [sd[p + n] for n in names], True, 1, 0.0, False, True, True)[0]
 
 
 def language_model(x, sd, prefix):

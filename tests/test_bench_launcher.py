@@ -66,3 +66,13 @@ def test_force_dist_creates_a_one_rank_group():
     assert rec['n_gpus'] == 1 and rec['process_group'] == 'gloo' and rec['ms_per_step'] == 1.0
     p = _run(['--gpus', '1', '--dry-run'])
     assert json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])['process_group'] is None
+
+
+def test_eight_ranks_rendezvous_and_relay_one_line():
+    """The driver's SCALE run is `--gpus 8`: eight fresh rank processes, one rendezvous, MAX over all eight, one relayed line."""
+    p = _run(['--gpus', '8', '--dry-run'], timeout=400)
+    assert p.returncode == 0, p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 8 and rec['ms_per_step'] == 8.0 and rec['process_group'] == 'gloo'

@@ -764,6 +764,67 @@ def test_config3_hcqt_frontend_fused_into_the_model():
         assert (out[key].cpu().numpy() != ref[key].numpy()).mean() < 5e-3
 
 
+@pytest.mark.timeout(900)
+def test_config3_at_full_clip_length_matches_the_oracle(capsys):
+    """BASELINE config 3 at its real size: 4 clips x 319 999 samples (625 frames) -- audio -> HIP HCQT (6 harmonics x
+    72 bins, amt_tools/features/hvqt.py:107-133) -> OnsetsFrames(dim_in 72, 6 channels, mc 2) in the x3 precision -> piano rolls.
+    (1) the HCQT map against oracle/cqt_np.hcqt_process_audio: 1e-3 absolute in the scaled [0,1] domain (tests/test_gpu_cqt.py's bound);
+    (2) the engine on the GPU's OWN feature map against the model oracle on the same map: logits within 1.5e-4, activations within 1e-4
+        (the x3 gate: isolates the model from the front-end's tolerance);
+    (3) end to end (audio -> rolls through run_on_batch, HCQT fused as model.frontend) against oracle front-end -> oracle model: rolls
+        identical except where the oracle's logit is inside the band the 1e-3 feature tolerance maps to; the band is measured here as the
+        largest end-to-end logit difference and bounded."""
+    from oracle import cqt_np as cq, model_ref
+    from amt_tools_amd.features import HCQT
+    g = load_golden('of1_hcqt_eval.npz')
+    model = _model(g, 'x3')
+    mod = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)
+    model.frontend = torch.nn.Sequential(mod.frontend())
+    audio = np.stack([synth_clip(70 + i) for i in range(4)])
+    assert audio.shape == (4, 319999)
+    x = torch.from_numpy(audio).cuda()
+    with torch.no_grad():
+        feats_gpu = mod.process_batch(x)                                            # (4, 6, 72, 625)
+        out = model.run_on_batch({tools.KEY_AUDIO: torch.from_numpy(audio)})
+        logits = model.engine_logits(feats_gpu)
+    feats_ref = np.stack([cq.hcqt_process_audio(a, sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12) for a in audio]).astype(np.float32)
+    assert feats_gpu.shape == feats_ref.shape == (4, 6, 72, 625)
+    err_fe = float(np.abs(feats_gpu.cpu().numpy() - feats_ref).max())
+    assert err_fe < 1e-3, err_fe
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith('frontend')}
+    old_impl, model_ref.LSTM_IMPL = model_ref.LSTM_IMPL, 'aten'
+    try:
+        with torch.no_grad():
+            ref_same = model_ref.run_on_batch(feats_gpu.cpu(), sd)                  # the model oracle on the GPU's own features
+            ref = model_ref.run_on_batch(torch.from_numpy(feats_ref), sd)           # the whole oracle path
+    finally:
+        model_ref.LSTM_IMPL = old_impl
+    err_model = err_act = err_e2e = 0.0
+    for key in ('onsets', 'multi_pitch'):
+        a, b = logits[key].cpu(), ref_same['logits'][key]
+        err_model = max(err_model, float((a - b).abs().max()))
+        err_act = max(err_act, float((torch.sigmoid(a) - torch.sigmoid(b)).abs().max()))
+        err_e2e = max(err_e2e, float((a - ref['logits'][key]).abs().max()))
+    assert err_model < 1.5e-4 and err_act < 1e-4, (err_model, err_act)
+    assert err_e2e < 5e-2, err_e2e
+    cells = diff = 0
+    for key in ('onsets', 'multi_pitch'):
+        got, want = out[key].cpu().numpy(), ref[key].numpy()
+        assert got.shape == want.shape == (4, 88, 625)
+        near = np.abs(ref['logits'][key].transpose(-1, -2).numpy()) <= err_e2e * 1.01 + 1e-6
+        assert np.all((got == want) | near), key
+        cells += got.size
+        diff += int((got != want).sum())
+        # and against the model oracle on the SAME features the rolls are the reference's outside the x3 band
+        same = ref_same[key].numpy()
+        near_s = np.abs(ref_same['logits'][key].transpose(-1, -2).numpy()) <= 1.5e-4
+        assert np.all((got == same) | near_s), key
+    assert diff / cells < 2e-3, diff / cells
+    with capsys.disabled():
+        print(f'\n[config 3 full size] 4 clips x 319999 samples: HCQT map max abs err {err_fe:.2e}; x3 engine vs oracle on the same map: logits '
+              f'{err_model:.2e}, activations {err_act:.2e}; end to end: logits {err_e2e:.2e}, {diff} of {cells} piano-roll cells differ')
+
+
 def test_run_offline_batched_pipeline_equals_per_clip_runs():
     """BASELINE config 5 driver: the three-stage pipeline (upload on a copy stream / kernels / host assembly of the previous
     batch) returns, per clip, exactly what one-clip-at-a-time `run_offline` + the host NoteTranscriber return; shards by rank

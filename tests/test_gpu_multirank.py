@@ -1,0 +1,98 @@
+"""The N > 1 GPU path executed for real on the ONE GPU of the test box: `python bench.py --gpus 2 --share-device
+--backend gloo` starts two fresh rank processes that both use cuda:0 -- every HIP kernel of the tree runs from two processes of a process
+group at once, the clip sharding (clip g belongs to rank g % world), the timing barrier / MAX / gather and, in train mode, the flat
+gradient all-reduce inside optimizer.step() are the code the 8-GPU run uses (only the transport differs: gloo through the host instead of
+RCCL over xGMI).  No kernel of this tree spins on another block's progress, so two processes time-slicing one device cannot deadlock each
+other; every child still runs under a wall-clock limit."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, limit_s):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'AMTX_DP_FORCE_COLLECTIVE')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    env['AMTX_BENCH_LAUNCH_TIMEOUT'] = str(limit_s - 20)
+    try:
+        p = subprocess.run([sys.executable, 'bench.py'] + args, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail(f'bench.py {" ".join(args)} did not finish within {limit_s} s\n{(e.stderr or b"")[-2000:]}')
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert p.returncode == 0 and lines, f'rc {p.returncode}\nstdout: {p.stdout[-2000:]}\nstderr: {p.stderr[-4000:]}'
+    return json.loads(lines[-1])
+
+
+COMMON = ['--cpu-seconds', '0', '--no-parity', '--no-train-probe', '--no-hcqt']
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('precision,clips', [('bf16', 8), ('bf16', 96), ('x3', 8)])
+def test_two_ranks_on_one_gpu_infer_rolls_equal_the_one_process_run(tmp_path, precision, clips):
+    """Two ranks x `clips` clips against one process x 2 `clips` clips: the piano rolls rank r computed for its i-th clip are, bit for bit, the
+    one-process run's rolls of clip 2 i + r (96 clips per rank: the fused conv stack and the eight-clip recurrence blocks; 8: the small-batch
+    kernels)."""
+    two, one = str(tmp_path / 'two'), str(tmp_path / 'one')
+    rec = _bench(['--gpus', '2', '--share-device', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--clips', str(clips), '--precision', precision,
+                  '--dump', two] + COMMON, 600)
+    cfg = rec['config']
+    assert rec['n_gpus'] == 2 and cfg['process_group'] == 'gloo' and cfg['rccl_ranks'] == 2
+    assert len(cfg['per_rank_frames_per_s']) == 2 and all(v > 0 for v in cfg['per_rank_frames_per_s'])
+    assert abs(rec['value'] - 2 * clips * 625 * 2 / (rec['ms_per_step'] * 2e-3)) < 1e-6 * rec['value']       # whole-job frames / MAX-over-ranks time
+    _bench(['--gpus', '1', '--steps', '1', '--warmup', '1', '--clips', str(2 * clips), '--precision', precision, '--dump', one] + COMMON, 400)
+    ref = np.load(os.path.join(one, 'rank0.npz'))
+    n_ref = len(ref['clip_ids'])
+    assert list(ref['clip_ids']) == list(range(n_ref))
+    checked = 0
+    for r in range(2):
+        got = np.load(os.path.join(two, f'rank{r}.npz'))
+        assert list(got['clip_ids']) == [2 * i + r for i in range(len(got['clip_ids']))]
+        for i, g in enumerate(got['clip_ids']):
+            if g >= n_ref:
+                continue
+            for key in ('onsets', 'multi_pitch'):
+                assert np.array_equal(got[key][i], ref[key][g]), (r, i, key)
+            checked += 1
+        assert got['onsets'].shape[1:] == (88, 625) and got['multi_pitch'].any()
+    assert checked >= min(2 * clips, 64)
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_train_identical_weights_and_the_union_batch_step(tmp_path, capsys):
+    """3 training steps (fwd + bwd + flat all-reduce + Adam, Dropout off) with 2 ranks x 8 clips: both ranks end with IDENTICAL weights and
+    running statistics (every tensor, every bit), and they are the weights of one process stepping on the 16-clip union batch up to the
+    BatchNorm policy (per-rank batch statistics, amt_tools_amd/dp.py) -- the bound tests/test_dp.py measures for this policy on the CPU:
+    median relative L2 distance per tensor < 5e-3, < 0.05 for every tensor with |w| > 0.1."""
+    two, one = str(tmp_path / 'two'), str(tmp_path / 'one')
+    args = ['--mode', 'train', '--steps', '2', '--warmup', '1', '--cpu-seconds', '0', '--dropout-off']
+    rec = _bench(args + ['--gpus', '2', '--share-device', '--backend', 'gloo', '--dump', two], 700)
+    cfg = rec['config']
+    assert rec['n_gpus'] == 2 and cfg['process_group'] == 'gloo' and cfg['global_batch'] == 16
+    assert cfg['collectives_per_step'] == 1.0 and cfg['allreduce_bytes'] >= 4854088 * 4
+    assert len(cfg['per_rank_ms_per_step']) == 2 and cfg['allreduce_ms_per_step'] > 0
+    a, b = np.load(os.path.join(two, 'rank0.npz')), np.load(os.path.join(two, 'rank1.npz'))
+    keys = [k for k in a.files if k != 'loss']
+    assert len(keys) > 60
+    for k in keys:
+        assert np.array_equal(a[k], b[k]), f'ranks disagree on {k}'
+    _bench(args + ['--gpus', '1', '--clips', '16', '--dump', one], 500)
+    ref = np.load(os.path.join(one, 'rank0.npz'))
+    rel, big = [], []
+    for k in keys:
+        if a[k].dtype.kind != 'f' or a[k].ndim == 0 or 'num_batches' in k:
+            continue
+        d = float(np.linalg.norm(a[k].astype(np.float64) - ref[k])) / max(1e-12, float(np.linalg.norm(ref[k].astype(np.float64))))
+        rel.append(d)
+        if np.abs(ref[k]).max() > 0.1:
+            big.append(d)
+    with capsys.disabled():
+        print(f'\n[2 ranks x 8 clips on one GPU vs 1 x 16, 3 steps] relative L2 per tensor: median {np.median(rel):.2e}, max over |w| > 0.1 {max(big):.2e}, '
+              f'max over all {max(rel):.2e}; losses {float(a["loss"]):.4f} (rank 0) / {float(b["loss"]):.4f} (rank 1) / {float(ref["loss"]):.4f} (one process)')
+    assert np.median(rel) < 5e-3 and max(big) < 0.05

@@ -38,8 +38,9 @@ def test_bilstm_autograd_matches_torch_lstm(B, T, I, H):
 
 
 def test_training_step_on_gpu_matches_reference_golden():
-    """The reference's training-mode losses and gradients (BatchNorm batch statistics, dropout off) with the model on the GPU:
-    ATen convolutions + the HIP BiLSTM forward/backward."""
+    """The reference's training-mode losses and gradients (BatchNorm batch statistics, dropout off) with the model on the GPU: every
+    layer on the HIP forward / backward kernels of amt_tools_amd/autograd.py (2 clips x 24 frames; the BASELINE-size step is
+    test_full_size_training_step_matches_the_oracle below)."""
     from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd.synth import synth_state_dict
     g = load_golden('of1_train.npz')
@@ -439,3 +440,97 @@ def test_multi_channel_first_conv_trains_on_the_hip_kernels(c_in, dim_in):
     w1r = dict(ref.named_parameters())['onset_head.0.layer1.0.weight'].grad
     assert float((w1 - w1r).norm() / w1r.norm()) < 3e-2
     assert np.median(rel) < 1e-3 and max(rel) < 3e-2, (np.median(rel), max(rel))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('of2', [False, True], ids=['OnsetsFrames_mc2', 'OnsetsFrames2_mc3'])
+def test_full_size_training_step_matches_the_oracle(of2, capsys):
+    """BASELINE config 4 at its real size: ONE training step of 8 clips x 625 frames -- audio -> HIP log-mel front-end
+    (model.frontend) -> HIP forward / backward kernels (625-step BPTT in split-bf16) -> losses, EVERY parameter gradient (all tensors, the
+    recurrent matrices `weight_hh_l0*` included), then one Adam step (lr 6e-4) -- against the CPU oracle: fp64 numpy front-end + the fp32
+    torch restatement `oracle/model_ref.run_on_batch(training=True)` (BatchNorm batch statistics, dropout off; LSTM_IMPL='aten', pinned to the
+    reference's goldens in tests/test_oracle_model.py).  Follows amt_tools/train.py:126-141 and models/common.py:541-584.
+    Bounds: losses 2e-4 relative; per tensor max|g - g_ref| <= 5e-3 max|g_ref|; Conv2d biases in front of a batch-statistics BatchNorm have
+    gradient exactly zero (compared as noise on the weight gradient's scale); after the Adam step |w - w_ref| <= 2 lr everywhere (Adam's first
+    step is lr sign(g)) and <= 1e-6 + 1e-3 lr wherever the reference gradient is clear of the gradient tolerance."""
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
+    from amt_tools_amd.synth import synth_clip, synth_labels, synth_state_dict
+    from oracle import frontend_np as fe, model_ref
+    B, mc, lr = 8, (3 if of2 else 2), 6e-4
+    sd_np = synth_state_dict(11, dim_in=229, in_channels=1, model_complexity=mc, offsets=of2)
+    audio = np.stack([synth_clip(40 + i) for i in range(B)])
+    lab = [synth_labels(40 + i) for i in range(B)]
+    labels = {'multi_pitch': torch.from_numpy(np.stack([l[0] for l in lab])), 'onsets': torch.from_numpy(np.stack([l[1] for l in lab]))}
+    if of2:
+        labels['offsets'] = torch.from_numpy(np.stack([l[1][:, ::-1].copy() for l in lab]))
+
+    # ---- the HIP path, through the product API (train.py:122-141)
+    cls = OnsetsFrames2 if of2 else OnsetsFrames
+    model = cls(229, tools.PianoProfile(), 1, mc, device='cuda:0')
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    model.frontend = torch.nn.Sequential(MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048, device='cuda:0').frontend())
+    model.change_device()
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    model.train()
+    from amt_tools_amd import autograd as ag
+    ag.reset_fallbacks()
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    batch = {tools.KEY_AUDIO: torch.from_numpy(audio), tools.KEY_MULTIPITCH: labels['multi_pitch'], tools.KEY_ONSETS: labels['onsets']}
+    if of2:
+        batch[tools.KEY_OFFSETS] = labels['offsets']
+    opt.zero_grad()
+    loss = model.run_on_batch(batch)[tools.KEY_LOSS]
+    loss[tools.KEY_LOSS_TOTAL].backward()
+    assert not ag.fallbacks(), ag.fallbacks()                  # every layer of the step ran on the HIP kernels
+    got_loss = {k: float(v.detach()) for k, v in loss.items()}
+    got_grad = {k: p.grad.detach().cpu().contiguous().numpy().copy() for k, p in model.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    got_w = {k: p.detach().cpu().contiguous().numpy().copy() for k, p in model.named_parameters()}
+
+    # ---- the oracle
+    old_impl, model_ref.LSTM_IMPL = model_ref.LSTM_IMPL, 'aten'
+    try:
+        feats = np.stack([fe.melspec_process_audio(a, 22050, 512, 229, 2048, dtype=np.float32) for a in audio]).astype(np.float32)
+        sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd_np.items()}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running_' not in k}
+        ref = model_ref.run_on_batch(torch.from_numpy(feats), sd, labels, training=True, detach_heads=of2)
+        ref['loss']['loss_total'].backward()
+    finally:
+        model_ref.LSTM_IMPL = old_impl
+    assert set(leaves) == set(got_grad), set(leaves) ^ set(got_grad)
+    for k, v in ref['loss'].items():
+        assert abs(got_loss[k] - float(v.detach())) <= 2e-4 * abs(float(v.detach())), (k, got_loss[k], float(v.detach()))
+    ref_grad = {k: v.grad.numpy().copy() for k, v in leaves.items()}
+    ropt = torch.optim.Adam(list(leaves.values()), lr=lr)
+    ropt.step()
+    worst, worst_k, n_tensors, flips, entries = 0.0, None, 0, 0, 0
+    for k, g_ref in ref_grad.items():
+        g = got_grad[k]
+        assert g.shape == g_ref.shape, k
+        if '.0.layer' in k and k.endswith('.0.bias'):          # exactly-zero gradient (bias in front of batch-statistics BatchNorm)
+            scale = np.abs(ref_grad[k[:-4] + 'weight']).max()
+            assert np.abs(g).max() <= 1e-2 * scale and np.abs(g_ref).max() <= 1e-2 * scale, k
+            continue
+        scale = max(1e-12, np.abs(g_ref).max())
+        err = np.abs(g - g_ref).max() / scale
+        n_tensors += 1
+        if err > worst:
+            worst, worst_k = err, k
+        assert err <= 5e-3, (k, err)
+        # one Adam step: lr sign(g) wherever |g| >> eps
+        w, w_ref = got_w[k], leaves[k].detach().numpy()
+        dw = np.abs(w - w_ref)
+        assert dw.max() <= 2 * lr * 1.001 + 1e-7, (k, dw.max())
+        clear = np.abs(g_ref) > 2 * 5e-3 * scale
+        if clear.any():
+            assert dw[clear].max() <= 1e-6 + 1e-3 * lr, (k, dw[clear].max())
+        flips += int((dw > 0.5 * lr).sum())
+        entries += dw.size
+    with capsys.disabled():
+        print(f'\n[config 4 full size, {"OnsetsFrames2 mc=3" if of2 else "OnsetsFrames mc=2"}] 8 clips x 625 frames: losses '
+              f'{ {k: round(v, 4) for k, v in got_loss.items()} }; {n_tensors} gradient tensors, worst relative error {worst:.2e} ({worst_k}); '
+              f'after one Adam step {flips} of {entries} weights moved the other way (|g_ref| inside the gradient tolerance)')
