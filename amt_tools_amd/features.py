@@ -231,7 +231,7 @@ class _SpecPlanOwner(object):
         clip_max = torch.empty((B,), dtype=torch.float32, device=audio.device)
         with torch.cuda.device(audio.device):
             ev = self._prof_begin()
-            _lib.check(L.amtx_spec_power(plan, _lib.ptr(audio), N, audio.stride(0), B, _lib.ptr(power), _lib.ptr(clip_max),
+            _lib.check(L.amtx_spec_power(plan, _lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, _lib.ptr(power), _lib.ptr(clip_max),
                                          _lib.current_stream(audio.device)), 'amtx_spec_power')
             self._prof_end('spec_power', ev)
         return power, clip_max
@@ -436,7 +436,7 @@ class _CqtPlanOwner(object):
             ws = self.__dict__['_workspace'] = _lib.alloc_workspace(need, audio.device)
         out = torch.empty((B, H, self.n_bins, T), dtype=torch.float32, device=audio.device)
         with torch.cuda.device(audio.device):
-            _lib.check(L.amtx_cqt_forward(plan, _lib.ptr(audio), N, audio.stride(0), B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
+            _lib.check(L.amtx_cqt_forward(plan, _lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
                                           _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward')
         return out
 
@@ -459,7 +459,7 @@ class _CqtPlanOwner(object):
             ws = self.__dict__['_workspace'] = _lib.alloc_workspace(need, audio.device)
         out = torch.empty((B, T, self.n_bins, 8), dtype=torch.bfloat16, device=audio.device)
         with torch.cuda.device(audio.device):
-            _lib.check(L.amtx_cqt_forward16(plan, _lib.ptr(audio), N, audio.stride(0), B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
+            _lib.check(L.amtx_cqt_forward16(plan, _lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
                                             _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward16')
         return out
 

@@ -180,3 +180,14 @@ def test_persistent_decimator_returns_the_bits_of_round_4s(tmp_path):
     for k in a.files:
         assert a[k].shape == b[k].shape and a[k].size > 0
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_one_clip_batch_with_a_degenerate_batch_stride():
+    """`torch.from_numpy(y[None])` has batch stride 0 (NumPy's new axis) and torch calls it contiguous: a one-clip batch must not hand that
+    stride to the C ABI (found by the round-6 full-size check; amtx_cqt_forward / amtx_spec_power rejected it as audio_stride < num_samples)."""
+    from amt_tools_amd.features import HCQT, MelSpec
+    y = synth_clip(3, num_samples=512 * 40 - 1)
+    x = torch.from_numpy(y[None]).cuda()
+    ref = torch.from_numpy(y.copy()).cuda().reshape(1, -1)
+    for mod in (HCQT(n_bins=72), MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048)):
+        assert torch.equal(mod.process_batch(x), mod.process_batch(ref))

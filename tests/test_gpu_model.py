@@ -768,7 +768,11 @@ def test_config3_hcqt_frontend_fused_into_the_model():
 def test_config3_at_full_clip_length_matches_the_oracle(capsys):
     """BASELINE config 3 at its real size: 4 clips x 319 999 samples (625 frames) -- audio -> HIP HCQT (6 harmonics x
     72 bins, amt_tools/features/hvqt.py:107-133) -> OnsetsFrames(dim_in 72, 6 channels, mc 2) in the x3 precision -> piano rolls.
-    (1) the HCQT map against oracle/cqt_np.hcqt_process_audio: 1e-3 absolute in the scaled [0,1] domain (tests/test_gpu_cqt.py's bound);
+    (1) the HCQT map against oracle/cqt_np.hcqt_process_audio.  LINEAR magnitudes within 6e-6 of each harmonic's map maximum (measured
+        1.4e-6 .. 3.9e-6: the two-plane bf16 products of the basis kernel carry 2^-17 per term) -- a fixed absolute error, which the dB
+        function divides by the level: scaled features within 5e-4 for cells above -60 dB (>= 0.25; measured 2e-4) and within 4e-3
+        between the -80 dB clamp and -60 dB (measured 2.6e-3 at -76 dB, where 3e-6 of the maximum IS 3 % of the value).  The 1e-3 of
+        tests/test_gpu_cqt.py holds on its 30 000-sample clips; at 319 999 samples more cells sit just above the floor;
     (2) the engine on the GPU's OWN feature map against the model oracle on the same map: logits within 1.5e-4, activations within 1e-4
         (the x3 gate: isolates the model from the front-end's tolerance);
     (3) end to end (audio -> rolls through run_on_batch, HCQT fused as model.frontend) against oracle front-end -> oracle model: rolls
@@ -789,8 +793,18 @@ def test_config3_at_full_clip_length_matches_the_oracle(capsys):
         logits = model.engine_logits(feats_gpu)
     feats_ref = np.stack([cq.hcqt_process_audio(a, sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12) for a in audio]).astype(np.float32)
     assert feats_gpu.shape == feats_ref.shape == (4, 6, 72, 625)
-    err_fe = float(np.abs(feats_gpu.cpu().numpy() - feats_ref).max())
-    assert err_fe < 1e-3, err_fe
+    err_map = np.abs(feats_gpu.cpu().numpy() - feats_ref)
+    err_fe, err_fe_hi = float(err_map.max()), float(err_map[feats_ref >= 0.25].max())
+    assert err_fe_hi < 5e-4 and err_fe < 4e-3, (err_fe_hi, err_fe)
+    lin = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, decibels=False)
+    with torch.no_grad():
+        lin_gpu = lin.process_batch(x[:2]).cpu().numpy()
+    err_lin = 0.0
+    for i in range(2):
+        lin_ref = cq.hcqt_process_audio(audio[i], sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12, decibels=False)
+        for h in range(6):
+            err_lin = max(err_lin, float(np.abs(lin_gpu[i, h] - lin_ref[h]).max() / lin_ref[h].max()))
+    assert err_lin < 6e-6, err_lin
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.startswith('frontend')}
     old_impl, model_ref.LSTM_IMPL = model_ref.LSTM_IMPL, 'aten'
     try:
@@ -806,7 +820,7 @@ def test_config3_at_full_clip_length_matches_the_oracle(capsys):
         err_act = max(err_act, float((torch.sigmoid(a) - torch.sigmoid(b)).abs().max()))
         err_e2e = max(err_e2e, float((a - ref['logits'][key]).abs().max()))
     assert err_model < 1.5e-4 and err_act < 1e-4, (err_model, err_act)
-    assert err_e2e < 5e-2, err_e2e
+    assert err_e2e < 3e-3, err_e2e                             # measured 6.1e-4
     cells = diff = 0
     for key in ('onsets', 'multi_pitch'):
         got, want = out[key].cpu().numpy(), ref[key].numpy()
@@ -821,7 +835,8 @@ def test_config3_at_full_clip_length_matches_the_oracle(capsys):
         assert np.all((got == same) | near_s), key
     assert diff / cells < 2e-3, diff / cells
     with capsys.disabled():
-        print(f'\n[config 3 full size] 4 clips x 319999 samples: HCQT map max abs err {err_fe:.2e}; x3 engine vs oracle on the same map: logits '
+        print(f'\n[config 3 full size] 4 clips x 319999 samples: HCQT linear magnitudes within {err_lin:.2e} of the map maximum; scaled map max abs err {err_fe_hi:.2e} above -60 dB, '
+              f'{err_fe:.2e} down to the -80 dB clamp; x3 engine vs oracle on the same map: logits '
               f'{err_model:.2e}, activations {err_act:.2e}; end to end: logits {err_e2e:.2e}, {diff} of {cells} piano-roll cells differ')
 
 
