@@ -20,7 +20,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <map>
-#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -85,12 +84,6 @@ struct amtx_of_model {
     // optional per-stage timing with HIP events recorded on the launch stream (bench.py roofline)
     mutable bool prof = false;
     mutable std::vector<std::vector<hipEvent_t>> prof_events;
-    // round 6: the folded pitch head (a pure HBM stream: 7.3 kB of a3 per frame, 0.17 of the matrix roof) runs on a SIDE stream beside the onset
-    // head's recurrence (a latency chain that leaves HBM and most issue slots idle); both fit a CU together (148 + 9 KB of LDS, 216 of 512 registers
-    // per SIMD lane).  One side stream + fork / join events per caller stream, created on first use, owned by the model.
-    struct Side { hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
-    mutable std::map<hipStream_t, Side> sides;
-    mutable std::mutex sides_mu;
 };
 
 enum { ST_CONV1 = 0, ST_CONV2, ST_CONV3, ST_FC1, ST_REC_XPROJ, ST_REC_LSTM, ST_REC_HEAD, ST_PITCH_HEAD, ST_ADJ_XPROJ, ST_ADJ_LSTM,
@@ -271,11 +264,6 @@ extern "C" int amtx_of_model_destroy(amtx_of_model* m) {
                       &m->rec_ih.w, &m->rec_ih.b, &m->rec_hh, &m->rec_out.w, &m->rec_out.b, &m->pitch_out.w, &m->pitch_out.b,
                       &m->adj_ih.w, &m->adj_ih.b, &m->adj_hh, &m->adj_out.w, &m->adj_out.b, &m->pack_scratch};
     for (DevBuf* b : bufs) b->release();
-    for (auto& kv : m->sides) {
-        if (kv.second.stream) { (void)hipStreamSynchronize(kv.second.stream); (void)hipStreamDestroy(kv.second.stream); }
-        if (kv.second.fork) (void)hipEventDestroy(kv.second.fork);
-        if (kv.second.join) (void)hipEventDestroy(kv.second.join);
-    }
     delete m;
     return AMTX_OK;
 }
@@ -765,22 +753,8 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, const voi
     l.xproj = w.xp; l.x_type = at; l.whh = (const bf16_t*)m->rec_hh.p; l.planes = pl; l.out = w.l1; l.out_type = at;
     l.B = B; l.T = T; l.groups = m->n_rec; l.x_gs = BT * m->xw; l.w_gs = (int64_t)amtx_bilstm_wfrag_elems_h(m->hid, pl); l.out_gs = BT * m->dim_lm;
     l.hidden = m->hid;
-    // Fork: the pitch head only needs the conv map, the recurrent heads' chain (x-projection -> recurrence -> LogisticBank) does not need the
-    // pitch head before the refinement stage.  From here the pitch head's GEMM is enqueued on the side stream and overlaps the recurrence.
-    // AMTX_OF_OVERLAP=0 keeps everything on the caller's stream (the A/B switch; same kernels, same bits either way).
-    static const bool overlap_env = !(getenv("AMTX_OF_OVERLAP") && atoi(getenv("AMTX_OF_OVERLAP")) == 0);
-    const bool overlap = overlap_env && BT >= 4096;          // small batches: nothing to hide, two extra event operations per call
-    amtx_of_model::Side side;
-    if (overlap) {
-        std::lock_guard<std::mutex> lk(m->sides_mu);
-        amtx_of_model::Side& sd = m->sides[s];
-        if (!sd.stream) {
-            AMTX_CHECK_HIP(hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking));
-            AMTX_CHECK_HIP(hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming));
-            AMTX_CHECK_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
-        }
-        side = sd;
-    }
+    if ((rc = launch_bilstm(l, s)) != AMTX_OK) return rc;
+    mark();
     // LogisticBank of each recurrent head -> joint[:, r*n_out : (r+1)*n_out]; group stride of C = n_out columns
     g = gemm_args(w.l1, m->dim_lm, at, m->rec_out, pl, w.joint, m->dim_aj, AMTX_T_F32, BT, m->n_rec, BT * m->dim_lm, m->n_out);
     // piano rolls (LogisticBank.finalize_output with threshold 0.5) come out of the LogisticBank GEMMs' epilogues where that kernel has
@@ -802,22 +776,10 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, const voi
         gp.copy16 = (bf16_t*)w.joint16; gp.copy16_ld = kp; gp.copy16_col0 = m->n_rec * m->n_out; gp.copy16_gs = 0; gp.copy16_pad = kp - m->dim_aj;
         if (roll_on && !logits_onsets && !logits_pitch_head && !m->has_offsets) { g.C = nullptr; gp.C = nullptr; }
     }
-    hipEvent_t pe0 = nullptr, pe1 = nullptr;
-    if (overlap) {
-        // side stream: pitch head (fc1 . LogisticBank folded), straight from its conv3 map -> last n_out columns of joint (and of joint16)
-        AMTX_CHECK_HIP(hipEventRecord(side.fork, s));
-        AMTX_CHECK_HIP(hipStreamWaitEvent(side.stream, side.fork, 0));
-        if (evs && hipEventCreate(&pe0) == hipSuccess) (void)hipEventRecord(pe0, side.stream);
-        if ((rc = launch_gemm(gp, side.stream)) != AMTX_OK) return rc;
-        if (evs && hipEventCreate(&pe1) == hipSuccess) (void)hipEventRecord(pe1, side.stream);
-        AMTX_CHECK_HIP(hipEventRecord(side.join, side.stream));
-    }
-    if ((rc = launch_bilstm(l, s)) != AMTX_OK) return rc;
-    mark();
     if ((rc = launch_gemm(g, s)) != AMTX_OK) return rc;
     mark();
-    if (overlap) AMTX_CHECK_HIP(hipStreamWaitEvent(s, side.join, 0));        // join: the refinement stage reads both heads' logits
-    else if ((rc = launch_gemm(gp, s)) != AMTX_OK) return rc;
+    // pitch head: (fc1 . LogisticBank) folded, straight from its conv3 map -> last n_out columns of joint
+    if ((rc = launch_gemm(gp, s)) != AMTX_OK) return rc;
     mark();
 
     // adjoin
@@ -853,7 +815,6 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, const voi
     if (out_multi_pitch && !roll_mp && (rc = amtx_launch_pianoroll((const float*)w.mp, m->n_out, 0, B, T, m->n_out, 0.5f, out_multi_pitch, s)) != AMTX_OK) return rc;
 
     mark();
-    if (evs && pe0 && pe1) { evs->push_back(pe0); evs->push_back(pe1); }     // amtx_of_profile_read: the pitch head's own time on the side stream
     // optional raw logits, contiguous (B, T, n_out)
     const size_t row = (size_t)m->n_out * sizeof(float);
     if (logits_onsets)
@@ -945,21 +906,12 @@ extern "C" int amtx_of_profile_read(amtx_of_model* m, double* stage_ms, int* num
     for (int i = 0; i < ST_COUNT; ++i) stage_ms[i] = 0.0;
     *num_forwards = 0;
     for (auto& v : m->prof_events) {
-        if ((int)v.size() != ST_COUNT + 1 && (int)v.size() != ST_COUNT + 3) continue;
-        AMTX_CHECK_HIP(hipEventSynchronize(v[ST_COUNT]));
+        if ((int)v.size() != ST_COUNT + 1) continue;
+        AMTX_CHECK_HIP(hipEventSynchronize(v.back()));
         for (int i = 0; i < ST_COUNT; ++i) {
             float ms = 0.f;
             AMTX_CHECK_HIP(hipEventElapsedTime(&ms, v[i], v[i + 1]));
             stage_ms[i] += ms;
-        }
-        if ((int)v.size() == ST_COUNT + 3) {
-            // overlapped forward: the pitch head ran on the side stream beside the recurrence.  Its stage entry is its OWN duration there (the
-            // caller-stream interval only holds the join); the stages it overlapped keep their caller-stream intervals, so the table's sum
-            // exceeds the step by the overlap won
-            float ms = 0.f;
-            AMTX_CHECK_HIP(hipEventSynchronize(v[ST_COUNT + 2]));
-            AMTX_CHECK_HIP(hipEventElapsedTime(&ms, v[ST_COUNT + 1], v[ST_COUNT + 2]));
-            stage_ms[ST_PITCH_HEAD] = stage_ms[ST_PITCH_HEAD] + ms;
         }
         ++*num_forwards;
     }

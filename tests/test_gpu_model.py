@@ -516,31 +516,6 @@ def test_engine_is_deterministic_run_to_run(mc, precision):
                 assert torch.equal(first[k], again[k]), k
 
 
-@pytest.mark.parametrize('precision', ['bf16', 'x3'])
-def test_overlapped_engine_is_deterministic_over_many_forwards(precision):
-    """The shape class where the pitch head runs on the engine's side stream (>= 4096 clip-frames): 12 forwards, stale workspace, interleaved
-    with a second model on the same stream -- identical bits every time (a missing fork / join dependency would show as a stale or torn joint row)."""
-    from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
-    models = []
-    for cls, seed in ((OnsetsFrames2, 5), (OnsetsFrames, 6)):
-        sd = synth_state_dict(seed, dim_in=229, in_channels=1, model_complexity=2, offsets=cls is OnsetsFrames2)
-        m = cls(229, tools.PianoProfile(), 1, 2, device='cuda:0', precision=precision)
-        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-        m.change_device()
-        m.eval()
-        models.append(m)
-    feats = torch.from_numpy(np.random.default_rng(4).random((12, 1, 229, 625)).astype(np.float32)).cuda()
-    with torch.no_grad():
-        first = [{k: v.clone() for k, v in m.engine_logits(feats).items()} for m in models]
-        for it in range(12):
-            for m, f in zip(models, first):
-                if it % 3 == 0:
-                    m._get_engine(feats.device).workspace.fill_(0xFF)
-                again = m.engine_logits(feats)
-                for k in f:
-                    assert torch.equal(f[k], again[k]), (it, k)
-
-
 def test_unbuilt_model_complexity_is_rejected_loudly_by_the_engine():
     from amt_tools_amd.models import OnsetsFrames
     from amt_tools_amd._lib import AmtxError

@@ -23,4 +23,4 @@ h = hashlib.sha256()
 for k in sorted(out):
     h.update(out[k].float().cpu().numpy().tobytes())
 print(json.dumps({'mc': mc, 'precision': prec, 'sha256': h.hexdigest(), 'finite': bool(all(torch.isfinite(v).all() for v in out.values())),
-                  'switches': {k: os.environ.get(k) for k in ('AMTX_CONVG_NO_WDMA', 'AMTX_CONVG_NO_CSPLIT', 'AMTX_OF_OVERLAP')}}))
+                  'switches': {k: os.environ.get(k) for k in ('AMTX_CONVG_NO_WDMA', 'AMTX_CONVG_NO_CSPLIT')}}))
