@@ -27,7 +27,7 @@
 // D = W . X^T exactly as in conv.hip (a lane ends up with consecutive channels of one position: MaxPool over the frequency pair,
 // ReLU and the channels-last store are lane-local); the accumulation order of every output equals conv.hip's, so the result is
 // BIT-IDENTICAL to the two-kernel path (tests/test_gpu_model.py::test_fused_conv_stack_is_bit_identical_to_the_two_kernel_path).
-// DESIGN.md ("Measured (round 3)") has the history of the structure, the ablation numbers and what was tried and rejected.
+// HISTORY.md ("Measured (round 3)") has the history of the structure, the ablation numbers and what was tried and rejected.
 //
 // LDS (137 KB of the CU's 160): a1 ring 4 chunk planes x 66 x 19 x 16 B, a2 ring 4 x 64 x 11 x 16 B (chunk-major: 16-byte chunk c of
 // position (row, slot) at c * PLANE + (row * pitch + slot) * 16; both row pitches are odd, so the 16 rows of a ds_read_b128 lane group

@@ -580,7 +580,7 @@ class OnsetsFrames(TranscriptionModel):
             # every op's backward on the stream of its forward, so the backward passes overlap the same way (11.0 -> 9.85 ms per step).
             # Tensors that cross streams are handed to the allocator with record_stream.  History: round 1 saw intermittent hangs with two
             # streams while the convolutions / Linear layers still ran on MIOpen / hipBLASLt; with the all-HIP step tools/two_stream_repro.py
-            # and tests/test_gpu_rccl.py run thousands of steps clean.  AMTX_TRAIN_OVERLAP=0 keeps one stream.
+            # and tests/test_gpu_rccl.py run thousands of steps clean (HISTORY.md "Measured (round 4)").  AMTX_TRAIN_OVERLAP=0 keeps one stream.
             main = torch.cuda.current_stream(feats.device)
             side = self.__dict__.get('_side_stream')
             if side is None or side.device != feats.device:

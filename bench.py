@@ -1002,7 +1002,7 @@ def run_train(args, rank, world, device):
         'roofline': {'kernel': 'whole step', 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_MFMA_BF16_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': ach / PEAK_MFMA_BF16_TFLOPS, 'traffic': None,
                      'note': f'{flops / 1e6:.1f} MFLOP per clip-frame (SURVEY 8d: ~3x forward) x frames / step time; at 8 clips per GPU the step is '
-                             f'latency-bound (three 625-step recurrences each way), see DESIGN.md'},
+                             f'latency-bound (4 x 625 dependent recurrence steps), see DESIGN.md 5.4'},
     }
     if world == 1 and args.cpu_seconds > 0 and not args.of2:
         res['cpu_baseline'] = cpu_train_baseline(args.cpu_seconds)

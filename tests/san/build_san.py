@@ -37,7 +37,7 @@ def build(verbose=False):
     def cc(job):
         src, f16 = job
         obj = os.path.join(OUT, os.path.splitext(src)[0] + ('_f16.o' if f16 else '.o'))
-        cmd = [HIPCC, '--cuda-host-only', '-std=c++17', '-fPIC', '-Wno-unused-function'] + SAN + (['-DAMTX_F16'] if f16 else []) + \
+        cmd = [HIPCC, '--cuda-host-only', '-std=c++17', '-fPIC', '-Wno-unused-function', '-DAMTX_WITH_F16'] + SAN + (['-DAMTX_F16'] if f16 else []) + \
               ['-x', 'hip', '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)

@@ -186,7 +186,7 @@ def test_onsetsframes2_training_step_hip_vs_stock_path(mc):
             continue
         # ReLU / max-pool gradients are discontinuous: an element whose pre-activation sits within an ulp of zero moves one channel's
         # gradients by a per cent or two between two correct fp32 evaluations (seen on either path against a float64 CPU run,
-        # depending on the input: tools notes in DESIGN.md).  Every tensor within 3e-2 in relative L2, the typical one within 1e-3.
+        # depending on the input: notes in HISTORY.md).  Every tensor within 3e-2 in relative L2, the typical one within 1e-3.
         rels.append((g_hip[n] - g_ref[n]).norm().item() / max(1e-9, g_ref[n].norm().item()))
         assert rels[-1] < 3e-2, n
     assert float(np.median(rels)) < 1e-3
