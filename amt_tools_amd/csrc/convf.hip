@@ -121,61 +121,29 @@ struct ConvFArgs {
 
 // position of one of the block's streams (feature loads, layer1, layer2, layer3) in its sequence of steps: all scalar
 struct Pos { int kk, j, b, r0; };
-// VIRT = false: a strip is R3 output frames of ONE clip (ntt strips per clip; the last one of a clip is mostly padding: 625 frames = 10 full
-// strips + one of 25 frames that costs a whole strip's steps).
-// VIRT = true (round 6): the batch is ONE stream of B (T + 1) "virtual rows" -- clip b's frame t is row b (T + 1) + t, row b (T + 1) + T is a
-// padding row that layer1 and layer2 write as zeros -- and strips are consecutive runs of R3 virtual rows, whatever clip(s) they fall into:
-// a 3 x 3 window over the virtual rows sees exactly the per-clip zero padding of the reference (a clip's first / last frame has the
-// neighbouring clip's padding row, or the zeroed rows outside the stream, next to it), every output keeps its accumulation order, and
-// 1024 clips x 625 frames are 10 684 strips instead of 11 264 (-5.1 %).  (b, r0) = clip and frame of the strip's first output row; rows of a
-// strip touch at most two clips (T >= 67: the launcher's condition for this mode).  `ntt` carries T + 1 in this mode.
-template <int R3_, bool VIRT>
+template <int R3_>
 __device__ __forceinline__ Pos pos_first_t(int first, int ntt) {
     Pos p;
-    p.kk = 0; p.j = 0;
-    if constexpr (VIRT) {
-        const unsigned v0 = (unsigned)first * (unsigned)R3_;
-        p.b = (int)(v0 / (unsigned)ntt); p.r0 = (int)(v0 - (unsigned)p.b * (unsigned)ntt);
-    } else {
-        p.b = first / ntt; p.r0 = (first - p.b * ntt) * R3_;
-    }
+    p.kk = 0; p.j = 0; p.b = first / ntt; p.r0 = (first - p.b * ntt) * R3_;
     return p;
 }
-template <int R3_, bool VIRT>
+template <int R3_>
 __device__ __forceinline__ void pos_next_t(Pos& p, int nstep, int ntt) {
     ++p.kk;
     if (++p.j == nstep) {
         p.j = 0;
         p.r0 += R3_;
-        if constexpr (VIRT) {
-            if (p.r0 >= ntt) { p.r0 -= ntt; ++p.b; }
-        } else {
-            if (p.r0 >= ntt * R3_) { p.r0 = 0; ++p.b; }
-        }
-    }
-}
-// clip, frame and validity of the row `d` rows behind a strip's first output row (d = -3 .. 65; per lane or scalar)
-template <bool VIRT>
-__device__ __forceinline__ void row_map(const Pos& p, int d, int T, int B, int& bb, int& tt, bool& ok) {
-    tt = p.r0 + d; bb = p.b;
-    if constexpr (VIRT) {
-        const int T1 = T + 1;
-        if (tt < 0) { tt += T1; bb -= 1; } else if (tt >= T1) { tt -= T1; bb += 1; }
-        ok = (unsigned)bb < (unsigned)B && tt < T;          // tt == T: the padding row between two clips
-    } else {
-        ok = (unsigned)tt < (unsigned)T;
+        if (p.r0 >= ntt * R3_) { p.r0 = 0; ++p.b; }
     }
 }
 
-template <bool HALO, bool VIRT>
+template <bool HALO>
 __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, int ntt, int nstrips, int per_block, int dbg) {
     constexpr int R3 = r3_of(HALO), R1 = r1_of(HALO), RF = R1 + 2;
     constexpr int FITEMS = RF * SLAB_LOAD;                     // feature values per step (660 / 680)
     constexpr int NUNITS = RT * XB + (HALO ? 1 : 0);           // layer1 units per step: 16 rows x 4 columns each (+ one unit for rows 64, 65)
-    auto pos_first = [](int first_, int ntt_) { return pos_first_t<R3, VIRT>(first_, ntt_); };
-    auto pos_next = [](Pos& p_, int nstep_, int ntt_) { pos_next_t<R3, VIRT>(p_, nstep_, ntt_); };
-    // rows of the stream behind the last real frame (VIRT: B (T + 1) - 1 virtual rows; the final padding row is never computed)
-    const int VR = VIRT ? a.B * (a.T + 1) - 1 : 0;
+    auto pos_first = [](int first_, int ntt_) { return pos_first_t<R3>(first_, ntt_); };
+    auto pos_next = [](Pos& p_, int nstep_, int ntt_) { pos_next_t<R3>(p_, nstep_, ntt_); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,19 +179,15 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         const uint4 bh = make_uint4(b0.x, b0.y, b1.x, b1.y);                                                \
         /* straight-line epilogue: the zero padding of the map is a mask, the ring slot a per-lane value, and lanes of the last unit */ \
         /* that have no position (column block >= 2) store to a scratch line: no branch, no exec mask */    \
-        int rb1_, rt1_; bool rok1_;                                                                         \
-        row_map<VIRT>((P), row1 - 2, a.T, a.B, rb1_, rt1_, rok1_);                                          \
-        const uint32_t rowmask = (rok1_ && xb < XB) ? 0xffffffffu : 0u;                                     \
+        const uint32_t rowmask = ((unsigned)((P).r0 - 2 + row1) < (unsigned)a.T && xb < XB) ? 0xffffffffu : 0u; \
         const int c1l = CS * (P).j - 1 + 4 * xb;                /* first a1 column of this lane's four positions */ \
         const int slotl = base1 + 4 * xb;                                                                   \
         const int dst_row = A1_OFF + g1 * PLANE1 + row1 * ROWB1;                                            \
         const int dst_scratch = SLAB_OFF + 2 * SLAB_BYTES + 128 + (lane_o & 63) * 16;                       \
         /* scalar: no position of the unit is padding -> the lean epilogue (a unit is ~50 instead of ~140 vector instructions, and */ \
         /* a wave's instruction stream, not the matrix pipe, is what a step of this kernel waits for) */    \
-        const int cu_ = CS * (P).j - 1 + 4 * (u & 1);                                                       \
-        int bu_, tu_; bool oku_;                                /* scalar: the unit's first row */          \
-        row_map<VIRT>((P), 16 * (u >> 1) - 2, a.T, a.B, bu_, tu_, oku_);                                    \
-        const bool lean = mainu && oku_ && tu_ + 15 < a.T && cu_ >= 0 && cu_ + 3 < a.F;                     \
+        const int tu_ = (P).r0 - 2 + 16 * (u >> 1), cu_ = CS * (P).j - 1 + 4 * (u & 1);                     \
+        const bool lean = mainu && tu_ >= 0 && tu_ + 15 < a.T && cu_ >= 0 && cu_ + 3 < a.F;                 \
         const int slots_ = base1 + 4 * (u & 1);                 /* scalar ring slot of a main unit's first column */
 #define CONVF_L1_STORE_LEAN(Q, ACC0, ACC1)                                                                  \
         do {                                                                                                \
@@ -304,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         // branch: three guarded loads were three memory round trips in the producer's critical path) and so are the slab stores (a thread
         // without an n-th cell writes to a scratch slot); the validity bit is applied when the value is written to the slab two steps later.
         float fpre[FPRE];
-        float fown = 0.f, fref = 0.f, fown2 = 0.f, fref2 = 0.f;    // VIRT: a strip's rows may belong to two clips (the second pair)
-        unsigned fvalid = 0;                                       // bit n: fpre[n] is a real feature value (not padding); bit 8 + n: of the strip's second clip
+        float fown = 0.f, fref = 0.f;
+        unsigned fvalid = 0;                                       // bit n: fpre[n] is a real feature value (not padding)
         int fcell[FPRE], foff[FPRE], loff[FPRE];                   // fi << 8 | fc (-1 << 8: no cell), element offset inside the step's window, slab byte offset
 #pragma unroll
         for (int n = 0; n < FPRE; ++n) {
@@ -319,58 +283,30 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
         // feature values of the step at P -> registers (written to a slab two steps later)
 #define CONVF_ISSUE_LOADS(P)                                                                                \
         do {                                                                                                \
+            const float* fb = a.feats + (int64_t)(P).b * a.f_stride_b;                                      \
             const int tb = (P).r0 - 3, cb = CS * (P).j - 2;                                                 \
             const int wb = tb * fst + cb * fsf;                 /* window origin; may be negative: only used when valid */ \
             fvalid = 0;                                                                                     \
-            if constexpr (VIRT) {                                                                           \
-                /* the (at most two) clips the strip's 68 feature rows fall into: bA and bA + 1; offsets are taken from clip bA's base */ \
-                const int T1 = a.T + 1;                                                                     \
-                const int bA = tb < 0 ? (P).b - 1 : (P).b;                                                  \
-                const int bAc = min(max(bA, 0), a.B - 1), bBc = min(max(bA + 1, 0), a.B - 1);               \
-                const float* fb = a.feats + (int64_t)bAc * a.f_stride_b;                                    \
-                const int sb = (bBc - bAc) * (int)a.f_stride_b;                                             \
-                /* a row of the first clip: its frame is tb + fi (+ T1 when the window starts in the clip before P.b); of the second: - T1 (or + 0) */ \
-                const int adjF = tb < 0 ? T1 * fst : 0, adjS = tb < 0 ? sb : sb - T1 * fst;                 \
-                _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                          \
-                    int rb_, rt_; bool rok_;                                                                \
-                    row_map<true>((P), (fcell[n] >> 8) - 3, a.T, a.B, rb_, rt_, rok_);                      \
-                    const bool second = rb_ != bA;                                                          \
-                    const bool ok = rok_ && (fcell[n] >> 8) >= 0 && (unsigned)(cb + (fcell[n] & 255)) < (unsigned)a.F; \
-                    fvalid |= (ok ? (1u << n) : 0u) | (second ? (256u << n) : 0u);                          \
-                    fpre[n] = fb[(unsigned)(ok ? wb + foff[n] + (second ? adjS : adjF) : 0)];               \
-                }                                                                                           \
-                if (db) {                                                                                   \
-                    fown = a.f_clip_max[bAc]; fref = a.f_ref[bAc];                                          \
-                    fown2 = a.f_clip_max[bBc]; fref2 = a.f_ref[bBc];                                        \
-                }                                                                                           \
-            } else {                                                                                        \
-                const float* fb = a.feats + (int64_t)(P).b * a.f_stride_b;                                  \
-                _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                          \
-                    const bool ok = (unsigned)(tb + (fcell[n] >> 8)) < (unsigned)a.T && (unsigned)(cb + (fcell[n] & 255)) < (unsigned)a.F; \
-                    fvalid |= ok ? (1u << n) : 0u;                                                          \
-                    fpre[n] = fb[(unsigned)(ok ? wb + foff[n] : 0)];                                        \
-                }                                                                                           \
-                if (db) {   /* two independent loads (f_ref = f_clip_max when the caller gave none): a select on a just-loaded value waits for it */ \
-                    fown = a.f_clip_max[(P).b];                                                             \
-                    fref = a.f_ref[(P).b];                                                                  \
-                }                                                                                           \
+            _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                              \
+                const bool ok = (unsigned)(tb + (fcell[n] >> 8)) < (unsigned)a.T && (unsigned)(cb + (fcell[n] & 255)) < (unsigned)a.F; \
+                fvalid |= ok ? (1u << n) : 0u;                                                              \
+                fpre[n] = fb[(unsigned)(ok ? wb + foff[n] : 0)];                                            \
+            }                                                                                               \
+            if (db) {   /* two independent loads (f_ref = f_clip_max when the caller gave none): a select on a just-loaded value waits for it */ \
+                fown = a.f_clip_max[(P).b];                                                                 \
+                fref = a.f_ref[(P).b];                                                                      \
             }                                                                                               \
         } while (0)
         // registers -> slab (KK & 1) as bf16, dB-scaled on the way when the input is raw power (db_scale_apply: the bits
         // amtx_spec_scale would have written, then the round-to-nearest-even conv.hip applies when it reads its fp32 tile)
 #define CONVF_WRITE_SLAB(KK)                                                                                \
         do {                                                                                                \
-            DbScale dbs = {0.f, 0.f}, dbs2 = {0.f, 0.f};                                                    \
+            DbScale dbs = {0.f, 0.f};                                                                       \
             if (db) dbs = db_scale_make(fown, fref);                                                        \
-            if (VIRT && db) dbs2 = db_scale_make(fown2, fref2);                                             \
             char* slab = smem + SLAB_OFF + ((KK) & 1) * SLAB_BYTES;                                         \
             _Pragma("unroll") for (int n = 0; n < FPRE; ++n) {                                              \
                 float v = fpre[n];                                                                          \
-                if (db) {                                                                                   \
-                    DbScale dsel = dbs;                                                                     \
-                    if (VIRT && ((fvalid >> (8 + n)) & 1u)) dsel = dbs2;   /* a value of the strip's second clip: that clip's own maximum */ \
-                    v = db_scale_apply(v, dsel);                                                            \
-                }                                                                                           \
+                if (db) v = db_scale_apply(v, dbs);                                                         \
                 v = (fvalid >> n) & 1u ? v : 0.f;                                                           \
                 *reinterpret_cast<uint16_t*>(slab + loff[n]) = (uint16_t)pack_bf16x2(v, 0.f);               \
             }                                                                                               \
@@ -438,9 +374,8 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
                     int slot2 = base2 + wave;
                     slot2 = slot2 >= RC2 ? slot2 - RC2 : slot2;
                     char* dst2 = smem + lane_a2 + slot2 * 16;
-                    // row tiles with a frame below T: r0 - 1 + 16 rt < T (VIRT: with a virtual row below the end of the stream)
-                    const int left2 = VIRT ? VR - (p0.b * (a.T + 1) + p0.r0) : a.T - p0.r0;
-                    const int nrt = pvalid ? min(RT, (left2 + 16) >> 4) : 0;
+                    // row tiles with a frame below T: r0 - 1 + 16 rt < T
+                    const int nrt = pvalid ? min(RT, (a.T - p0.r0 + 16) >> 4) : 0;
                     uint4 x[3][4];
 #define CONVF_LOAD_ROW2(KH, RTI)                                                                            \
                     _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                        \
@@ -482,9 +417,8 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
                             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
-                            int rb2_, rt2_; bool rok2_;
-                            row_map<VIRT>(p0, 16 * rt + trow - 1, a.T, a.B, rb2_, rt2_, rok2_);
-                            const uint32_t rowmask = rok2_ ? 0xffffffffu : 0u;
+                            const int t2 = p0.r0 - 1 + 16 * rt + trow;
+                            const uint32_t rowmask = (unsigned)t2 < (unsigned)a.T ? 0xffffffffu : 0u;
                             o = make_uint4(pack_bf16x2(v[0], v[1]) & rowmask, pack_bf16x2(v[2], v[3]) & rowmask,
                                            pack_bf16x2(v[4], v[5]) & rowmask, pack_bf16x2(v[6], v[7]) & rowmask);
                         }
@@ -606,9 +540,8 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
                     const int base2 = (pc.kk * CP) % RC2;           // ring slot of pooled column 4 j - 1 of the step consumed now
                     const int m = (CP / 2) * pc.j - 1 + mi;         // output column; its a2 columns 2 m - 1 + cc at ring offsets 2 mi - 2 + cc
                     const bool mvalid = m >= 0 && m < F4;
-                    // this wave's row tiles with an output frame below T: r0 + 16 rt < T (VIRT: a virtual row below the end of the stream)
-                    const int left3 = VIRT ? VR - (pc.b * (a.T + 1) + pc.r0) : a.T - pc.r0;
-                    const int nrt = mvalid ? min(2, (left3 + 15 - 16 * rt0) >> 4) : 0;
+                    // this wave's row tiles with an output frame below T: r0 + 16 rt < T
+                    const int nrt = mvalid ? min(2, (a.T - pc.r0 + 15 - 16 * rt0) >> 4) : 0;
                     int addr[4];
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) addr[cc] = lane_a2 + ((base2 + RC2 + 2 * mi - 2 + cc) % RC2) * 16;
@@ -647,15 +580,14 @@ __global__ __launch_bounds__(512, 2) void convf_kernel(ConvFArgs a, int nstep, i
                                 }
                             }
                             const int o = 16 * (rt0 + ri) + trow;
-                            int ob_, t; bool ok3_;
-                            row_map<VIRT>(pc, o, a.T, a.B, ob_, t, ok3_);
-                            if (o < R3 && ok3_) {
+                            const int t = pc.r0 + o;
+                            if (o < R3 && t < a.T) {
                                 float v[16];
 #pragma unroll
                                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) v[nt * 4 + r] = fmaxf(fmaxf(acc[0][nt][r], acc[1][nt][r]), 0.f);
-                                const int64_t orow = (int64_t)ob_ * a.T + t;
+                                const int64_t orow = (int64_t)pc.b * a.T + t;
                                 uint4* dst = reinterpret_cast<uint4*>(a.out + (int64_t)grp * a.out_gs + (a.out_plane ? m * a.out_plane + orow * 64 : (orow * F4 + m) * 64) + g * 8);
 #pragma unroll
                                 for (int q = 0; q < 2; ++q)
@@ -726,16 +658,10 @@ int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_
     a.w3frag = w3frag; a.w3_gs = w3_gs; a.shift3 = shift3;
     a.out = (bf16_t*)out; a.out_gs = out_gs; a.out_plane = out_plane;
     a.B = c2.B; a.T = c2.T; a.F = c2.F;
-    // Round 6: strips over the batch's virtual-row stream (see Pos) whenever a strip's rows touch at most two clips and the 32-bit
-    // offsets of the feature staging reach the second clip's rows.  AMTX_CONVF_NO_VIRT=1: strips per clip as in rounds 3 - 5 (same bits).
-    static const bool no_virt = getenv("AMTX_CONVF_NO_VIRT") != nullptr;
-    const bool virt = !no_virt && c2.T >= 67 && c2.f_stride_b >= 0 &&
-                      c2.f_stride_b + (int64_t)(c2.T + 1) * c2.f_stride_t + (int64_t)c2.F * c2.f_stride_f < (1ll << 31) &&
-                      (int64_t)c2.B * (c2.T + 1) < (1ll << 30);
-    const bool halo = !virt && convf_halo(c2.T);
+    const bool halo = convf_halo(c2.T);
     const int r3 = r3_of(halo);
-    const int ntt = virt ? c2.T + 1 : (c2.T + r3 - 1) / r3;
-    const int64_t nstrips = virt ? ((int64_t)c2.B * (c2.T + 1) - 1 + r3 - 1) / r3 : (int64_t)c2.B * ntt;
+    const int ntt = (c2.T + r3 - 1) / r3;
+    const int64_t nstrips = (int64_t)c2.B * ntt;
     AMTX_REQUIRE(nstrips < (1ll << 30), "conv_stack: grid too large");
     const int nstep = convf_steps(c2.F);
     AMTX_REQUIRE((int64_t)nstep * (nstrips + 1) < (1ll << 31), "conv_stack: too many steps");
@@ -743,10 +669,9 @@ int amtx_launch_conv_stack(const ConvArgs& c2, const bf16_t* w3frag, int64_t w3_
     if (gx > nstrips) gx = (int)nstrips;
     const int per_block = (int)((nstrips + gx - 1) / gx);
     gx = (int)((nstrips + per_block - 1) / per_block);
-    auto kern = virt ? convf_kernel<false, true> : halo ? convf_kernel<true, false> : convf_kernel<false, false>;
-    AMTX_GRANT_LDS((convf_kernel<true, false>), LDS_BYTES);
-    AMTX_GRANT_LDS((convf_kernel<false, false>), LDS_BYTES);
-    AMTX_GRANT_LDS((convf_kernel<false, true>), LDS_BYTES);
+    auto kern = halo ? convf_kernel<true> : convf_kernel<false>;
+    AMTX_GRANT_LDS(convf_kernel<true>, LDS_BYTES);
+    AMTX_GRANT_LDS(convf_kernel<false>, LDS_BYTES);
     int dbg = 0;
 #if defined(AMTX_CONVF_TIMING) || defined(AMTX_CONVF_ABLATE)
     if (const char* e = getenv("AMTX_CONVF_DBG")) dbg = atoi(e);
