@@ -622,6 +622,17 @@ def hcqt_leg(device, clips=512, steps=5):
           'frontend': {'kernel': 'HCQT front-end (7 decimations, basis products, scaling)', 'bound': 'hbm', 'achieved': fe_bytes / (fe_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                        'frac': fe_bytes / (fe_ms * 1e-3) / 1e9 / 8000.0, 'ms': fe_ms, 'algorithmic_bytes': fe_bytes,
                        'note': 'algorithmic bytes = audio in + feature map out; the pyramid levels and the power map in between are the traffic on top (profiles/r05ze_hcqt_pmc.txt)'}}
+    # the front-end's HBM traffic from the committed PMC passes (profiles/pmc_traffic_hcqt.json, tools/pmc_hcqt_traffic.py), scaled to this batch
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic_hcqt.json')) as f:
+            pmc = json.load(f)
+        rl['frontend']['traffic'] = pmc['frontend_hbm_bytes_per_pass'] * clips / pmc['clips']
+        rl['frontend']['traffic_unit'] = 'bytes per front-end pass'
+        rl['frontend']['traffic_over_algorithmic'] = rl['frontend']['traffic'] / fe_bytes
+        rl['frontend']['traffic_source'] = pmc.get('_source')
+        rl['frontend']['traffic_by_kernel'] = {k: v['hbm_bytes_per_pass'] * clips / pmc['clips'] for k, v in pmc.items() if isinstance(v, dict)}
+    except (OSError, ValueError, KeyError):
+        rl['frontend']['traffic'] = None
     # OF1 + HCQT(6 x 72) = 10.3 MFLOP per frame
     return {'frames_per_s': fps, 'ms_per_step': dt * 1e3, 'clips_per_step': clips, 'frames_per_clip': int(T), 'frontend_ms_per_step': fe_ms,
             'features': '(B,T,F,8) bf16, amtx_cqt_forward16 -> amtx_of_forward_feats16' if feats16 else '(B,C,F,T) fp32',
