@@ -276,6 +276,47 @@ class SpectralFrontend(nn.Module):
         return self.module.process_batch(audio[:, 0].float())                            # CQT family: (B,C,F,T)
 
 
+def _pick_side_stream(device, candidates=6, spins=20, spin_cycles=20000):
+    """A side stream that really runs BESIDE the caller's current stream, for the training step's pitch head.  HIP multiplexes a process's
+    streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues in creation order, and two streams that land on the same queue execute one
+    after the other.  Measured in round 6: as soon as the process holds an RCCL communicator -- whose own streams shift the order -- the
+    first `torch.cuda.Stream()` sits on the null stream's queue, and the training step ran its two heads back to back: 11.4 instead of 9.5
+    ms (GPU_MAX_HW_QUEUES=8 / 16: 9.5; =1: 11.3; the data-parallel step of BASELINE config 4 is exactly that case).  So the stream is chosen
+    by a test: a chain of short one-block spin kernels (torch.cuda._sleep) on the current stream and on the candidate at once takes ~1.4 x
+    one chain's time when the two overlap and ~1.9 x when they share a queue (tools/_dbg/pick3.py: the same verdicts as a chain of 40
+    small GEMMs per stream; ONE long spin kernel is not a reliable probe against the null stream).  The first candidate below 1.7 x is
+    kept; without one (or without _sleep) the first stream created.  Running BOTH heads on tested streams of their own costs 0.45 ms of
+    extra cross-stream waits per step (measured 9.9 vs 9.45 ms), so the recurrent heads stay on the caller's stream."""
+    import time
+    sleep = getattr(torch.cuda, '_sleep', None)
+    main = torch.cuda.current_stream(device)
+    first = None
+    try:
+        with torch.cuda.device(device):
+            def chains(streams):
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        for _ in range(spins):
+                            sleep(spin_cycles)
+                for st in streams:
+                    st.synchronize()
+                return time.perf_counter() - t0
+            for _ in range(candidates):
+                s = torch.cuda.Stream(device=device)
+                first = first or s
+                if sleep is None:
+                    return s
+                chains((main, s))                               # first use of the stream (and of the spin kernel)
+                one = min(chains((main,)) for _ in range(2))
+                if min(chains((main, s)) for _ in range(2)) < 1.7 * one:
+                    return s
+    except Exception:                                           # noqa: BLE001 -- a probe: any stream is a correct stream
+        pass
+    return first or torch.cuda.Stream(device=device)
+
+
 class PendingFeatures(object):
     """What OnsetsFrames.pre_proc puts under KEY_FEATS inside run_on_batch when the dB scaling of the front-end is deferred into the
     engine's first conv kernel (amtx_of_forward_power): the raw power mel spectrogram (B,T,F), the clips' own maxima (B,) and the
@@ -584,7 +625,7 @@ class OnsetsFrames(TranscriptionModel):
             main = torch.cuda.current_stream(feats.device)
             side = self.__dict__.get('_side_stream')
             if side is None or side.device != feats.device:
-                side = torch.cuda.Stream(device=feats.device)
+                side = _pick_side_stream(feats.device)       # tested to run beside the caller's stream
                 self.__dict__['_side_stream'] = side
             side.wait_stream(main)
             feats.record_stream(side)
@@ -618,7 +659,8 @@ class OnsetsFrames(TranscriptionModel):
         GEMMs in the two heads the side stream stops in the first head's fc1 GEMM within 2 - 90 steps (either library alone, or the
         all-HIP step: thousands of steps clean).  So the first training forward of a model runs on one stream, and the overlap is armed
         only if THIS model's previous training forward recorded no ATen fallback (bracketed with autograd.fallback_total() in forward():
-        fallbacks of other models or of a validation pass do not count); with more than one rank it stays off unless AMTX_TRAIN_OVERLAP=1."""
+        fallbacks of other models or of a validation pass do not count).  The side stream is picked by a concurrency test
+        (_pick_side_stream): a stream that shares a hardware queue with the caller's does not overlap anything."""
         if not (feats.is_cuda and self.training and torch.is_grad_enabled()):
             return False
         if os.environ.get('AMTX_TRAIN_OVERLAP', '1') == '0' or not self.__dict__.get('overlap_heads', True):
@@ -626,11 +668,12 @@ class OnsetsFrames(TranscriptionModel):
         from . import autograd as ag
         if not ag.USE_HIP_DENSE:
             return False
-        # several ranks: the overlap has only ever been soaked on one GPU (with a one-rank RCCL group); with a real process group it stays
-        # off unless asked for explicitly (AMTX_TRAIN_OVERLAP=1) until an 8-GPU soak has run
-        if 'AMTX_TRAIN_OVERLAP' not in os.environ and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            return False
+        # Several ranks (round 6): on by default too.  Rounds 4 - 5 kept it off under a real process group "until an 8-GPU soak has run"; what
+        # is known since: the round-1 hang needs MIOpen + hipBLASLt kernels on the two streams (none in this step); 300 steps with a one-rank
+        # RCCL communicator and both streams run clean and bit-identical (tests/test_gpu_rccl.py); two rank processes with both streams each
+        # run on one GPU (tests/test_gpu_multirank.py); and the gradient all-reduce is enqueued only after autograd has joined the side stream
+        # back into the main one and the next forward forks only after the optimizer step -- RCCL's kernels never run beside the two-stream
+        # phase.  AMTX_TRAIN_OVERLAP=0 is the switch back.
         # THIS model's previous training forward must have run without an ATen fallback (the count is bracketed per forward in forward():
         # other models, or a validation pass, do not switch the overlap off for the rest of the process).  The switch is STICKY per model:
         # one training forward of this model that recorded a fallback (an odd-shaped batch sent a layer to MIOpen / hipBLASLt) latches the

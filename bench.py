@@ -206,13 +206,24 @@ def init_ranks(args):
         os.environ.setdefault('MASTER_PORT', str(_free_port()) if world == 1 else '29500')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        if args.backend == 'nccl' and rank == 0 and 'NCCL_DEBUG' not in os.environ:
-            # which algorithm / protocol RCCL picks for the 19.4 MB gradient all-reduce (ring vs tree vs direct) decides
-            # whether a hand-rolled exchange is worth writing: rank 0 logs RCCL's tuning decisions into a file that rccl_choices() parses
-            # into the result line, so the first multi-GPU run answers the question without a second one
+        if args.backend == 'nccl':
             import tempfile
-            _RCCL_LOG['path'] = os.path.join(tempfile.gettempdir(), f'amtx_rccl_{os.getpid()}.log')
-            os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,TUNING', NCCL_DEBUG_FILE=_RCCL_LOG['path'])
+            base = os.path.join(tempfile.gettempdir(), f'amtx_rccl_{os.getpid()}')
+            if rank == 0 and os.environ.get('NCCL_DEBUG', '').upper() in ('', 'VERSION', 'WARN'):
+                # which algorithm / protocol RCCL picks for the 19.4 MB gradient all-reduce (ring vs tree vs direct) decides
+                # whether a hand-rolled exchange is worth writing: rank 0 logs RCCL's tuning decisions into a file that rccl_choices() parses
+                # into the result line, so the first multi-GPU run answers the question without a second one
+                _RCCL_LOG['path'] = base + '.log'
+                os.environ.update(NCCL_DEBUG='INFO', NCCL_DEBUG_SUBSYS='INIT,TUNING', NCCL_DEBUG_FILE=_RCCL_LOG['path'])
+            # RCCL prints its version banner with printf, i.e. to this process's STDOUT, whenever NCCL_DEBUG is VERSION or higher (the GPU boxes
+            # of this pool export it: the banner showed up BEHIND the result line).  The contract is ONE JSON line there: file descriptor 1
+            # points at a side file until main() has torn the group down, then comes back for the result line
+            _RCCL_LOG['stdout_path'] = base + '.stdout'
+            sys.stdout.flush()
+            _RCCL_LOG['saved_stdout'] = os.dup(1)
+            fd = os.open(_RCCL_LOG['stdout_path'], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            os.dup2(fd, 1)
+            os.close(fd)
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(device))
         else:
@@ -221,7 +232,22 @@ def init_ranks(args):
     return rank, world, device
 
 
-_RCCL_LOG = {'path': None}
+_RCCL_LOG = {'path': None, 'stdout_path': None, 'saved_stdout': None}
+
+
+def restore_stdout():
+    """Undo init_ranks' redirection of file descriptor 1 (C stdio flushed into the side file first)."""
+    saved = _RCCL_LOG.get('saved_stdout')
+    if saved is None:
+        return
+    sys.stdout.flush()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:                                            # noqa: BLE001
+        pass
+    os.dup2(saved, 1)
+    os.close(saved)
+    _RCCL_LOG['saved_stdout'] = None
 
 
 def rccl_choices(nbytes=None, limit=12):
@@ -231,7 +257,12 @@ def rccl_choices(nbytes=None, limit=12):
     path = _RCCL_LOG.get('path')
     if not path or not os.path.exists(path):
         return None
+    spath = _RCCL_LOG.get('stdout_path') or ''
     algo, init = {}, []
+    try:
+        C.CDLL(None).fflush(None)                       # RCCL's printf output sits in C stdio's buffer while stdout is a file
+    except Exception:                                            # noqa: BLE001
+        pass
     try:
         with open(path, errors='replace') as f:
             for line in f:
@@ -243,6 +274,11 @@ def rccl_choices(nbytes=None, limit=12):
                     init.append(line.strip()[-200:])
     except OSError:
         return None
+    try:
+        with open(spath, errors='replace') as f:
+            init = [l.strip()[-200:] for l in f if re.search(r'(RCCL|HIP|ROCm) version', l)][:3] + init
+    except OSError:
+        pass
     rows = [{'bytes': k[0], 'algo': k[1], 'proto': k[2], 'times': n} for k, n in sorted(algo.items())]
     rec = {'log': path, 'env': 'NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,TUNING (rank 0)', 'decisions': rows[:limit * 2], 'init_lines': init}
     if nbytes is not None:
@@ -1040,13 +1076,16 @@ def main(argv=None):
         if _dist_on():
             dist.destroy_process_group()
         return
-    res = run_infer(args, rank, world, device) if args.mode == 'infer' else run_train(args, rank, world, device)
+    try:
+        res = run_infer(args, rank, world, device) if args.mode == 'infer' else run_train(args, rank, world, device)
+        if _dist_on():
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+    finally:
+        restore_stdout()
     if rank == 0:
-        print(json.dumps(res), flush=True)
-    if _dist_on():
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(res), flush=True)          # the last thing this process writes to stdout
 
 
 if __name__ == '__main__':
