@@ -93,6 +93,7 @@ _SIGNATURES = {
     'amtx_cqt_workspace_bytes': (C.c_size_t, [_P, _I, _L]),
     'amtx_cqt_forward': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _P]),
     'amtx_cqt_forward16': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _P]),
+    'amtx_cqt_forward16_split': (_I, [_P, _P, _L, _L, _I, _I, _P, C.c_size_t, _P, _L, _P]),
     'amtx_bilstm_h_pack_device': (_I, [_P, _P, _I, _I, _P, _P, _P]),
     'amtx_bilstm_h_train_fwd': (_I, [_P, _P, _I, _I, _P, _P, _I, _I, _I, _P]),
     'amtx_bilstm_h_train_bwd': (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I, _P]),

@@ -253,24 +253,43 @@ __global__ __launch_bounds__(512) void convx3_kernel(ConvArgs a, int ft, int ntf
 //     layer2 alone 6.6 ms -- 5.65 without its reads and epilogue --, layer1 2.0, staging 0.7).
 // Both roles index ONE weight-register array (a kernel's waves share one register allocation: two arrays would not fit 256).
 // Same arithmetic as conv.hip's kernel (Toeplitz first conv, the same fragments, tap order and product order): identical bits.
-constexpr int YFT = 24;                         // output columns per tile
-constexpr int YP = 29;                          // a1 tile pitch in positions (>= YFT + 2, = 1 mod 4)
-constexpr int YPLANE = XROWS * YP * 64;         // 33 408 bytes
-constexpr int YBUF = 2 * YPLANE;
-constexpr int YFROWS = XROWS + 2;               // feature rows of a tile
-constexpr int YFW = 40;                         // feature row pitch in 16-bit values: 80 bytes -> 16 consecutive rows on 16 distinct 8-byte slots of a bank row
-constexpr int YFPLANE = (YFROWS * YFW + 16) * 2;   // one 16-bit plane of a feature tile (+ slack for the 8-value reads of the last unit)
-constexpr int YFEAT = 2 * YFPLANE;              // hi | lo: the features are split ONCE, when they are staged (layer1's overlapping 8-value
-                                                // windows would otherwise each convert them again)
+// MC = false: the one-channel kernel described above.  MC = true (round 6): 2 .. 8 input channels (HCQT: one per harmonic) with the features
+// handed over as the two 16-bit planes themselves ([2][B][T][F][8] channels-last, amtx_cqt_forward16_split): the first conv is the TAP-MAJOR
+// product of convg.hip's fused first conv (k = 8 tap + channel, three 32-deep steps; k-group g of step s = the 8 channel slots of the feature
+// position at tap 4 s + g: ONE 16-byte LDS read per plane), same fragments (amtx_conv1g_pack_host), same step and product order -> the
+// same a1 bits; a tile's feature staging is 3.4 sixteen-byte copies per thread instead of strided fp32 loads + splits.  Tiles are 18 output
+// columns wide (the HCQT map's 72 bins = 4 tiles; 24 would need 178 KB of LDS with channels-last feature tiles).
+template <bool MC>
+struct Y12 {
+    static constexpr int FT = MC ? 18 : 24;                      // output columns per tile
+    static constexpr int P = MC ? 21 : 29;                       // a1 tile pitch in positions (>= FT + 2, = 1 mod 4)
+    static constexpr int PLANE = XROWS * P * 64;                 // 33 408 / 24 192 bytes
+    static constexpr int BUF = 2 * PLANE;
+    static constexpr int FROWS = XROWS + 2;                      // feature rows of a tile
+    // MC = false: one 16-bit value per cell, row pitch FW values (80 bytes -> 16 consecutive rows on 16 distinct 8-byte slots of a bank row)
+    // MC = true: 16 bytes (8 channel slots) per cell, row pitch FW cells = 23 x 16 = 112 (mod 256) bytes: the 16 rows of a ds_read_b128 lane
+    // group on 16 distinct 16-byte slots
+    static constexpr int FW = MC ? 23 : 40;
+    static constexpr int FPLANE = MC ? FROWS * FW * 16 : (FROWS * FW + 16) * 2;   // one 16-bit plane of a feature tile
+    static constexpr int FEAT = 2 * FPLANE;                      // hi | lo: the features are split ONCE (MC: by the front-end)
+    static constexpr int LDS = 2 * BUF + 2 * FEAT + 2 * 256 * 16 + 256;   // + one 16-byte scratch slot per layer1 thread and plane for masked stores + the shift tables
+};
+constexpr int YFT = Y12<false>::FT, YP = Y12<false>::P, YPLANE = Y12<false>::PLANE, YBUF = Y12<false>::BUF, YFROWS = Y12<false>::FROWS, YFW = Y12<false>::FW,
+              YFPLANE = Y12<false>::FPLANE, YFEAT = Y12<false>::FEAT, YLDS = Y12<false>::LDS;
 constexpr int YFPRE = 3;                        // feature values per layer1-wave thread and tile (20 x 28 = 560 <= 768)
-constexpr int YLDS = 2 * YBUF + 2 * YFEAT + 2 * 256 * 16 + 256;   // + one 16-byte scratch slot per layer1 thread and plane for masked stores + the shift tables
+constexpr int YMPRE = 4;                        // MC: 16-byte feature cells per layer1-wave thread and tile (2 planes x 20 x 22 = 880 <= 1024)
+static_assert(Y12<true>::LDS <= 160 * 1024 && Y12<false>::LDS <= 160 * 1024, "LDS");
 
 // Chunk swizzle of the a1 tile: layer1's lanes run along ROWS (8 rows of one column and chunk per ds_write_b128 lane group; LDS stores bank
 // mod 128 bytes), layer2's fragment reads take rows r .. r + 15 of one column (ds_read_b128, mod 256 bytes).  (i >> 1) & 3 keeps the reads
 // conflict-free for every tap row and the stores conflict-free too (xswz: 4-way stores; tools/lds_swizzle_check_convx.py).
 __device__ __forceinline__ int yswz(int i) { return (i >> 1) & 3; }
 
+template <bool MC>
 __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int ntf, int ntt, int ntiles, int inv_fcols) {
+    // this instantiation's tile shape (shadows the one-channel constants of the same names)
+    constexpr int YP = Y12<MC>::P, YPLANE = Y12<MC>::PLANE, YBUF = Y12<MC>::BUF, YFROWS = Y12<MC>::FROWS, YFW = Y12<MC>::FW, YFPLANE = Y12<MC>::FPLANE,
+                  YFEAT = Y12<MC>::FEAT, YLDS = Y12<MC>::LDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][a1 hi | a1 lo] | [2] feature tiles | scratch
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
     {
         const uint4* w = reinterpret_cast<const uint4*>(l2role ? a.wfrag + (int64_t)grp * a.w_gs : a.w1frag + (int64_t)grp * a.w1_gs) + lane;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) wreg[i] = w[(l2role || i < 16 ? i : 0) * 64];
+        for (int i = 0; i < 36; ++i) wreg[i] = w[(l2role || i < (MC ? 12 : 16) ? i : 0) * 64];
     }
     const int c0 = g * 8;                                         // this lane's first channel (of both layers)
 #pragma unroll
@@ -308,7 +327,28 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
     // ---- feature staging (layer1 waves): cells it = ltid + 256 n of the 20 x fcols tile; issue -> registers, (dB scaling +) split + store later
     float fpre[YFPRE];
     float fown = 0.f, fref = 0.f;
+    // MC: cells it = ltid + 256 n of [2 planes][20 rows][fcols] 16-byte cells, straight copies of the caller's two planes
+    uint4 mpre[MC ? YMPRE : 1];
+    const int64_t f16_plane = MC ? a.in_split / 8 : 0;            // 16-byte cells between the hi and the lo plane of feats16
     auto feat_issue = [&](const XTile& tc) {
+        if constexpr (MC) {
+            const uint4* fb = reinterpret_cast<const uint4*>(a.feats16) + (int64_t)tc.b * a.T * a.F;
+            int tid_l = ltid;
+            asm volatile("" : "+v"(tid_l));
+#pragma unroll
+            for (int n = 0; n < YMPRE; ++n) {
+                const int it = tid_l + 256 * n;
+                const int cells = YFROWS * fcols;
+                const int pl = it >= cells ? 1 : 0, ic = it - pl * cells;
+                const int fi = (ic * inv_fcols) >> 16, fj = ic - fi * fcols;
+                const int t = tc.t0 - 2 + fi, f = tc.f0 - 2 + fj;
+                const bool ok = it < 2 * cells && (unsigned)t < (unsigned)a.T && (unsigned)f < (unsigned)a.F;
+                // unconditional load from a clamped offset (a guarded load is waited for at the join of its branch); masked at the store
+                const uint4 v = fb[(ok ? (int64_t)t * a.F + f : 0) + (pl ? f16_plane : 0)];
+                mpre[n] = ok ? v : make_uint4(0, 0, 0, 0);
+            }
+            return;
+        }
         const float* fb = a.feats + (int64_t)tc.b * a.f_stride_b;
         int tid_l = ltid;
         asm volatile("" : "+v"(tid_l));
@@ -326,6 +366,19 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         }
     };
     auto feat_store = [&](int buf) {
+        if constexpr (MC) {
+            int tid_l = ltid;
+            asm volatile("" : "+v"(tid_l));
+#pragma unroll
+            for (int n = 0; n < YMPRE; ++n) {
+                const int it = tid_l + 256 * n;
+                const int cells = YFROWS * fcols;
+                const int pl = it >= cells ? 1 : 0, ic = it - pl * cells;
+                const int fi = (ic * inv_fcols) >> 16, fj = ic - fi * fcols;
+                if (it < 2 * cells) *reinterpret_cast<uint4*>(feat0 + buf * YFEAT + pl * YFPLANE + (fi * YFW + fj) * 16) = mpre[n];
+            }
+            return;
+        }
         bf16_t* ftile = reinterpret_cast<bf16_t*>(feat0 + buf * YFEAT);
         DbScale dbs = {0.f, 0.f};
         if (a.f_clip_max) dbs = db_scale_make(fown, fref);
@@ -429,6 +482,81 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         }
     };
 
+    // ---- MC: layer1 of one tile as the tap-major product (convg.hip's fused first conv): groups of 16 positions -- column j of rows 0 .. 15 for
+    // j < cols, then the two halo rows (16, 17) as ceil(2 cols / 16) groups -- dealt to the four layer1 waves, TWO groups in flight per wave.
+    // Lane (k-group g, position n): step s reads the 8 channel slots of the feature cell at tap 4 s + g of its position, 16 bytes per plane.
+    auto layer1m = [&](const XTile& tc, int buf) {
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+        const int n16 = lane_o & 15, g = lane_o >> 4;
+        int tapoff[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int tap = 4 * ks + g, tp = tap < 9 ? tap : 0;   // taps 9 .. 11 meet zero weights: any cell of the (finite) tile will do
+            tapoff[ks] = ((tp / 3) * YFW + tp % 3) * 16;
+        }
+        const char* fbytes = feat0 + buf * YFEAT;
+        char* ob = smem + buf * YBUF;
+        const int ngroups = cols + ((2 * cols + 15) >> 4);
+        f32x4_t sh1m[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) sh1m[nt] = *reinterpret_cast<const f32x4_t*>(shtab + 32 + 16 * nt + 4 * g);
+        for (int u0 = wq; u0 < ngroups; u0 += 8) {
+            int pi[2], pj[2];
+            bool pok[2];
+            uint4 ph[2][3], pl[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int u = u0 + 4 * q;
+                const int hp = (u - cols) * 16 + n16;                         // halo groups: position hp of rows 16, 17 laid end to end
+                const bool main_g = u < cols;                                 // scalar
+                pi[q] = main_g ? n16 : XT + (hp >= cols ? 1 : 0);
+                pj[q] = main_g ? u : (hp >= cols ? hp - cols : hp);
+                pok[q] = u < ngroups && (main_g || hp < 2 * cols);
+                if (!pok[q]) { pi[q] = 0; pj[q] = 0; }
+                const int src = (pi[q] * YFW + pj[q]) * 16;
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    ph[q][ks] = *reinterpret_cast<const uint4*>(fbytes + src + tapoff[ks]);
+                    pl[q][ks] = *reinterpret_cast<const uint4*>(fbytes + YFPLANE + src + tapoff[ks]);
+                }
+            }
+            f32x4_t d[2][2];
+            // per accumulator: steps 0, 1, 2, each hi.hi, hi.lo, lo.hi (convg.hip's order); fragment (tile nt, step ks, plane) = wreg[(nt * 3 + ks) * 2 + plane]
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    f32x4_t dd = sh1m[nt];
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        dd = mfma16(wreg[(nt * 3 + ks) * 2], ph[q][ks], dd);
+                        dd = mfma16(wreg[(nt * 3 + ks) * 2], pl[q][ks], dd);
+                        dd = mfma16(wreg[(nt * 3 + ks) * 2 + 1], ph[q][ks], dd);
+                    }
+                    d[q][nt] = dd;
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool inside = pok[q] && (unsigned)(tc.t0 - 1 + pi[q]) < (unsigned)a.T && (unsigned)(tc.f0 - 1 + pj[q]) < (unsigned)a.F;
+                const float lim = inside ? __builtin_inff() : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = __builtin_amdgcn_fmed3f(d[q][nt][r], 0.f, lim);   // ReLU and the map's zero padding
+                    uint2 hi, lo;
+                    split_bf16x2(o[0], o[1], hi.x, lo.x);
+                    split_bf16x2(o[2], o[3], hi.y, lo.y);
+                    // channels 16 nt + 4 g .. + 3 = half (g & 1) of 16-byte chunk 2 nt + (g >> 1) of the position
+                    const int off = ((pi[q] * YP + pj[q]) * 4 + ((2 * nt + (g >> 1)) ^ yswz(pi[q]))) * 16 + (g & 1) * 8;
+                    *reinterpret_cast<uint2*>(pok[q] ? ob + off : scratch) = hi;
+                    *reinterpret_cast<uint2*>(pok[q] ? ob + YPLANE + off : scratch + 4096) = lo;
+                }
+            }
+        }
+    };
+
     // ---- layer2 of one tile (layer2 waves): pairs jp = wq, wq + 4, ... of this tile, all 32 channels, fragment rows through a two-row ring
     auto layer2 = [&](const XTile& tc, int buf) {
         int lane_o = lane;
@@ -518,7 +646,10 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         }
     }
     __syncthreads();
-    if (!l2role && tile < ntiles) layer1(xtile(tile, ntf, ntt, ft, ntiles), 0);
+    if (!l2role && tile < ntiles) {
+        if constexpr (MC) layer1m(xtile(tile, ntf, ntt, ft, ntiles), 0);
+        else layer1(xtile(tile, ntf, ntt, ft, ntiles), 0);
+    }
     __syncthreads();
 
     int cur = 0;
@@ -528,7 +659,10 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
         } else {
             const bool has1 = tile + G < ntiles, has2 = tile + 2 * G < ntiles;
             if (has2) feat_issue(xtile(tile + 2 * G, ntf, ntt, ft, ntiles));
-            if (has1) layer1(xtile(tile + G, ntf, ntt, ft, ntiles), cur ^ 1);
+            if (has1) {
+                if constexpr (MC) layer1m(xtile(tile + G, ntf, ntt, ft, ntiles), cur ^ 1);
+                else layer1(xtile(tile + G, ntf, ntt, ft, ntiles), cur ^ 1);
+            }
             if (has2) feat_store(cur);                // tile k's features were consumed an iteration ago
         }
         lds_only_barrier();                           // LDS traffic only: the a2 stores stay in flight across it
@@ -536,24 +670,26 @@ __global__ __launch_bounds__(512) void convx12_kernel(ConvArgs a, int ft, int nt
     }
 }
 
+template <bool MC>
 int launch_x12(const ConvArgs& a, hipStream_t stream) {
+    constexpr int FT = Y12<MC>::FT, LDSB = Y12<MC>::LDS;
     const int fe = (a.F + 1) & ~1;
-    const int ntf = (fe + YFT - 1) / YFT;
+    const int ntf = (fe + FT - 1) / FT;
     const int ft = 2 * (((fe >> 1) + ntf - 1) / ntf);
     const int ntt = (a.T + XT - 1) / XT;
     const int64_t nblocks = (int64_t)ntf * ntt * a.B;
     AMTX_REQUIRE(nblocks < (1ll << 31), "convx12: grid too large");
-    auto kern = convx12_kernel;
-    AMTX_GRANT_LDS(kern, YLDS);
+    auto kern = convx12_kernel<MC>;
+    AMTX_GRANT_LDS(kern, LDSB);
     int64_t gx = std::max<int64_t>(8, 256 / std::max(1, a.groups) / 8 * 8);
     if (gx > nblocks) gx = nblocks;
     const int fcols = ft + 4, inv_fcols = 65536 / fcols + 1;
-    for (int it = 0; it < YFPRE * 256; ++it)
+    for (int it = 0; it < (MC ? Y12<MC>::FROWS * fcols : YFPRE * 256); ++it)
         if (((it * inv_fcols) >> 16) != it / fcols) {
             amtx_set_error("convx12: internal: reciprocal division inexact for fcols=%d", fcols);
             return AMTX_ERR_ARG;
         }
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(512), YLDS, stream, a, ft, ntf, ntt, (int)nblocks, inv_fcols);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.groups), dim3(512), LDSB, stream, a, ft, ntf, ntt, (int)nblocks, inv_fcols);
     AMTX_CHECK_LAUNCH();
     return AMTX_OK;
 }
@@ -580,12 +716,22 @@ int launch_x3(const ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-// fused layer1 + layer2 of a one-channel model, two-plane weights, a2 as AMTX_T_SPLIT planes (ConvArgs as for conv.hip's fused kernel)
+// fused layer1 + layer2, two-plane weights, a2 as AMTX_T_SPLIT planes (ConvArgs as for conv.hip's fused kernel).  One input channel: fp32 features
+// (or raw power) in `feats`, Toeplitz fragments in `w1frag`.  2 .. 8 input channels (round 6): the features as the two 16-bit planes themselves in
+// `feats16` ([B][T][F][8] channels-last, the lo plane `in_split` elements behind the hi plane: amtx_cqt_forward16_split), `w1frag` =
+// amtx_conv1g_pack_host's tap-major fragments, `wfrag` = amtx_conv3x3_pack_host's (conv.hip's order, NOT convg.hip's)
 int amtx_launch_convx12(const ConvArgs& a, hipStream_t stream) {
-    AMTX_REQUIRE(a.feats && a.w1frag && a.shift1 && a.wfrag && a.shift && a.out && a.c_in == 1 && a.c_out == 32 && a.planes == 2 && a.out_type == AMTX_T_SPLIT,
-                 "convx12: one input channel, 32 -> 32 channels, two-plane weights and maps only");
+    AMTX_REQUIRE(a.w1frag && a.shift1 && a.wfrag && a.shift && a.out && a.c_out == 32 && a.planes == 2 && a.out_type == AMTX_T_SPLIT,
+                 "convx12: 32 -> 32 channels, two-plane weights and maps only");
     AMTX_REQUIRE(a.out_split > 0 && a.out_split % 8 == 0 && ((uintptr_t)a.out % 16) == 0, "convx12: planes must be 16-byte aligned");
-    return launch_x12(a, stream);
+    if (a.feats16) {
+        AMTX_REQUIRE(a.c_in >= 2 && a.c_in <= 8 && !a.feats && !a.f_clip_max, "convx12: 16-bit channels-last features are the 2 .. 8-channel form");
+        AMTX_REQUIRE(a.in_split >= (int64_t)a.B * a.T * a.F * 8 && a.in_split % 8 == 0 && ((uintptr_t)a.feats16 % 16) == 0 && (int64_t)a.T * a.F < (1ll << 31),
+                     "convx12: feats16 needs its lo plane in_split elements (a multiple of 8, >= B T F 8) behind the hi plane, 16-byte aligned");
+        return launch_x12<true>(a, stream);
+    }
+    AMTX_REQUIRE(a.feats && a.c_in == 1, "convx12: fp32 features are the one-channel form");
+    return launch_x12<false>(a, stream);
 }
 
 // 32 -> c_out channels on AMTX_T_SPLIT maps; the caller (amtx_launch_conv3x3) has checked pointers, sizes and plane strides

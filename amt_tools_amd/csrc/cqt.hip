@@ -129,13 +129,17 @@ __global__ __launch_bounds__(256) void cqt_scale_kernel(const float* __restrict_
 constexpr int SC16_TT = 32;
 constexpr int SC16_U = 9;          // 72 bins = one round of 8 rows x 9
 __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restrict__ mag, const float* __restrict__ maxbuf, int n_harm, int n_bins, int nbc,
-                                                          int64_t t_buf, int64_t t_out, int decibels, uint4* __restrict__ out16) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [SC16_TT][nbc + 1] slots of 16 bytes, then 8 x 2 floats
+                                                          int64_t t_buf, int64_t t_out, int decibels, uint4* __restrict__ out16, int64_t lo_plane) {
+    // lo_plane != 0 (amtx_cqt_forward16_split, the x3 engine's hand-over): a second map, lo = 16-bit(v - 16-bit(v)), lo_plane 16-byte slots
+    // behind the first -- the two planes split_bf16x2 makes of the fp32 feature, i.e. what the two-plane conv kernels made of it themselves
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [planes][SC16_TT][nbc + 1] slots of 16 bytes, then 8 x 2 floats
     const int tid = threadIdx.x, b = blockIdx.y;
     const int64_t t0 = (int64_t)blockIdx.x * SC16_TT;
     const int rs = nbc + 1;                                   // slots per frame row (+ 1: rows start 4 banks apart)
+    const int npl = lo_plane ? 2 : 1;
     uint4* tile = reinterpret_cast<uint4*>(smem);
-    float* refs = reinterpret_cast<float*>(smem + (size_t)SC16_TT * rs * 16);
+    uint4* tile_lo = tile + SC16_TT * rs;
+    float* refs = reinterpret_cast<float*>(smem + (size_t)npl * SC16_TT * rs * 16);
     const float amin2 = 1e-10f;                              // amin = 1e-5 on magnitude
     if (tid < n_harm) {
         const float ref = maxbuf[b * n_harm + tid];            // a power, like `mag` (cqt_scale_kernel)
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restric
         refs[2 * tid] = offs;
         refs[2 * tid + 1] = (10.0f * log10f(fmaxf(amin2, ref)) - offs) - 80.0f;
     }
-    for (int i = tid; i < SC16_TT * rs; i += 256) tile[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < npl * SC16_TT * rs; i += 256) tile[i] = make_uint4(0, 0, 0, 0);
     const int tt = tid & 31, r = tid >> 5;
     const bool t_ok = t0 + tt < t_out;
     for (int bin0 = 0; bin0 < n_bins; bin0 += nbc) {
@@ -169,14 +173,23 @@ __global__ __launch_bounds__(256) void cqt_scale16_kernel(const float* __restric
                     } else {
                         v = sqrtf(a[u]);
                     }
-                    if (k < nb) reinterpret_cast<unsigned short*>(tile + tt * rs + k)[h] = (unsigned short)pack_bf16x2(v, 0.f);
+                    if (k < nb) {
+                        uint32_t hi, lo;
+                        split_bf16x2(v, 0.f, hi, lo);         // hi = the rounding pack_bf16x2 applies
+                        reinterpret_cast<unsigned short*>(tile + tt * rs + k)[h] = (unsigned short)hi;
+                        if (lo_plane) reinterpret_cast<unsigned short*>(tile_lo + tt * rs + k)[h] = (unsigned short)lo;
+                    }
                 }
             }
         }
         __syncthreads();
         for (int i = tid; i < SC16_TT * nb; i += 256) {
             const int ti = i / nb, k = i - ti * nb;
-            if (t0 + ti < t_out) out16[((int64_t)b * t_out + t0 + ti) * n_bins + bin0 + k] = tile[ti * rs + k];
+            if (t0 + ti < t_out) {
+                const int64_t o = ((int64_t)b * t_out + t0 + ti) * n_bins + bin0 + k;
+                out16[o] = tile[ti * rs + k];
+                if (lo_plane) out16[lo_plane + o] = tile_lo[ti * rs + k];
+            }
         }
     }
 }
@@ -813,7 +826,7 @@ extern "C" size_t amtx_cqt_workspace_bytes(const amtx_cqt_plan* p, int batch, in
 
 // out16 != null: the map as [B][T][n_bins][8] bf16 (amtx_cqt_forward16) instead of `out`
 static int cqt_forward_impl(const amtx_cqt_plan* p, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
-                            void* workspace, size_t workspace_bytes, float* out, void* out16, void* stream_) {
+                            void* workspace, size_t workspace_bytes, float* out, void* out16, void* stream_, int64_t lo_plane = 0) {
     AMTX_REQUIRE(p && audio && workspace && (out || out16), "amtx_cqt_forward: null pointer");
     AMTX_REQUIRE(batch > 0 && batch < 65536 && num_samples > 0 && audio_stride >= num_samples, "amtx_cqt_forward: bad batch/num_samples");
     AMTX_REQUIRE(((uintptr_t)workspace % 256) == 0, "amtx_cqt_forward: workspace must be 256-byte aligned");
@@ -965,9 +978,10 @@ static int cqt_forward_impl(const amtx_cqt_plan* p, const float* audio, int64_t 
     if (out16) {
         AMTX_REQUIRE(p->n_harm <= 8 && ((uintptr_t)out16 % 16) == 0, "amtx_cqt_forward16: at most 8 harmonics, output 16-byte aligned");
         const int nbc = std::min(p->n_bins, 120);            // bins per pass: 32 x 121 x 16 bytes of LDS
-        const size_t lds = (size_t)SC16_TT * (nbc + 1) * 16 + 64;
+        const size_t lds = (size_t)(lo_plane ? 2 : 1) * SC16_TT * (nbc + 1) * 16 + 64;
+        AMTX_GRANT_LDS(cqt_scale16_kernel, lds);
         hipLaunchKernelGGL(cqt_scale16_kernel, dim3((unsigned)((d.t_out + SC16_TT - 1) / SC16_TT), B), dim3(256), lds, s, (const float*)mag,
-                           (const float*)maxbuf, p->n_harm, p->n_bins, nbc, d.t_buf, d.t_out, decibels, (uint4*)out16);
+                           (const float*)maxbuf, p->n_harm, p->n_bins, nbc, d.t_buf, d.t_out, decibels, (uint4*)out16, lo_plane);
         AMTX_CHECK_LAUNCH();
         return AMTX_OK;
     }
@@ -987,4 +1001,12 @@ extern "C" int amtx_cqt_forward16(const amtx_cqt_plan* p, const float* audio, in
                                   void* workspace, size_t workspace_bytes, void* out16, void* stream_) {
     AMTX_REQUIRE(out16, "amtx_cqt_forward16: null pointer");
     return cqt_forward_impl(p, audio, num_samples, audio_stride, batch, decibels, workspace, workspace_bytes, nullptr, out16, stream_);
+}
+
+// The same map as TWO 16-bit planes for the two-plane (x3) engine: hi = bf16(v) at out16 (exactly amtx_cqt_forward16's map), lo = bf16(v - hi)
+// `plane_elems` 16-bit elements behind it (>= B T n_bins 8, a multiple of 8) -- split_bf16x2 of the fp32 feature amtx_cqt_forward writes.
+extern "C" int amtx_cqt_forward16_split(const amtx_cqt_plan* p, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
+                                        void* workspace, size_t workspace_bytes, void* out16, int64_t plane_elems, void* stream_) {
+    AMTX_REQUIRE(out16 && plane_elems > 0 && plane_elems % 8 == 0, "amtx_cqt_forward16_split: null pointer / plane stride not a multiple of 8 elements");
+    return cqt_forward_impl(p, audio, num_samples, audio_stride, batch, decibels, workspace, workspace_bytes, nullptr, out16, stream_, plane_elems / 8);
 }

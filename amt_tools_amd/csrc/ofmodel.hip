@@ -68,6 +68,8 @@ struct amtx_of_model {
     bool packed_once = false;                  // the packed buffers hold a weight version that forwards may still be reading
     // packed device weights (group-major)
     DevBuf conv1_w, conv1_s, conv1_frag, conv2_w, conv2_s, conv3_w, conv3_s;
+    DevBuf conv2_wx;                           // x12m: layer2's weights a second time, in conv.hip's fragment order (convx12_kernel<true> reads them; conv2_w is convg.hip's)
+    bool x12m = false;                         // round 6: two planes, 2 .. 8 input channels, 32 / 32 channels: conv1 + conv2 from two-plane 16-bit features on convx.hip
     bool fuse_conv1 = false;                   // first conv computed inside the conv2 kernel (9*C_in <= 64)
     bool fuse_stack = false;                   // layer1 -> layer2 -> layer3 in one kernel (convf.hip) for batches that fill the chip with strips
     bool split_acts = false;                   // x3 (round 5): the dense layers' activations live in HBM as two 16-bit planes (AMTX_T_SPLIT), written by
@@ -254,13 +256,16 @@ extern "C" int amtx_of_model_create(amtx_of_model** out, int dim_in, int in_chan
     // kernel writes a2 as planes, convx.hip's conv3 and the GEMMs behind it are the same)
     m->split_acts = m->planes == 2 && !m->gen_conv && m->fuse_conv1 && getenv("AMTX_X3_NO_SPLIT") == nullptr &&
                     ((!m->gen_conv2 && in_channels == 1) || (m->gen_conv2 && in_channels > 1 && (9 * in_channels + 31) / 32 <= 2));
+    // A/B switch: AMTX_NO_CONVX12M=1 keeps convg.hip's two-plane kernel (fp32 features) for the multi-channel first conv
+    m->x12m = m->split_acts && m->gen_conv2 && in_channels >= 2 && in_channels <= 8 && m->nf1 == 32 && m->nf2 == 32 && amtx_conv1g_tapk(in_channels, 2) &&
+              getenv("AMTX_NO_CONVX12M") == nullptr;
     *out = m;
     return AMTX_OK;
 }
 
 extern "C" int amtx_of_model_destroy(amtx_of_model* m) {
     if (!m) return AMTX_OK;
-    DevBuf* bufs[] = {&m->conv1_w, &m->conv1_s, &m->conv1_frag, &m->conv2_w, &m->conv2_s, &m->conv3_w, &m->conv3_s, &m->fc1.w, &m->fc1.b,
+    DevBuf* bufs[] = {&m->conv1_w, &m->conv1_s, &m->conv1_frag, &m->conv2_w, &m->conv2_wx, &m->conv2_s, &m->conv3_w, &m->conv3_s, &m->fc1.w, &m->fc1.b,
                       &m->rec_ih.w, &m->rec_ih.b, &m->rec_hh, &m->rec_out.w, &m->rec_out.b, &m->pitch_out.w, &m->pitch_out.b,
                       &m->adj_ih.w, &m->adj_ih.b, &m->adj_hh, &m->adj_out.w, &m->adj_out.b, &m->pack_scratch};
     for (DevBuf* b : bufs) b->release();
@@ -303,6 +308,8 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
         return AMTX_ERR_UNSUPPORTED;
     }
     std::vector<bf16_t> c2w(c2w_per * nh), c3w(c3w_per * nh);
+    const size_t c2x_per = amtx_conv3x3_wfrag_elems(m->nf2, m->planes);
+    std::vector<bf16_t> c2x(m->x12m ? c2x_per * nh : 0);
     std::vector<float> c2s((size_t)nh * m->nf2), c3s((size_t)nh * m->nf3);
     std::vector<std::vector<float>> fcw(nh), fcb(nh);
     for (int h = 0; h < nh; ++h) {
@@ -324,6 +331,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
         NEED(am + ".layer2.0.weight", (size_t)m->nf2 * m->nf1 * 9, w);
         if (m->gen_conv2) (m->f16 ? amtx_conv3x3_gen_pack_host_f16 : amtx_conv3x3_gen_pack_host)(w, scale.data(), m->nf1, m->nf2, m->planes, c2w.data() + c2w_per * h);
         else (m->f16 ? amtx_conv3x3_pack_host_f16 : amtx_conv3x3_pack_host)(w, scale.data(), m->nf2, m->planes, c2w.data() + c2w_per * h);
+        if (m->x12m) amtx_conv3x3_pack_host(w, scale.data(), m->nf2, m->planes, c2x.data() + c2x_per * h);
         memcpy(c2s.data() + (size_t)h * m->nf2, shift.data(), sizeof(float) * m->nf2);
 
         rc = fold_bn(m, am + ".layer3.0", am + ".layer3.1", m->nf3, scale, shift);
@@ -349,6 +357,7 @@ extern "C" int amtx_of_model_finalize(amtx_of_model* m) {
     if ((rc = m->conv1_s.upload(c1s.data(), c1s.size() * 4)) != AMTX_OK) return rc;
     if (m->fuse_conv1 && (rc = m->conv1_frag.upload(c1f.data(), c1f.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv2_w.upload(c2w.data(), c2w.size() * 2)) != AMTX_OK) return rc;
+    if (m->x12m && (rc = m->conv2_wx.upload(c2x.data(), c2x.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv2_s.upload(c2s.data(), c2s.size() * 4)) != AMTX_OK) return rc;
     if ((rc = m->conv3_w.upload(c3w.data(), c3w.size() * 2)) != AMTX_OK) return rc;
     if ((rc = m->conv3_s.upload(c3s.data(), c3s.size() * 4)) != AMTX_OK) return rc;
@@ -563,6 +572,7 @@ static int finalize_device_pass(amtx_of_model* m, hipStream_t s, const bool dry)
         PACK_TRY(amtx_pack_bn_fold_dev(cb, g, be, mu, var, m->nf2, scale, (float*)m->conv2_s.p + (size_t)h * m->nf2, s));
         if (m->gen_conv2) PACK_TRY(pack_conv_gen(w, scale, m->nf1, m->nf2, pl, (bf16_t*)m->conv2_w.p + c2w_per * h, s));
         else PACK_TRY(pack_conv(w, scale, m->nf2, pl, (bf16_t*)m->conv2_w.p + c2w_per * h, s));
+        if (m->x12m) PACK_TRY(pack_conv(w, scale, m->nf2, pl, (bf16_t*)m->conv2_wx.p + (size_t)amtx_conv3x3_wfrag_elems(m->nf2, pl) * h, s));
         NEED_DEV(am + ".layer3.0.weight", (size_t)m->nf3 * m->nf2 * 9, w);
         NEED_DEV(am + ".layer3.0.bias", (size_t)m->nf3, cb); NEED_DEV(am + ".layer3.1.weight", (size_t)m->nf3, g); NEED_DEV(am + ".layer3.1.bias", (size_t)m->nf3, be);
         NEED_DEV(am + ".layer3.1.running_mean", (size_t)m->nf3, mu); NEED_DEV(am + ".layer3.1.running_var", (size_t)m->nf3, var);
@@ -707,6 +717,13 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, const voi
         c2.f_clip_max = clip_max; c2.f_ref = ref;
         if (feats16) { c2.feats = nullptr; c2.feats16 = feats16; }
     }
+    // two-plane 16-bit features into a two-plane model: conv1 + conv2 on convx.hip's layer-specialised kernel (layer2's weights in conv.hip's order)
+    const bool x12m_now = feats16 && m->x12m;
+    if (x12m_now) {
+        c2.in_split = BT * F * 8;                              // the lo plane of the features: right behind the hi plane
+        c2.wfrag = (const bf16_t*)m->conv2_wx.p;
+        c2.w_gs = (int64_t)amtx_conv3x3_wfrag_elems(m->nf2, pl);
+    }
     const bool fused_stack = m->fuse_stack && amtx_conv_stack_fused_ok(B, T, F, m->n_heads);
     // the fused stack writes its output in planes of 64 channels per pooled frequency column ([F / 4][B T][64]): a k-tile of the two GEMMs
     // that read it (fc1, the folded pitch head) is then contiguous memory.  A/B switch: AMTX_OF_ROWMAJOR_A3=1
@@ -716,6 +733,8 @@ static int of_forward_impl(const amtx_of_model* m, const float* feats, const voi
         // layer1 -> layer2 -> layer3 in one kernel: neither intermediate map reaches HBM (stage timer: all of it under conv2_pool)
         if ((rc = (f16 ? amtx_launch_conv_stack_f16 : amtx_launch_conv_stack)(c2, (const bf16_t*)m->conv3_w.p, (int64_t)amtx_conv3x3_wfrag_elems(m->nf3, pl), (const float*)m->conv3_s.p,
                                          w.a3, BT * m->kfc_pad, a3_plane, s)) != AMTX_OK) return rc;
+    } else if (x12m_now) {
+        if ((rc = amtx_launch_convx12(c2, s)) != AMTX_OK) return rc;
     } else if ((rc = m->gen_conv2 ? launch_convg(c2, m->nf1, s) : launch_conv(c2, s)) != AMTX_OK) return rc;
     mark();
 
@@ -856,8 +875,9 @@ extern "C" int amtx_of_forward_power(const amtx_of_model* m, const float* power,
 // 1 when amtx_of_forward_feats16 applies: 2 .. 8 input channels and the first conv fused tap-major into the general conv kernel's 32-channel
 // pipelined variant (convg.hip: one-plane bf16 mode, model_complexity 2) -- the HCQT configuration (BASELINE config 3)
 extern "C" int amtx_of_takes_feats16(const amtx_of_model* m) {
-    return m && m->finalized && m->fuse_conv1 && m->gen_conv2 && !m->f16 && m->planes == 1 && m->nf1 == 32 && amtx_conv1g_tapk(m->in_channels, m->planes) &&
-           m->act_type == AMTX_T_BF16;
+    if (!(m && m->finalized && m->fuse_conv1 && m->gen_conv2 && !m->f16)) return 0;
+    if (m->x12m) return 2;     // two planes: [2][B][T][F][8], the lo plane B T F 8 elements behind the hi plane (amtx_cqt_forward16_split)
+    return m->planes == 1 && m->nf1 == 32 && amtx_conv1g_tapk(m->in_channels, m->planes) && m->act_type == AMTX_T_BF16;
 }
 
 extern "C" int amtx_of_forward_feats16(const amtx_of_model* m, const void* feats16, int batch, int num_frames, void* workspace, size_t workspace_bytes,

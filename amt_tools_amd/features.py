@@ -440,10 +440,12 @@ class _CqtPlanOwner(object):
                                           _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward')
         return out
 
-    def process_batch16(self, audio):
+    def process_batch16(self, audio, split=False):
         """(B, N) float32 CUDA tensor -> (B, T, F, 8) bfloat16: the features of process_batch rounded to bf16 and laid out the way the
         Onsets & Frames engine's first conv kernel stages them (amtx_cqt_forward16: a position's harmonics in one 16-byte slot, slots
-        C .. 7 zero) -- what OnsetsFrames.run_on_batch hands its engine when the model takes it (amtx_of_forward_feats16)."""
+        C .. 7 zero) -- what OnsetsFrames.run_on_batch hands its engine when the model takes it (amtx_of_forward_feats16).
+        split=True: (2, B, T, F, 8) -- plane 0 that map, plane 1 = bf16(feature - plane 0): the two planes the x3 engine multiplies with
+        (amtx_cqt_forward16_split)."""
         import torch
         assert audio.is_cuda and audio.dtype == torch.float32 and audio.dim() == 2
         audio = audio.contiguous()
@@ -457,10 +459,14 @@ class _CqtPlanOwner(object):
         if ws is None or ws.numel() < need or ws.device != audio.device:
             self.__dict__['_workspace'] = None
             ws = self.__dict__['_workspace'] = _lib.alloc_workspace(need, audio.device)
-        out = torch.empty((B, T, self.n_bins, 8), dtype=torch.bfloat16, device=audio.device)
+        out = torch.empty(((2,) if split else ()) + (B, T, self.n_bins, 8), dtype=torch.bfloat16, device=audio.device)
         with torch.cuda.device(audio.device):
-            _lib.check(L.amtx_cqt_forward16(plan, _lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
-                                            _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward16')
+            if split:
+                _lib.check(L.amtx_cqt_forward16_split(plan, _lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, int(bool(self.decibels)), _lib.ptr(ws),
+                                                      ws.numel(), _lib.ptr(out), out[0].numel(), _lib.current_stream(audio.device)), 'amtx_cqt_forward16_split')
+            else:
+                _lib.check(L.amtx_cqt_forward16(plan, _lib.ptr(audio), N, audio.stride(0) if B > 1 else N, B, int(bool(self.decibels)), _lib.ptr(ws), ws.numel(),
+                                                _lib.ptr(out), _lib.current_stream(audio.device)), 'amtx_cqt_forward16')
         return out
 
     def _process_host(self, audio):

@@ -413,7 +413,8 @@ class _OFEngine(object):
         return bool(_lib.lib().amtx_of_fuses_db_scale(self.handle))
 
     def takes_feats16(self):
-        return bool(_lib.lib().amtx_of_takes_feats16(self.handle))
+        """0: no; 1: (B,T,F,8) 16-bit channels-last features (one-plane engine); 2: the same as two planes (2,B,T,F,8) (x3 engine, round 6)."""
+        return int(_lib.lib().amtx_of_takes_feats16(self.handle))
 
     def conv_stack_fused(self, batch, num_frames):
         """True when a forward pass of this shape runs the three convolution layers as one kernel (csrc/convf.hip)."""
@@ -425,8 +426,8 @@ class _OFEngine(object):
         pending = feats if isinstance(feats, PendingFeatures) else None
         pending16 = isinstance(pending, PendingFeatures16)
         if pending16:
-            feats = pending.feats16                         # (B,T,F,8): shape and device only
-            B, T = feats.shape[:2]
+            feats = pending.feats16                         # (B,T,F,8) or two planes (2,B,T,F,8): shape and device only
+            B, T = feats.shape[-4], feats.shape[-3]
         elif pending is not None:
             feats = pending.power.unsqueeze(1)
         if not pending16:
@@ -442,7 +443,7 @@ class _OFEngine(object):
         lo = torch.empty((B, T, n_out), **opts) if want_logits else None
         lm = torch.empty((B, T, n_out), **opts) if want_logits else None
         lp = torch.empty((B, T, n_out), **opts) if want_logits else None
-        sb, sc, st, sf = feats.stride()
+        sb, sc, st, sf = (0, 0, 0, 0) if pending16 else feats.stride()
         with torch.cuda.device(feats.device):
             if pending16:
                 _lib.check(L.amtx_of_forward_feats16(self.handle, _lib.ptr(feats), B, T, _lib.ptr(self.workspace), self.workspace.numel(),
@@ -534,7 +535,8 @@ class OnsetsFrames(TranscriptionModel):
         """Inside run_on_batch, eval mode, raw audio only, a front-end of this package on the GPU and an engine whose first conv stages the
         features itself.  dB-scaled log-mel / STFT: the front-end stops after its power kernel and the dB scaling happens inside the conv
         kernel (PendingFeatures; one kernel launch and one write + read of the feature tensor less per batch).  CQT family (HCQT / HVQT: one
-        channel per harmonic) in bf16 precision: the front-end writes its map in the conv kernel's own staging format (PendingFeatures16).
+        channel per harmonic): the front-end writes its map in the conv kernel's own staging format (PendingFeatures16: one 16-bit plane for
+        the bf16 engine, the two planes of the split for x3).
         Returns the pre-processed batch, or None when none of that holds (the ordinary path then runs)."""
         if self.training or len(self.frontend) != 1 or not isinstance(self.frontend[0], SpectralFrontend):
             return None
@@ -558,14 +560,15 @@ class OnsetsFrames(TranscriptionModel):
         if not (torch.is_tensor(audio) and audio.is_cuda and audio.dim() == 2):
             return None
         if cqt:
-            if not self._get_engine(audio.device).takes_feats16():
+            form = self._get_engine(audio.device).takes_feats16()
+            if not form:
                 return None
             # amtx_of_forward_feats16 takes a bare (B,T,F,8) pointer and indexes it with the MODEL's dim_in / in_channels: a front-end of
             # another shape goes through the ordinary path, whose strides and shapes are explicit (and which raises on a mismatch)
             if int(getattr(module, 'n_bins', -1)) != int(self.dim_in) or int(module.get_num_channels()) != int(self.in_channels):
                 return None
             audio = audio.float()
-            batch[tools.KEY_FEATS] = PendingFeatures16(module, module.process_batch16(audio), audio)
+            batch[tools.KEY_FEATS] = PendingFeatures16(module, module.process_batch16(audio, split=(form == 2)), audio)
             return batch
         if not self._get_engine(audio.device).fuses_db_scale():
             return None

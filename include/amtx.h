@@ -125,8 +125,10 @@ int amtx_of_forward_power(const amtx_of_model* model, const float* power, int64_
  * feats16 = [batch][num_frames][dim_in][8] bf16, the input channels (harmonics of an HCQT, amt_tools/features/hvqt.py:107-133) of a
  * position in one 16-byte slot, slots in_channels .. 7 zero.  The kernel then fetches a position with one load instead of in_channels
  * strided fp32 loads + conversions; the values are the bf16 roundings it would make of the fp32 features itself, so the results are the
- * bits of amtx_of_forward.  Only for models where amtx_of_takes_feats16() is 1 (2 .. 8 input channels, model_complexity 2, bf16
- * precision: BASELINE config 3); AMTX_ERR_ARG otherwise -- callers then run amtx_cqt_forward + amtx_of_forward. */
+ * bits of amtx_of_forward.  Only for models where amtx_of_takes_feats16() is non-zero (2 .. 8 input channels, model_complexity 2: BASELINE
+ * config 3): 1 = bf16 precision, feats16 = [B][T][F][8]; 2 (round 6) = x3 precision, feats16 = the TWO planes of the split, [2][B][T][F][8] with
+ * the lo plane exactly B T F 8 elements behind the hi plane (amtx_cqt_forward16_split).  AMTX_ERR_ARG otherwise -- callers then run
+ * amtx_cqt_forward + amtx_of_forward. */
 int amtx_of_takes_feats16(const amtx_of_model* model);
 int amtx_of_forward_feats16(const amtx_of_model* model, const void* feats16, int batch, int num_frames, void* workspace, size_t workspace_bytes,
                             float* out_onsets, float* out_multi_pitch, float* logits_onsets, float* logits_multi_pitch,
@@ -307,6 +309,10 @@ int amtx_cqt_forward(const amtx_cqt_plan* plan, const float* audio, int64_t num_
  * The values are amtx_cqt_forward's rounded to bf16 (round to nearest even), i.e. what the conv kernel would make of them itself. */
 int amtx_cqt_forward16(const amtx_cqt_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
                        void* workspace, size_t workspace_bytes, void* out16, void* stream);
+/* ... and as the TWO 16-bit planes the two-plane (x3) engine multiplies with: hi = bf16(v) at out16 (amtx_cqt_forward16's map), lo = bf16(v - hi)
+ * `plane_elems` 16-bit elements behind it (>= B T n_bins 8, a multiple of 8): what amtx_of_forward_feats16 takes when amtx_of_takes_feats16() is 2. */
+int amtx_cqt_forward16_split(const amtx_cqt_plan* plan, const float* audio, int64_t num_samples, int64_t audio_stride, int batch, int decibels,
+                             void* workspace, size_t workspace_bytes, void* out16, int64_t plane_elems, void* stream);
 
 /* RMS normalisation of a batch of clips: tools.rms_norm (tools/utils.py:2789-2814) as applied by
  * tools.load_normalize_audio (tools/io.py:80-82): clip / sqrt(mean(clip^2)), all-zero clips untouched. */

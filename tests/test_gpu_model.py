@@ -1146,13 +1146,13 @@ def test_engine_takes_16_bit_channels_last_features_bit_for_bit(F, C, B, T):
 
 
 def test_feats16_entry_refuses_models_it_is_not_built_for():
-    """amtx_of_takes_feats16 is 0 for the x3 precision (two planes) and for a one-channel model, and amtx_of_forward_feats16 then fails loudly
-    instead of computing something else."""
+    """amtx_of_takes_feats16 is 0 for a one-channel model and for model_complexity 3 in x3, and amtx_of_forward_feats16 then fails loudly instead of
+    computing something else; the x3 HCQT model (round 6) answers 2 = the two-plane form."""
     from amt_tools_amd import _lib
     from amt_tools_amd.models import OnsetsFrames, PendingFeatures16
-    for F, C, prec in ((72, 6, 'x3'), (229, 1, 'bf16')):
-        sd = synth_state_dict(3, dim_in=F, in_channels=C, model_complexity=2)
-        model = OnsetsFrames(F, tools.PianoProfile(), C, 2, device='cuda:0', precision=prec)
+    for F, C, mc, prec in ((72, 6, 3, 'x3'), (229, 1, 2, 'bf16')):
+        sd = synth_state_dict(3, dim_in=F, in_channels=C, model_complexity=mc)
+        model = OnsetsFrames(F, tools.PianoProfile(), C, mc, device='cuda:0', precision=prec)
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         model.change_device()
         model.eval()
@@ -1160,6 +1160,69 @@ def test_feats16_entry_refuses_models_it_is_not_built_for():
         assert not eng.takes_feats16()
         with pytest.raises(_lib.AmtxError):
             eng.forward(PendingFeatures16(None, torch.zeros((1, 16, F, 8), dtype=torch.bfloat16, device='cuda:0'), None))
+    model = OnsetsFrames(72, tools.PianoProfile(), 6, 2, device='cuda:0', precision='x3')
+    model.change_device()
+    model.eval()
+    assert model._get_engine(torch.device('cuda:0')).takes_feats16() == 2
+
+
+def test_cqt_forward16_split_planes_are_the_split_of_the_fp32_map():
+    """amtx_cqt_forward16_split: plane 0 = amtx_cqt_forward16's map (bf16 of the fp32 feature, channels last, slots 6 .. 7 zero), plane 1 =
+    bf16(feature - plane 0): the two planes the x3 kernels' own conversion (split_bf16x2) makes -- hi + lo restores the feature to 2^-16."""
+    from amt_tools_amd.features import HCQT
+    mod = HCQT(sample_rate=22050, hop_length=512, n_bins=72, bins_per_octave=12)
+    audio = torch.from_numpy(np.stack([synth_clip(i, num_samples=512 * 50 - 3) for i in range(3)])).cuda()
+    f32 = mod.process_batch(audio)                                   # (B, 6, 72, T)
+    one = mod.process_batch16(audio)                                 # (B, T, 72, 8)
+    two = mod.process_batch16(audio, split=True)                     # (2, B, T, 72, 8)
+    assert two.shape == (2,) + tuple(one.shape) and torch.equal(two[0], one)
+    want = f32.permute(0, 3, 2, 1)                                   # (B, T, 72, 6)
+    hi = want.to(torch.bfloat16)
+    lo = (want - hi.float()).to(torch.bfloat16)
+    assert torch.equal(two[0][..., :6], hi) and torch.equal(two[1][..., :6], lo)
+    assert not two[..., 6:].any()
+    assert ((two[0].float() + two[1].float())[..., :6] - want).abs().max().item() < 2.0 ** -15
+
+
+@pytest.mark.parametrize('shape', [(3, 50, 72), (2, 33, 84), (37, 140, 72), (1, 17, 20)])
+def test_x3_multichannel_first_conv_on_convx_matches_the_general_kernel(shape, monkeypatch):
+    """Round 6: in the x3 precision a model with 2 .. 8 input channels takes its features as the two planes of the split ((2,B,T,F,8),
+    amtx_cqt_forward16_split) and runs conv1 + conv2 on convx.hip's layer-specialised kernel (`convx12_kernel<true>`: tap-major first conv by the
+    layer1 waves, layer2 by the others) instead of convg.hip's two-plane kernel on fp32 features.  Same fragments, same step and product order in
+    both layers' accumulators as the kernel it replaces: the engine's logits must be the bits of the fp32-feature path (AMTX_NO_CONVX12M is read when
+    the engine is created).  72 bins = four 18-column tiles, 84 = five narrower ones, 20 = one partial tile; frame counts inside a 16-row tile."""
+    from amt_tools_amd.models import OnsetsFrames, PendingFeatures16
+    B, T, F = shape
+    sd = synth_state_dict(9, dim_in=F, in_channels=6, model_complexity=2)
+    rng = np.random.default_rng(B * 1000 + T)
+    feats = torch.from_numpy(rng.random((B, 6, F, T)).astype(np.float32)).cuda()            # (B, C, F, T)
+    want = feats.permute(0, 3, 2, 1)                                                          # (B, T, F, C)
+    hi = want.to(torch.bfloat16)
+    lo = (want - hi.float()).to(torch.bfloat16)
+    planes = torch.zeros((2, B, T, F, 8), dtype=torch.bfloat16, device='cuda')
+    planes[0, ..., :6], planes[1, ..., :6] = hi, lo
+    got = {}
+    for mode in ('convx', 'convg'):
+        if mode == 'convg':
+            monkeypatch.setenv('AMTX_NO_CONVX12M', '1')
+        else:
+            monkeypatch.delenv('AMTX_NO_CONVX12M', raising=False)
+        model = OnsetsFrames(F, tools.PianoProfile(), 6, 2, device='cuda:0', precision='x3')
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        model.change_device()
+        model.eval()
+        eng = model._get_engine(torch.device('cuda:0'))
+        with torch.no_grad():
+            if mode == 'convx':
+                assert eng.takes_feats16() == 2
+                out = eng.forward(PendingFeatures16(None, planes, None))
+            else:
+                assert eng.takes_feats16() == 0
+                out = eng.forward(feats.transpose(-1, -2))
+        got[mode] = [o.clone() for o in out]
+        del model
+    for a, b in zip(got['convx'], got['convg']):
+        assert torch.equal(a, b), (shape, (a - b).abs().max().item())
 
 
 _STRIP_MC3_AB = r'''
