@@ -613,7 +613,7 @@ def hcqt_leg(device, clips=512, steps=5):
             out = model.run_on_batch({tools.KEY_AUDIO: audio})
         torch.cuda.synchronize()
         # the front-end alone, in the form run_on_batch uses it: (B,T,F,8) bf16 in the first conv's staging format when the engine takes that
-        feats16 = model._get_engine(torch.device(device)).takes_feats16()
+        feats16 = bool(model._get_engine(torch.device(device)).takes_feats16())
         (mod.process_batch16 if feats16 else mod.process_batch)(audio)      # untimed: first call of this form (allocations)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -680,7 +680,8 @@ def hcqt_leg(device, clips=512, steps=5):
 
 def hcqt_x3_leg(device, clips=512, steps=3):
     """BASELINE config 3 in the engine precision that is inside north_star's 1e-4 (x3: split-bf16, three MFMAs per product): the same audio ->
-    HCQT -> OnsetsFrames pass as hcqt_leg, fp32 (B,C,F,T) features."""
+    HCQT -> OnsetsFrames pass as hcqt_leg; since round 6 the features travel as the two 16-bit planes of the split ((2,B,T,F,8),
+    amtx_cqt_forward16_split) and conv1 + conv2 run on convx.hip's layer-specialised kernel."""
     from amt_tools_amd import tools
     from amt_tools_amd.features import HCQT
     from amt_tools_amd.models import OnsetsFrames
@@ -703,10 +704,12 @@ def hcqt_x3_leg(device, clips=512, steps=3):
             out = model.run_on_batch({tools.KEY_AUDIO: audio})
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        feats16 = int(model._get_engine(torch.device(device)).takes_feats16())
     T = out[tools.KEY_ONSETS].shape[-1]
     del model, out, audio
     torch.cuda.empty_cache()
     return {'frames_per_s': clips * T / dt, 'ms_per_step': dt * 1e3, 'clips_per_step': clips,
+            'features': '(2,B,T,F,8) bf16 planes, amtx_cqt_forward16_split -> amtx_of_forward_feats16' if feats16 == 2 else '(B,C,F,T) fp32',
             'note': 'engine precision x3 (inside 1e-4 of the fp32 reference: tests/test_gpu_model.py::test_config3_hcqt_frontend_fused_into_the_model)'}
 
 
