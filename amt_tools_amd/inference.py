@@ -39,7 +39,7 @@ def _frame_times(model, num_frames):
 
 @torch.no_grad()
 def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=1, decode_notes=False, keep=None):
-    """clips: (num_clips, N) float32 array / CPU tensor of equally long clips (the model needs a front-end in
+    """clips: (num_clips, N) float32 -- or int16 PCM -- array / CPU tensor of equally long clips (the model needs a front-end in
     `model.frontend`) or (num_clips, C, F, T) features.  Returns {clip index: predictions dict} for the clips
     this rank owns.  With decode_notes=True the note lists are decoded on the device (amtx_notes_decode).
     `keep`: keys of the model output to bring back to the host (default: every array; () = notes only).
@@ -49,6 +49,11 @@ def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=
     clips = torch.as_tensor(np.asarray(clips) if not torch.is_tensor(clips) else clips)
     mine = shard_indices(clips.shape[0], rank, world)
     key = tools.KEY_AUDIO if clips.dim() == 2 else tools.KEY_FEATS
+    # 16-bit PCM hand-over (round 6): int16 clips travel over PCIe as they are -- half the bytes of the float32 array the reference's loader makes
+    # of the same file (amt_tools/tools/io.py:80-82: librosa / soundfile return sample / 32768 for 16-bit files) -- and become exactly that
+    # float32 array on the device: sample * 2^-15 is exact.  Host-to-host transcription is bound by the upload (2 KB per frame as float32)
+    pcm16 = key == tools.KEY_AUDIO and clips.dtype == torch.int16
+    wire = torch.int16 if pcm16 else torch.float32
     device = torch.device(f'cuda:{model.device}' if isinstance(model.device, int) else model.device)
     on_gpu = device.type == 'cuda' and torch.cuda.is_available()
     out = {}
@@ -69,15 +74,17 @@ def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=
         lo, hi = int(idx[0]), int(idx[-1]) + 1
         contiguous = hi - lo == len(idx)
         if not on_gpu:
-            return (clips[lo:hi] if contiguous else clips[torch.as_tensor(idx)]).float(), None
+            sel = (clips[lo:hi] if contiguous else clips[torch.as_tensor(idx)]).float()
+            return (sel * (1.0 / 32768.0) if pcm16 else sel), None
         with torch.cuda.stream(copy_stream):
-            if contiguous and clips.is_pinned() and clips.dtype == torch.float32:
+            zero_copy = contiguous and clips.is_pinned() and clips.dtype == wire
+            if zero_copy:
                 src = clips[lo:hi]                                # zero-copy: the caller's pinned memory is the DMA source
             else:
                 slot = stage_count[0] % 2
                 stage_count[0] += 1
                 if staging[slot] is None:
-                    staging[slot] = [torch.empty((batch_size,) + tuple(clips.shape[1:]), dtype=torch.float32).pin_memory(), None]
+                    staging[slot] = [torch.empty((batch_size,) + tuple(clips.shape[1:]), dtype=wire).pin_memory(), None]
                 buf, last = staging[slot]
                 if last is not None:
                     last.synchronize()                            # the copy that read this buffer two batches ago is done
@@ -85,11 +92,13 @@ def run_offline_batched(clips, model, times=None, batch_size=256, rank=0, world=
                 if contiguous:
                     src.copy_(clips[lo:hi])
                 else:
-                    torch.index_select(clips.float() if clips.dtype != torch.float32 else clips, 0, torch.as_tensor(idx), out=src)
+                    torch.index_select(clips.to(wire) if clips.dtype != wire else clips, 0, torch.as_tensor(idx), out=src)
             dev = src.to(device, non_blocking=True)
+            if pcm16:
+                dev = dev.to(torch.float32).mul_(1.0 / 32768.0)   # on the copy stream, behind the DMA: the model's stream sees float32 audio
             ev = torch.cuda.Event()
             ev.record(copy_stream)
-            if not (contiguous and clips.is_pinned() and clips.dtype == torch.float32):
+            if not zero_copy:
                 staging[slot][1] = ev
         return dev, (ev, src)
 

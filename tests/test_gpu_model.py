@@ -865,6 +865,32 @@ def test_run_offline_batched_pipeline_equals_per_clip_runs():
     np.testing.assert_array_equal(shard[3][tools.KEY_NOTES], res[3][tools.KEY_NOTES])
 
 
+def test_run_offline_batched_takes_16_bit_pcm_and_returns_the_float32_results():
+    """Round 6: int16 clips travel to the GPU as they are (half the PCIe bytes) and become sample / 32768 there -- exactly the float32 array the
+    reference's loader makes of a 16-bit file (amt_tools/tools/io.py:80-82) -- so every result equals the float32 hand-over's, bit for bit;
+    contiguous batches from pinned and pageable memory, a sharded (strided) selection, and the CPU model."""
+    from amt_tools_amd.features import MelSpec
+    from amt_tools_amd.inference import run_offline_batched
+    g = load_golden('of1_eval.npz')
+    model = _model(g, 'x3')
+    model.frontend = torch.nn.Sequential(MelSpec(sample_rate=22050, hop_length=512, n_mels=229, n_fft=2048).frontend())
+    f = np.stack([synth_clip(i, num_samples=512 * 40 - 1) for i in range(7)])
+    pcm = np.clip(np.round(f / np.abs(f).max() * 32767.0), -32768, 32767).astype(np.int16)
+    as_float = (pcm.astype(np.float32) / 32768.0).astype(np.float32)
+    times = (np.arange(40) * 512 / 22050.0).astype(np.float32)
+    ref = run_offline_batched(as_float, model, times=times, batch_size=3, decode_notes=True)
+    for src in (pcm, torch.from_numpy(pcm).pin_memory()):
+        got = run_offline_batched(src, model, times=times, batch_size=3, decode_notes=True)
+        assert sorted(got) == sorted(ref)
+        for i in ref:
+            for k in (tools.KEY_ONSETS, tools.KEY_MULTIPITCH, tools.KEY_NOTES):
+                np.testing.assert_array_equal(got[i][k], ref[i][k])
+    shard = run_offline_batched(pcm, model, times=times, batch_size=2, rank=1, world=2, decode_notes=True)
+    assert sorted(shard) == [1, 3, 5]
+    for i in shard:
+        np.testing.assert_array_equal(shard[i][tools.KEY_NOTES], ref[i][tools.KEY_NOTES])
+
+
 def test_engine_long_single_clip():
     """One long track (T = 1500 frames, not a multiple of the 16-frame conv tile, of 4, or of the reference's 512-frame LSTM
     chunk): the whole-sequence recurrence and the tiled convolutions against the oracle (fp32-class mode)."""

@@ -6,7 +6,7 @@ batch's kernels.
 A long run amortises the pipeline's fill and drain (one upload and one batch of compute + host work that nothing overlaps); the
 steady state is bound by the upload: 2 KB per frame over a measured 57 GB/s link = 27.8 M frames/s.  Two warm-up runs, then the
 median and the best of three timed runs (single runs on a shared host vary by 2x).
-Usage: python tools/bench_transcribe.py [num_clips=8192] [batch=256] [--rolls]"""
+Usage: python tools/bench_transcribe.py [num_clips=8192] [batch=256] [--rolls] [--pcm16]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -18,8 +18,11 @@ args = [a for a in sys.argv[1:] if not a.startswith('--')]
 N = int(args[0]) if args else 8192
 B = int(args[1]) if len(args) > 1 else 256
 rolls = '--rolls' in sys.argv
+pcm16 = '--pcm16' in sys.argv      # the clips as 16-bit PCM (what the audio files hold): half the upload
 model, mel, sd = bench.build_model('cuda:0', 'bf16')
 base = np.stack([synth_clip(i) for i in range(8)])
+if pcm16:
+    base = np.clip(np.round(base / np.abs(base).max() * 32767.0), -32768, 32767).astype(np.int16)
 host = torch.from_numpy(np.tile(base, ((N + 7) // 8, 1))[:N]).pin_memory()
 times = np.arange(CLIP_FRAMES) * 512 / 22050.0
 model.frontend = torch.nn.Sequential(mel.frontend())
@@ -43,4 +46,4 @@ for _ in range(3):
 dt, best = sorted(dts)[1], min(dts)
 print(f'{N} clips x {CLIP_FRAMES} frames, batches of {B}, host audio -> host notes{" + piano rolls" if rolls else ""}: {dt * 1e3:.1f} ms, '
       f'{N / dt:.0f} clips/s, {N * CLIP_FRAMES / dt / 1e6:.2f} M frames/s median of 3 (best {N * CLIP_FRAMES / best / 1e6:.2f} M; {total} notes); '
-      f'H2D {host.numel() * 4 / 1e9:.2f} GB')
+      f'H2D {host.numel() * host.element_size() / 1e9:.2f} GB{" (int16 PCM)" if pcm16 else ""}')
