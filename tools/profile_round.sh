@@ -28,6 +28,7 @@ python3 tools/pmc_summary.py $O/pmc_${TAG}_* > $O/${TAG}_pmc_counters.txt
   echo "== tools/bench_train.py --of2 (OnsetsFrames2 as shipped, one GPU)"; timeout 300 python3 tools/watchdog_run.py 250 tools/bench_train.py --of2 --steps 5 --warmup 2 2>&1 | grep -v amdgpu.ids | tail -1
   echo "== tools/latency.py"; timeout 300 python3 tools/latency.py 2>&1 | grep -v amdgpu.ids | tail -6
   echo "== tools/bench_transcribe.py (BASELINE config 5 on one GPU, host to host)"; timeout 600 python3 tools/bench_transcribe.py 2>&1 | grep -v amdgpu.ids | tail -4
+  echo "== tools/bench_transcribe.py --pcm16 (the same clips as 16-bit PCM)"; timeout 600 python3 tools/bench_transcribe.py 8192 256 --pcm16 2>&1 | grep -v amdgpu.ids | tail -1
   echo "== tools/bench_gemm.py / bench_gemm_vendor.py"; timeout 200 python3 tools/bench_gemm.py 2>&1 | grep "^M=" | head -3; timeout 200 python3 tools/bench_gemm_vendor.py 2>&1 | grep hipBLASLt
 } > $O/${TAG}_secondary_benches.txt 2>&1
 ls -la $O | grep $TAG
