@@ -96,3 +96,21 @@ def test_two_ranks_on_one_gpu_train_identical_weights_and_the_union_batch_step(t
         print(f'\n[2 ranks x 8 clips on one GPU vs 1 x 16, 3 steps] relative L2 per tensor: median {np.median(rel):.2e}, max over |w| > 0.1 {max(big):.2e}, '
               f'max over all {max(rel):.2e}; losses {float(a["loss"]):.4f} (rank 0) / {float(b["loss"]):.4f} (rank 1) / {float(ref["loss"]):.4f} (one process)')
     assert np.median(rel) < 5e-3 and max(big) < 0.05
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_train_soak_with_the_head_overlap_on():
+    """Since round 6 the two detector heads overlap on two streams also under a process group (amt_tools_amd/models.py `_overlap_heads`).  160
+    training steps of two rank processes sharing the GPU -- four compute streams, two gloo all-reduces per step in flight between them -- under a
+    wall-clock limit: a hang is a killed child and a failed test; the ranks must end with identical weights."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        rec = _bench(['--mode', 'train', '--steps', '150', '--warmup', '10', '--cpu-seconds', '0', '--gpus', '2', '--share-device', '--backend', 'gloo',
+                      '--dump', d], 800)
+        cfg = rec['config']
+        assert cfg['collectives_per_step'] == 1.0 and cfg['global_batch'] == 16 and rec['ms_per_step'] > 0
+        a, b = np.load(os.path.join(d, 'rank0.npz')), np.load(os.path.join(d, 'rank1.npz'))
+        for k in a.files:
+            if k != 'loss':
+                assert np.array_equal(a[k], b[k]), f'ranks disagree on {k}'
+        assert np.isfinite(float(a['loss'])) and np.isfinite(float(b['loss']))

@@ -244,3 +244,12 @@ def test_strict_training_switch_turns_a_fallback_into_an_error(monkeypatch):
     ag.note_fallback('somewhere', 'some shape')
     assert ag.fallbacks() == {'somewhere': ('some shape', 1)}
     ag.reset_fallbacks()
+
+
+def test_default_precision_of_the_drop_in_classes_is_the_compliant_one():
+    """Round 6: a user who only swaps the imports gets the engine mode that is inside north_star's 1e-4 (`x3`); the bf16
+    throughput mode of BASELINE config 2 is an explicit opt-in.  The keyword does not exist in the reference and changes nothing on a CPU."""
+    from amt_tools_amd.models import OnsetsFrames, OnsetsFrames2
+    assert OnsetsFrames(40, tools.PianoProfile(), 1, 2).precision == 'x3'
+    assert OnsetsFrames2(40, tools.PianoProfile(), 1, 2).precision == 'x3'
+    assert OnsetsFrames(40, tools.PianoProfile(), 1, 2, precision='bf16').precision == 'bf16'
