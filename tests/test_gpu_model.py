@@ -1210,30 +1210,31 @@ def test_cqt_forward16_split_planes_are_the_split_of_the_fp32_map():
     assert ((two[0].float() + two[1].float())[..., :6] - want).abs().max().item() < 2.0 ** -15
 
 
-@pytest.mark.parametrize('shape', [(3, 50, 72), (2, 33, 84), (37, 140, 72), (1, 17, 20)])
+@pytest.mark.parametrize('shape', [(3, 50, 72, 6), (2, 33, 84, 6), (37, 140, 72, 6), (1, 17, 20, 6), (2, 21, 73, 2), (3, 40, 36, 7), (2, 16, 229, 3)])
 def test_x3_multichannel_first_conv_on_convx_matches_the_general_kernel(shape, monkeypatch):
     """Round 6: in the x3 precision a model with 2 .. 8 input channels takes its features as the two planes of the split ((2,B,T,F,8),
     amtx_cqt_forward16_split) and runs conv1 + conv2 on convx.hip's layer-specialised kernel (`convx12_kernel<true>`: tap-major first conv by the
     layer1 waves, layer2 by the others) instead of convg.hip's two-plane kernel on fp32 features.  Same fragments, same step and product order in
     both layers' accumulators as the kernel it replaces: the engine's logits must be the bits of the fp32-feature path (AMTX_NO_CONVX12M is read when
-    the engine is created).  72 bins = four 18-column tiles, 84 = five narrower ones, 20 = one partial tile; frame counts inside a 16-row tile."""
+    the engine is created).  72 bins = four 18-column tiles, 84 = five narrower ones, 20 = one partial tile, 73 an odd width, 229 thirteen tiles;
+    frame counts inside a 16-row tile; 2, 3, 6 and 7 input channels (8 keeps fp32 activations: ofmodel.hip split_acts)."""
     from amt_tools_amd.models import OnsetsFrames, PendingFeatures16
-    B, T, F = shape
-    sd = synth_state_dict(9, dim_in=F, in_channels=6, model_complexity=2)
+    B, T, F, Cin = shape
+    sd = synth_state_dict(9, dim_in=F, in_channels=Cin, model_complexity=2)
     rng = np.random.default_rng(B * 1000 + T)
-    feats = torch.from_numpy(rng.random((B, 6, F, T)).astype(np.float32)).cuda()            # (B, C, F, T)
+    feats = torch.from_numpy(rng.random((B, Cin, F, T)).astype(np.float32)).cuda()          # (B, C, F, T)
     want = feats.permute(0, 3, 2, 1)                                                          # (B, T, F, C)
     hi = want.to(torch.bfloat16)
     lo = (want - hi.float()).to(torch.bfloat16)
     planes = torch.zeros((2, B, T, F, 8), dtype=torch.bfloat16, device='cuda')
-    planes[0, ..., :6], planes[1, ..., :6] = hi, lo
+    planes[0, ..., :Cin], planes[1, ..., :Cin] = hi, lo
     got = {}
     for mode in ('convx', 'convg'):
         if mode == 'convg':
             monkeypatch.setenv('AMTX_NO_CONVX12M', '1')
         else:
             monkeypatch.delenv('AMTX_NO_CONVX12M', raising=False)
-        model = OnsetsFrames(F, tools.PianoProfile(), 6, 2, device='cuda:0', precision='x3')
+        model = OnsetsFrames(F, tools.PianoProfile(), Cin, 2, device='cuda:0', precision='x3')
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
         model.change_device()
         model.eval()
