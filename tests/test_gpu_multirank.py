@@ -114,3 +114,27 @@ def test_two_ranks_on_one_gpu_train_soak_with_the_head_overlap_on():
             if k != 'loss':
                 assert np.array_equal(a[k], b[k]), f'ranks disagree on {k}'
         assert np.isfinite(float(a['loss'])) and np.isfinite(float(b['loss']))
+
+
+@pytest.mark.timeout(900)
+def test_the_drivers_launch_command_torchrun_two_ranks_on_one_gpu():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N --steps K --warmup W`: the same line with two ranks sharing the one GPU (gloo).  Rank 0 prints the ONE JSON line; the world size in it is
+    torchrun's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'AMTX_DP_FORCE_COLLECTIVE')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           'bench.py', '--gpus', '2', '--steps', '2', '--warmup', '1', '--share-device', '--backend', 'gloo', '--clips', '16'] + COMMON
+    try:
+        p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail(f'torchrun did not finish within 600 s\n{(e.stderr or b"")[-2000:]}')
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert p.returncode == 0 and len(lines) == 1, f'rc {p.returncode}\nstdout: {p.stdout[-2000:]}\nstderr: {p.stderr[-3000:]}'
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['config']['rccl_ranks'] == 2 and rec['config']['process_group'] == 'gloo' and rec['value'] > 0
+    assert len(rec['config']['per_rank_frames_per_s']) == 2
