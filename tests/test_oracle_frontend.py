@@ -161,3 +161,25 @@ def test_mel_scale_and_filterbank_reproduce_the_values_librosa_documents():
     fb = fe.mel_filterbank(22050, 2048)                     # librosa.filters.mel(sr=22050, n_fft=2048): 128 bands
     assert fb.shape == (128, 1025)
     assert abs(fb[0, 0]) < 5e-4 and abs(fb[0, 1] - 0.016) < 5e-4 and np.all(np.abs(fb[-1, :2]) < 5e-4) and np.all(np.abs(fb[1, :2]) < 5e-4)
+
+
+import pytest    # noqa: E402
+
+
+@pytest.mark.parametrize('lv,pad_mode', [('0.10', 'constant'), ('0.9', 'reflect')])
+@pytest.mark.parametrize('n_fft,win_length,hop', [(2048, None, 512), (2048, 1024, 256), (512, 400, 160)])
+def test_stft_agrees_with_torch_stft_a_third_implementation(lv, pad_mode, n_fft, win_length, hop):
+    """torch.stft is documented as librosa-compatible (centre padding by n_fft // 2 in `pad_mode`, a window shorter than n_fft zero-padded on
+    both sides to n_fft, frame count 1 + N // hop) and shares no code with NumPy's FFT, scipy or this oracle: complex spectra of both
+    librosa-version switches of the oracle ('0.10' = zero centre pad, '0.9' = reflect) agree to 1e-9 in float64, a short analysis window and
+    a non-power-of-two one included.  Still not librosa -- but three unrelated implementations now agree on the conventions the known-answer
+    tests pin one by one."""
+    import torch
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal(7000)
+    X = fe.stft(y, n_fft=n_fft, hop_length=hop, win_length=win_length, lv=lv)                   # (1 + n_fft / 2, T) complex128
+    wl = win_length or n_fft
+    want = torch.stft(torch.from_numpy(y), n_fft=n_fft, hop_length=hop, win_length=wl, window=torch.hann_window(wl, periodic=True, dtype=torch.float64),
+                      center=True, pad_mode=pad_mode, normalized=False, onesided=True, return_complex=True).numpy()
+    assert X.shape == want.shape == (1 + n_fft // 2, 1 + len(y) // hop)
+    np.testing.assert_allclose(X, want, rtol=0, atol=1e-9 * np.abs(want).max())
