@@ -283,7 +283,7 @@ def _pick_side_stream(device, candidates=6, spins=20, spin_cycles=20000):
     first `torch.cuda.Stream()` sits on the null stream's queue, and the training step ran its two heads back to back: 11.4 instead of 9.5
     ms (GPU_MAX_HW_QUEUES=8 / 16: 9.5; =1: 11.3; the data-parallel step of BASELINE config 4 is exactly that case).  So the stream is chosen
     by a test: a chain of short one-block spin kernels (torch.cuda._sleep) on the current stream and on the candidate at once takes ~1.4 x
-    one chain's time when the two overlap and ~1.9 x when they share a queue (tools/_dbg/pick3.py: the same verdicts as a chain of 40
+    one chain's time when the two overlap and ~1.9 x when they share a queue (tools/stream_queue_probe.py: the same verdicts as a chain of 40
     small GEMMs per stream; ONE long spin kernel is not a reliable probe against the null stream).  The first candidate below 1.7 x is
     kept; without one (or without _sleep) the first stream created.  Running BOTH heads on tested streams of their own costs 0.45 ms of
     extra cross-stream waits per step (measured 9.9 vs 9.45 ms), so the recurrent heads stay on the caller's stream."""
